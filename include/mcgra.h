@@ -1,0 +1,199 @@
+/*
+ * mcgra.h - C ABI of the MI355X-native MC-GRA adjacency-optimisation hot path.
+ *
+ * Drop-in boundary for the inner loop of MC-GRA/topology_attack.py
+ * (PGDAttack.attack, lines 161-298) and the functions it calls.  The reference
+ * is Python/PyTorch, so the binding a maintainer adds is a ctypes stub
+ * (INTEGRATION.md); every entry point takes plain device pointers, sizes and a
+ * hipStream_t passed as void*.  No torch types cross this boundary.
+ *
+ * Conventions
+ *   - all matrices are row-major fp32 in device (HBM) memory unless stated;
+ *   - "ld" arguments are leading dimensions in elements;
+ *   - every function returns 0 on success, a negative MCGRA_E* code otherwise;
+ *     mcgra_last_error() returns a static description of the last failure on
+ *     the calling thread;
+ *   - functions enqueue on `stream` and do not synchronise unless documented.
+ *
+ * Reference citations are relative to /root/reference/MC-GRA.
+ */
+#ifndef MCGRA_H
+#define MCGRA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCGRA_OK 0
+#define MCGRA_EINVAL (-1)  /* bad argument */
+#define MCGRA_EHIP (-2)    /* HIP runtime error */
+#define MCGRA_ENOSUP (-3)  /* valid in the reference, not implemented on this path yet */
+#define MCGRA_ENOMEM (-4)
+
+#define MCGRA_MAX_LAYERS 8
+
+/* args.measure (main.py:109, topology_attack.py:190-208) */
+enum mcgra_measure {
+  MCGRA_MEASURE_HSIC = 0, /* CudaCKA.linear_HSIC utils.py:1085 */
+  MCGRA_MEASURE_MSE = 1,  /* torch.nn.MSELoss  topology_attack.py:194 */
+  MCGRA_MEASURE_KL = 2,   /* PGDAttack.calc_kl topology_attack.py:483 */
+  MCGRA_MEASURE_CKA = 3,  /* CudaCKA.linear_CKA utils.py:1091 */
+  MCGRA_MEASURE_DP = 4    /* PGDAttack.dot_product topology_attack.py:480 */
+  /* "KDE" (utils.MutualInformation, utils.py:980) hard-codes cuda:0 and cannot
+     run on the reference CPU path; not provided. */
+};
+
+const char* mcgra_version(void);
+const char* mcgra_last_error(void);
+/* number of HIP devices visible, or a negative error */
+int mcgra_device_count(void);
+
+/* ------------------------------------------------------------------ GEMM --
+ * C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C, fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), row-major.  ta/tb: 0 = as stored, 1 = transposed.
+ * This is the torch.mm / torch.matmul the reference calls at models/gcn.py:41-42,
+ * utils.py:1086-1087 and topology_attack.py:416. */
+int mcgra_sgemm(void* stream, int ta, int tb, int m, int n, int k, float alpha,
+                const float* A, int lda, const float* B, int ldb, float beta,
+                float* C, int ldc);
+
+/* ------------------------------------------------------- standalone ops --
+ * Each mirrors one reference function on its own inputs; the attack engine
+ * below runs fused forms of the same kernels. */
+
+/* PGDAttack.get_modified_adj (topology_attack.py:365-379):
+ * out = (1 - I) * sym(tril^-1(adj_changes)) + ori_adj; ori_adj may be NULL (zeros).
+ * adj_changes has n(n-1)/2 entries in torch.tril_indices(n, n, -1) order. */
+int mcgra_get_modified_adj(void* stream, int n, const float* adj_changes,
+                           const float* ori_adj, float* out);
+
+/* inverse data movement: out[p(i,j)] = M[i][j], i > j */
+int mcgra_pack_tril(void* stream, int n, const float* M, int ld, float* out);
+
+/* utils.normalize_adj_tensor dense branch (utils.py:211-230):
+ * out = D^-1/2 (adj + I) D^-1/2, D = rowsum(adj + I), inf -> 0. */
+int mcgra_normalize_adj(void* stream, int n, const float* adj, float* out);
+
+/* Info_entropy (topology_attack.py:44-47): *out (device scalar) =
+ * -mean(q log2 q), q = clamp(p, 1e-4, 1 - 1e-4) over an n x n matrix. */
+int mcgra_info_entropy(void* stream, int n, const float* prob, float* out);
+
+/* PGDAttack.dot_product_decode (topology_attack.py:414-419):
+ * out[p(i,j)] = relu(<Z_i, Z_j> / (max(|Z_i|,1e-12) max(|Z_j|,1e-12))), i > j. */
+int mcgra_dot_product_decode(void* stream, int n, int d, const float* Z, float* out);
+
+/* CudaCKA.linear_HSIC (utils.py:1085-1089) for X [m x dx], Y [m x dy]:
+ * *out = sum(center(X X^T) * center(Y Y^T)).  Evaluated as |Xc^T Yc|_F^2. */
+int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X,
+                      const float* Y, float* out);
+
+/* torch.nn.MSELoss()(X, Y) over `count` elements, *out device scalar. */
+int mcgra_mse(void* stream, int64_t count, const float* X, const float* Y, float* out);
+
+/* GCN.forward in eval mode (models/gcn.py:164-174): log_softmax(linear1(
+ * relu(adj @ (... relu(adj @ (X @ W0) + b0) ...)))).  X [n x nfeat],
+ * W[l] [dims[l] x dims[l+1]], b[l] [dims[l+1]], Wlin [nclass x dims[nlayer]].
+ * emb_out (optional, may be NULL) receives embedding_GCN.forward with
+ * emb_nlayer layers (models/gcn.py:71-76); out [n x nclass] log-probabilities. */
+int mcgra_gcn_forward(void* stream, int n, int nfeat, int nlayer, const int32_t* dims,
+                      const float* X, const float* adj, const float* const* W,
+                      const float* const* b, const float* Wlin, const float* blin,
+                      int nclass, int emb_nlayer, float* emb_out, float* out);
+
+/* -------------------------------------------------------- attack engine --
+ * One object per PGDAttack instance.  It owns the learnable adjacency
+ * (adj_changes, kept dense-symmetric in HBM), the Adam moments and all
+ * per-step workspace. */
+typedef struct mcgra_attack mcgra_attack_t;
+
+typedef struct mcgra_attack_config {
+  int32_t n;           /* nnodes */
+  int32_t nfeat;       /* feature width */
+  int32_t nclass;
+  int32_t nlayer;      /* len(victim_model.gc) */
+  int32_t emb_nlayer;  /* embedding.nlayer at loop entry (main.py:240 leaves 2) */
+  int32_t dims[MCGRA_MAX_LAYERS + 1]; /* dims[0] = nfeat, dims[l+1] = out width of gc[l] */
+  int32_t measure;     /* enum mcgra_measure */
+  int32_t n_attack;    /* len(idx_attack) */
+  float weight_sup;    /* weight_supervised */
+  float w[10];         /* weight_param (w1..w10), topology_attack.py:151 */
+  float lr;            /* Adam lr (lr_ori) */
+  float eps;           /* args.eps; != 0 needs noise passed to mcgra_attack_step */
+  double num_edges;    /* projection budget (topology_attack.py:338) */
+  /* row-block sharding over ranks (one process per GPU).  row_begin/row_end
+     is the block of adjacency rows this object computes; a single-GPU object
+     uses [0, n).  The caller runs the collectives named in DESIGN.md between
+     the phases of mcgra_attack_step_phase(). */
+  int32_t row_begin, row_end;
+} mcgra_attack_config_t;
+
+int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg);
+int mcgra_attack_destroy(mcgra_attack_t* h);
+
+/* victim_model / embedding weights (models/gcn.py GCN.gc[l].weight/.bias,
+ * GCN.linear1); device pointers, copied. */
+int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W,
+                           const float* const* b, const float* Wlin, const float* blin);
+
+/* constant inputs of PGDAttack.attack (topology_attack.py:95-98): ori_features
+ * [n x nfeat], adj (true graph, used only for the H_A / Y_A priors :177-182),
+ * ori_adj (init_adj; NULL = zeros, the only value dataset.py:433 produces),
+ * feature_adj [n x n], labels [n] int32, idx_attack [n_attack] int32.
+ * Computes T0 = X W0, H_A_cur and Y_A once.  Synchronises. */
+int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* features,
+                           const float* adj, const float* ori_adj, const float* feature_adj,
+                           const int32_t* labels, const int32_t* idx_attack);
+
+/* adj_changes in the reference's packed order (n(n-1)/2 floats). */
+int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed);
+int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed);
+
+/* One iteration of the loop at topology_attack.py:161-298: forward, losses,
+ * backward into adj_changes, Adam step, projection, clamp.  noise (n x n,
+ * stands for torch.randn_like at :475) may be NULL when eps == 0.
+ * scalars_out (host, may be NULL) receives after a stream sync:
+ *   [0] loss  [1] origin_loss  [2] c1 [3] c2 [4] c6 [5] c7 [6] c9 [7] c10
+ *   [8] sum(clamp(adj_changes,0,1)) after the update  [9] nll
+ * Passing NULL keeps the call asynchronous. */
+int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
+                      double* scalars_out);
+
+/* Monitoring forward of topology_attack.py:290-296 on the current adjacency:
+ * out_logp [n x nclass] = victim(features, normalize(get_modified_adj)),
+ * *sparsity (host) = mean(modified_adj).  Synchronises if sparsity != NULL. */
+int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, double* sparsity);
+
+/* After the loop (topology_attack.py:300-324): adj_changes <- decode(embedding(
+ * features, adj_norm of the last iteration)); modified_adj = get_modified_adj +
+ * dd2(H_A1) + dd2(H_A2) + feature_adj + dd2(Y_A2) [+ dd2(H_A)] [+ dd2(Y_A)]
+ * [+ label_adj].  decode_mode selects the dot_product_decode2 branch
+ * (topology_attack.py:421-467): 0 sigmoid(relu(ZZ^T - I)) (cora, AIDS);
+ * 1 same on row-normalised Z (citeseer); 2 relu(ZZ^T - I) (brazil);
+ * 3 relu(rownorm(ZZ^T) - I) (polblogs / usair default); 4,5,6 relu(Zn Zn^T - I)
+ * with Zn rows normalised in p = 2, 3, 5 (usair prior-specific branches).
+ * H_A [n x dims[emb]] / Y_A [n x nclass] / label_adj [n x n] may be NULL when
+ * the matching use* flag is 0.  out [n x n]. */
+int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode,
+                          const float* H_A, const float* Y_A, const float* label_adj,
+                          float* out);
+
+/* Device pointer + shape of a named intermediate of the last step, for parity
+ * tests ("adj_norm", "A1", "em", "G_adjn", "G_A1", "G_A", "G_sym", "M", "d",
+ * "r", "logp", "sm2", "HA", "YA", "T0").  ld receives the leading dimension. */
+int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr,
+                        int* rows, int* cols, int* ld);
+
+/* Timing of the dominant kernel: the engine brackets every launch of the fp32
+ * MFMA GEMM with HIP events on the launch stream when profiling is enabled.
+ * mcgra_attack_gemm_stats synchronises, then returns launch count, total
+ * milliseconds and total flops since the last reset. */
+int mcgra_attack_profile(mcgra_attack_t* h, int enable);
+int mcgra_attack_gemm_stats(mcgra_attack_t* h, int reset, int64_t* launches,
+                            double* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCGRA_H */

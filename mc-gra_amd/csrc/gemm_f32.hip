@@ -1,0 +1,334 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled.
+//
+// C[M x N] = alpha * op(A) * op(B) + beta * C, all row-major.  This is the
+// torch.mm / torch.matmul of the reference hot path: the dense A.X.W layer
+// (models/gcn.py:41-42), the Gram matrices of CudaCKA.linear_HSIC
+// (utils.py:1086-1087), the decode Z Z^T (topology_attack.py:416) and every
+// product autograd derives from them.  Exact fp32: the MFMA is a k-ordered
+// fmaf chain, so results differ from a CPU BLAS only by summation order.
+//
+// Layout choices (MI355X, wave64):
+//  * an operand whose K index is contiguous in HBM ("KC", e.g. A of an NN
+//    product) is staged as [row][BK+4] and its fragments are read with one
+//    ds_read_b128 per 4 k-steps; the +4 pad makes the 16-lane b128 groups hit
+//    16 distinct 4-bank slots (row stride 36 floats: 9*m mod 16 is a bijection);
+//  * an operand whose K index is strided ("XC", e.g. B of an NN product) is
+//    staged as [k][BX] and read with ds_read_b32 (lanes = consecutive x);
+//  * both operands use the same k permutation inside an 8-deep chunk: MFMA
+//    step t takes k = kc + t on lanes 0-31 and k = kc + 4 + t on lanes 32-63,
+//    which is legal because the MFMA sums over k;
+//  * global -> LDS goes through registers (one tile prefetched while the
+//    current one is multiplied), 16-byte loads when pointers/ld allow.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace mcgra {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GEMM_THREADS = 256;
+
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC>
+struct GemmCfg {
+  static constexpr int KPAD = 4;
+  // A tile in LDS: KC layout [BM][BK+KPAD] when !TA, XC layout [BK][BM] when TA
+  static constexpr int A_ROWS = TA ? BK : BM;
+  static constexpr int A_COLS = TA ? BM : BK;
+  static constexpr int A_LD = TA ? BM : BK + KPAD;
+  // B tile: XC layout [BK][BN] when !TB, KC layout [BN][BK+KPAD] when TB
+  static constexpr int B_ROWS = TB ? BN : BK;
+  static constexpr int B_COLS = TB ? BK : BN;
+  static constexpr int B_LD = TB ? BK + KPAD : BN;
+  static constexpr int A_ELEMS = A_ROWS * A_LD;
+  static constexpr int B_ELEMS = B_ROWS * B_LD;
+  static constexpr int A_V4 = A_ROWS * A_COLS / 4;  // float4 per tile
+  static constexpr int B_V4 = B_ROWS * B_COLS / 4;
+  static constexpr int A_PER_T = (A_V4 + GEMM_THREADS - 1) / GEMM_THREADS;
+  static constexpr int B_PER_T = (B_V4 + GEMM_THREADS - 1) / GEMM_THREADS;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == GEMM_THREADS / 64, "4 waves");
+  static_assert(BK % 8 == 0, "k chunk of 8");
+};
+
+// Load one float4 of a [rows x cols] global tile (cols contiguous) with zero fill.
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_v4(const float* __restrict__ base, int ld, int r, int c,
+                                          int rmax, int cmax) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (r < rmax) {
+    const float* p = base + (size_t)r * ld + c;
+    if (VEC && c + 3 < cmax) {
+      v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+      if (c + 0 < cmax) v[0] = p[0];
+      if (c + 1 < cmax) v[1] = p[1];
+      if (c + 2 < cmax) v[2] = p[2];
+      if (c + 3 < cmax) v[3] = p[3];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
+    int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
+    const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
+    int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n) {
+  using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB, VEC>;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::A_ELEMS + Cfg::B_ELEMS];
+  float* As = smem;
+  float* Bs = smem + Cfg::A_ELEMS;
+
+  // ---- block -> tile map: XCD-aware (blocks b and b+8 share an XCD's L2), then
+  // GROUP_M-row panels so co-resident tiles share A row-panels and B col-panels.
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int group_sz = GROUP_M * tiles_n;
+  const int group_id = bid / group_sz;
+  const int first_m = group_id * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (bid % group_sz) % gm;
+  const int tile_n = (bid % group_sz) / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int kz = blockIdx.z;
+  const int k_begin = kz * k_per_split;
+  const int k_end = min(K, k_begin + k_per_split);
+  C += (size_t)kz * c_split_stride;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / Cfg::WAVES_N) * WM;
+  const int wn0 = (wave % Cfg::WAVES_N) * WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[Cfg::A_PER_T], rb[Cfg::B_PER_T];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_T; ++i) {
+      const int f = tid + i * GEMM_THREADS;
+      constexpr int V4R = Cfg::A_COLS / 4;
+      const int row = f / V4R, c4 = (f % V4R) * 4;
+      if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
+        if (TA)  // global [k][m]
+          ra[i] = load_v4<VEC>(A, lda, k0 + row, m0 + c4, k_end, M);
+        else  // global [m][k]
+          ra[i] = load_v4<VEC>(A, lda, m0 + row, k0 + c4, M, k_end);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PER_T; ++i) {
+      const int f = tid + i * GEMM_THREADS;
+      constexpr int V4R = Cfg::B_COLS / 4;
+      const int row = f / V4R, c4 = (f % V4R) * 4;
+      if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4) {
+        if (TB)  // global [n][k]
+          rb[i] = load_v4<VEC>(B, ldb, n0 + row, k0 + c4, N, k_end);
+        else  // global [k][n]
+          rb[i] = load_v4<VEC>(B, ldb, k0 + row, n0 + c4, k_end, N);
+      }
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_T; ++i) {
+      const int f = tid + i * GEMM_THREADS;
+      constexpr int V4R = Cfg::A_COLS / 4;
+      const int row = f / V4R, c4 = (f % V4R) * 4;
+      if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4)
+        *reinterpret_cast<f32x4*>(&As[row * Cfg::A_LD + c4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PER_T; ++i) {
+      const int f = tid + i * GEMM_THREADS;
+      constexpr int V4R = Cfg::B_COLS / 4;
+      const int row = f / V4R, c4 = (f % V4R) * 4;
+      if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4)
+        *reinterpret_cast<f32x4*>(&Bs[row * Cfg::B_LD + c4]) = rb[i];
+    }
+  };
+
+  if (k_begin < k_end) {
+    load_tiles(k_begin);
+    store_tiles();
+  }
+  __syncthreads();
+
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool has_next = (k0 + BK) < k_end;
+    if (has_next) load_tiles(k0 + BK);  // in flight while this tile is multiplied
+
+#pragma unroll
+    for (int kc = 0; kc < BK; kc += 8) {
+      float af[Cfg::TM][4], bf[Cfg::TN][4];
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const int x = wm0 + i * 32 + l31;
+        if (!TA) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&As[x * Cfg::A_LD + kc + 4 * lh]);
+          af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) af[i][t] = As[(kc + 4 * lh + t) * Cfg::A_LD + x];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int x = wn0 + j * 32 + l31;
+        if (TB) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[x * Cfg::B_LD + kc + 4 * lh]);
+          bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[j][t] = Bs[(kc + 4 * lh + t) * Cfg::B_LD + x];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < Cfg::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (has_next) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) {
+          float* p = C + (size_t)row * ldc + col;
+          float v = alpha * acc[i][j][r];
+          if (beta != 0.f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+// out[i] = sum_s slabs[s][i] (+ beta * out[i]) : deterministic split-K combine
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, size_t stride, int nsplit,
+                                 float* __restrict__ out, size_t count, float beta) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += step) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * stride + i];
+    out[i] = beta != 0.f ? s + beta * out[i] : s;
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K,
+                             float alpha, const float* A, int lda, const float* B, int ldb,
+                             float beta, float* C, int ldc, int nsplit, int k_per_split,
+                             size_t c_split_stride) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, 1, nsplit), block(GEMM_THREADS);
+#define MCGRA_GEMM_LAUNCH(TA_, TB_, VEC_)                                                       \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, TA_, TB_, VEC_>), grid, block, 0, st, \
+                     M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, k_per_split, c_split_stride, \
+                     tiles_m, tiles_n)
+  if (vec) {
+    if (!ta && !tb) MCGRA_GEMM_LAUNCH(false, false, true);
+    else if (!ta && tb) MCGRA_GEMM_LAUNCH(false, true, true);
+    else if (ta && !tb) MCGRA_GEMM_LAUNCH(true, false, true);
+    else MCGRA_GEMM_LAUNCH(true, true, true);
+  } else {
+    if (!ta && !tb) MCGRA_GEMM_LAUNCH(false, false, false);
+    else if (!ta && tb) MCGRA_GEMM_LAUNCH(false, true, false);
+    else if (ta && !tb) MCGRA_GEMM_LAUNCH(true, false, false);
+    else MCGRA_GEMM_LAUNCH(true, true, false);
+  }
+#undef MCGRA_GEMM_LAUNCH
+  return hipGetLastError();
+}
+
+// Workspace-free entry: no split-K.  `ws`/`ws_bytes` (optional) enable split-K
+// for skinny outputs whose tile grid cannot fill 256 CUs.
+hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha,
+                 const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                 float* ws, size_t ws_bytes) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (K <= 0) {  // C = beta * C
+    if (beta == 0.f) {
+      return hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st);
+    }
+    K = 0;
+  }
+  const bool vec = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0);
+  const bool skinny = N <= 32;
+  const int BM = 128, BN = skinny ? 32 : 128, BK = 32;
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int nsplit = 1;
+  if (ws && tiles < 256 && K >= 4 * BK) {
+    nsplit = min(min(64, (512 + tiles - 1) / tiles), K / (2 * BK));
+    while (nsplit > 1 && (size_t)nsplit * M * N * sizeof(float) > ws_bytes) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  int k_per_split = K;
+  if (nsplit > 1) {
+    k_per_split = (((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK;
+    nsplit = (K + k_per_split - 1) / k_per_split;
+  }
+  hipError_t e;
+  if (nsplit > 1) {
+    const size_t stride = (size_t)M * N;
+    if (skinny)
+      e = launch_cfg<128, 32, 32, 32, 32>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
+                                          nsplit, k_per_split, stride);
+    else
+      e = launch_cfg<128, 128, 32, 64, 64>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
+                                           nsplit, k_per_split, stride);
+    if (e != hipSuccess) return e;
+    if (ldc == N) {
+      const size_t cnt = stride;
+      int blocks = (int)min((size_t)2048, (cnt + 255) / 256);
+      hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, stride, nsplit, C, cnt, beta);
+    } else {
+      // strided C: combine row by row
+      for (int r = 0; r < M; ++r)
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws + (size_t)r * N,
+                           stride, nsplit, C + (size_t)r * ldc, (size_t)N, beta);
+    }
+    return hipGetLastError();
+  }
+  if (skinny)
+    return launch_cfg<128, 32, 32, 32, 32>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 1,
+                                           K, 0);
+  return launch_cfg<128, 128, 32, 64, 64>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 1, K,
+                                          0);
+}
+
+}  // namespace mcgra

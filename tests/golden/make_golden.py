@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes under tests/golden/ are data (inputs + the reference's outputs) and are
+what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cora]
+
+Environment shims applied before importing the reference (none of them is on
+the computed path):
+  * ``np.int = int``        - alias removed in numpy>=1.24, used by utils.py:505
+  * ``torchmetrics.AUROC``  - imported at topology_attack.py:10 but only used by
+                              ``metric()`` (:15-21), which main.py never calls;
+                              the package is not installed here, so an empty
+                              module object satisfies the import.
+  * matplotlib Agg backend  - plt.cla() at topology_attack.py:122.
+The attack needs ./saved_data/<dataset>.npy (label adjacency, main.prepare()
+main.py:440-450; the zip that ships it is a missing large blob), so the script
+works in a temp cwd and writes label_adj[i,j] = (labels[i] == labels[j]) there.
+"""
+import argparse
+import os
+import random
+import sys
+import tempfile
+import types
+import zlib
+from copy import deepcopy
+
+import numpy as np
+
+REF = "/root/reference/MC-GRA"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    np.int = int
+    tm = types.ModuleType("torchmetrics")
+    tm.AUROC = None
+    sys.modules.setdefault("torchmetrics", tm)
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    import torch  # noqa
+    import utils  # noqa  (reference utils.py)
+    import topology_attack  # noqa
+    from models.gcn import GCN, embedding_GCN  # noqa
+    return torch, utils, topology_attack, GCN, embedding_GCN
+
+
+torch, rutils, rta, GCN, embedding_GCN = _import_reference()
+from sklearn.metrics import auc, roc_curve  # noqa: E402
+
+
+def ref_dot_product_decode_main(Z, dataset):
+    """main.dot_product_decode (main.py:44-55) - feature_adj construction."""
+    import torch.nn.functional as F
+    if dataset in ("cora", "citeseer", "AIDS"):
+        Z = torch.matmul(Z, Z.t())
+        return torch.sigmoid(torch.relu(Z - torch.eye(Z.shape[0])))
+    Z = F.normalize(Z, p=2, dim=1)
+    Z = torch.matmul(Z, Z.t())
+    return torch.relu(Z - torch.eye(Z.shape[0]))
+
+
+def metric_pool(adj, inference_adj, idx):
+    """main.metric_pool (main.py:66-75)."""
+    real = adj[idx, :][:, idx].reshape(-1)
+    pred = inference_adj[idx, :][:, idx].reshape(-1)
+    fpr, tpr, _ = roc_curve(real, pred)
+    return float(auc(fpr, tpr))
+
+
+def weights_of(victim):
+    d = {}
+    for l, layer in enumerate(victim.gc):
+        d[f"W{l}"] = layer.weight.detach().numpy().copy()
+        d[f"b{l}"] = layer.bias.detach().numpy().copy()
+    d["Wlin"] = victim.linear1.weight.detach().numpy().copy()
+    d["blin"] = victim.linear1.bias.detach().numpy().copy()
+    return d
+
+
+def run_reference_attack(adj, features, labels, victim, idx_attack, measure, weight_param,
+                         weight_sup, lr, epochs, dataset, use, num_edges, eps=0.0,
+                         capture_steps=True):
+    """Drive topology_attack.PGDAttack.attack exactly as main.objective does
+    (main.py:298-307) and capture per-step adj_changes / grads through a global
+    optimizer post-hook."""
+    device = torch.device("cpu")
+    n = adj.shape[0]
+    nl = len(victim.gc)
+    embedding = embedding_GCN(nfeat=features.shape[1], nhid=victim.hidden_sizes[0], nlayer=nl, device=device)
+    embedding.gc = deepcopy(victim.gc)                                  # main.py:190
+    victim.eval()
+    H_A = embedding(features, adj); Y_A = victim(features, adj)         # main.py:235-236
+    embedding.set_layers(1); embedding(features, adj)
+    embedding.set_layers(2); H_A2 = embedding(features, adj)            # main.py:238-241
+    feature_adj = ref_dot_product_decode_main(features, dataset)        # main.py:165
+    init_adj = torch.zeros(n, n)                                        # dataset.init_matrix (dataset.py:433)
+    args = argparse.Namespace(max_eval=100, lr=0, dataset=dataset, eps=eps, measure=measure,
+                              useH_A=use[0], useY_A=use[1], useY=use[2],
+                              w1=0, w2=0, w6=0, w7=0, w8=0, w9=0, w10=0)
+    model = rta.PGDAttack(model=victim, embedding=embedding, H_A=H_A2, Y_A=Y_A, nnodes=n,
+                          loss_type="CE", device=device).to(device)
+    steps_a, steps_g = [], []
+
+    def hook(opt, a, k):
+        p = opt.param_groups[0]["params"][0]
+        steps_a.append(p.detach().numpy().copy())
+        steps_g.append(p.grad.detach().numpy().copy())
+
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    handle = register_optimizer_step_post_hook(hook) if capture_steps else None
+    try:
+        model.attack(args, None, lr, 0, weight_sup, weight_param, feature_adj, 0, 0, 0,
+                     None, None, np.arange(min(8, n)), adj, features, init_adj, labels, idx_attack,
+                     num_edges, 0, epochs=epochs)
+    finally:
+        if handle is not None:
+            handle.remove()
+    final = model.modified_adj.detach().numpy().copy()
+    return dict(final=final, steps_a=steps_a, steps_g=steps_g, H_A2=H_A2.detach().numpy(),
+                Y_A=Y_A.detach().numpy(), feature_adj=feature_adj.numpy(),
+                auc=metric_pool(adj.numpy(), final, idx_attack))
+
+
+def make_synth(n, f, c, hid, nlayer, seed, p_edge=0.08):
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed); random.seed(seed)
+    labels = rng.randint(0, c, size=n)
+    # class-correlated features + homophilous edges so the attack has signal
+    centers = rng.randn(c, f).astype(np.float32)
+    feats = (centers[labels] * 0.6 + rng.randn(n, f) * 0.8).astype(np.float32)
+    feats = (feats > 0.5).astype(np.float32)           # binary bag-of-words like cora
+    same = labels[:, None] == labels[None, :]
+    prob = np.where(same, p_edge * 3, p_edge * 0.5)
+    up = np.triu(rng.rand(n, n) < prob, 1)
+    adj = (up | up.T).astype(np.float32)
+    device = torch.device("cpu")
+    victim = GCN(nfeat=f, nclass=c, nhid=hid, nlayer=nlayer, dropout=0.5, weight_decay=5e-4, device=device)
+    # reference GraphConvolution.reset_parameters init (models/gcn.py:28-33); no training
+    return torch.FloatTensor(adj), torch.FloatTensor(feats), torch.LongTensor(labels), victim
+
+
+def gen_small(tmp):
+    os.chdir(tmp)
+    os.makedirs("saved_data", exist_ok=True)
+    cases = []
+    base_wp = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)
+    spec = [
+        # name, n, f, c, hid, nlayer, measure, weight_param, wsup, lr, epochs, num_edges
+        ("s48_mse", 48, 24, 4, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 4, 1e12),
+        ("s48_hsic", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 4, 1e12),
+        ("s48_kl", 48, 24, 4, 16, 2, "KL", base_wp, 1.0, 0.01, 3, 1e12),
+        # CKA with w9/w10 is 0/0 at adj_changes == 0 (identical em / softmax rows): the reference returns
+        # rounding noise there, so the pinned CKA case uses the N x N terms only (README polblogs/AIDS CKA lines)
+        ("s48_cka", 48, 24, 4, 16, 2, "CKA", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 0, 0), 1.0, 0.01, 3, 1e12),
+        ("s48_dp", 48, 24, 4, 16, 2, "DP", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s80_hsic_l3", 80, 40, 5, 16, 3, "HSIC", (0.1, 0.1, 0, 0, 0, 1, 1, 0, 100, 10), 0.0, 0.003, 3, 1e12),
+        ("s80_mse_proj", 80, 40, 5, 16, 2, "MSELoss", (1, 0.1, 0, 0, 0, 100, 1, 0, 10, 10), 1.0, 0.1, 5, 30.0),
+        ("s200_mse", 200, 64, 6, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s200_hsic", 200, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
+    ]
+    for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:
+        adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000)
+        lab = labels.numpy()
+        np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
+        random.seed(7)
+        idx_attack = np.array(random.sample(range(n), n if "l3" not in name else int(n * 0.75)))
+        res = run_reference_attack(adj, feats, labels, victim, idx_attack, measure, wp, wsup, lr,
+                                   epochs, "cora", (True, True, True), ne)
+        out = dict(adj=adj.numpy(), features=feats.numpy(), labels=lab, idx_attack=idx_attack,
+                   measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup,
+                   lr=lr, epochs=epochs, num_edges=ne, nlayer=nl, final=res["final"],
+                   steps_a=np.stack(res["steps_a"]), steps_g=np.stack(res["steps_g"]),
+                   H_A2=res["H_A2"], Y_A=res["Y_A"], feature_adj=res["feature_adj"], auc=res["auc"],
+                   **weights_of(victim))
+        np.savez_compressed(os.path.join(OUT, f"attack_{name}.npz"), **out)
+        print(name, "auc", res["auc"], "steps", len(res["steps_a"]))
+        cases.append(name)
+    return cases
+
+
+def gen_ops(tmp):
+    """Op-level known answers from the reference's own functions (+autograd)."""
+    rng = np.random.RandomState(3)
+    out = {}
+    # normalize_adj_tensor (utils.py:211) incl. an isolated... (d >= 1 always with +I)
+    A = rng.rand(37, 37).astype(np.float32); A = (A + A.T) / 2; np.fill_diagonal(A, 0)
+    out["norm_in"] = A
+    out["norm_out"] = rutils.normalize_adj_tensor(torch.tensor(A)).numpy()
+    # CudaCKA linear_HSIC / linear_CKA (utils.py:1085-1096) with autograd
+    cka = rutils.CudaCKA(device="cpu")
+    for tag, (m, dx, dy) in {"a": (29, 16, 7), "b": (40, 40, 40)}.items():
+        X = torch.tensor(rng.randn(m, dx).astype(np.float32), requires_grad=True)
+        Y = torch.tensor(rng.randn(m, dy).astype(np.float32), requires_grad=True)
+        for nm, fn in (("hsic", cka.linear_HSIC), ("cka", cka.linear_CKA)):
+            X.grad = Y.grad = None
+            v = fn(X, Y); v.backward()
+            out[f"{nm}_{tag}_X"] = X.detach().numpy(); out[f"{nm}_{tag}_Y"] = Y.detach().numpy()
+            out[f"{nm}_{tag}_val"] = v.item()
+            out[f"{nm}_{tag}_gX"] = X.grad.numpy().copy(); out[f"{nm}_{tag}_gY"] = Y.grad.numpy().copy()
+    # Info_entropy (topology_attack.py:44)
+    P = torch.tensor(rng.rand(31, 31).astype(np.float32) * 1.2 - 0.1, requires_grad=True)
+    v = rta.Info_entropy(P); v.backward()
+    out["ie_in"] = P.detach().numpy(); out["ie_val"] = v.item(); out["ie_grad"] = P.grad.numpy().copy()
+    # calc_kl / dot_product (topology_attack.py:480-487) with autograd; MSELoss
+    import warnings
+    warnings.simplefilter("ignore")
+    dummy = rta.PGDAttack.__new__(rta.PGDAttack)
+    for nm, fn in (("kl", lambda a, b: rta.PGDAttack.calc_kl(dummy, a, b)),
+                   ("dp", lambda a, b: rta.PGDAttack.dot_product(dummy, a, b)),
+                   ("mse", torch.nn.MSELoss())):
+        X = torch.tensor(rng.randn(23, 9).astype(np.float32), requires_grad=True)
+        Y = torch.tensor(rng.randn(23, 9).astype(np.float32), requires_grad=True)
+        v = fn(X, Y); v.backward()
+        out[f"{nm}_X"] = X.detach().numpy(); out[f"{nm}_Y"] = Y.detach().numpy()
+        out[f"{nm}_val"] = v.item(); out[f"{nm}_gX"] = X.grad.numpy().copy(); out[f"{nm}_gY"] = Y.grad.numpy().copy()
+    # dot_product_decode2 variants (topology_attack.py:421-467)
+    Zr = rng.rand(19, 6).astype(np.float32)
+    out["dd2_Z"] = Zr
+    for ds, use in (("cora", (1, 1, 1)), ("AIDS", (1, 0, 0)), ("citeseer", (1, 1, 1)), ("brazil", (1, 1, 1)),
+                    ("polblogs", (1, 1, 1)), ("polblogs", (1, 0, 1)), ("usair", (0, 0, 1)),
+                    ("usair", (1, 1, 0)), ("usair", (1, 0, 1)), ("usair", (1, 1, 1))):
+        dummy.args = argparse.Namespace(dataset=ds, useH_A=bool(use[0]), useY_A=bool(use[1]), useY=bool(use[2]))
+        dummy.device = "cpu"
+        out[f"dd2_{ds}_{use[0]}{use[1]}{use[2]}"] = rta.PGDAttack.dot_product_decode2(dummy, torch.tensor(Zr)).numpy()
+    # projection with bisection (topology_attack.py:338-347, 397-412)
+    class _P(torch.nn.Module):
+        pass
+    pm = rta.PGDAttack(model=None, embedding=None, nnodes=30, device="cpu")
+    vec = (rng.rand(435).astype(np.float32) * 1.6 - 0.3)
+    pm.adj_changes.data = torch.tensor(vec)
+    pm.projection(40)
+    out["proj_in"] = vec; out["proj_edges"] = 40.0; out["proj_out"] = pm.adj_changes.detach().numpy().copy()
+    # get_modified_adj (topology_attack.py:365-379)
+    pm.adj_changes.data = torch.tensor(rng.rand(435).astype(np.float32))
+    ori = (rng.rand(30, 30) < 0.1).astype(np.float32)
+    out["gma_a"] = pm.adj_changes.detach().numpy().copy(); out["gma_ori"] = ori
+    out["gma_out"] = pm.get_modified_adj(torch.tensor(ori)).detach().numpy()
+    # dot_product_decode packed (topology_attack.py:414-419)
+    pm.nnodes = 19
+    out["dd_out"] = pm.dot_product_decode(torch.tensor(Zr)).numpy()
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("ops.npz", len(out), "arrays")
+
+
+def gen_cora(tmp):
+    """Cora through the reference's own data path and victim training
+    (main.py:148-190), README headline MSELoss config + an HSIC config."""
+    os.chdir(tmp)
+    if not os.path.exists("dataset"):
+        os.symlink(os.path.join(REF, "dataset"), "dataset")
+    os.makedirs("saved_data", exist_ok=True)
+    from dataset import Dataset
+    seed = 15
+    np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)
+    data = Dataset(root="./dataset", name="cora", setting="GCN")
+    adj, features, labels = data.adj, data.features, data.labels
+    idx_train, idx_val, idx_test = data.idx_train, data.idx_val, data.idx_test
+    idx_attack = np.array(random.sample(range(adj.shape[0]), int(adj.shape[0] * 1.0)))   # main.py:155
+    adj, features, labels = rutils.preprocess(adj, features, labels, preprocess_adj=False, onehot_feature=False)
+    device = torch.device("cpu")
+    victim = GCN(nfeat=features.shape[1], nclass=labels.max().item() + 1, nhid=16, nlayer=2,
+                 dropout=0.5, weight_decay=5e-4, device=device).to(device)
+    victim.fit(features, adj, labels, idx_train, idx_val, verbose=False)
+    idx_attack = np.array(random.sample(range(adj.shape[0]), int(adj.shape[0] * 1.0)))   # main.py:244
+    num_edges = int(0.5 * 1e7 * adj.sum() / adj.shape[0] ** 2 * len(idx_attack) ** 2)
+    lab = labels.numpy()
+    np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
+    rng = np.random.RandomState(0)
+    n = adj.shape[0]
+    samp = rng.randint(0, n, size=(8192, 2))
+    fx = features.numpy()
+    assert set(np.unique(fx)) <= {0.0, 1.0}
+    ei = np.argwhere(np.triu(adj.numpy(), 1) > 0).astype(np.int32)
+    assert np.array_equal(adj.numpy(), adj.numpy().T) and np.trace(adj.numpy()) == 0
+    common = dict(idx_attack=idx_attack, idx_test=idx_test, num_edges=float(num_edges), sample_pos=samp,
+                  features_bits=np.packbits(fx.astype(np.uint8), axis=1), nfeat=fx.shape[1],
+                  adj_edges=ei, labels=lab, **weights_of(victim))
+    runs = [
+        # README.md "K = {X, H_A, Y^, Y}" cora line: --w1=0.01 --w6=10 --w7=10 --w9=10 --w10=1000 --lr=-2 MSELoss
+        ("cora_mse_readme", "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 10 ** -2, 100),
+        ("cora_hsic", "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 10 ** -2, 12),
+    ]
+    for name, measure, wp, wsup, lr, epochs in runs:
+        res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs,
+                                   "cora", (True, True, True), num_edges)
+        sa = np.stack(res["steps_a"])
+        out = dict(measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup, lr=lr,
+                   epochs=epochs, auc=res["auc"],
+                   final_sample=res["final"][samp[:, 0], samp[:, 1]],
+                   final_sum=float(res["final"].astype(np.float64).sum()),
+                   step_sum=sa.astype(np.float64).sum(1), step_sqsum=(sa.astype(np.float64) ** 2).sum(1),
+                   step_a_sample=sa[:, :: max(1, sa.shape[1] // 4096)],
+                   **common)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+        print(name, "auc", res["auc"])
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    with tempfile.TemporaryDirectory() as tmp:
+        if a.only in ("all", "ops"):
+            gen_ops(tmp)
+        if a.only in ("all", "small"):
+            gen_small(tmp)
+        if a.only in ("all", "cora"):
+            gen_cora(tmp)

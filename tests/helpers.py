@@ -1,0 +1,56 @@
+"""Shared test helpers: load golden fixtures, build oracle objects from them."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import mcgra_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def attack_cases():
+    return sorted(os.path.basename(p)[len("attack_"):-4] for p in glob.glob(os.path.join(GOLDEN, "attack_*.npz")))
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, f"attack_{name}.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def weights_from(z):
+    L = int(z["nlayer"]) if "nlayer" in z else 2
+    return O.GCNWeights([z[f"W{l}"] for l in range(L)], [z[f"b{l}"] for l in range(L)], z["Wlin"], z["blin"])
+
+
+def cfg_from(z):
+    return O.AttackConfig(measure=str(z["measure"]), weight_sup=float(z["weight_sup"]),
+                          weight_param=tuple(float(x) for x in z["weight_param"]), lr=float(z["lr"]),
+                          num_edges=float(z["num_edges"]), eps=0.0, emb_nlayer=2)
+
+
+def oracle_from(z):
+    n = z["adj"].shape[0]
+    return O.PGDAttackOracle(weights_from(z), z["features"], z["adj"], np.zeros((n, n), np.float32),
+                             z["feature_adj"], z["labels"], z["idx_attack"], cfg_from(z))
+
+
+def load_cora(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    z = {k: z[k] for k in z.files}
+    nfeat = int(z["nfeat"])
+    feats = np.unpackbits(z["features_bits"], axis=1)[:, :nfeat].astype(np.float32)
+    n = feats.shape[0]
+    adj = np.zeros((n, n), np.float32)
+    e = z["adj_edges"]
+    adj[e[:, 0], e[:, 1]] = 1
+    adj[e[:, 1], e[:, 0]] = 1
+    z["features"], z["adj"] = feats, adj
+    return z
+
+
+def cora_feature_adj(feats):
+    """main.dot_product_decode for cora (main.py:44-48)."""
+    Z = feats @ feats.T
+    Z = np.maximum(Z - np.eye(Z.shape[0], dtype=np.float32), 0)
+    return (1.0 / (1.0 + np.exp(-Z.astype(np.float64)))).astype(np.float32)
