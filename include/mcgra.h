@@ -184,6 +184,8 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode,
  * "r", "logp", "sm2", "HA", "YA", "T0").  ld receives the leading dimension. */
 int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr,
                         int* rows, int* cols, int* ld);
+/* copy of the same intermediate into a caller buffer dst [rows x cols], leading dimension dst_ld */
+int mcgra_attack_copy_buffer(mcgra_attack_t* h, void* stream, const char* name, float* dst, int dst_ld);
 
 /* Timing of the dominant kernel: the engine brackets every launch of the fp32
  * MFMA GEMM with HIP events on the launch stream when profiling is enabled.

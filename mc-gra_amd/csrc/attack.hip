@@ -1,0 +1,674 @@
+// Attack engine: one iteration of PGDAttack.attack's loop
+// (topology_attack.py:161-298) as a fixed sequence of HIP launches on one
+// stream, with a hand-derived backward (no autograd).  Host code only enqueues;
+// nothing here reads device memory back unless the caller asks for scalars.
+//
+// State layout in HBM (all fp32, leading dimension ld = round_up(n, 4)):
+//   M            learnable adjacency, dense symmetric, zero diagonal
+//                (adj_changes of the reference is its strict lower triangle)
+//   am, av       Adam moments, same layout (mirrored halves stay identical
+//                because the packed gradient is mirrored)
+//   ADJN, A1     adj_norm and modified_adj1 of the current step
+//   G_ADJN, G_A1, G_A   gradients w.r.t. those and w.r.t. modified_adj
+//   KX, KY, KFC  Gram matrices of linear_HSIC on N x N operands
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mcgra.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace mcgra {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+}  // namespace mcgra
+
+using namespace mcgra;
+
+// utils.Align_Parameter_Cora (utils.py:1100-1111)
+static const double AP_C1 = 100, AP_C2 = 1000, AP_C6 = 10, AP_C7 = 10, AP_C9 = 1, AP_C10 = 1;
+
+enum Scal {  // device scalar slots (double)
+  S_SQ = 0, S_SUM, S_NLL, S_V1, S_V2, S_V6, S_V7, S_H1, S_H2, S_C9, S_C10, S_TOTX, S_TOTY, S_CLAMPSUM,
+  S_TMP, S_COUNT = 32
+};
+
+struct GemmTimer {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  int64_t launches = 0;
+  double flops = 0;
+};
+
+struct mcgra_attack {
+  mcgra_attack_config_t cfg;
+  int n = 0, ld = 0, L = 0, Le = 0, C = 0, na = 0, hsum = 0, hmax = 0;
+  int off[MCGRA_MAX_LAYERS + 1];   // column offset of layer l inside the concatenated node buffers
+  int wdt[MCGRA_MAX_LAYERS + 1];   // width of layer l output (dims[l+1])
+  int64_t t = 0;                   // Adam step count
+  bool have_step = false;
+  bool graph_set = false, model_set = false;
+  std::vector<void*> allocs;
+  // N x N
+  float *M = 0, *am = 0, *av = 0, *ADJN = 0, *A1 = 0, *G_ADJN = 0, *G_A1 = 0, *G_A = 0;
+  float *KX = 0, *KY = 0, *KFC = 0, *FADJ = 0, *GSYM = 0;
+  // vectors
+  float *d = 0, *r = 0, *rowpart = 0, *colpart = 0, *gd = 0, *nrm = 0, *cnt = 0, *rowmin = 0, *rowmax = 0, *mm = 0;
+  double *rowsq = 0, *rowsum = 0, *rowvals = 0, *rowsx = 0, *rowsy = 0, *scal = 0;
+  int *labels = 0, *idx = 0, *correct = 0;
+  // weights
+  float* W[MCGRA_MAX_LAYERS] = {0};
+  float* b[MCGRA_MAX_LAYERS] = {0};
+  float *Wlin = 0, *blin = 0;
+  // node-level
+  float *Tv = 0, *Pv = 0, *Hv = 0, *GPv = 0;   // victim(adj_norm) chain, [n x hsum]
+  float *Tu = 0, *Pu = 0, *Hu = 0, *GPu = 0;   // victim/embedding(modified_adj) chain
+  float *Y = 0, *GT = 0, *Z = 0, *logp = 0, *sm = 0, *Z2 = 0, *sm2 = 0, *GZ = 0, *GZ2 = 0, *Gsm = 0;
+  float *Zn = 0, *GZn = 0, *Gem = 0;
+  float *HA = 0, *YA = 0, *HAg = 0, *HAc = 0, *YAg = 0, *YAc = 0, *Yg = 0, *Gg = 0, *Q = 0;
+  float* ws = 0;
+  size_t ws_bytes = 0;
+  int nstrips = 32;
+  bool profile = false;
+  GemmTimer timer;
+};
+
+#define CHK(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+template <typename T>
+static int dalloc(mcgra_attack* h, T** p, size_t count) {
+  void* q = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    return MCGRA_ENOMEM;
+  }
+  e = hipMemset(q, 0, count * sizeof(T));
+  if (e != hipSuccess) { set_error("hipMemset: %s", hipGetErrorString(e)); return MCGRA_EHIP; }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+// every GEMM of the engine goes through here (timed when profiling)
+static int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A,
+              int lda, const float* B, int ldb, float beta, float* C, int ldc) {
+  const bool big = h->profile && (double)M * N * K >= 0.25 * (double)h->n * h->n * h->n;
+  if (big) {
+    GemmTimer& T = h->timer;
+    if (T.used + 2 > T.ev.size()) {
+      for (int i = 0; i < 2; ++i) { hipEvent_t e; MCGRA_HIP(hipEventCreate(&e)); T.ev.push_back(e); }
+    }
+    MCGRA_HIP(hipEventRecord(T.ev[T.used], st));
+  }
+  MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws, h->ws_bytes));
+  if (big) {
+    GemmTimer& T = h->timer;
+    MCGRA_HIP(hipEventRecord(T.ev[T.used + 1], st));
+    T.used += 2;
+    T.launches += 1;
+    T.flops += 2.0 * M * N * K;
+  }
+  return 0;
+}
+
+// x = relu(adj @ (x W_l) + b_l) for `depth` layers (models/gcn.py:71-76,164-172).
+// T[:, off[0]..] must already hold T_0 = X W_0.
+static int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int depth, float* T, float* P,
+                         float* H) {
+  const int n = h->n, hs = h->hsum;
+  for (int l = 0; l < depth; ++l) {
+    CHK(eg(h, st, false, false, n, h->wdt[l], n, 1.f, adj, adj_ld, T + h->off[l], hs, 0.f, h->Y, h->hmax));
+    launch_bias_relu(st, n, h->wdt[l], h->Y, h->hmax, h->b[l], P + h->off[l], H + h->off[l], hs);
+    if (l + 1 < h->L)
+      launch_rowmat(st, n, h->wdt[l], h->wdt[l + 1], H + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr,
+                    T + h->off[l + 1], hs);
+  }
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+// linear1 + log_softmax (models/gcn.py:173-174)
+static int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, float* logp, float* sm) {
+  const int l = h->L - 1;
+  launch_rowmat(st, h->n, h->wdt[l], h->C, H + h->off[l], h->hsum, h->Wlin, 1, h->wdt[l], h->blin, Z, h->C);
+  launch_log_softmax(st, h->n, h->C, Z, h->C, logp, sm, h->C);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+// Backward through layers ltop..0 of a chain.  GP[:, off[ltop]] holds G_P_ltop on
+// entry.  add_at/Add: extra gradient w.r.t. H_{add_at} (e.g. d loss / d em).
+static int chain_backward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int ltop, const float* P,
+                          float* GP, int add_at, const float* Add, int add_ld) {
+  const int n = h->n, hs = h->hsum;
+  for (int l = ltop; l >= 1; --l) {
+    // G_T_l = adj^T @ G_P_l
+    CHK(eg(h, st, true, false, n, h->wdt[l], n, 1.f, adj, adj_ld, GP + h->off[l], hs, 0.f, h->GT, h->hmax));
+    // G_P_{l-1} = (G_T_l @ W_l^T [+ Add]) * (P_{l-1} > 0)
+    launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], P + h->off[l - 1], hs,
+                       (l - 1 == add_at) ? Add : nullptr, add_ld, GP + h->off[l - 1], hs);
+  }
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+static double sign_of(const mcgra_attack* h) { return h->cfg.measure == MCGRA_MEASURE_HSIC ? -1.0 : 1.0; }
+
+extern "C" {
+
+const char* mcgra_version(void) { return "mcgra-hip 0.1 (gfx950)"; }
+const char* mcgra_last_error(void) { return mcgra::last_error(); }
+int mcgra_device_count(void) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return MCGRA_EHIP; }
+  return c;
+}
+
+int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) {
+  if (!out || !cfg) { set_error("null argument"); return MCGRA_EINVAL; }
+  if (cfg->n < 2 || cfg->nlayer < 2 || cfg->nlayer > MCGRA_MAX_LAYERS || cfg->emb_nlayer < 1 ||
+      cfg->emb_nlayer > cfg->nlayer || cfg->nclass < 1 || cfg->n_attack < 1) {
+    set_error("bad config: n=%d nlayer=%d emb_nlayer=%d nclass=%d n_attack=%d", cfg->n, cfg->nlayer, cfg->emb_nlayer,
+              cfg->nclass, cfg->n_attack);
+    return MCGRA_EINVAL;
+  }
+  if (cfg->measure != MCGRA_MEASURE_HSIC && cfg->measure != MCGRA_MEASURE_MSE) {
+    set_error("measure %d (KL/CKA/DP) is not implemented on the HIP path yet", cfg->measure);
+    return MCGRA_ENOSUP;
+  }
+  if (cfg->eps != 0.f) { set_error("eps != 0 (adding_noise) is not implemented on the HIP path yet"); return MCGRA_ENOSUP; }
+  if (cfg->row_begin != 0 || (cfg->row_end != cfg->n && cfg->row_end != 0)) {
+    set_error("row-block sharding is driven from the host layer; engine objects are full-range");
+    return MCGRA_ENOSUP;
+  }
+  mcgra_attack* h = new mcgra_attack();
+  h->cfg = *cfg;
+  h->n = cfg->n;
+  h->ld = (cfg->n + 3) & ~3;
+  h->L = cfg->nlayer;
+  h->Le = cfg->emb_nlayer;
+  h->C = cfg->nclass;
+  h->na = cfg->n_attack;
+  int o = 0, hm = cfg->nclass;
+  for (int l = 0; l < h->L; ++l) {
+    h->off[l] = o;
+    h->wdt[l] = cfg->dims[l + 1];
+    if (h->wdt[l] < 1) { delete h; set_error("bad dims[%d]", l + 1); return MCGRA_EINVAL; }
+    o += (h->wdt[l] + 3) & ~3;
+    if (h->wdt[l] > hm) hm = h->wdt[l];
+  }
+  h->hsum = o;
+  h->hmax = (hm + 3) & ~3;
+  const size_t n = h->n, ld = h->ld, nn = n * ld;
+  int rc = 0;
+#define A_(p, cnt) if (!rc) rc = dalloc(h, &h->p, (cnt))
+  A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
+  A_(KX, nn); A_(FADJ, nn); A_(GSYM, nn);
+  if (cfg->measure == MCGRA_MEASURE_HSIC) { A_(KY, nn); A_(KFC, nn); }
+  A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
+  A_(rowmin, ld); A_(rowmax, ld); A_(mm, 4);
+  A_(rowsq, 2 * ld); h->rowsum = h->rowsq ? h->rowsq + n : nullptr;
+  A_(rowvals, 8 * ld); A_(rowsx, ld); A_(rowsy, ld); A_(scal, S_COUNT);
+  A_(labels, n); A_(idx, (size_t)h->na); A_(correct, 4);
+  for (int l = 0; l < h->L && !rc; ++l) {
+    rc = dalloc(h, &h->W[l], (size_t)cfg->dims[l] * cfg->dims[l + 1]);
+    if (!rc) rc = dalloc(h, &h->b[l], (size_t)cfg->dims[l + 1]);
+  }
+  A_(Wlin, (size_t)h->C * h->wdt[h->L - 1]); A_(blin, (size_t)h->C);
+  const size_t nh = n * h->hsum, nm = n * h->hmax, nc = n * h->C;
+  A_(Tv, nh); A_(Pv, nh); A_(Hv, nh); A_(GPv, nh); A_(Tu, nh); A_(Pu, nh); A_(Hu, nh); A_(GPu, nh);
+  A_(Y, nm); A_(GT, nm); A_(Z, nc); A_(logp, nc); A_(sm, nc); A_(Z2, nc); A_(sm2, nc); A_(GZ, nc); A_(GZ2, nc); A_(Gsm, nc);
+  A_(Zn, nm); A_(GZn, nm); A_(Gem, nm);
+  const size_t am_ = (size_t)h->na * h->hmax;
+  A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
+  A_(Q, (size_t)h->hmax * h->hmax);
+  h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
+  A_(ws, h->ws_bytes / sizeof(float));
+#undef A_
+  if (rc) { mcgra_attack_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+int mcgra_attack_destroy(mcgra_attack_t* h) {
+  if (!h) return 0;
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->timer.ev) (void)hipEventDestroy(e);
+  delete h;
+  return 0;
+}
+
+int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W, const float* const* b,
+                           const float* Wlin, const float* blin) {
+  if (!h || !W || !b || !Wlin || !blin) { set_error("null argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 0; l < h->L; ++l) {
+    MCGRA_HIP(hipMemcpyAsync(h->W[l], W[l], sizeof(float) * h->cfg.dims[l] * h->cfg.dims[l + 1], hipMemcpyDeviceToDevice, st));
+    MCGRA_HIP(hipMemcpyAsync(h->b[l], b[l], sizeof(float) * h->cfg.dims[l + 1], hipMemcpyDeviceToDevice, st));
+  }
+  MCGRA_HIP(hipMemcpyAsync(h->Wlin, Wlin, sizeof(float) * h->C * h->wdt[h->L - 1], hipMemcpyDeviceToDevice, st));
+  MCGRA_HIP(hipMemcpyAsync(h->blin, blin, sizeof(float) * h->C, hipMemcpyDeviceToDevice, st));
+  h->model_set = true;
+  return 0;
+}
+
+int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* features, const float* adj,
+                           const float* ori_adj, const float* feature_adj, const int32_t* labels,
+                           const int32_t* idx_attack) {
+  if (!h || !features || !adj || !feature_adj || !labels || !idx_attack) { set_error("null argument"); return MCGRA_EINVAL; }
+  if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
+  if (ori_adj) {
+    set_error("ori_adj != zeros is not implemented on the HIP path yet (dataset.py:433 only produces zeros)");
+    return MCGRA_ENOSUP;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int n = h->n, ld = h->ld, hs = h->hsum;
+  MCGRA_HIP(hipMemcpy2DAsync(h->FADJ, (size_t)ld * 4, feature_adj, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+  MCGRA_HIP(hipMemcpyAsync(h->labels, labels, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+  MCGRA_HIP(hipMemcpyAsync(h->idx, idx_attack, sizeof(int) * h->na, hipMemcpyDeviceToDevice, st));
+  MCGRA_HIP(hipMemsetAsync(h->cnt, 0, sizeof(float) * ld, st));
+  launch_count_idx(st, h->na, h->idx, h->cnt);
+  // T0 = X @ W_0 : the only use of the features inside the loop (models/gcn.py:41)
+  CHK(eg(h, st, false, false, n, h->wdt[0], h->cfg.dims[0], 1.f, features, h->cfg.dims[0], h->W[0], h->wdt[0], 0.f, h->Tv, hs));
+  MCGRA_HIP(hipMemcpy2DAsync(h->Tu, (size_t)hs * 4, h->Tv, (size_t)hs * 4, (size_t)h->wdt[0] * 4, n, hipMemcpyDeviceToDevice, st));
+  // priors on the TRUE, un-normalised adjacency (topology_attack.py:177-182, :243)
+  CHK(chain_forward(h, st, adj, n, h->L, h->Tu, h->Pu, h->Hu));
+  CHK(head_forward(h, st, h->Hu, h->Z2, h->YA, nullptr));                                  // Y_A (log-probs)
+  const int le = h->Le - 1;
+  MCGRA_HIP(hipMemcpy2DAsync(h->HA, (size_t)h->hmax * 4, h->Hu + h->off[le], (size_t)hs * 4, (size_t)h->wdt[le] * 4, n,
+                             hipMemcpyDeviceToDevice, st));                                // H_A_cur
+  launch_gather_rows(st, h->na, h->wdt[le], h->HA, h->hmax, h->idx, h->HAg, h->hmax);
+  launch_gather_rows(st, h->na, h->wdt[le], h->HA, h->hmax, h->idx, h->HAc, h->hmax);
+  launch_colmean_center(st, h->na, h->wdt[le], h->HAc, h->hmax);
+  launch_gather_rows(st, h->na, h->C, h->YA, h->C, h->idx, h->YAg, h->hmax);
+  launch_gather_rows(st, h->na, h->C, h->YA, h->C, h->idx, h->YAc, h->hmax);
+  launch_colmean_center(st, h->na, h->C, h->YAc, h->hmax);
+  if (h->cfg.measure == MCGRA_MEASURE_HSIC && h->cfg.w[0] != 0.f) {
+    // centred Gram of feature_adj: constant left factor of c1 (utils.py:1086,1089)
+    CHK(eg(h, st, false, true, n, n, n, 1.f, h->FADJ, ld, h->FADJ, ld, 0.f, h->KFC, ld));
+    launch_rowsum(st, n, ld, h->KFC, h->rowsx);
+    launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_TOTX);
+    launch_center(st, n, ld, h->KFC, h->rowsx, h->scal + S_TOTX);
+  }
+  MCGRA_KERNEL_CHECK();
+  // feature_adj.max() != feature_adj.min() (topology_attack.py:212) is evaluated by the host layer
+  MCGRA_HIP(hipStreamSynchronize(st));
+  h->graph_set = true;
+  return 0;
+}
+
+int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed) {
+  if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
+  launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed) {
+  if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
+  launch_pack_tril((hipStream_t)stream, h->n, h->ld, h->M, packed, false);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+// calc(X[idx], Y[idx]) on small operands: gradient w.r.t. Y scattered into G (zero-filled by caller).
+// Xg raw gathered constant, Xc its column-centred copy.  Value lands in scal[slot].
+static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg,
+                      const float* Xc, double k_signed, float* G, int ldg, int slot) {
+  const int na = h->na, hm = h->hmax;
+  launch_gather_rows(st, na, width, Ysrc, ldy, h->idx, h->Yg, hm);
+  if (h->cfg.measure == MCGRA_MEASURE_MSE) {
+    launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot);   // sum of squares
+    launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
+  } else {  // HSIC: value |Xc^T Y|_F^2, gradient 2 Xc (Xc^T Y)   (utils.py:1085-1089)
+    MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
+    CHK(eg(h, st, true, false, width, width, na, 1.f, Xc, hm, h->Yg, hm, 0.f, h->Q, hm));
+    launch_sumsq(st, (size_t)width * hm, h->Q, h->scal + slot);              // pad columns of Q are zero
+    CHK(eg(h, st, false, false, na, width, width, 1.f, Xc, hm, h->Q, hm, 0.f, h->Gg, hm));
+    launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)(2.0 * k_signed), G, ldg);
+  }
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out) {
+  const int n = h->n, ld = h->ld;
+  launch_prep(st, false, n, ld, h->M, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum);
+  launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
+  launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
+  launch_adjn(st, n, ld, h->M, h->r, adjn_out);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+__global__ void k_cn(const double* __restrict__ scal, float coef, float* __restrict__ out) {
+  // d/da (coef * |a|_2) = coef * a / |a|, 0 at the origin (torch.norm backward); |a|^2 = sum_{i!=j} M^2 / 2
+  const double sq = scal[S_SQ] * 0.5;
+  out[0] = sq > 0.0 ? (float)(coef / sqrt(sq)) : 0.f;
+}
+
+// func(x) = clamp(adj_changes - x, 0, 1).sum() (topology_attack.py:398-399), over the strict lower triangle
+static int clamp_sum(mcgra_attack* h, hipStream_t st, float x, bool minmax, double* out, float* mn, float* mx) {
+  launch_clamp_rowsum(st, h->n, h->ld, h->M, x, h->rowsx, minmax ? h->rowmin : nullptr, minmax ? h->rowmax : nullptr);
+  launch_reduce_rows(st, h->rowsx, h->n, 1, h->scal + S_CLAMPSUM);
+  if (minmax) launch_minmax(st, h->n, h->rowmin, h->rowmax, h->mm);
+  MCGRA_KERNEL_CHECK();
+  double s;
+  float m2[2] = {0, 0};
+  MCGRA_HIP(hipMemcpyAsync(&s, h->scal + S_CLAMPSUM, sizeof(double), hipMemcpyDeviceToHost, st));
+  if (minmax) MCGRA_HIP(hipMemcpyAsync(m2, h->mm, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  *out = 0.5 * s;   // the symmetric matrix counts every pair twice
+  if (minmax) { *mn = m2[0]; *mx = m2[1]; }
+  return 0;
+}
+
+// PGDAttack.projection + bisection (topology_attack.py:338-347, 397-412).  Host-driven:
+// only reachable when num_edges < n(n-1)/2, never with main.py's default density.
+static int project(mcgra_attack* h, hipStream_t st) {
+  const double ne = h->cfg.num_edges;
+  double s0; float mn, mx;
+  CHK(clamp_sum(h, st, 0.f, true, &s0, &mn, &mx));
+  float miu = 0.f;
+  if ((float)s0 > ne) {
+    float a = mn - 1.f, b = mx;     // left = (adj_changes - 1).min(); right = adj_changes.max()
+    double fa_s; float fa;
+    CHK(clamp_sum(h, st, a, false, &fa_s, nullptr, nullptr));
+    fa = (float)fa_s - (float)ne;
+    miu = a;
+    while ((b - a) >= 1e-5f) {
+      miu = (a + b) / 2.f;
+      double fm_s;
+      CHK(clamp_sum(h, st, miu, false, &fm_s, nullptr, nullptr));
+      const float fm = (float)fm_s - (float)ne;
+      if (fm == 0.0f) break;
+      if (fm * fa < 0.f) b = miu;
+      else { a = miu; fa = fm; }
+    }
+  }
+  launch_shift_clamp(st, h->n, h->ld, h->M, miu);   // clamp(adj_changes - miu, 0, 1); miu = 0 is the plain clamp
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out) {
+  if (!h) { set_error("null handle"); return MCGRA_EINVAL; }
+  if (!h->graph_set) { set_error("mcgra_attack_set_graph must be called first"); return MCGRA_EINVAL; }
+  if (noise) { set_error("noise (eps != 0) is not implemented on the HIP path yet"); return MCGRA_ENOSUP; }
+  hipStream_t st = (hipStream_t)stream;
+  const mcgra_attack_config_t& c = h->cfg;
+  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C;
+  const double sg = sign_of(h);
+  const double w1 = c.w[0], w2 = c.w[1], w6 = c.w[5], w7 = c.w[6], w9 = c.w[8], w10 = c.w[9];
+  const double k1 = w1 * 1000 * AP_C1, k2 = w2 * 100 * AP_C2, k6 = w6 * 100 * AP_C6, k7 = w7 * AP_C7;
+  const double k9 = w9 * AP_C9, k10 = w10 * AP_C10;
+  const double n2 = (double)n * n;
+  const bool hsic = c.measure == MCGRA_MEASURE_HSIC;
+  MCGRA_HIP(hipMemsetAsync(h->scal, 0, sizeof(double) * S_COUNT, st));
+
+  // ---- forward: adjacency, normalisation (:164-166)
+  CHK(forward_common(h, st, h->ADJN));
+  const float* A = h->M;   // modified_adj == M when ori == 0, eps == 0
+  // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
+  CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv));
+  CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
+  launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
+  launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
+  // ---- embedding(features, modified_adj - ori_adj) (:185) == first Le layers of victim(features, modified_adj) (:259)
+  CHK(chain_forward(h, st, A, ld, L, h->Tu, h->Pu, h->Hu));
+  CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
+  const float* em = h->Hu + h->off[Le - 1];
+  const int he = h->wdt[Le - 1];
+  // ---- dot_product_decode + get_modified_adj_after (:187-188)
+  launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
+  CHK(eg(h, st, false, true, n, n, he, 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->A1, ld));
+  launch_decode_post(st, n, ld, h->A1, nullptr);
+
+  // ---- N x N loss terms (:212-236)
+  const bool use1 = (w1 != 0), use2 = (w2 != 0);
+  if (!hsic) {
+    launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, (float)(k1 * 2.0 / n2), (float)(k2 * 2.0 / n2),
+                     (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN, h->G_A1, h->rowvals);
+    launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
+  } else {
+    launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
+                     h->G_A1, h->rowvals);
+    launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
+    if (use1 || use2) {
+      const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
+      CHK(eg(h, st, false, true, n, n, n, 1.f, h->ADJN, ld, h->ADJN, ld, 0.f, h->KX, ld));        // Kx = X X^T
+      launch_rowsum(st, n, ld, h->KX, h->rowsx);
+      launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_TOTX);
+      if (use2) {
+        CHK(eg(h, st, false, true, n, n, n, 1.f, h->A1, ld, h->A1, ld, 0.f, h->KY, ld));          // Ky = Y Y^T
+        launch_rowsum(st, n, ld, h->KY, h->rowsy);
+        launch_reduce_rows(st, h->rowsy, n, 1, h->scal + S_TOTY);
+      }
+      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, h->rowsx, h->scal + S_TOTX, h->rowsy, h->scal + S_TOTY,
+                          use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->rowvals + 4 * (size_t)ld);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+      // G_adjn += 2 (s1 Kfc + s2 Kyc) @ adj_norm ;  G_A1 += 2 s2 Kxc @ A1
+      CHK(eg(h, st, false, false, n, n, n, 1.f, h->KY, ld, h->ADJN, ld, 1.f, h->G_ADJN, ld));
+      if (use2) CHK(eg(h, st, false, false, n, n, n, 1.f, h->KX, ld, h->A1, ld, 1.f, h->G_A1, ld));
+    }
+  }
+
+  // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
+  MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
+  if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
+  if (w10 != 0) {
+    MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
+    CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
+    launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
+  }
+
+  // ---- backward: victim(adj_norm) chain -> G_adjn
+  launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, h->Pv + h->off[L - 1], hs, nullptr, 0,
+                     h->GPv + h->off[L - 1], hs);
+  CHK(chain_backward(h, st, h->ADJN, ld, L - 1, h->Pv, h->GPv, -1, nullptr, 0));
+  CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 1.f, h->G_ADJN, ld));   // sum_l G_P_l T_l^T
+
+  // ---- backward: decode (S = Zn Zn^T, A1 = offdiag relu(S))
+  launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
+  CHK(eg(h, st, false, false, n, he, n, 1.f, h->G_A, ld, h->Zn, h->hmax, 0.f, h->GZn, h->hmax));
+  launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
+
+  // ---- backward: modified_adj chain (embedding + output2) -> G_A
+  int ltop;
+  if (w10 != 0) {
+    ltop = L - 1;
+    launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, h->Pu + h->off[L - 1], hs,
+                       (L - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[L - 1], hs);
+  } else {
+    ltop = Le - 1;
+    if (L > Le) MCGRA_HIP(hipMemsetAsync(h->GPu, 0, sizeof(float) * (size_t)n * hs, st));
+    launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, h->Pu + h->off[Le - 1], hs, h->Gem, h->hmax,
+                       h->GPu + h->off[Le - 1], hs);
+  }
+  CHK(chain_backward(h, st, A, ld, ltop, h->Pu, h->GPu, Le - 1, h->Gem, h->hmax));
+  // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
+  launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, h->G_A);
+  CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 1.f, h->G_A, ld));
+
+  // ---- packed-gradient mirror + Adam + projection + clamp (:274-283)
+  h->t += 1;
+  const double b1 = 0.9, b2 = 0.999;
+  const double bc1 = 1.0 - pow(b1, (double)h->t), bc2 = 1.0 - pow(b2, (double)h->t);
+  hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
+  // clamp(a,0,1).sum() <= n(n-1)/2, so a larger budget can never trigger the bisection (:339)
+  const bool may_project = c.num_edges < 0.5 * n2;
+  launch_adam_sym(st, n, ld, h->G_A, nullptr, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
+                  (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->GSYM, may_project ? 0 : 1);
+  MCGRA_KERNEL_CHECK();
+  h->have_step = true;
+  if (may_project) CHK(project(h, st));
+
+  if (scalars_out) {
+    launch_clamp_rowsum(st, n, ld, h->M, 0.f, h->rowsx, nullptr, nullptr);
+    launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_CLAMPSUM);
+    double s[S_COUNT];
+    MCGRA_HIP(hipMemcpyAsync(s, h->scal, sizeof(s), hipMemcpyDeviceToHost, st));
+    MCGRA_HIP(hipStreamSynchronize(st));
+    const double nll = s[S_NLL] / h->na;
+    const double norm_a = sqrt(0.5 * s[S_SQ]);
+    const double origin = nll + norm_a * 0.001;
+    double c1v = 0, c2v = 0;
+    if (hsic) { c1v = k1 * s[S_H1]; c2v = k2 * s[S_H2]; }
+    else { c1v = k1 * s[S_V1] / n2; c2v = k2 * s[S_V2] / n2; }
+    if (!use1) c1v = 0;
+    if (!use2) c2v = 0;
+    const double c6v = k6 * (-s[S_V6] / n2), c7v = k7 * (-s[S_V7] / n2);
+    double c9v = 0, c10v = 0;
+    if (w9 != 0) c9v = hsic ? k9 * s[S_C9] : k9 * s[S_C9] / ((double)h->na * he);
+    if (w10 != 0) c10v = hsic ? k10 * s[S_C10] : k10 * s[S_C10] / ((double)h->na * C);
+    scalars_out[0] = c.weight_sup * origin + sg * (c1v + c2v + c9v + c10v) + c6v + c7v;
+    scalars_out[1] = origin; scalars_out[2] = c1v; scalars_out[3] = c2v; scalars_out[4] = c6v; scalars_out[5] = c7v;
+    scalars_out[6] = c9v; scalars_out[7] = c10v; scalars_out[8] = 0.5 * s[S_CLAMPSUM]; scalars_out[9] = nll;
+  }
+  return 0;
+}
+
+int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, double* sparsity) {
+  if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  // adj_norm2 goes to the A1 buffer: ADJN must survive for the post-loop decode (:300)
+  CHK(forward_common(h, st, h->A1));
+  CHK(chain_forward(h, st, h->A1, h->ld, h->L, h->Tv, h->Pv, h->Hv));
+  CHK(head_forward(h, st, h->Hv, h->Z, h->logp, nullptr));
+  if (out_logp)
+    MCGRA_HIP(hipMemcpyAsync(out_logp, h->logp, sizeof(float) * (size_t)h->n * h->C, hipMemcpyDeviceToDevice, st));
+  if (sparsity) {
+    double s;
+    MCGRA_HIP(hipMemcpyAsync(&s, h->scal + S_SUM, sizeof(double), hipMemcpyDeviceToHost, st));
+    MCGRA_HIP(hipStreamSynchronize(st));
+    *sparsity = s / ((double)h->n * h->n);
+  }
+  return 0;
+}
+
+// out += dot_product_decode2(Z) (topology_attack.py:421-467); Z is [n x w] with leading dim ldz
+static int dd2(mcgra_attack* h, hipStream_t st, int mode, const float* Z, int w, int ldz, float* out) {
+  const int n = h->n, ld = h->ld;
+  const float* src = Z;
+  int lsrc = ldz;
+  if (mode == 1 || mode >= 4) {
+    const float p = mode == 5 ? 3.f : (mode == 6 ? 5.f : 2.f);
+    launch_row_normalize(st, n, w, Z, ldz, h->GZn, h->hmax, nullptr, p);
+    src = h->GZn; lsrc = h->hmax;
+  }
+  CHK(eg(h, st, false, true, n, n, w, 1.f, src, lsrc, src, lsrc, 0.f, h->KX, ld));
+  const int emode = (mode == 0 || mode == 1) ? 0 : (mode == 3 ? 3 : 2);
+  launch_dd2_accum(st, n, ld, h->KX, emode, h->rowpart, out, n);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, const float* H_A, const float* Y_A,
+                          const float* label_adj, float* out) {
+  if (!h || !out || !h->graph_set) { set_error("engine not set up / null out"); return MCGRA_EINVAL; }
+  if (decode_mode < 0 || decode_mode > 6) { set_error("decode_mode %d", decode_mode); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
+  if (!h->have_step) CHK(forward_common(h, st, h->ADJN));   // epochs == 0: adj_norm of :142
+  // em = embedding(features, adj_norm) ; adj_changes <- dot_product_decode(em) (:300-301)
+  CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu));
+  launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);
+  CHK(eg(h, st, false, true, n, n, h->wdt[Le - 1], 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->M, ld));
+  launch_decode_post(st, n, ld, h->M, nullptr);            // modified_adj = get_modified_adj (:302)
+  // out = modified_adj + feature_adj (:314)
+  launch_axpby2d(st, n, h->M, ld, 1.f, h->FADJ, ld, 1.f, out, n);
+  // H_A1, H_A2 = embedding(features, modified_adj) with 1 / 2 layers; Y_A2 = victim (:304-308)
+  CHK(chain_forward(h, st, h->M, ld, L, h->Tu, h->Pu, h->Hu));
+  CHK(head_forward(h, st, h->Hu, h->Z2, h->logp, nullptr));
+  CHK(dd2(h, st, decode_mode, h->Hu + h->off[0], h->wdt[0], hs, out));
+  CHK(dd2(h, st, decode_mode, h->Hu + h->off[1], h->wdt[1], hs, out));
+  CHK(dd2(h, st, decode_mode, h->logp, h->C, h->C, out));
+  if (H_A) CHK(dd2(h, st, decode_mode, H_A, h->wdt[Le - 1], h->wdt[Le - 1], out));   // (:315-316)
+  if (Y_A) CHK(dd2(h, st, decode_mode, Y_A, h->C, h->C, out));                        // (:317-318)
+  if (label_adj) launch_axpby2d(st, n, out, n, 1.f, label_adj, n, 1.f, out, n);       // (:319-320)
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr, int* rows, int* cols, int* ldp) {
+  if (!h || !name || !ptr) { set_error("null argument"); return MCGRA_EINVAL; }
+  const int n = h->n, ld = h->ld;
+  struct E { const char* nm; float* p; int r, c, l; };
+  const int le = h->Le - 1;
+  const E tab[] = {
+      {"M", h->M, n, n, ld}, {"adj_norm", h->ADJN, n, n, ld}, {"A1", h->A1, n, n, ld},
+      {"G_adjn", h->G_ADJN, n, n, ld}, {"G_A1", h->G_A1, n, n, ld}, {"G_A", h->G_A, n, n, ld},
+      {"G_sym", h->GSYM, n, n, ld}, {"adam_m", h->am, n, n, ld}, {"adam_v", h->av, n, n, ld},
+      {"d", h->d, 1, n, ld}, {"r", h->r, 1, n, ld}, {"logp", h->logp, n, h->C, h->C}, {"sm2", h->sm2, n, h->C, h->C},
+      {"em", h->Hu + h->off[le], n, h->wdt[le], h->hsum}, {"G_em", h->Gem, n, h->wdt[le], h->hmax},
+      {"HA", h->HA, n, h->wdt[le], h->hmax}, {"YA", h->YA, n, h->C, h->C}, {"T0", h->Tv, n, h->wdt[0], h->hsum},
+      {"KFC", h->KFC, n, n, ld},
+  };
+  for (const E& e : tab)
+    if (strcmp(e.nm, name) == 0) {
+      *ptr = e.p;
+      if (rows) *rows = e.r;
+      if (cols) *cols = e.c;
+      if (ldp) *ldp = e.l;
+      return 0;
+    }
+  set_error("unknown buffer '%s'", name);
+  return MCGRA_EINVAL;
+}
+
+int mcgra_attack_copy_buffer(mcgra_attack_t* h, void* stream, const char* name, float* dst, int dst_ld) {
+  float* p = nullptr;
+  int r = 0, c = 0, l = 0;
+  CHK(mcgra_attack_buffer(h, name, &p, &r, &c, &l));
+  if (!dst || dst_ld < c) { set_error("bad destination"); return MCGRA_EINVAL; }
+  MCGRA_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 4, p, (size_t)l * 4, (size_t)c * 4, r, hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+  return 0;
+}
+
+int mcgra_attack_profile(mcgra_attack_t* h, int enable) {
+  if (!h) return MCGRA_EINVAL;
+  h->profile = enable != 0;
+  return 0;
+}
+
+int mcgra_attack_gemm_stats(mcgra_attack_t* h, int reset, int64_t* launches, double* ms, double* flops) {
+  if (!h) return MCGRA_EINVAL;
+  GemmTimer& T = h->timer;
+  double tot = 0;
+  if (T.used) {
+    MCGRA_HIP(hipEventSynchronize(T.ev[T.used - 1]));
+    for (size_t i = 0; i + 1 < T.used; i += 2) {
+      float e = 0.f;
+      MCGRA_HIP(hipEventElapsedTime(&e, T.ev[i], T.ev[i + 1]));
+      tot += e;
+    }
+  }
+  if (launches) *launches = T.launches;
+  if (ms) *ms = tot;
+  if (flops) *flops = T.flops;
+  if (reset) { T.used = 0; T.launches = 0; T.flops = 0; }
+  return 0;
+}
+
+}  // extern "C"

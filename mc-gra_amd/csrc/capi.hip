@@ -1,0 +1,187 @@
+// Standalone C-ABI ops: one reference function each, on caller-provided device
+// buffers.  They allocate their own scratch (hipMalloc/hipFree) and are meant
+// for integration and parity tests; the attack engine (attack.hip) runs the
+// same kernels on pre-allocated workspace.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <vector>
+
+#include "../../include/mcgra.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace mcgra;
+
+namespace {
+struct Scratch {
+  std::vector<void*> p;
+  ~Scratch() { for (void* q : p) (void)hipFree(q); }
+  template <typename T>
+  T* get(size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, (count ? count : 1) * sizeof(T));
+    p.push_back(q);
+    return (T*)q;
+  }
+};
+}  // namespace
+
+#define NEED(ptr) if (!(ptr)) { set_error("hipMalloc failed"); return MCGRA_ENOMEM; }
+
+extern "C" {
+
+int mcgra_sgemm(void* stream, int ta, int tb, int m, int n, int k, float alpha, const float* A, int lda,
+                const float* B, int ldb, float beta, float* C, int ldc) {
+  if (m < 0 || n < 0 || k < 0 || !A || !B || !C) { set_error("bad sgemm argument"); return MCGRA_EINVAL; }
+  MCGRA_HIP(sgemm((hipStream_t)stream, ta != 0, tb != 0, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0));
+  return 0;
+}
+
+int mcgra_get_modified_adj(void* stream, int n, const float* adj_changes, const float* ori_adj, float* out) {
+  if (n < 1 || !adj_changes || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  launch_unpack_sym((hipStream_t)stream, n, n, adj_changes, ori_adj, n, out);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+int mcgra_pack_tril(void* stream, int n, const float* M, int ld, float* out) {
+  if (n < 1 || !M || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  launch_pack_tril((hipStream_t)stream, n, ld, M, out, false);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+int mcgra_normalize_adj(void* stream, int n, const float* adj, float* out) {
+  if (n < 1 || !adj || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = (n + 3) & ~3;
+  Scratch s;
+  float* A = s.get<float>((size_t)n * ld); NEED(A);
+  float* O = s.get<float>((size_t)n * ld); NEED(O);
+  unsigned char* gate = s.get<unsigned char>((size_t)n * ld); NEED(gate);
+  float* d = s.get<float>(ld); float* r = s.get<float>(ld); NEED(d); NEED(r);
+  double* rs = s.get<double>(2 * (size_t)ld); NEED(rs);
+  MCGRA_HIP(hipMemcpy2DAsync(A, (size_t)ld * 4, adj, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+  // rowsum of the matrix as given (no clamp, diagonal kept): GENERAL=false path on A itself
+  launch_prep(st, false, n, ld, A, nullptr, nullptr, 0.f, nullptr, nullptr, d, r, rs, rs + ld);
+  launch_adjn(st, n, ld, A, r, O);
+  MCGRA_KERNEL_CHECK();
+  MCGRA_HIP(hipMemcpy2DAsync(out, (size_t)n * 4, O, (size_t)ld * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int mcgra_info_entropy(void* stream, int n, const float* prob, float* out) {
+  if (n < 1 || !prob || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  double* rows = s.get<double>(n); NEED(rows);
+  double* tot = s.get<double>(1); NEED(tot);
+  launch_ie_rows(st, n, n, prob, rows);
+  launch_reduce_rows(st, rows, n, 1, tot);
+  MCGRA_KERNEL_CHECK();
+  double t;
+  MCGRA_HIP(hipMemcpyAsync(&t, tot, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  const float v = (float)(-t / ((double)n * n));
+  MCGRA_HIP(hipMemcpy(out, &v, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mcgra_dot_product_decode(void* stream, int n, int d, const float* Z, float* out) {
+  if (n < 2 || d < 1 || !Z || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = (n + 3) & ~3, dd = (d + 3) & ~3;
+  Scratch s;
+  float* Zn = s.get<float>((size_t)n * dd); NEED(Zn);
+  float* S = s.get<float>((size_t)n * ld); NEED(S);
+  launch_row_normalize(st, n, d, Z, d, Zn, dd, nullptr, 2.f);
+  MCGRA_HIP(sgemm(st, false, true, n, n, d, 1.f, Zn, dd, Zn, dd, 0.f, S, ld, nullptr, 0));
+  launch_pack_tril(st, n, ld, S, out, true);
+  MCGRA_KERNEL_CHECK();
+  MCGRA_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X, const float* Y, float* out) {
+  if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  // sum(centre(XX^T) * centre(YY^T)) = |Xc^T Yc|_F^2 with column-centred Xc, Yc
+  const int lx = (dx + 3) & ~3, ly = (dy + 3) & ~3;
+  Scratch s;
+  float* Xc = s.get<float>((size_t)m * lx); NEED(Xc);
+  float* Yc = s.get<float>((size_t)m * ly); NEED(Yc);
+  float* Q = s.get<float>((size_t)dx * ly); NEED(Q);
+  double* v = s.get<double>(1); NEED(v);
+  size_t wsb = (size_t)64 * dx * dy * sizeof(float);
+  float* ws = s.get<float>(wsb / sizeof(float)); NEED(ws);
+  MCGRA_HIP(hipMemcpy2DAsync(Xc, (size_t)lx * 4, X, (size_t)dx * 4, (size_t)dx * 4, m, hipMemcpyDeviceToDevice, st));
+  MCGRA_HIP(hipMemcpy2DAsync(Yc, (size_t)ly * 4, Y, (size_t)dy * 4, (size_t)dy * 4, m, hipMemcpyDeviceToDevice, st));
+  launch_colmean_center(st, m, dx, Xc, lx);
+  launch_colmean_center(st, m, dy, Yc, ly);
+  MCGRA_HIP(sgemm(st, true, false, dx, dy, m, 1.f, Xc, lx, Yc, ly, 0.f, Q, ly, ws, wsb));
+  launch_sumsq(st, (size_t)dx * ly, Q, v);
+  MCGRA_KERNEL_CHECK();
+  double t;
+  MCGRA_HIP(hipMemcpyAsync(&t, v, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  const float f = (float)t;
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mcgra_mse(void* stream, int64_t count, const float* X, const float* Y, float* out) {
+  if (count < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  const int nb = 1024;
+  double* part = s.get<double>(nb); NEED(part);
+  double* tot = s.get<double>(1); NEED(tot);
+  launch_sqdiff(st, (size_t)count, X, Y, part, nb);
+  launch_reduce_rows(st, part, nb, 1, tot);
+  MCGRA_KERNEL_CHECK();
+  double t;
+  MCGRA_HIP(hipMemcpyAsync(&t, tot, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  const float f = (float)(t / (double)count);
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mcgra_gcn_forward(void* stream, int n, int nfeat, int nlayer, const int32_t* dims, const float* X,
+                      const float* adj, const float* const* W, const float* const* b, const float* Wlin,
+                      const float* blin, int nclass, int emb_nlayer, float* emb_out, float* out) {
+  if (n < 1 || nlayer < 1 || nlayer > MCGRA_MAX_LAYERS || !dims || !X || !adj || !W || !b || !Wlin || !blin || !out ||
+      dims[0] != nfeat) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  int hm = nclass;
+  for (int l = 0; l < nlayer; ++l) hm = dims[l + 1] > hm ? dims[l + 1] : hm;
+  hm = (hm + 3) & ~3;
+  Scratch s;
+  float* T = s.get<float>((size_t)n * hm); NEED(T);
+  float* Yb = s.get<float>((size_t)n * hm); NEED(Yb);
+  float* P = s.get<float>((size_t)n * hm); NEED(P);
+  float* H = s.get<float>((size_t)n * hm); NEED(H);
+  float* Z = s.get<float>((size_t)n * nclass); NEED(Z);
+  size_t wsb = (size_t)64 * n * hm * sizeof(float);
+  float* ws = s.get<float>(wsb / sizeof(float)); NEED(ws);
+  // support = input @ weight ; output = adj @ support + bias (models/gcn.py:38-46)
+  MCGRA_HIP(sgemm(st, false, false, n, dims[1], nfeat, 1.f, X, nfeat, W[0], dims[1], 0.f, T, hm, ws, wsb));
+  for (int l = 0; l < nlayer; ++l) {
+    const int w = dims[l + 1];
+    MCGRA_HIP(sgemm(st, false, false, n, w, n, 1.f, adj, n, T, hm, 0.f, Yb, hm, ws, wsb));
+    launch_bias_relu(st, n, w, Yb, hm, b[l], P, H, hm);
+    if (emb_out && l + 1 == emb_nlayer)
+      MCGRA_HIP(hipMemcpy2DAsync(emb_out, (size_t)w * 4, H, (size_t)hm * 4, (size_t)w * 4, n, hipMemcpyDeviceToDevice, st));
+    if (l + 1 < nlayer) launch_rowmat(st, n, w, dims[l + 2], H, hm, W[l + 1], dims[l + 2], 1, nullptr, T, hm);
+  }
+  launch_rowmat(st, n, dims[nlayer], nclass, H, hm, Wlin, 1, dims[nlayer], blin, Z, nclass);
+  launch_log_softmax(st, n, nclass, Z, nclass, out, nullptr, nclass);
+  MCGRA_KERNEL_CHECK();
+  MCGRA_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

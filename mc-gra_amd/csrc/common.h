@@ -1,0 +1,62 @@
+// Shared declarations for the MC-GRA HIP hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mcgra {
+
+void set_error(const char* fmt, ...);
+
+#define MCGRA_HIP(expr)                                                              \
+  do {                                                                               \
+    hipError_t e__ = (expr);                                                         \
+    if (e__ != hipSuccess) {                                                         \
+      ::mcgra::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+                         hipGetErrorString(e__));                                    \
+      return MCGRA_EHIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+#define MCGRA_KERNEL_CHECK() MCGRA_HIP(hipGetLastError())
+
+// gemm_f32.hip
+hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha,
+                 const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                 float* ws, size_t ws_bytes);
+
+// ---- wave / block reductions (wave = 64 lanes) -------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// Sum over a block of up to 1024 threads; result valid in every thread.
+// `sh` must hold 16 floats.  Deterministic (fixed tree).
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+
+}  // namespace mcgra

@@ -1,0 +1,66 @@
+// Host-side launchers of the N x N (nxn_kernels.hip) and node-level
+// (node_kernels.hip) kernels.  All enqueue on `st` and return immediately.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace mcgra {
+
+// ---- nxn_kernels.hip
+void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, const float* ori,
+                 const float* noise, float eps, float* A, unsigned char* gate, float* d, float* r,
+                 double* rowsq, double* rowsum);
+void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out);
+void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori);
+void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float* Y, const float* F,
+                      float kmse1, float kmse2, float kie6, float kie7, float* GX, float* GY,
+                      double* rowvals);
+void launch_reduce_rows(hipStream_t st, const double* rowvals, int n, int nvec, double* out);
+void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows);
+void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total);
+void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC,
+                         const double* rowsx, const double* totx, const double* rowsy, const double* toty,
+                         float s1, float s2, double* rowvals);
+void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
+                    const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
+void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);
+void launch_adam_sym(hipStream_t st, int n, int ld, const float* GA, const unsigned char* gate, float* M,
+                     float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size,
+                     float sqrt_bc2, float eps, float* gsym_dbg, int do_clamp);
+void launch_clamp_rowsum(hipStream_t st, int n, int ld, const float* M, float x, double* rows, float* rowmin, float* rowmax);
+void launch_shift_clamp(hipStream_t st, int n, int ld, float* M, float x);
+void launch_minmax(hipStream_t st, int n, const float* rowmin, const float* rowmax, float* out);
+void launch_unpack_sym(hipStream_t st, int n, int ld, const float* packed, const float* ori, int ori_ld, float* out);
+void launch_pack_tril(hipStream_t st, int n, int ld, const float* M, float* packed, bool relu);
+void launch_dd2_accum(hipStream_t st, int n, int ld, const float* S, int mode, float* rownorm, float* out, int out_ld);
+void launch_axpby2d(hipStream_t st, int n, const float* X, int ldx, float a, const float* Y, int ldy, float b,
+                    float* out, int ldo);
+void launch_sqdiff(hipStream_t st, size_t count, const float* X, const float* Y, double* part, int nblocks);
+void launch_ie_rows(hipStream_t st, int n, int ld, const float* P, double* rows);
+
+// ---- node_kernels.hip
+void launch_bias_relu(hipStream_t st, int n, int h, const float* Y, int ldy, const float* b, float* P, float* H, int ldo);
+void launch_rowmat(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
+                   int sc, const float* bias, float* Out, int ldo);
+void launch_rowmat_mask(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
+                        int sc, const float* P, int ldp, const float* Add, int lda, float* Out, int ldo);
+void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo);
+void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,
+                     const float* cnt, float scale, float* GZ, double* rownll);
+void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p);
+void launch_row_normalize_bwd(hipStream_t st, int n, int h, const float* GZn, const float* Zn, int ld,
+                              const float* nrm, float* GZ, int ldg);
+void launch_softmax_bwd(hipStream_t st, int n, int c, const float* sm, const float* Gsm, int ld, float* GZ);
+void launch_gather_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float* dst, int ldd);
+void launch_scatter_add_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float scale,
+                             float* dst, int ldd);
+void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld);
+void launch_sumsq(hipStream_t st, size_t count, const float* X, double* out);
+void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* out);
+void launch_kl_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* rowval);
+void launch_fill(hipStream_t st, size_t count, float* p, float v);
+void launch_scale(hipStream_t st, size_t count, float* p, float v);
+void launch_count_idx(hipStream_t st, int m, const int* idx, float* cnt);
+void launch_argmax_eq(hipStream_t st, int m, int c, const float* logp, int ld, const int* idx, const int* labels, int* correct);
+
+}  // namespace mcgra

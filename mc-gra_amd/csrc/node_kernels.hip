@@ -1,0 +1,291 @@
+// Node-level (N x h, h <= 64) kernels of the GCN chains and the small-operand
+// loss terms.  These touch O(N h) data; they are launch-bound, not HBM-bound,
+// so they are written for clarity: one thread per output element or per row.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace mcgra {
+
+#define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
+
+// P = Y + b (+ self), H = relu(P)   (GraphConvolution.forward + F.relu, models/gcn.py:42-46,75)
+__global__ void k_bias_relu(int n, int h, const float* __restrict__ Y, int ldy, const float* __restrict__ b,
+                            float* __restrict__ P, float* __restrict__ H, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * h) return;
+  const int i = e / h, c = e % h;
+  const float p = Y[(size_t)i * ldy + c] + b[c];
+  P[(size_t)i * ldo + c] = p;
+  H[(size_t)i * ldo + c] = fmaxf(p, 0.f);
+}
+
+// Out[i][c] = sum_k In[i][k] * W(k, c) (+ bias[c]);  W(k,c) = W[k*sk + c*sc]
+__global__ void k_rowmat(int n, int kdim, int cdim, const float* __restrict__ In, int ldi,
+                         const float* __restrict__ W, int sk, int sc, const float* __restrict__ bias,
+                         float* __restrict__ Out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * cdim) return;
+  const int i = e / cdim, c = e % cdim;
+  float s = 0.f;
+  for (int k = 0; k < kdim; ++k) s = fmaf(In[(size_t)i * ldi + k], W[(size_t)k * sk + (size_t)c * sc], s);
+  if (bias) s += bias[c];
+  Out[(size_t)i * ldo + c] = s;
+}
+
+// Gout = (Gin @ W^T) * (P > 0):  relu backward fused with the linear backward
+__global__ void k_rowmat_mask(int n, int kdim, int cdim, const float* __restrict__ In, int ldi,
+                              const float* __restrict__ W, int sk, int sc, const float* __restrict__ P,
+                              int ldp, const float* __restrict__ Add, int lda, float* __restrict__ Out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * cdim) return;
+  const int i = e / cdim, c = e % cdim;
+  float s = 0.f;
+  for (int k = 0; k < kdim; ++k) s = fmaf(In[(size_t)i * ldi + k], W[(size_t)k * sk + (size_t)c * sc], s);
+  if (Add) s += Add[(size_t)i * lda + c];
+  Out[(size_t)i * ldo + c] = P[(size_t)i * ldp + c] > 0.f ? s : 0.f;
+}
+
+// logp = log_softmax(Z), sm = softmax(Z) per row (models/gcn.py:174)
+__global__ void k_log_softmax(int n, int c, const float* __restrict__ Z, int ldz, float* __restrict__ logp,
+                              float* __restrict__ sm, int ldo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* z = Z + (size_t)i * ldz;
+  float mx = -INFINITY;
+  for (int k = 0; k < c; ++k) mx = fmaxf(mx, z[k]);
+  float s = 0.f;
+  for (int k = 0; k < c; ++k) s += expf(z[k] - mx);
+  const float ls = logf(s);
+  for (int k = 0; k < c; ++k) {
+    const float l = z[k] - mx - ls;
+    if (logp) logp[(size_t)i * ldo + k] = l;
+    if (sm) sm[(size_t)i * ldo + k] = expf(l);
+  }
+}
+
+// F.nll_loss(output[idx], labels[idx]) (:172, :326-328): per-row value and
+// G_Z = scale * cnt_i * (softmax - onehot), scale = weight_sup / n_attack
+__global__ void k_nll_grad(int n, int c, const float* __restrict__ logp, const float* __restrict__ sm, int ld,
+                           const int* __restrict__ labels, const float* __restrict__ cnt, float scale,
+                           float* __restrict__ GZ, double* __restrict__ rownll) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int y = labels[i];
+  const float w = cnt[i];
+  for (int k = 0; k < c; ++k)
+    GZ[(size_t)i * ld + k] = scale * w * (sm[(size_t)i * ld + k] - (k == y ? 1.f : 0.f));
+  rownll[i] = -(double)logp[(size_t)i * ld + y] * w;
+}
+
+// F.normalize(Z, p=2, dim=1) (:415): nrm_i = |Z_i|, Zn = Z / max(nrm, 1e-12)
+__global__ void k_row_normalize(int n, int h, const float* __restrict__ Z, int ldz, float* __restrict__ Zn,
+                                int ldo, float* __restrict__ nrm, float pnorm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  if (pnorm == 2.f) {
+    for (int k = 0; k < h; ++k) { const float v = Z[(size_t)i * ldz + k]; s += v * v; }
+    s = sqrtf(s);
+  } else {
+    for (int k = 0; k < h; ++k) s += powf(fabsf(Z[(size_t)i * ldz + k]), pnorm);
+    s = powf(s, 1.f / pnorm);
+  }
+  if (nrm) nrm[i] = s;
+  const float den = fmaxf(s, 1e-12f);
+  for (int k = 0; k < h; ++k) Zn[(size_t)i * ldo + k] = Z[(size_t)i * ldz + k] / den;
+}
+
+// backward of F.normalize: G_Z += (G_Zn - Zn <Zn, G_Zn>) / nrm   (nrm >= eps)
+//                          G_Z += G_Zn / eps                      (nrm <  eps)
+__global__ void k_row_normalize_bwd(int n, int h, const float* __restrict__ GZn, const float* __restrict__ Zn,
+                                    int ld, const float* __restrict__ nrm, float* __restrict__ GZ, int ldg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float nr = nrm[i];
+  const float den = fmaxf(nr, 1e-12f);
+  float pr = 0.f;
+  if (nr >= 1e-12f)
+    for (int k = 0; k < h; ++k) pr += Zn[(size_t)i * ld + k] * GZn[(size_t)i * ld + k];
+  for (int k = 0; k < h; ++k) {
+    const float g = GZn[(size_t)i * ld + k];
+    GZ[(size_t)i * ldg + k] += (nr >= 1e-12f ? g - Zn[(size_t)i * ld + k] * pr : g) / den;
+  }
+}
+
+// G_Z = sm * (G_sm - <G_sm, sm>)   (torch.softmax backward, :267-271)
+__global__ void k_softmax_bwd(int n, int c, const float* __restrict__ sm, const float* __restrict__ Gsm, int ld,
+                              float* __restrict__ GZ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float pr = 0.f;
+  for (int k = 0; k < c; ++k) pr += sm[(size_t)i * ld + k] * Gsm[(size_t)i * ld + k];
+  for (int k = 0; k < c; ++k) GZ[(size_t)i * ld + k] = sm[(size_t)i * ld + k] * (Gsm[(size_t)i * ld + k] - pr);
+}
+
+__global__ void k_gather_rows(int m, int h, const float* __restrict__ src, int lds_, const int* __restrict__ idx,
+                              float* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * h) return;
+  const int i = e / h, c = e % h;
+  dst[(size_t)i * ldd + c] = src[(size_t)idx[i] * lds_ + c];
+}
+
+// dst[idx[i]] += scale * src[i]; idx may repeat -> float atomics
+__global__ void k_scatter_add_rows(int m, int h, const float* __restrict__ src, int lds_,
+                                   const int* __restrict__ idx, float scale, float* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * h) return;
+  const int i = e / h, c = e % h;
+  atomicAdd(&dst[(size_t)idx[i] * ldd + c], scale * src[(size_t)i * lds_ + c]);
+}
+
+// column means of an [m x h] matrix, then centre in place (H X of CudaCKA.centering)
+__global__ void k_colmean_center(int m, int h, float* __restrict__ X, int ld) {
+  __shared__ double shd[16];
+  const int c = blockIdx.x;
+  double s = 0;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) s += X[(size_t)i * ld + c];
+  s = block_sum_d(s, shd);
+  const float mu = (float)(s / m);
+  for (int i = threadIdx.x; i < m; i += blockDim.x) X[(size_t)i * ld + c] -= mu;
+}
+
+// sum of squares of a small buffer (|Q|_F^2), single block
+__global__ void k_sumsq(size_t count, const float* __restrict__ X, double* __restrict__ out) {
+  __shared__ double shd[16];
+  double s = 0;
+  for (size_t i = threadIdx.x; i < count; i += blockDim.x) s += (double)X[i] * X[i];
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// MSELoss on small [m x h] operands: G = 2 (Y - X) / (m h), value partial
+__global__ void k_mse_small(int m, int h, const float* __restrict__ X, const float* __restrict__ Y, int ld,
+                            float* __restrict__ G, double* __restrict__ out) {
+  __shared__ double shd[16];
+  double s = 0;
+  const float sc = 2.f / ((float)m * (float)h);
+  for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < m * h; e += blockDim.x * gridDim.x) {
+    const int i = e / h, c = e % h;
+    const float d = X[(size_t)i * ld + c] - Y[(size_t)i * ld + c];
+    s += (double)d * d;
+    G[(size_t)i * ld + c] = -sc * d;
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) atomicAdd(out, s);   // gridDim.x == 1 in practice: deterministic
+}
+
+// calc_kl on small operands (:483-487): X raw (softmax target), Y raw (log_softmax input);
+// G_Y = (softmax(Y) - softmax(X)) / m ; value = sum xs (log xs - log_softmax(Y)) / m
+__global__ void k_kl_small(int m, int h, const float* __restrict__ X, const float* __restrict__ Y, int ld,
+                           float* __restrict__ G, double* __restrict__ rowval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const float* x = X + (size_t)i * ld;
+  const float* y = Y + (size_t)i * ld;
+  float mx = -INFINITY, my = -INFINITY;
+  for (int k = 0; k < h; ++k) { mx = fmaxf(mx, x[k]); my = fmaxf(my, y[k]); }
+  float sx = 0.f, sy = 0.f;
+  for (int k = 0; k < h; ++k) { sx += expf(x[k] - mx); sy += expf(y[k] - my); }
+  const float lsx = logf(sx), lsy = logf(sy);
+  double v = 0;
+  for (int k = 0; k < h; ++k) {
+    const float lx = x[k] - mx - lsx, ly = y[k] - my - lsy;
+    const float xs = expf(lx);
+    if (xs > 0.f) v += (double)xs * (lx - ly);
+    G[(size_t)i * ld + k] = (expf(ly) - xs) / (float)m;
+  }
+  rowval[i] = v / m;
+}
+
+__global__ void k_fill(size_t count, float* __restrict__ p, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_scale(size_t count, float* __restrict__ p, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] *= v;
+}
+// cnt[idx[i]] += 1
+__global__ void k_count_idx(int m, const int* __restrict__ idx, float* __restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) atomicAdd(&cnt[idx[i]], 1.f);
+}
+// accuracy numerator over idx rows: argmax(logp) == label  (utils.accuracy)
+__global__ void k_argmax_eq(int m, int c, const float* __restrict__ logp, int ld, const int* __restrict__ idx,
+                            const int* __restrict__ labels, int* __restrict__ correct) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const int i = idx ? idx[t] : t;
+  int best = 0; float bv = logp[(size_t)i * ld];
+  for (int k = 1; k < c; ++k) { const float v = logp[(size_t)i * ld + k]; if (v > bv) { bv = v; best = k; } }
+  if (best == labels[i]) atomicAdd(correct, 1);
+}
+
+static inline dim3 g1(size_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+void launch_bias_relu(hipStream_t st, int n, int h, const float* Y, int ldy, const float* b, float* P, float* H, int ldo) {
+  LAUNCH(k_bias_relu, g1((size_t)n * h), dim3(256), st, n, h, Y, ldy, b, P, H, ldo);
+}
+void launch_rowmat(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
+                   int sc, const float* bias, float* Out, int ldo) {
+  LAUNCH(k_rowmat, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, bias, Out, ldo);
+}
+void launch_rowmat_mask(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
+                        int sc, const float* P, int ldp, const float* Add, int lda, float* Out, int ldo) {
+  LAUNCH(k_rowmat_mask, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, P, ldp, Add, lda, Out, ldo);
+}
+void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo) {
+  LAUNCH(k_log_softmax, g1(n), dim3(256), st, n, c, Z, ldz, logp, sm, ldo);
+}
+void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,
+                     const float* cnt, float scale, float* GZ, double* rownll) {
+  LAUNCH(k_nll_grad, g1(n), dim3(256), st, n, c, logp, sm, ld, labels, cnt, scale, GZ, rownll);
+}
+void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p) {
+  LAUNCH(k_row_normalize, g1(n), dim3(256), st, n, h, Z, ldz, Zn, ldo, nrm, p);
+}
+void launch_row_normalize_bwd(hipStream_t st, int n, int h, const float* GZn, const float* Zn, int ld,
+                              const float* nrm, float* GZ, int ldg) {
+  LAUNCH(k_row_normalize_bwd, g1(n), dim3(256), st, n, h, GZn, Zn, ld, nrm, GZ, ldg);
+}
+void launch_softmax_bwd(hipStream_t st, int n, int c, const float* sm, const float* Gsm, int ld, float* GZ) {
+  LAUNCH(k_softmax_bwd, g1(n), dim3(256), st, n, c, sm, Gsm, ld, GZ);
+}
+void launch_gather_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float* dst, int ldd) {
+  LAUNCH(k_gather_rows, g1((size_t)m * h), dim3(256), st, m, h, src, lds_, idx, dst, ldd);
+}
+void launch_scatter_add_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float scale,
+                             float* dst, int ldd) {
+  LAUNCH(k_scatter_add_rows, g1((size_t)m * h), dim3(256), st, m, h, src, lds_, idx, scale, dst, ldd);
+}
+void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld) {
+  LAUNCH(k_colmean_center, dim3(h), dim3(256), st, m, h, X, ld);
+}
+void launch_sumsq(hipStream_t st, size_t count, const float* X, double* out) {
+  LAUNCH(k_sumsq, dim3(1), dim3(1024), st, count, X, out);
+}
+void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* out) {
+  (void)hipMemsetAsync(out, 0, sizeof(double), st);
+  LAUNCH(k_mse_small, dim3(1), dim3(1024), st, m, h, X, Y, ld, G, out);
+}
+void launch_kl_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* rowval) {
+  LAUNCH(k_kl_small, g1(m), dim3(256), st, m, h, X, Y, ld, G, rowval);
+}
+void launch_fill(hipStream_t st, size_t count, float* p, float v) {
+  if (count == 0) return;
+  LAUNCH(k_fill, dim3((unsigned)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256)), dim3(256), st, count, p, v);
+}
+void launch_scale(hipStream_t st, size_t count, float* p, float v) {
+  if (count == 0) return;
+  LAUNCH(k_scale, dim3((unsigned)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256)), dim3(256), st, count, p, v);
+}
+void launch_count_idx(hipStream_t st, int m, const int* idx, float* cnt) {
+  LAUNCH(k_count_idx, g1(m), dim3(256), st, m, idx, cnt);
+}
+void launch_argmax_eq(hipStream_t st, int m, int c, const float* logp, int ld, const int* idx, const int* labels, int* correct) {
+  LAUNCH(k_argmax_eq, g1(m), dim3(256), st, m, c, logp, ld, idx, labels, correct);
+}
+
+}  // namespace mcgra

@@ -1,0 +1,635 @@
+// N x N elementwise / reduction kernels of the attack step (HBM-bound).
+//
+// Every matrix is row-major fp32 with leading dimension ld (ld % 4 == 0,
+// pad columns hold zeros).  Row kernels use one 256-thread block per row with
+// 16-byte loads; reductions are deterministic (fixed trees, per-row partials
+// reduced by a second single-block kernel) so that two runs on the same inputs
+// give the same bits.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace mcgra {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ROW_THREADS 256
+
+// ---------------------------------------------------------------------------
+// get_modified_adj (:365) + adding_noise (:474) + rowsum of normalize_adj (:218)
+// A = clamp((i!=j) * M + ori + eps*noise, 0, 1); d = 1 + rowsum(A); r = d^-1/2.
+// GENERAL=false: ori == 0, eps == 0 and 0 <= M <= 1, so A == M (no copy).
+// ---------------------------------------------------------------------------
+template <bool GENERAL>
+__global__ __launch_bounds__(ROW_THREADS) void k_prep(int n, int ld, const float* __restrict__ M,
+                                                      const float* __restrict__ ori,
+                                                      const float* __restrict__ noise, float eps,
+                                                      float* __restrict__ A, unsigned char* __restrict__ gate,
+                                                      float* __restrict__ d, float* __restrict__ r,
+                                                      double* __restrict__ rowsq, double* __restrict__ rowsum) {
+  __shared__ float shf[16];
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  float s = 0.f;
+  double sq = 0.0;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    f32x4 m = *reinterpret_cast<const f32x4*>(M + base + j);
+    f32x4 a = m;
+    if (GENERAL) {
+      f32x4 o = ori ? *reinterpret_cast<const f32x4*>(ori + base + j) : f32x4{0, 0, 0, 0};
+      f32x4 z = (noise && eps != 0.f) ? *reinterpret_cast<const f32x4*>(noise + base + j) : f32x4{0, 0, 0, 0};
+      unsigned char g[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int jj = j + t;
+        float pre = (jj != i ? m[t] : 0.f) + o[t];
+        if (noise && eps != 0.f) pre += z[t] * eps;
+        g[t] = (pre >= 0.f && pre <= 1.f) ? 1 : 0;
+        a[t] = jj < n ? fminf(fmaxf(pre, 0.f), 1.f) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(A + base + j) = a;
+      *reinterpret_cast<uchar4*>(gate + base + j) = make_uchar4(g[0], g[1], g[2], g[3]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jj = j + t;
+      if (jj < n) {
+        s += a[t];
+        if (jj != i) sq += (double)m[t] * (double)m[t];
+      }
+    }
+  }
+  const float tot = block_sum(s, shf);
+  const double tsq = block_sum_d(sq, shd);
+  if (threadIdx.x == 0) {
+    const float di = tot + 1.0f;  // rowsum(A + I)
+    float ri = 1.0f / sqrtf(di);
+    if (isinf(ri)) ri = 0.f;      // r_inv[isinf] = 0 (utils.py:225)
+    d[i] = di;
+    r[i] = ri;
+    rowsq[i] = tsq;
+    rowsum[i] = (double)tot;
+  }
+}
+
+// adj_norm = (r_i * (A + I)_ij) * r_j   (utils.py:226-228)
+__global__ __launch_bounds__(ROW_THREADS) void k_adjn(int n, int ld, const float* __restrict__ A,
+                                                      const float* __restrict__ r, float* __restrict__ out) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const float ri = r[i];
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(A + base + j);
+    f32x4 rj = *reinterpret_cast<const f32x4*>(r + j);
+    f32x4 o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jj = j + t;
+      const float mx = a[t] + (jj == i ? 1.f : 0.f);
+      o[t] = jj < n ? (ri * mx) * rj[t] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + base + j) = o;
+  }
+}
+
+// modified_adj1 = (1-I) * relu(Zn Zn^T) (+ ori)   (:187-188), in place on S.
+__global__ __launch_bounds__(ROW_THREADS) void k_decode_post(int n, int ld, float* __restrict__ S,
+                                                             const float* __restrict__ ori) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    f32x4 s = *reinterpret_cast<f32x4*>(S + base + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jj = j + t;
+      float v = (jj != i && jj < n) ? fmaxf(s[t], 0.f) : 0.f;
+      if (ori && jj < n) v += ori[base + jj];
+      s[t] = v;
+    }
+    *reinterpret_cast<f32x4*>(S + base + j) = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise loss terms on (adj_norm, modified_adj1, feature_adj):
+//   c1 = calc(feature_adj, adj_norm) (:212)   c2 = calc(adj_norm, A1) (:221)
+//   c6 = Info_entropy(adj_norm) (:230)        c7 = Info_entropy(A1) (:233)
+// MSE: value and gradient are elementwise.  Other measures: only the entropy
+// terms are handled here; their calc() parts come from GEMMs.
+// kmse1/kmse2 are the full scalar multipliers (w * align * 2/n^2), 0 to skip.
+// rowvals[4][n]: per-row partials of sum (f-x)^2, (x-y)^2, q log2 q (x), (y).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ie_term(float p, float k, float& val, float& grad) {
+  const float lo = 1e-4f, hi = 1.f - 1e-4f;
+  const float q = fminf(fmaxf(p, lo), hi);
+  const float l2 = log2f(q);
+  val = q * l2;
+  grad = (p >= lo && p <= hi) ? -k * (l2 + 1.4426950408889634f) : 0.f;
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void k_loss_elem(
+    int n, int ld, const float* __restrict__ X, const float* __restrict__ Y,
+    const float* __restrict__ F, float kmse1, float kmse2, float kie6, float kie7,
+    float* __restrict__ GX, float* __restrict__ GY, double* __restrict__ rowvals) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  double v1 = 0, v2 = 0, v6 = 0, v7 = 0;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(X + base + j);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + base + j);
+    f32x4 f = {0, 0, 0, 0};
+    if (kmse1 != 0.f) f = *reinterpret_cast<const f32x4*>(F + base + j);
+    f32x4 gx, gy;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float a = 0.f, b = 0.f;
+      if (j + t < n) {
+        if (kmse1 != 0.f) { const float e = f[t] - x[t]; v1 += (double)e * e; a -= kmse1 * e; }
+        if (kmse2 != 0.f) { const float e = x[t] - y[t]; v2 += (double)e * e; a += kmse2 * e; b -= kmse2 * e; }
+        if (kie6 != 0.f) { float v, g; ie_term(x[t], kie6, v, g); v6 += v; a += g; }
+        if (kie7 != 0.f) { float v, g; ie_term(y[t], kie7, v, g); v7 += v; b += g; }
+      }
+      gx[t] = a; gy[t] = b;
+    }
+    *reinterpret_cast<f32x4*>(GX + base + j) = gx;
+    *reinterpret_cast<f32x4*>(GY + base + j) = gy;
+  }
+  v1 = block_sum_d(v1, shd); v2 = block_sum_d(v2, shd);
+  v6 = block_sum_d(v6, shd); v7 = block_sum_d(v7, shd);
+  if (threadIdx.x == 0) {
+    rowvals[i] = v1; rowvals[(size_t)n + i] = v2;
+    rowvals[2 * (size_t)n + i] = v6; rowvals[3 * (size_t)n + i] = v7;
+  }
+}
+
+// out[k] = sum_i rowvals[k][i]; one block per vector, deterministic.
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ rowvals, int n,
+                                                      double* __restrict__ out) {
+  __shared__ double shd[16];
+  const double* v = rowvals + (size_t)blockIdx.x * n;
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// row sums of a matrix (double partial per row) - Gram centering (utils.py:1060)
+__global__ __launch_bounds__(ROW_THREADS) void k_rowsum(int n, int ld, const float* __restrict__ K,
+                                                        double* __restrict__ rows) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  double s = 0;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    const f32x4 k = *reinterpret_cast<const f32x4*>(K + base + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) if (j + t < n) s += k[t];
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) rows[i] = s;
+}
+
+// In-place Gram centering: K <- K - rm_i - rm_j + tm   (H K H of utils.py:1065;
+// Gram matrices are symmetric so column means equal row means).
+__global__ __launch_bounds__(ROW_THREADS) void k_center(int n, int ld, float* __restrict__ K,
+                                                        const double* __restrict__ rows,
+                                                        const double* __restrict__ total) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const double inv = 1.0 / n;
+  const double rmi = rows[i] * inv, tm = total[0] * inv * inv;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    f32x4 k = *reinterpret_cast<f32x4*>(K + base + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      k[t] = (j + t < n) ? (float)((double)k[t] - rmi - rows[j + t] * inv + tm) : 0.f;
+    *reinterpret_cast<f32x4*>(K + base + j) = k;
+  }
+}
+
+// linear_HSIC on N x N operands (utils.py:1085-1089), value + left factors of
+// the gradient GEMMs.  KX = X X^T, KY = Y Y^T (uncentred, symmetric), KFC =
+// centred Gram of feature_adj (constant).  On exit
+//   KY <- 2*(s1*KFC + s2*centre(KY))   so that  G_X += KY @ X
+//   KX <- 2*s2*centre(KX)              so that  G_Y += KX @ Y
+// rowvals[0][i] = sum_j KFC_ij*KX_ij (c1), rowvals[1][i] = sum_j KXc_ij*KYc_ij (c2).
+__global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
+    int n, int ld, float* __restrict__ KX, float* __restrict__ KY, const float* __restrict__ KFC,
+    const double* __restrict__ rowsx, const double* __restrict__ totx,
+    const double* __restrict__ rowsy, const double* __restrict__ toty, float s1, float s2,
+    double* __restrict__ rowvals) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const double inv = 1.0 / n;
+  const double rxi = rowsx[i] * inv, tx = totx[0] * inv * inv;
+  const double ryi = (s2 != 0.f) ? rowsy[i] * inv : 0.0, ty = (s2 != 0.f) ? toty[0] * inv * inv : 0.0;
+  double v1 = 0, v2 = 0;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    f32x4 kx = *reinterpret_cast<f32x4*>(KX + base + j);
+    f32x4 ky = {0, 0, 0, 0}, kf = {0, 0, 0, 0};
+    if (s2 != 0.f) ky = *reinterpret_cast<f32x4*>(KY + base + j);
+    if (s1 != 0.f) kf = *reinterpret_cast<const f32x4*>(KFC + base + j);
+    f32x4 ox, oy;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float a = 0.f, b = 0.f;
+      if (j + t < n) {
+        const float kxc = (float)((double)kx[t] - rxi - rowsx[j + t] * inv + tx);
+        float kyc = 0.f;
+        if (s2 != 0.f) kyc = (float)((double)ky[t] - ryi - rowsy[j + t] * inv + ty);
+        v1 += (double)kf[t] * kx[t];
+        v2 += (double)kxc * kyc;
+        a = 2.f * s2 * kxc;
+        b = 2.f * (s1 * kf[t] + s2 * kyc);
+      }
+      ox[t] = a; oy[t] = b;
+    }
+    *reinterpret_cast<f32x4*>(KX + base + j) = ox;
+    *reinterpret_cast<f32x4*>(KY + base + j) = oy;
+  }
+  v1 = block_sum_d(v1, shd); v2 = block_sum_d(v2, shd);
+  if (threadIdx.x == 0) { rowvals[i] = v1; rowvals[(size_t)n + i] = v2; }
+}
+
+// ---------------------------------------------------------------------------
+// normalize_adj backward.  adj_norm_ij = r_i mx_ij r_j, r = d^-1/2, d = rowsum(mx).
+//   gr_i = sum_j G_ij mx_ij r_j  +  sum_j G_ji mx_ji r_j
+// k_normbwd_row gives the first sum per row; k_colsum_part gives column partials
+// of W_ij = G_ij mx_ij r_i (second sum, index renamed) for row strips.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void k_normbwd_row(int n, int ld, const float* __restrict__ G,
+                                                             const float* __restrict__ A,
+                                                             const float* __restrict__ r,
+                                                             float* __restrict__ rowpart) {
+  __shared__ float shf[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  float s = 0.f;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(G + base + j);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(A + base + j);
+    const f32x4 rj = *reinterpret_cast<const f32x4*>(r + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (j + t < n) s += g[t] * (a[t] + (j + t == i ? 1.f : 0.f)) * rj[t];
+  }
+  s = block_sum(s, shf);
+  if (threadIdx.x == 0) rowpart[i] = s;
+}
+
+// column partial sums: part[strip][j] = sum_{i in strip} G_ij mx_ij r_i
+__global__ __launch_bounds__(256) void k_normbwd_colpart(int n, int ld, const float* __restrict__ G,
+                                                         const float* __restrict__ A,
+                                                         const float* __restrict__ r, int rows_per_strip,
+                                                         float* __restrict__ part) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int strip = blockIdx.y;
+  const int i0 = strip * rows_per_strip, i1 = min(n, i0 + rows_per_strip);
+  if (j >= n) return;
+  float s = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const size_t o = (size_t)i * ld + j;
+    s += G[o] * (A[o] + (i == j ? 1.f : 0.f)) * r[i];
+  }
+  part[(size_t)strip * n + j] = s;
+}
+
+// gd_i = -1/2 d_i^-3/2 (rowpart_i + sum_strips part[s][i])
+__global__ void k_normbwd_gd(int n, const float* __restrict__ rowpart, const float* __restrict__ part,
+                             int nstrips, const float* __restrict__ d, float* __restrict__ gd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = rowpart[i];
+  for (int t = 0; t < nstrips; ++t) s += part[(size_t)t * n + i];
+  const float di = d[i];
+  gd[i] = di > 0.f ? -0.5f * s * (1.0f / (di * sqrtf(di))) : 0.f;
+}
+
+// G_A_ij = G_adjn_ij r_i r_j + gd_i   (A = mx - I)
+__global__ __launch_bounds__(ROW_THREADS) void k_normbwd_apply(int n, int ld, const float* __restrict__ G,
+                                                               const float* __restrict__ r,
+                                                               const float* __restrict__ gd,
+                                                               float* __restrict__ GA) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const float ri = r[i], gdi = gd[i];
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(G + base + j);
+    const f32x4 rj = *reinterpret_cast<const f32x4*>(r + j);
+    f32x4 o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = (j + t < n) ? g[t] * ri * rj[t] + gdi : 0.f;
+    *reinterpret_cast<f32x4*>(GA + base + j) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tile-pair kernels: out_ij needs G_ij and G_ji.  64x64 tiles, transposed tile
+// staged through LDS ([64][65] floats, conflict-free column reads).
+// ---------------------------------------------------------------------------
+#define TP 64
+
+// decode backward (S = Zn Zn^T, A1 = (1-I) sym_lower(relu(S)) + ori):
+// out_ij = (i != j) [S_ij > 0] (G_ij + G_ji).  `pos` marks S > 0 (A1 - ori > 0).
+__global__ __launch_bounds__(256) void k_sym_mask(int n, int ld, const float* __restrict__ G,
+                                                  const float* __restrict__ A1,
+                                                  const float* __restrict__ ori, float* __restrict__ out) {
+  __shared__ float tile[TP][TP + 1];
+  const int bi = blockIdx.y * TP, bj = blockIdx.x * TP;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int rr = ty; rr < TP; rr += 4) {  // load G[bj + rr][bi + tx] (the mirrored tile)
+    const int gi = bj + rr, gj = bi + tx;
+    tile[rr][tx] = (gi < n && gj < n) ? G[(size_t)gi * ld + gj] : 0.f;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < TP; rr += 4) {
+    const int i = bi + rr, j = bj + tx;
+    if (i < n && j < n) {
+      const size_t o = (size_t)i * ld + j;
+      float s = A1[o];
+      if (ori) s -= ori[o];
+      out[o] = (i != j && s > 0.f) ? G[o] + tile[tx][rr] : 0.f;
+    }
+  }
+}
+
+// Packed gradient mirrored to both halves + torch.optim.Adam + projection clamp:
+//   g_ij = gate_ij*G_A_ij + gate_ji*G_A_ji + cn * M_ij     (i != j)
+//   m <- m + (1-b1)(g - m); v <- b2 v + (1-b2) g^2
+//   M <- clamp(M - step_size * m / (sqrt(v)/sqrt(bc2) + eps), 0, 1)   (:279-283)
+// rowsum_new[i] accumulates sum_j M_new (for projection :339 and sparsity :291).
+__global__ __launch_bounds__(256) void k_adam_sym(int n, int ld, const float* __restrict__ GA,
+                                                  const unsigned char* __restrict__ gate,
+                                                  float* __restrict__ M, float* __restrict__ am,
+                                                  float* __restrict__ av, const float* __restrict__ cn_ptr, float omb1, float b2,
+                                                  float omb2, float step_size, float sqrt_bc2, float eps,
+                                                  float* __restrict__ gsym_dbg, int do_clamp) {
+  __shared__ float tile[TP][TP + 1];
+  const int bi = blockIdx.y * TP, bj = blockIdx.x * TP;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float cn = cn_ptr[0];   // weight_sup * 0.001 / |adj_changes|_2 (0 at the origin), device scalar
+  for (int rr = ty; rr < TP; rr += 4) {
+    const int gi = bj + rr, gj = bi + tx;
+    float v = 0.f;
+    if (gi < n && gj < n) {
+      const size_t o = (size_t)gi * ld + gj;
+      v = GA[o];
+      if (gate && !gate[o]) v = 0.f;
+    }
+    tile[rr][tx] = v;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < TP; rr += 4) {
+    const int i = bi + rr, j = bj + tx;
+    if (i < n && j < n && i != j) {
+      const size_t o = (size_t)i * ld + j;
+      float g0 = GA[o];
+      if (gate && !gate[o]) g0 = 0.f;
+      const float p = M[o];
+      const float g = g0 + tile[tx][rr] + cn * p;
+      float m = am[o], v = av[o];
+      m = m + omb1 * (g - m);            // exp_avg.lerp_(grad, 1 - beta1)
+      v = v * b2 + omb2 * g * g;         // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(v) / sqrt_bc2 + eps;
+      float pn = p - step_size * (m / denom);
+      if (do_clamp) pn = fminf(fmaxf(pn, 0.f), 1.f);
+      am[o] = m; av[o] = v; M[o] = pn;
+      if (gsym_dbg) gsym_dbg[o] = g;
+    }
+  }
+}
+
+// projection helpers (:338-347, :397-412): sum_{i>j} clamp(M_ij - x, 0, 1) as
+// per-row partials over the full symmetric matrix (halved by the caller),
+// plus min/max of M over i != j.
+__global__ __launch_bounds__(ROW_THREADS) void k_clamp_rowsum(int n, int ld, const float* __restrict__ M,
+                                                              float x, double* __restrict__ rows,
+                                                              float* __restrict__ rowmin,
+                                                              float* __restrict__ rowmax) {
+  __shared__ double shd[16];
+  __shared__ float shmn[4], shmx[4];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  double s = 0;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) {
+    if (j == i) continue;
+    const float m = M[base + j];
+    s += fminf(fmaxf(m - x, 0.f), 1.f);
+    mn = fminf(mn, m); mx = fmaxf(mx, m);
+  }
+  s = block_sum_d(s, shd);
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { shmn[threadIdx.x >> 6] = mn; shmx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rows[i] = s;
+    if (rowmin) { rowmin[i] = fminf(fminf(shmn[0], shmn[1]), fminf(shmn[2], shmn[3]));
+                  rowmax[i] = fmaxf(fmaxf(shmx[0], shmx[1]), fmaxf(shmx[2], shmx[3])); }
+  }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void k_shift_clamp(int n, int ld, float* __restrict__ M, float x) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS)
+    if (j != i) M[base + j] = fminf(fmaxf(M[base + j] - x, 0.f), 1.f);
+}
+
+__global__ void k_minmax(int n, const float* __restrict__ rowmin, const float* __restrict__ rowmax,
+                         float* __restrict__ out) {
+  __shared__ float smn[16], smx[16];
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { mn = fminf(mn, rowmin[i]); mx = fmaxf(mx, rowmax[i]); }
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
+    out[0] = mn; out[1] = mx;
+  }
+}
+
+// packed <-> dense data movement (topology_attack.py:371-377)
+__global__ void k_unpack_sym(int n, int ld, const float* __restrict__ packed, const float* __restrict__ ori,
+                             int ori_ld, float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n) return;
+  float v = 0.f;
+  if (i != j) {
+    const int a = i > j ? i : j, b = i > j ? j : i;
+    v = packed[(size_t)a * (a - 1) / 2 + b];
+  }
+  if (ori) v += ori[(size_t)i * ori_ld + j];
+  out[(size_t)i * ld + j] = v;
+}
+
+__global__ void k_pack_tril(int n, int ld, const float* __restrict__ M, float* __restrict__ packed) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= i) return;
+  packed[(size_t)i * (i - 1) / 2 + j] = M[(size_t)i * ld + j];
+}
+
+// dot_product_decode packed output (:414-419): out[p(i,j)] = relu(S_ij), i > j
+__global__ void k_pack_tril_relu(int n, int ld, const float* __restrict__ S, float* __restrict__ packed) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= i) return;
+  packed[(size_t)i * (i - 1) / 2 + j] = fmaxf(S[(size_t)i * ld + j], 0.f);
+}
+
+// dot_product_decode2 epilogues (:421-467), accumulated into the ensemble:
+//   mode 0: out += sigmoid(relu(S - I))       mode 2: out += relu(S - I)
+//   mode 3: out += relu(S / max(|S_i|_2, 1e-12) - I)   (rownorm = |S_i|_2 given)
+__global__ __launch_bounds__(ROW_THREADS) void k_dd2_accum(int n, int ld, const float* __restrict__ S,
+                                                           int mode, const float* __restrict__ rownorm,
+                                                           float* __restrict__ out, int out_ld) {
+  const int i = blockIdx.x;
+  float inv = 1.f;
+  if (mode == 3) inv = 1.f / fmaxf(rownorm[i], 1e-12f);
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) {
+    float s = S[(size_t)i * ld + j];
+    if (mode == 3) s *= inv;
+    s = fmaxf(s - (i == j ? 1.f : 0.f), 0.f);
+    if (mode == 0) s = 1.f / (1.f + expf(-s));
+    out[(size_t)i * out_ld + j] += s;
+  }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void k_row_l2(int n, int ld, const float* __restrict__ S,
+                                                        float* __restrict__ rownorm) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  double s = 0;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) { const float v = S[(size_t)i * ld + j]; s += (double)v * v; }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) rownorm[i] = (float)sqrt(s);
+}
+
+// out (ld_o) = a * X (ld_x) + b * Y (ld_y) over an n x n window; Y may be NULL
+__global__ void k_axpby2d(int n, const float* __restrict__ X, int ldx, float a, const float* __restrict__ Y,
+                          int ldy, float b, float* __restrict__ out, int ldo) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n) return;
+  float v = a * X[(size_t)i * ldx + j];
+  if (Y) v += b * Y[(size_t)i * ldy + j];
+  out[(size_t)i * ldo + j] = v;
+}
+
+// generic elementwise sum of squares of differences (mcgra_mse), double partials
+__global__ void k_sqdiff_part(size_t count, const float* __restrict__ X, const float* __restrict__ Y,
+                              double* __restrict__ part) {
+  __shared__ double shd[16];
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const float e = X[i] - Y[i];
+    s += (double)e * e;
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// info entropy value only (mcgra_info_entropy)
+__global__ __launch_bounds__(ROW_THREADS) void k_ie_rows(int n, int ld, const float* __restrict__ P,
+                                                         double* __restrict__ rows) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  double s = 0;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) {
+    float v, g;
+    ie_term(P[(size_t)i * ld + j], 0.f, v, g);
+    s += v;
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) rows[i] = s;
+}
+
+// ---- host launchers ---------------------------------------------------------
+#define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
+
+void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, const float* ori,
+                 const float* noise, float eps, float* A, unsigned char* gate, float* d, float* r,
+                 double* rowsq, double* rowsum) {
+  if (general) LAUNCH(k_prep<true>, dim3(n), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum);
+  else LAUNCH(k_prep<false>, dim3(n), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum);
+}
+void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out) {
+  LAUNCH(k_adjn, dim3(n), dim3(ROW_THREADS), st, n, ld, A, r, out);
+}
+void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori) {
+  LAUNCH(k_decode_post, dim3(n), dim3(ROW_THREADS), st, n, ld, S, ori);
+}
+void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float* Y, const float* F,
+                      float kmse1, float kmse2, float kie6, float kie7, float* GX, float* GY,
+                      double* rowvals) {
+  LAUNCH(k_loss_elem, dim3(n), dim3(ROW_THREADS), st, n, ld, X, Y, F, kmse1, kmse2, kie6, kie7, GX, GY, rowvals);
+}
+void launch_reduce_rows(hipStream_t st, const double* rowvals, int n, int nvec, double* out) {
+  LAUNCH(k_reduce_rows, dim3(nvec), dim3(1024), st, rowvals, n, out);
+}
+void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows) {
+  LAUNCH(k_rowsum, dim3(n), dim3(ROW_THREADS), st, n, ld, K, rows);
+}
+void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total) {
+  LAUNCH(k_center, dim3(n), dim3(ROW_THREADS), st, n, ld, K, rows, total);
+}
+void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC,
+                         const double* rowsx, const double* totx, const double* rowsy, const double* toty,
+                         float s1, float s2, double* rowvals) {
+  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, rowsx, totx, rowsy, toty, s1, s2, rowvals);
+}
+void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
+                    const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {
+  LAUNCH(k_normbwd_row, dim3(n), dim3(ROW_THREADS), st, n, ld, G, A, r, rowpart);
+  const int rows_per_strip = (n + nstrips - 1) / nstrips;
+  LAUNCH(k_normbwd_colpart, dim3((n + 255) / 256, nstrips), dim3(256), st, n, ld, G, A, r, rows_per_strip, colpart);
+  LAUNCH(k_normbwd_gd, dim3((n + 255) / 256), dim3(256), st, n, rowpart, colpart, nstrips, d, gd);
+  LAUNCH(k_normbwd_apply, dim3(n), dim3(ROW_THREADS), st, n, ld, G, r, gd, GA);
+}
+void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out) {
+  const int t = (n + TP - 1) / TP;
+  LAUNCH(k_sym_mask, dim3(t, t), dim3(256), st, n, ld, G, A1, ori, out);
+}
+void launch_adam_sym(hipStream_t st, int n, int ld, const float* GA, const unsigned char* gate, float* M,
+                     float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size,
+                     float sqrt_bc2, float eps, float* gsym_dbg, int do_clamp) {
+  const int t = (n + TP - 1) / TP;
+  LAUNCH(k_adam_sym, dim3(t, t), dim3(256), st, n, ld, GA, gate, M, am, av, cn, omb1, b2, omb2, step_size, sqrt_bc2, eps, gsym_dbg, do_clamp);
+}
+void launch_clamp_rowsum(hipStream_t st, int n, int ld, const float* M, float x, double* rows, float* rowmin, float* rowmax) {
+  LAUNCH(k_clamp_rowsum, dim3(n), dim3(ROW_THREADS), st, n, ld, M, x, rows, rowmin, rowmax);
+}
+void launch_shift_clamp(hipStream_t st, int n, int ld, float* M, float x) {
+  LAUNCH(k_shift_clamp, dim3(n), dim3(ROW_THREADS), st, n, ld, M, x);
+}
+void launch_minmax(hipStream_t st, int n, const float* rowmin, const float* rowmax, float* out) {
+  LAUNCH(k_minmax, dim3(1), dim3(1024), st, n, rowmin, rowmax, out);
+}
+void launch_unpack_sym(hipStream_t st, int n, int ld, const float* packed, const float* ori, int ori_ld, float* out) {
+  LAUNCH(k_unpack_sym, dim3((n + 255) / 256, n), dim3(256), st, n, ld, packed, ori, ori_ld, out);
+}
+void launch_pack_tril(hipStream_t st, int n, int ld, const float* M, float* packed, bool relu) {
+  if (relu) LAUNCH(k_pack_tril_relu, dim3((n + 255) / 256, n), dim3(256), st, n, ld, M, packed);
+  else LAUNCH(k_pack_tril, dim3((n + 255) / 256, n), dim3(256), st, n, ld, M, packed);
+}
+void launch_dd2_accum(hipStream_t st, int n, int ld, const float* S, int mode, float* rownorm, float* out, int out_ld) {
+  if (mode == 3) LAUNCH(k_row_l2, dim3(n), dim3(ROW_THREADS), st, n, ld, S, rownorm);
+  LAUNCH(k_dd2_accum, dim3(n), dim3(ROW_THREADS), st, n, ld, S, mode, rownorm, out, out_ld);
+}
+void launch_axpby2d(hipStream_t st, int n, const float* X, int ldx, float a, const float* Y, int ldy, float b,
+                    float* out, int ldo) {
+  LAUNCH(k_axpby2d, dim3((n + 255) / 256, n), dim3(256), st, n, X, ldx, a, Y, ldy, b, out, ldo);
+}
+void launch_sqdiff(hipStream_t st, size_t count, const float* X, const float* Y, double* part, int nblocks) {
+  LAUNCH(k_sqdiff_part, dim3(nblocks), dim3(256), st, count, X, Y, part);
+}
+void launch_ie_rows(hipStream_t st, int n, int ld, const float* P, double* rows) {
+  LAUNCH(k_ie_rows, dim3(n), dim3(ROW_THREADS), st, n, ld, P, rows);
+}
+
+}  // namespace mcgra

@@ -1,0 +1,234 @@
+"""Thin host wrapper over the C-ABI attack engine and standalone ops.
+
+PyTorch is used only as plumbing: it owns the caller-side device buffers and
+the HIP stream.  All arithmetic happens in libmcgra_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AttackConfig, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev_f32(x, device):
+    if isinstance(x, torch.Tensor):
+        if x.is_sparse:
+            x = x.to_dense()
+        return x.detach().to(device=device, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)), device=device)
+
+
+def _dev_i32(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(device=device, dtype=torch.int32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.int32)), device=device)
+
+
+# ------------------------------------------------------------- standalone ops
+def sgemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
+    """torch.mm on the fp32 MFMA kernel (mcgra_sgemm)."""
+    m = A.shape[1] if ta else A.shape[0]
+    k = A.shape[0] if ta else A.shape[1]
+    n = B.shape[0] if tb else B.shape[1]
+    assert (B.shape[1] if tb else B.shape[0]) == k
+    if out is None:
+        out = torch.zeros(m, n, device=A.device, dtype=torch.float32)
+    check(lib.mcgra_sgemm(_stream(), int(ta), int(tb), m, n, k, float(alpha), _p(A), A.stride(0), _p(B),
+                          B.stride(0), float(beta), _p(out), out.stride(0)))
+    return out
+
+
+def normalize_adj_tensor(adj):
+    """utils.normalize_adj_tensor, dense branch (utils.py:211-230)."""
+    out = torch.empty_like(adj)
+    check(lib.mcgra_normalize_adj(_stream(), adj.shape[0], _p(adj), _p(out)))
+    return out
+
+
+def get_modified_adj(adj_changes, ori_adj, n):
+    out = torch.empty(n, n, device=adj_changes.device, dtype=torch.float32)
+    check(lib.mcgra_get_modified_adj(_stream(), n, _p(adj_changes), _p(ori_adj), _p(out)))
+    return out
+
+
+def info_entropy(prob):
+    out = torch.zeros(1, device=prob.device, dtype=torch.float32)
+    check(lib.mcgra_info_entropy(_stream(), prob.shape[0], _p(prob), _p(out)))
+    return out[0]
+
+
+def dot_product_decode(Z):
+    n, d = Z.shape
+    out = torch.empty(n * (n - 1) // 2, device=Z.device, dtype=torch.float32)
+    check(lib.mcgra_dot_product_decode(_stream(), n, d, _p(Z), _p(out)))
+    return out
+
+
+def linear_hsic(X, Y):
+    out = torch.zeros(1, device=X.device, dtype=torch.float32)
+    check(lib.mcgra_linear_hsic(_stream(), X.shape[0], X.shape[1], Y.shape[1], _p(X), _p(Y), _p(out)))
+    return out[0]
+
+
+def mse(X, Y):
+    out = torch.zeros(1, device=X.device, dtype=torch.float32)
+    check(lib.mcgra_mse(_stream(), X.numel(), _p(X), _p(Y), _p(out)))
+    return out[0]
+
+
+def gcn_forward(X, adj, W, b, Wlin, blin, emb_nlayer=0):
+    """GCN.forward (eval) and, when emb_nlayer > 0, embedding_GCN.forward."""
+    n, nfeat = X.shape
+    L = len(W)
+    dims = (C.c_int32 * (L + 1))(*([nfeat] + [w.shape[1] for w in W]))
+    Wp = (C.c_void_p * L)(*[w.data_ptr() for w in W])
+    bp = (C.c_void_p * L)(*[x.data_ptr() for x in b])
+    nclass = Wlin.shape[0]
+    out = torch.empty(n, nclass, device=X.device, dtype=torch.float32)
+    emb = torch.empty(n, W[emb_nlayer - 1].shape[1], device=X.device, dtype=torch.float32) if emb_nlayer else None
+    check(lib.mcgra_gcn_forward(_stream(), n, nfeat, L, dims, _p(X), _p(adj), Wp, bp, _p(Wlin), _p(blin), nclass,
+                                emb_nlayer, _p(emb), _p(out)))
+    return out, emb
+
+
+# ---------------------------------------------------------------- the engine
+class AttackEngine:
+    """One mcgra_attack_t.  Mirrors the state PGDAttack keeps across the loop of
+    topology_attack.py:161-298 (adj_changes + Adam moments) in HBM."""
+
+    def __init__(self, n, dims, nclass, emb_nlayer, measure, weight_sup, weight_param, lr, num_edges,
+                 n_attack, eps=0.0, device="cuda:0"):
+        _lib.require_device()
+        self.device = torch.device(device)
+        self.n, self.nclass, self.dims = int(n), int(nclass), list(int(d) for d in dims)
+        cfg = AttackConfig()
+        cfg.n, cfg.nfeat, cfg.nclass = self.n, self.dims[0], self.nclass
+        cfg.nlayer, cfg.emb_nlayer = len(self.dims) - 1, int(emb_nlayer)
+        for i, d in enumerate(self.dims):
+            cfg.dims[i] = d
+        if measure not in _lib.MEASURES:
+            raise ValueError(f"measure {measure!r}: KDE needs cuda:0-only utils.MutualInformation and is not provided")
+        cfg.measure = _lib.MEASURES[measure]
+        cfg.n_attack = int(n_attack)
+        cfg.weight_sup = float(weight_sup)
+        for i in range(10):
+            cfg.w[i] = float(weight_param[i])
+        cfg.lr, cfg.eps = float(lr), float(eps)
+        cfg.num_edges = float(min(num_edges, 1e300))
+        cfg.row_begin, cfg.row_end = 0, self.n
+        self._h = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_create(C.byref(self._h), C.byref(cfg)))
+        self.cfg = cfg
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib.mcgra_attack_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_model(self, W, b, Wlin, blin):
+        dev = self.device
+        W = [_dev_f32(w, dev) for w in W]
+        b = [_dev_f32(x, dev) for x in b]
+        Wlin, blin = _dev_f32(Wlin, dev), _dev_f32(blin, dev)
+        L = len(W)
+        Wp = (C.c_void_p * L)(*[w.data_ptr() for w in W])
+        bp = (C.c_void_p * L)(*[x.data_ptr() for x in b])
+        with torch.cuda.device(dev):
+            check(lib.mcgra_attack_set_model(self._h, _stream(), Wp, bp, _p(Wlin), _p(blin)))
+            torch.cuda.current_stream().synchronize()
+
+    def set_graph(self, features, adj, ori_adj, feature_adj, labels, idx_attack):
+        dev = self.device
+        X = _dev_f32(features, dev)
+        A = _dev_f32(adj, dev)
+        F = _dev_f32(feature_adj, dev)
+        O = None
+        if ori_adj is not None:
+            O = _dev_f32(ori_adj, dev)
+            if not bool((O != 0).any()):
+                O = None          # dataset.init_matrix (dataset.py:433): all zeros
+        lab = _dev_i32(labels, dev)
+        idx = _dev_i32(idx_attack, dev)
+        with torch.cuda.device(dev):
+            check(lib.mcgra_attack_set_graph(self._h, _stream(), _p(X), _p(A), _p(O), _p(F), _p(lab), _p(idx)))
+
+    def set_adj_changes(self, packed):
+        t = _dev_f32(packed, self.device)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_set_adj_changes(self._h, _stream(), _p(t)))
+            torch.cuda.current_stream().synchronize()
+
+    def get_adj_changes(self):
+        n = self.n
+        out = torch.empty(n * (n - 1) // 2, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_get_adj_changes(self._h, _stream(), _p(out)))
+        return out
+
+    def step(self, want_scalars=False, noise=None):
+        with torch.cuda.device(self.device):
+            if want_scalars:
+                buf = (C.c_double * 10)()
+                check(lib.mcgra_attack_step(self._h, _stream(), _p(noise), buf))
+                keys = ("loss", "origin_loss", "c1", "c2", "c6", "c7", "c9", "c10", "clamp_sum", "nll")
+                return dict(zip(keys, list(buf)))
+            check(lib.mcgra_attack_step(self._h, _stream(), _p(noise), None))
+        return None
+
+    def monitor(self, want_sparsity=False):
+        out = torch.empty(self.n, self.nclass, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            if want_sparsity:
+                s = C.c_double(0)
+                check(lib.mcgra_attack_monitor(self._h, _stream(), _p(out), C.byref(s)))
+                return out, s.value
+            check(lib.mcgra_attack_monitor(self._h, _stream(), _p(out), None))
+        return out, None
+
+    def finalize(self, decode_mode, H_A=None, Y_A=None, label_adj=None):
+        dev = self.device
+        H_A = _dev_f32(H_A, dev) if H_A is not None else None
+        Y_A = _dev_f32(Y_A, dev) if Y_A is not None else None
+        label_adj = _dev_f32(label_adj, dev) if label_adj is not None else None
+        out = torch.empty(self.n, self.n, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(lib.mcgra_attack_finalize(self._h, _stream(), int(decode_mode), _p(H_A), _p(Y_A), _p(label_adj),
+                                            _p(out)))
+            torch.cuda.current_stream().synchronize()
+        return out
+
+    def buffer(self, name):
+        """Copy of a named intermediate (parity tests)."""
+        ptr, r, c, ld = C.c_void_p(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib.mcgra_attack_buffer(self._h, name.encode(), C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))
+        out = torch.empty(r.value, c.value, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_copy_buffer(self._h, _stream(), name.encode(), _p(out), c.value))
+            torch.cuda.current_stream().synchronize()
+        return out
+
+    def profile(self, enable=True):
+        check(lib.mcgra_attack_profile(self._h, int(enable)))
+
+    def gemm_stats(self, reset=True):
+        n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+        check(lib.mcgra_attack_gemm_stats(self._h, int(reset), C.byref(n), C.byref(ms), C.byref(fl)))
+        return dict(launches=n.value, ms=ms.value, flops=fl.value)

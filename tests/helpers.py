@@ -54,3 +54,51 @@ def cora_feature_adj(feats):
     Z = feats @ feats.T
     Z = np.maximum(Z - np.eye(Z.shape[0], dtype=np.float32), 0)
     return (1.0 / (1.0 + np.exp(-Z.astype(np.float64)))).astype(np.float32)
+
+
+# ---------------------------------------------------------------- GPU-side helpers
+def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None):
+    """AttackEngine (C-ABI handle) set up from a golden attack case."""
+    import torch  # noqa: F401
+    cfg = cfg_from(z)
+    w = weights_from(z)
+    dims = [w.W[0].shape[0]] + [x.shape[1] for x in w.W]
+    eng = pkg.AttackEngine(z["adj"].shape[0], dims, w.Wlin.shape[0], 2, measure or cfg.measure, cfg.weight_sup,
+                           weight_param or cfg.weight_param, cfg.lr, cfg.num_edges, len(z["idx_attack"]),
+                           device=device)
+    eng.set_model(w.W, w.b, w.Wlin, w.blin)
+    eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
+    return eng
+
+
+class _Layer:
+    def __init__(self, W, b):
+        import torch
+        self.weight = torch.tensor(np.asarray(W, np.float32))
+        self.bias = torch.tensor(np.asarray(b, np.float32))
+
+
+class _Lin:
+    def __init__(self, W, b):
+        import torch
+        self.weight = torch.tensor(np.asarray(W, np.float32))
+        self.bias = torch.tensor(np.asarray(b, np.float32))
+
+
+class FakeGCN:
+    """Duck-typed stand-in for models/gcn.py GCN / embedding_GCN: the attributes
+    PGDAttack reads (gc[l].weight/.bias, linear1, nclass, nfeat, hidden_sizes, nlayer)."""
+
+    def __init__(self, w: O.GCNWeights):
+        self.gc = [_Layer(W, b) for W, b in zip(w.W, w.b)]
+        self.linear1 = _Lin(w.Wlin, w.blin)
+        self.nclass = w.Wlin.shape[0]
+        self.nfeat = w.W[0].shape[0]
+        self.hidden_sizes = [w.W[0].shape[1]]
+        self.nlayer = 2
+
+    def eval(self):
+        return self
+
+    def set_layers(self, n):
+        self.nlayer = n

@@ -1,0 +1,273 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the
+numpy oracle and the reference-generated golden fixtures.  Run with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mcgra_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+OPS = np.load(os.path.join(H.GOLDEN, "ops.npz"))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import mcgra_loader
+    p = mcgra_loader.load()
+    p._lib.require_device()
+    return p
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def dev(t, x):
+    return t.as_tensor(np.ascontiguousarray(x), device="cuda:0")
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (130, 67, 45), (300, 257, 129), (1000, 16, 1000),
+                                   (16, 16, 3000), (2708, 7, 2708), (515, 515, 515), (64, 200, 1)])
+def test_sgemm_matches_fp64(pkg, torch_, ta, tb, m, n, k):
+    rng = np.random.RandomState(m * 7 + n * 3 + k + 2 * ta + tb)
+    A = rng.randn(*((k, m) if ta else (m, k))).astype(np.float32)
+    B = rng.randn(*((n, k) if tb else (k, n))).astype(np.float32)
+    from mc_gra_amd import engine as E
+    C = E.sgemm(dev(torch_, A), dev(torch_, B), ta=bool(ta), tb=bool(tb)).cpu().numpy()
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    # fp32 fmaf chain: error <= ~1e-7 * sum|a b| (guide: 0.75-1.5e-7 at K <= 1024)
+    bound = 4e-7 * (np.abs(A.T if ta else A).astype(np.float64) @ np.abs(B.T if tb else B).astype(np.float64))
+    assert np.all(np.abs(C - ref) <= bound + 1e-30)
+
+
+def test_sgemm_identity_asymmetric_and_beta(pkg, torch_):
+    from mc_gra_amd import engine as E
+    n = 200
+    B = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) - 48      # asymmetric, exact in fp32
+    I = np.eye(n, dtype=np.float32)
+    out = E.sgemm(dev(torch_, I), dev(torch_, B)).cpu().numpy()
+    assert np.array_equal(out, B)
+    out = E.sgemm(dev(torch_, B), dev(torch_, I), tb=True).cpu().numpy()
+    assert np.array_equal(out, B)
+    C0 = np.ones((n, n), np.float32)
+    out = E.sgemm(dev(torch_, I), dev(torch_, B), alpha=2.0, beta=3.0, out=dev(torch_, C0).clone()).cpu().numpy()
+    assert np.array_equal(out, 2 * B + 3)
+    # non-contiguous (ld > cols) operands and unaligned base pointers (scalar-load path)
+    big = np.random.RandomState(0).randn(300, 301).astype(np.float32)
+    tb_ = dev(torch_, big)
+    Av, Bv = tb_[1:201, 1:130], tb_[3:132, 2:99]
+    ref = big[1:201, 1:130].astype(np.float64) @ big[3:132, 2:99].astype(np.float64)
+    got = E.sgemm(Av, Bv).cpu().numpy()
+    assert rel(got, ref) < 1e-5
+
+
+# ------------------------------------------------------------------ standalone ops
+def test_ops_against_reference_goldens(pkg, torch_):
+    from mc_gra_amd import engine as E
+    t = torch_
+    out = E.normalize_adj_tensor(dev(t, OPS["norm_in"])).cpu().numpy()
+    assert rel(out, OPS["norm_out"]) < 1e-6
+    assert abs(float(E.info_entropy(dev(t, OPS["ie_in"]))) - float(OPS["ie_val"])) < 1e-6
+    got = E.dot_product_decode(dev(t, OPS["dd2_Z"])).cpu().numpy()
+    assert rel(got, OPS["dd_out"]) < 2e-6
+    for tag in ("a", "b"):
+        X, Y = OPS[f"hsic_{tag}_X"], OPS[f"hsic_{tag}_Y"]
+        v = float(E.linear_hsic(dev(t, X), dev(t, Y)))
+        assert abs(v - float(OPS[f"hsic_{tag}_val"])) <= 3e-5 * abs(float(OPS[f"hsic_{tag}_val"]))
+    v = float(E.mse(dev(t, OPS["mse_X"]), dev(t, OPS["mse_Y"])))
+    assert abs(v - float(OPS["mse_val"])) <= 1e-6 * abs(float(OPS["mse_val"]))
+    got = E.get_modified_adj(dev(t, OPS["gma_a"]), dev(t, OPS["gma_ori"]), 30).cpu().numpy()
+    assert np.array_equal(got, OPS["gma_out"])            # data movement: bit exact
+
+
+def test_ops_edge_cases(pkg, torch_):
+    from mc_gra_amd import engine as E
+    t = torch_
+    # isolated nodes / all-zero adjacency: d = 1, adj_norm = I
+    z = np.zeros((9, 9), np.float32)
+    assert np.array_equal(E.normalize_adj_tensor(dev(t, z)).cpu().numpy(), np.eye(9, dtype=np.float32))
+    # ragged n (not a multiple of 4) and n = 2
+    for n in (2, 5, 131):
+        A = np.random.RandomState(n).rand(n, n).astype(np.float32)
+        ref, _, _ = O.normalize_adj_tensor(A)
+        assert rel(E.normalize_adj_tensor(dev(t, A)).cpu().numpy(), ref) < 1e-6
+    # zero embedding rows: F.normalize clamps the norm at 1e-12 -> decode gives 0, not NaN
+    Z = np.zeros((6, 4), np.float32); Z[0] = 1
+    got = E.dot_product_decode(dev(t, Z)).cpu().numpy()
+    assert np.all(np.isfinite(got)) and np.all(got == 0)
+    # entropy clamp boundaries
+    P = np.array([[0, 1e-4], [1 - 1e-4, 1.5]], np.float32)
+    assert abs(float(E.info_entropy(dev(t, P))) - float(O.info_entropy(P))) < 1e-7
+
+
+def test_gcn_forward_matches_oracle(pkg, torch_):
+    from mc_gra_amd import engine as E
+    t = torch_
+    z = H.load_case("s80_hsic_l3")
+    w = H.weights_from(z)
+    T0 = (z["features"] @ w.W[0]).astype(np.float32)
+    _, Hs, _ = O.gcn_chain(T0, z["adj"], w.f32(), 3)
+    _, logp = O.victim_head(Hs[-1], w.f32())
+    out, emb = E.gcn_forward(dev(t, z["features"]), dev(t, z["adj"]), [dev(t, x) for x in w.W],
+                             [dev(t, x) for x in w.b], dev(t, w.Wlin), dev(t, w.blin), emb_nlayer=2)
+    assert rel(out.cpu().numpy(), logp) < 2e-5
+    assert rel(emb.cpu().numpy(), Hs[1]) < 2e-5
+    assert rel(out.cpu().numpy(), z["Y_A"]) < 2e-5          # the reference's own Y_A
+    assert rel(emb.cpu().numpy(), z["H_A2"]) < 2e-5
+
+
+# ------------------------------------------------------------------ attack engine
+ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss")]
+
+
+@pytest.mark.parametrize("name", ENGINE_CASES)
+def test_step_gradients_match_reference(pkg, torch_, name):
+    """Teacher-forced: every step starts from the reference's adj_changes; the packed
+    gradient mirrored by the engine (G_sym) must equal the reference's autograd gradient."""
+    z = H.load_case(name)
+    eng = H.engine_from(pkg, z)
+    orc = H.oracle_from(z)
+    free_run = float(z["num_edges"]) < 1e9
+    for t in range(int(z["epochs"])):
+        if t > 0 and not free_run:
+            a = np.clip(z["steps_a"][t - 1], 0, 1)
+            eng.set_adj_changes(a)
+            orc.set_adj_changes(a)
+        sc = eng.step(want_scalars=True)
+        orc.step()
+        g = O.pack_tril(eng.buffer("G_sym").cpu().numpy())
+        g_ref = z["steps_g"][t]
+        scale = np.abs(g_ref).max()
+        assert np.abs(g - g_ref).max() <= 3e-4 * scale, (name, t, np.abs(g - g_ref).max(), scale)
+        # intermediates against the oracle
+        last = orc.last
+        assert rel(eng.buffer("adj_norm").cpu().numpy(), last["adj_norm"]) < 2e-6
+        assert rel(eng.buffer("A1").cpu().numpy(), last["A1"]) < 2e-5
+        assert rel(eng.buffer("em").cpu().numpy(), last["em"]) < 2e-5
+        assert abs(sc["loss"] - last["loss"]) <= 2e-4 * abs(last["loss"]) + 1e-5, (sc, last["loss"], last["terms"])
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ENGINE_CASES)
+def test_free_run_final_matches_reference(pkg, torch_, name):
+    """Free-running loop + post-loop ensemble: final modified_adj and its AUC."""
+    z = H.load_case(name)
+    eng = H.engine_from(pkg, z)
+    for t in range(int(z["epochs"])):
+        eng.step()
+        a = eng.get_adj_changes().cpu().numpy()
+        assert np.abs(a - np.clip(z["steps_a"][t], 0, 1)).max() < 0.05 * float(z["lr"]) + 1e-6 or float(z["num_edges"]) < 1e9
+    lab = z["labels"]
+    label_adj = (lab[:, None] == lab[None, :]).astype(np.float32)
+    final = eng.finalize(0, z["H_A2"], z["Y_A"], label_adj).cpu().numpy()
+    assert np.abs(final - z["final"]).max() < 1e-3
+    auc = O.metric_pool(z["adj"], final, z["idx_attack"])
+    assert abs(auc - float(z["auc"])) < 1e-4
+    eng.close()
+
+
+def test_projection_bisection_matches_oracle(pkg, torch_):
+    z = H.load_case("s80_mse_proj")
+    eng = H.engine_from(pkg, z)
+    orc = H.oracle_from(z)
+    for t in range(int(z["epochs"])):
+        eng.step(); orc.step()
+        a = eng.get_adj_changes().cpu().numpy()
+        assert np.abs(a - O.pack_tril(orc.M)).max() < 2e-3
+        assert a.min() >= 0 and a.max() <= 1
+        assert a.sum() <= float(z["num_edges"]) * (1 + 1e-3) + 1e-2
+    eng.close()
+
+
+def test_engine_invariants_and_determinism(pkg, torch_):
+    """Integer-like structure must be bit exact: zero diagonal, exact symmetry of the
+    mirrored state, clamp range; two runs give identical bits (deterministic reductions)."""
+    z = H.load_case("s200_hsic")
+    outs = []
+    for rep in range(2):
+        eng = H.engine_from(pkg, z)
+        for _ in range(3):
+            eng.step()
+        M = eng.buffer("M").cpu().numpy()
+        outs.append(M)
+        assert np.array_equal(M, M.T)
+        assert np.all(np.diag(M) == 0)
+        assert M.min() >= 0 and M.max() <= 1
+        m, v = eng.buffer("adam_m").cpu().numpy(), eng.buffer("adam_v").cpu().numpy()
+        assert np.array_equal(m, m.T) and np.array_equal(v, v.T)
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_unsupported_arguments_fail_loudly(pkg, torch_):
+    z = H.load_case("s48_mse")
+    with pytest.raises(NotImplementedError):
+        H.engine_from(pkg, z, measure="KL")
+    with pytest.raises(ValueError):
+        H.engine_from(pkg, z, measure="KDE")
+
+
+# ------------------------------------------------------------------ class surface + Cora
+def _args(measure, dataset="cora"):
+    import argparse
+    return argparse.Namespace(max_eval=100, lr=0, dataset=dataset, eps=0, measure=measure, useH_A=True,
+                              useY_A=True, useY=True, w1=0, w2=0, w6=0, w7=0, w8=0, w9=0, w10=0)
+
+
+def test_pgdattack_class_small(pkg, torch_):
+    z = H.load_case("s48_hsic")
+    w = H.weights_from(z)
+    victim, emb = H.FakeGCN(w), H.FakeGCN(w)
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=torch_.tensor(z["H_A2"]), Y_A=torch_.tensor(z["Y_A"]),
+                          nnodes=48, loss_type="CE", device="cuda:0")
+    lab = z["labels"]
+    ret = model.attack(_args("HSIC"), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]),
+                       torch_.tensor(z["feature_adj"]), 0, 0, 0, None, None, np.arange(8), torch_.tensor(z["adj"]),
+                       torch_.tensor(z["features"]), torch_.zeros(48, 48), torch_.tensor(lab), z["idx_attack"],
+                       float(z["num_edges"]), 0, epochs=int(z["epochs"]),
+                       label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    assert ret == (0, 0, 0, 0)
+    final = model.modified_adj.cpu().numpy()
+    assert np.abs(final - z["final"]).max() < 1e-3
+    assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
+    assert len(model.history["acc_test"]) == int(z["epochs"])
+
+
+@pytest.mark.parametrize("name", ["cora_mse_readme", "cora_hsic"])
+def test_cora_auc_matches_reference(pkg, torch_, name):
+    """BASELINE configs[0]/[1]: Cora, 2-layer GCN trained by the reference, priors H_A+Y_A+Y.
+    north_star bar: recovered-adjacency AUC within 1e-4 of the reference CPU path."""
+    z = H.load_cora(name)
+    w = O.GCNWeights([z["W0"], z["W1"]], [z["b0"], z["b1"]], z["Wlin"], z["blin"])
+    victim, emb = H.FakeGCN(w), H.FakeGCN(w)
+    X, adj, lab = z["features"], z["adj"], z["labels"]
+    fadj = H.cora_feature_adj(X)
+    from mc_gra_amd import engine as E
+    t = torch_
+    Wd = [dev(t, x) for x in w.W]; bd = [dev(t, x) for x in w.b]
+    Y_A, H_A2 = E.gcn_forward(dev(t, X), dev(t, adj), Wd, bd, dev(t, w.Wlin), dev(t, w.blin), emb_nlayer=2)
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=H_A2, Y_A=Y_A, nnodes=adj.shape[0], loss_type="CE",
+                          device="cuda:0")
+    model.attack(_args(str(z["measure"])), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]),
+                 fadj, 0, 0, 0, None, None, z["idx_test"], adj, X, np.zeros_like(adj), lab, z["idx_attack"],
+                 float(z["num_edges"]), 0, epochs=int(z["epochs"]),
+                 label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    final = model.modified_adj.cpu().numpy()
+    auc = O.metric_pool(adj, final, z["idx_attack"])
+    assert abs(auc - float(z["auc"])) <= 1e-4, (auc, float(z["auc"]))
+    sp = z["sample_pos"]
+    assert np.abs(final[sp[:, 0], sp[:, 1]] - z["final_sample"]).max() < 5e-3
+    assert abs(final.astype(np.float64).sum() - float(z["final_sum"])) <= 1e-4 * abs(float(z["final_sum"]))
