@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""attack-steps/sec of the MC-GRA adjacency-optimisation hot path on MI355X.
+
+One "step" = one iteration of PGDAttack.attack's loop (topology_attack.py:161-298):
+forward over the learnable N x N adjacency, HSIC/entropy/CE losses against the
+H_A / Y_A / Y priors, backward into the adjacency, Adam + projection, and the
+per-step monitoring forward (:290-296).  Inputs are resident in HBM before the
+timed region.  Prints ONE JSON line (rank 0).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synthetic-10k-hsic|cora-shape-hsic|...]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU).  In this round the
+ranks run independent replicas of the workload (no data-path collective); the
+row-block sharded step is DESIGN.md section (e).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+WORKLOADS = {
+    # name: (N, nfeat, nclass, hidden, nlayer, measure, weight_param)
+    "synthetic-10k-hsic": (10000, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    "synthetic-10k-mse": (10000, 128, 7, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    "cora-shape-hsic": (2708, 1433, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    "cora-shape-mse": (2708, 1433, 7, 16, 2, "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    "synthetic-4k-hsic": (4096, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+}
+
+
+def make_inputs(n, f, c, hid, nlayer, seed):
+    """Synthetic homophilous graph of the workload's shape + random-init victim GCN
+    (GraphConvolution.reset_parameters, models/gcn.py:28-33; nn.Linear default)."""
+    rng = np.random.RandomState(seed)
+    labels = rng.randint(0, c, size=n)
+    centers = rng.randn(c, f).astype(np.float32)
+    feats = ((centers[labels] * 0.6 + rng.randn(n, f).astype(np.float32) * 0.8) > 0.5).astype(np.float32)
+    # sparse symmetric adjacency, ~8 expected neighbours, 3:1 intra-class preference
+    deg = 8.0
+    p_in, p_out = 3.0 * deg / n / (3.0 / c + (1 - 1.0 / c)), deg / n / (3.0 / c + (1 - 1.0 / c))
+    adj = np.zeros((n, n), np.float32)
+    blk = 2048
+    for i0 in range(0, n, blk):
+        same = labels[i0:i0 + blk, None] == labels[None, :]
+        u = rng.rand(min(blk, n - i0), n).astype(np.float32)
+        adj[i0:i0 + blk] = (u < np.where(same, p_in, p_out))
+    adj = np.triu(adj, 1)
+    adj = adj + adj.T
+    dims = [f] + [hid] * nlayer
+    W, b = [], []
+    for l in range(nlayer):
+        stdv = 1.0 / np.sqrt(dims[l + 1])
+        W.append(rng.uniform(-stdv, stdv, size=(dims[l], dims[l + 1])).astype(np.float32))
+        b.append(rng.uniform(-stdv, stdv, size=(dims[l + 1],)).astype(np.float32))
+    k = 1.0 / np.sqrt(hid)
+    Wlin = rng.uniform(-k, k, size=(c, hid)).astype(np.float32)
+    blin = rng.uniform(-k, k, size=(c,)).astype(np.float32)
+    idx_attack = rng.permutation(n)
+    return dict(adj=adj, features=feats, labels=labels, W=W, b=b, Wlin=Wlin, blin=blin, idx_attack=idx_attack, dims=dims)
+
+
+def feature_adj_cora(feats_dev, torch):
+    """main.dot_product_decode for cora (main.py:44-48), on device (setup, untimed)."""
+    from mc_gra_amd import engine as E
+    Z = E.sgemm(feats_dev, feats_dev, tb=True)
+    Z.sub_(torch.eye(Z.shape[0], device=Z.device)).clamp_(min=0)
+    return torch.sigmoid(Z)
+
+
+def gpu_auc(real, pred, torch):
+    """Mann-Whitney AUC with average ranks for ties (== sklearn roc_curve + auc)."""
+    pred = pred.reshape(-1).double()
+    real = real.reshape(-1) > 0
+    order = torch.argsort(pred)
+    ps = pred[order]
+    n = ps.numel()
+    newgrp = torch.ones(n, dtype=torch.bool, device=ps.device)
+    newgrp[1:] = ps[1:] != ps[:-1]
+    gid = torch.cumsum(newgrp.long(), 0) - 1
+    starts = torch.nonzero(newgrp).flatten()
+    ends = torch.cat([starts[1:], torch.tensor([n], device=ps.device)])
+    avg = (starts + ends - 1).double() * 0.5 + 1.0
+    ranks = torch.empty(n, dtype=torch.float64, device=ps.device)
+    ranks[order] = avg[gid]
+    npos = int(real.sum()); nneg = n - npos
+    return float((ranks[real].sum() - npos * (npos + 1) / 2.0) / (npos * nneg))
+
+
+def cpu_baseline(workload, seed):
+    """Oracle (numpy restatement of the reference CPU path) timed on the host cores on a bounded sample."""
+    from oracle import mcgra_oracle as O
+    n0, f, c, hid, nl, measure, wp = WORKLOADS[workload]
+    ns = min(n0, 3072)
+    inp = make_inputs(ns, f, c, hid, nl, seed)
+    X = inp["features"]
+    Z = X @ X.T
+    fadj = (1.0 / (1.0 + np.exp(-np.maximum(Z - np.eye(ns, dtype=np.float32), 0)))).astype(np.float32)
+    w = O.GCNWeights(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
+    cfg = O.AttackConfig(measure=measure, weight_sup=1.0, weight_param=wp, lr=0.01, num_edges=float("inf"))
+    orc = O.PGDAttackOracle(w, X, inp["adj"], np.zeros((ns, ns), np.float32), fadj, inp["labels"], inp["idx_attack"], cfg)
+    orc.step()                                   # warm-up (BLAS thread pool, page faults)
+    t0 = time.perf_counter(); steps = 0
+    while steps < 2 or (time.perf_counter() - t0 < 10.0 and steps < 50):
+        orc.step(); steps += 1
+    dt = time.perf_counter() - t0
+    v = steps / dt
+    scale = (ns / n0) ** 3 if measure in ("HSIC",) else (ns / n0) ** 2
+    return dict(value=v, unit="attack-steps/s", cores=os.cpu_count(), kind="port",
+                sample=f"{steps} oracle steps at N={ns} (same generator/config as the workload, numpy+BLAS on "
+                       f"{os.cpu_count()} host threads); N={n0} estimate by {'N^3' if measure == 'HSIC' else 'N^2'} "
+                       f"scaling = {v * scale:.4g} steps/s",
+                scaled_to_workload=v * scale)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="synthetic-10k-hsic", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-monitor", action="store_true", help="skip the per-step monitoring forward (:290-296)")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    import mcgra_loader
+    pkg = mcgra_loader.load()
+
+    n, f, c, hid, nl, measure, wp = WORKLOADS[a.workload]
+    inp = make_inputs(n, f, c, hid, nl, a.seed + rank)          # replicas: every rank its own graph
+    X = torch.as_tensor(inp["features"], device=dev)
+    fadj = feature_adj_cora(X, torch)
+    eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, 1.0, wp, 0.01, 1e30, n, device=dev)
+    eng.set_model(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
+    adj_dev = torch.as_tensor(inp["adj"], device=dev)
+    eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
+    monitor = not a.no_monitor
+
+    def one_step():
+        eng.step()
+        if monitor:
+            eng.monitor()
+
+    for _ in range(a.warmup):
+        one_step()
+    eng.profile(True); eng.gemm_stats(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st = eng.gemm_stats(reset=True)
+    eng.profile(False)
+
+    # recovered-adjacency AUC of the run (post-loop ensemble, topology_attack.py:300-324), untimed
+    lab = torch.as_tensor(inp["labels"], device=dev)
+    label_adj = (lab[:, None] == lab[None, :]).float()
+    H_A = eng.buffer("HA"); Y_A = eng.buffer("YA")
+    final = eng.finalize(0, H_A, Y_A, label_adj)
+    auc = gpu_auc(adj_dev, final, torch)
+
+    if rank == 0:
+        out = {
+            "metric": "attack-steps/sec", "value": world * a.steps / dt, "unit": "attack-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": a.workload, "nodes": n, "features": f, "gcn_layers": nl, "hidden": hid,
+                       "classes": c, "measure": measure, "priors": "H_A+Y_A+Y", "weight_param": list(wp),
+                       "monitor_forward": monitor, "parallelism": "replicas" if world > 1 else "single"},
+            "auc": auc,
+        }
+        if st["launches"]:
+            avg_ms = st["ms"] / st["launches"]
+            ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (N x N x N products of linear_HSIC)",
+                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
+                               "gemm_share_of_step": st["ms"] / (1e3 * dt)}
+        else:
+            out["roofline"] = None
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

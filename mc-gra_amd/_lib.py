@@ -7,6 +7,12 @@ calling into it without a HIP device, raises.
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  It must be the
+# first HIP runtime mapped into the process, otherwise torch binds to the system one and
+# loses the device; libmcgra_hip.so then resolves its libamdhip64.so.7 to the loaded copy,
+# so device pointers and streams are shared with torch.
+import torch  # noqa: F401  isort:skip
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcgra_hip.so")
 

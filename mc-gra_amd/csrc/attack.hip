@@ -65,7 +65,7 @@ struct mcgra_attack {
   std::vector<void*> allocs;
   // N x N
   float *M = 0, *am = 0, *av = 0, *ADJN = 0, *A1 = 0, *G_ADJN = 0, *G_A1 = 0, *G_A = 0;
-  float *KX = 0, *KY = 0, *KFC = 0, *FADJ = 0, *GSYM = 0;
+  float *KX = 0, *KY = 0, *KFC = 0, *FADJ = 0, *GSYM = 0, *XC = 0, *YC = 0;
   // vectors
   float *d = 0, *r = 0, *rowpart = 0, *colpart = 0, *gd = 0, *nrm = 0, *cnt = 0, *rowmin = 0, *rowmax = 0, *mm = 0;
   double *rowsq = 0, *rowsum = 0, *rowvals = 0, *rowsx = 0, *rowsy = 0, *scal = 0;
@@ -225,7 +225,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
 #define A_(p, cnt) if (!rc) rc = dalloc(h, &h->p, (cnt))
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn); A_(GSYM, nn);
-  if (cfg->measure == MCGRA_MEASURE_HSIC) { A_(KY, nn); A_(KFC, nn); }
+  if (cfg->measure == MCGRA_MEASURE_HSIC) { A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn); }
   A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
   A_(rowmin, ld); A_(rowmax, ld); A_(mm, 4);
   A_(rowsq, 2 * ld); h->rowsum = h->rowsq ? h->rowsq + n : nullptr;
@@ -305,11 +305,10 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   launch_gather_rows(st, h->na, h->C, h->YA, h->C, h->idx, h->YAc, h->hmax);
   launch_colmean_center(st, h->na, h->C, h->YAc, h->hmax);
   if (h->cfg.measure == MCGRA_MEASURE_HSIC && h->cfg.w[0] != 0.f) {
-    // centred Gram of feature_adj: constant left factor of c1 (utils.py:1086,1089)
-    CHK(eg(h, st, false, true, n, n, n, 1.f, h->FADJ, ld, h->FADJ, ld, 0.f, h->KFC, ld));
-    launch_rowsum(st, n, ld, h->KFC, h->rowsx);
-    launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_TOTX);
-    launch_center(st, n, ld, h->KFC, h->rowsx, h->scal + S_TOTX);
+    // centred Gram of feature_adj: constant left factor of c1 (utils.py:1086,1089), from centred columns
+    launch_rowsum(st, n, ld, h->FADJ, h->rowsx);
+    launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->XC);
+    CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
   }
   MCGRA_KERNEL_CHECK();
   // feature_adj.max() != feature_adj.min() (topology_attack.py:212) is evaluated by the host layer
@@ -340,7 +339,10 @@ static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Y
   if (h->cfg.measure == MCGRA_MEASURE_MSE) {
     launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot);   // sum of squares
     launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
-  } else {  // HSIC: value |Xc^T Y|_F^2, gradient 2 Xc (Xc^T Y)   (utils.py:1085-1089)
+  } else {  // HSIC: value |Xc^T Yc|_F^2, gradient 2 Xc (Xc^T Yc)   (utils.py:1085-1089)
+    // Y is centred explicitly: Xc^T Y == Xc^T Yc only in exact arithmetic, and with identical rows of Y
+    // (adj_changes == 0) the fp32 residue of Xc's column sums would otherwise be the whole "gradient"
+    launch_colmean_center(st, na, width, h->Yg, hm);
     MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
     CHK(eg(h, st, true, false, width, width, na, 1.f, Xc, hm, h->Yg, hm, 0.f, h->Q, hm));
     launch_sumsq(st, (size_t)width * hm, h->Q, h->scal + slot);              // pad columns of Q are zero
@@ -456,20 +458,21 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
     if (use1 || use2) {
       const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
-      CHK(eg(h, st, false, true, n, n, n, 1.f, h->ADJN, ld, h->ADJN, ld, 0.f, h->KX, ld));        // Kx = X X^T
-      launch_rowsum(st, n, ld, h->KX, h->rowsx);
-      launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_TOTX);
+      // adj_norm and A1 are symmetric here (ori == 0, eps == 0): column means == row means
+      launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
+      launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
+      CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KX, ld));            // H Kx H
       if (use2) {
-        CHK(eg(h, st, false, true, n, n, n, 1.f, h->A1, ld, h->A1, ld, 0.f, h->KY, ld));          // Ky = Y Y^T
-        launch_rowsum(st, n, ld, h->KY, h->rowsy);
-        launch_reduce_rows(st, h->rowsy, n, 1, h->scal + S_TOTY);
+        launch_rowsum(st, n, ld, h->A1, h->rowsy);
+        launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
+        CHK(eg(h, st, false, true, n, n, n, 1.f, h->YC, ld, h->YC, ld, 0.f, h->KY, ld));          // H Ky H
       }
-      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, h->rowsx, h->scal + S_TOTX, h->rowsy, h->scal + S_TOTY,
-                          use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->rowvals + 4 * (size_t)ld);
+      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f,
+                          h->rowvals + 4 * (size_t)ld);
       launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
-      // G_adjn += 2 (s1 Kfc + s2 Kyc) @ adj_norm ;  G_A1 += 2 s2 Kxc @ A1
-      CHK(eg(h, st, false, false, n, n, n, 1.f, h->KY, ld, h->ADJN, ld, 1.f, h->G_ADJN, ld));
-      if (use2) CHK(eg(h, st, false, false, n, n, n, 1.f, h->KX, ld, h->A1, ld, 1.f, h->G_A1, ld));
+      // G_adjn += 2 (s1 Kfc + s2 Kyc) @ Xc ;  G_A1 += 2 s2 Kxc @ Yc   (K 1 = 0, so Xc may replace X)
+      CHK(eg(h, st, false, false, n, n, n, 1.f, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
+      if (use2) CHK(eg(h, st, false, false, n, n, n, 1.f, h->KX, ld, h->YC, ld, 1.f, h->G_A1, ld));
     }
   }
 

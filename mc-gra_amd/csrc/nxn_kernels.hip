@@ -211,23 +211,37 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center(int n, int ld, float* __
   }
 }
 
-// linear_HSIC on N x N operands (utils.py:1085-1089), value + left factors of
-// the gradient GEMMs.  KX = X X^T, KY = Y Y^T (uncentred, symmetric), KFC =
-// centred Gram of feature_adj (constant).  On exit
-//   KY <- 2*(s1*KFC + s2*centre(KY))   so that  G_X += KY @ X
-//   KX <- 2*s2*centre(KX)              so that  G_Y += KX @ Y
-// rowvals[0][i] = sum_j KFC_ij*KX_ij (c1), rowvals[1][i] = sum_j KXc_ij*KYc_ij (c2).
-__global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
-    int n, int ld, float* __restrict__ KX, float* __restrict__ KY, const float* __restrict__ KFC,
-    const double* __restrict__ rowsx, const double* __restrict__ totx,
-    const double* __restrict__ rowsy, const double* __restrict__ toty, float s1, float s2,
-    double* __restrict__ rowvals) {
-  __shared__ double shd[16];
+// Column-centre a symmetric matrix: out_ij = X_ij - colmean_j, colmean_j = rows[j] / n
+// (row sums == column sums by symmetry).  H X of CudaCKA.centering (utils.py:1060-1065):
+// H X X^T H = (H X)(H X)^T, so the centred Gram is formed from centred operands.  This is the
+// same matrix as centring the Gram afterwards, but the fp32 GEMM then sums zero-mean products
+// instead of cancelling an O(n) mean (measured on Cora's feature_adj: 3e-7 vs 2e-4 relative).
+__global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, const float* __restrict__ X,
+                                                             const double* __restrict__ rows,
+                                                             float* __restrict__ out) {
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   const double inv = 1.0 / n;
-  const double rxi = rowsx[i] * inv, tx = totx[0] * inv * inv;
-  const double ryi = (s2 != 0.f) ? rowsy[i] * inv : 0.0, ty = (s2 != 0.f) ? toty[0] * inv * inv : 0.0;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(X + base + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = (j + t < n) ? (float)((double)x[t] - rows[j + t] * inv) : 0.f;
+    *reinterpret_cast<f32x4*>(out + base + j) = x;
+  }
+}
+
+// linear_HSIC on N x N operands (utils.py:1085-1089), value + left factors of
+// the gradient GEMMs.  KX = Xc Xc^T, KY = Yc Yc^T (centred Grams), KFC = centred
+// Gram of feature_adj (constant).  On exit
+//   KY <- 2*(s1*KFC + s2*KY)   so that  G_X += KY @ Xc
+//   KX <- 2*s2*KX              so that  G_Y += KX @ Yc
+// rowvals[0][i] = sum_j KFC_ij*KX_ij (c1), rowvals[1][i] = sum_j KX_ij*KY_ij (c2).
+__global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
+    int n, int ld, float* __restrict__ KX, float* __restrict__ KY, const float* __restrict__ KFC,
+    float s1, float s2, double* __restrict__ rowvals) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
   double v1 = 0, v2 = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     f32x4 kx = *reinterpret_cast<f32x4*>(KX + base + j);
@@ -239,13 +253,10 @@ __global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
     for (int t = 0; t < 4; ++t) {
       float a = 0.f, b = 0.f;
       if (j + t < n) {
-        const float kxc = (float)((double)kx[t] - rxi - rowsx[j + t] * inv + tx);
-        float kyc = 0.f;
-        if (s2 != 0.f) kyc = (float)((double)ky[t] - ryi - rowsy[j + t] * inv + ty);
         v1 += (double)kf[t] * kx[t];
-        v2 += (double)kxc * kyc;
-        a = 2.f * s2 * kxc;
-        b = 2.f * (s1 * kf[t] + s2 * kyc);
+        v2 += (double)kx[t] * ky[t];
+        a = 2.f * s2 * kx[t];
+        b = 2.f * (s1 * kf[t] + s2 * ky[t]);
       }
       ox[t] = a; oy[t] = b;
     }
@@ -578,10 +589,12 @@ void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows) 
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total) {
   LAUNCH(k_center, dim3(n), dim3(ROW_THREADS), st, n, ld, K, rows, total);
 }
-void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC,
-                         const double* rowsx, const double* totx, const double* rowsy, const double* toty,
-                         float s1, float s2, double* rowvals) {
-  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, rowsx, totx, rowsy, toty, s1, s2, rowvals);
+void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out) {
+  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, rows, out);
+}
+void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
+                         double* rowvals) {
+  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals);
 }
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {
