@@ -151,6 +151,10 @@ def main():
     eng.set_model(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
     adj_dev = torch.as_tensor(inp["adj"], device=dev)
     eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
+    # seeded non-zero start: with measure=HSIC the origin is a fixed point of the exact dynamics
+    # (DESIGN.md section 5, fact 2), so a zero start would time a run that optimises nothing
+    g = torch.Generator(device=dev); g.manual_seed(a.seed + 1000 + rank)
+    eng.set_adj_changes(torch.rand(n * (n - 1) // 2, device=dev, generator=g) * 0.05)
     monitor = not a.no_monitor
 
     def one_step():

@@ -59,6 +59,20 @@ int mcgra_sgemm(void* stream, int ta, int tb, int m, int n, int k, float alpha,
                 const float* A, int lda, const float* B, int ldb, float beta,
                 float* C, int ldc);
 
+/* Symmetric variants used for the Gram matrices of linear_HSIC (utils.py:1086-1089).
+ * "Lower tile storage": element (i,j) of an n x n symmetric matrix is valid iff
+ * j < (i/128 + 1) * 128, i.e. the 128 x 128 tiles on or below the diagonal.
+ *   mcgra_ssyrk_lower: C = alpha A A^T + beta C, A [n x k]; writes lower tile storage only.
+ *   mcgra_ssymm_lower: C[n x m] = alpha S B + beta C, S [n x n] read from lower tile storage. */
+int mcgra_ssyrk_lower(void* stream, int n, int k, float alpha, const float* A, int lda,
+                      float beta, float* C, int ldc);
+int mcgra_ssymm_lower(void* stream, int n, int m, float alpha, const float* S, int lds,
+                      const float* B, int ldb, float beta, float* C, int ldc);
+
+/* Tuning knob for A/B measurements in one process: 2 = double-buffered LDS K loop
+ * (default), 1 = single LDS stage with two barriers per K tile.  Same results bit for bit. */
+int mcgra_set_gemm_variant(int v);
+
 /* ------------------------------------------------------- standalone ops --
  * Each mirrors one reference function on its own inputs; the attack engine
  * below runs fused forms of the same kernels. */

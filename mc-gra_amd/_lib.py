@@ -21,7 +21,8 @@ MEASURES = {"HSIC": 0, "MSELoss": 1, "KL": 2, "CKA": 3, "DP": 4}
 
 # every symbol include/mcgra.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
-    "mcgra_version", "mcgra_last_error", "mcgra_device_count", "mcgra_sgemm",
+    "mcgra_version", "mcgra_last_error", "mcgra_device_count", "mcgra_sgemm", "mcgra_set_gemm_variant",
+    "mcgra_ssyrk_lower", "mcgra_ssymm_lower",
     "mcgra_get_modified_adj", "mcgra_pack_tril", "mcgra_normalize_adj", "mcgra_info_entropy",
     "mcgra_dot_product_decode", "mcgra_linear_hsic", "mcgra_mse", "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
@@ -62,6 +63,9 @@ def _load():
     sig = {
         "mcgra_sgemm": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp, C.c_int, fp, C.c_int,
                         C.c_float, fp, C.c_int],
+        "mcgra_set_gemm_variant": [C.c_int],
+        "mcgra_ssyrk_lower": [vp, C.c_int, C.c_int, C.c_float, fp, C.c_int, C.c_float, fp, C.c_int],
+        "mcgra_ssymm_lower": [vp, C.c_int, C.c_int, C.c_float, fp, C.c_int, fp, C.c_int, C.c_float, fp, C.c_int],
         "mcgra_get_modified_adj": [vp, C.c_int, fp, fp, fp],
         "mcgra_pack_tril": [vp, C.c_int, fp, C.c_int, fp],
         "mcgra_normalize_adj": [vp, C.c_int, fp, fp],

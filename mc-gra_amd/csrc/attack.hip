@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -84,6 +85,7 @@ struct mcgra_attack {
   size_t ws_bytes = 0;
   int nstrips = 32;
   bool profile = false;
+  bool use_sym = true;             // SYRK / SYMM on lower tile storage for the linear_HSIC Grams (MCGRA_NO_SYM=1 disables)
   GemmTimer timer;
 };
 
@@ -109,26 +111,51 @@ static int dalloc(mcgra_attack* h, T** p, size_t count) {
   return 0;
 }
 
+// HIP-event bracket around the N x N x N launches of the MFMA GEMM (roofline numbers of bench.py)
+static int timer_begin(mcgra_attack* h, hipStream_t st, bool big) {
+  if (!big) return 0;
+  GemmTimer& T = h->timer;
+  if (T.used + 2 > T.ev.size()) {
+    for (int i = 0; i < 2; ++i) { hipEvent_t e; MCGRA_HIP(hipEventCreate(&e)); T.ev.push_back(e); }
+  }
+  MCGRA_HIP(hipEventRecord(T.ev[T.used], st));
+  return 0;
+}
+static int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops) {
+  if (!big) return 0;
+  GemmTimer& T = h->timer;
+  MCGRA_HIP(hipEventRecord(T.ev[T.used + 1], st));
+  T.used += 2;
+  T.launches += 1;
+  T.flops += flops;     // multiply-adds actually issued (a SYRK launch counts its lower tiles only)
+  return 0;
+}
+
 // every GEMM of the engine goes through here (timed when profiling)
 static int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A,
               int lda, const float* B, int ldb, float beta, float* C, int ldc) {
   const bool big = h->profile && (double)M * N * K >= 0.25 * (double)h->n * h->n * h->n;
-  if (big) {
-    GemmTimer& T = h->timer;
-    if (T.used + 2 > T.ev.size()) {
-      for (int i = 0; i < 2; ++i) { hipEvent_t e; MCGRA_HIP(hipEventCreate(&e)); T.ev.push_back(e); }
-    }
-    MCGRA_HIP(hipEventRecord(T.ev[T.used], st));
-  }
+  CHK(timer_begin(h, st, big));
   MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws, h->ws_bytes));
-  if (big) {
-    GemmTimer& T = h->timer;
-    MCGRA_HIP(hipEventRecord(T.ev[T.used + 1], st));
-    T.used += 2;
-    T.launches += 1;
-    T.flops += 2.0 * M * N * K;
-  }
-  return 0;
+  return timer_end(h, st, big, 2.0 * M * N * K);
+}
+// C = A A^T (A is [n x k]); sym: lower tile storage only
+static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, const float* A, int lda, float* C, int ldc) {
+  if (!sym) return eg(h, st, false, true, n, n, k, 1.f, A, lda, A, lda, 0.f, C, ldc);
+  const bool big = h->profile;
+  CHK(timer_begin(h, st, big));
+  MCGRA_HIP(ssyrk_lower(st, n, k, 1.f, A, lda, 0.f, C, ldc));
+  const double t = (n + SYM_TILE - 1) / SYM_TILE;
+  return timer_end(h, st, big, 2.0 * (t * (t + 1) / 2) * SYM_TILE * SYM_TILE * k);
+}
+// C = S B + beta C (S symmetric [n x n], B [n x m]); sym: S is in lower tile storage
+static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, const float* S, int lds_, const float* B,
+                   int ldb, float beta, float* C, int ldc) {
+  if (!sym) return eg(h, st, false, false, n, m, n, 1.f, S, lds_, B, ldb, beta, C, ldc);
+  const bool big = h->profile;
+  CHK(timer_begin(h, st, big));
+  MCGRA_HIP(ssymm_lower(st, n, m, 1.f, S, lds_, B, ldb, beta, C, ldc));
+  return timer_end(h, st, big, 2.0 * n * (double)m * n);
 }
 
 // x = relu(adj @ (x W_l) + b_l) for `depth` layers (models/gcn.py:71-76,164-172).
@@ -204,6 +231,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   }
   mcgra_attack* h = new mcgra_attack();
   h->cfg = *cfg;
+  { const char* e = getenv("MCGRA_NO_SYM"); h->use_sym = !(e && e[0] == '1'); }
   h->n = cfg->n;
   h->ld = (cfg->n + 3) & ~3;
   h->L = cfg->nlayer;
@@ -461,18 +489,22 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
       // adj_norm and A1 are symmetric here (ori == 0, eps == 0): column means == row means
       launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
       launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
-      CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KX, ld));            // H Kx H
+      // Grams are symmetric: only the 128x128 tiles on or below the diagonal are computed (lower tile
+      // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
+      // step instead of 4.
+      const bool sym = h->use_sym;
+      CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld));                                       // H Kx H
       if (use2) {
         launch_rowsum(st, n, ld, h->A1, h->rowsy);
         launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
-        CHK(eg(h, st, false, true, n, n, n, 1.f, h->YC, ld, h->YC, ld, 0.f, h->KY, ld));          // H Ky H
+        CHK(eg_syrk(h, st, sym, n, n, h->YC, ld, h->KY, ld));                                     // H Ky H
       }
       launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f,
-                          h->rowvals + 4 * (size_t)ld);
+                          h->rowvals + 4 * (size_t)ld, sym);
       launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
       // G_adjn += 2 (s1 Kfc + s2 Kyc) @ Xc ;  G_A1 += 2 s2 Kxc @ Yc   (K 1 = 0, so Xc may replace X)
-      CHK(eg(h, st, false, false, n, n, n, 1.f, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
-      if (use2) CHK(eg(h, st, false, false, n, n, n, 1.f, h->KX, ld, h->YC, ld, 1.f, h->G_A1, ld));
+      CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
+      if (use2) CHK(eg_symm(h, st, sym, n, n, h->KX, ld, h->YC, ld, 1.f, h->G_A1, ld));
     }
   }
 

@@ -39,6 +39,24 @@ int mcgra_sgemm(void* stream, int ta, int tb, int m, int n, int k, float alpha, 
   return 0;
 }
 
+int mcgra_ssyrk_lower(void* stream, int n, int k, float alpha, const float* A, int lda, float beta, float* C, int ldc) {
+  if (n < 1 || k < 0 || !A || !C) { set_error("bad argument"); return MCGRA_EINVAL; }
+  MCGRA_HIP(ssyrk_lower((hipStream_t)stream, n, k, alpha, A, lda, beta, C, ldc));
+  return 0;
+}
+
+int mcgra_ssymm_lower(void* stream, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
+                      float beta, float* C, int ldc) {
+  if (n < 1 || m < 1 || !S || !B || !C) { set_error("bad argument"); return MCGRA_EINVAL; }
+  MCGRA_HIP(ssymm_lower((hipStream_t)stream, n, m, alpha, S, lds_, B, ldb, beta, C, ldc));
+  return 0;
+}
+
+int mcgra_set_gemm_variant(int v) {
+  set_gemm_variant(v);
+  return 0;
+}
+
 int mcgra_get_modified_adj(void* stream, int n, const float* adj_changes, const float* ori_adj, float* out) {
   if (n < 1 || !adj_changes || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
   launch_unpack_sym((hipStream_t)stream, n, n, adj_changes, ori_adj, n, out);

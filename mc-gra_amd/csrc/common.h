@@ -25,6 +25,16 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                  float* ws, size_t ws_bytes);
 
+void set_gemm_variant(int v);
+
+// "Lower tile storage" of a symmetric n x n matrix: element (i, j) is valid iff
+// j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.
+constexpr int SYM_TILE = 128;
+hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A, int lda, float beta, float* C,
+                       int ldc);
+hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
+                       float beta, float* C, int ldc);
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

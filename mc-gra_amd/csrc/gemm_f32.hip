@@ -18,7 +18,15 @@
 //    step t takes k = kc + t on lanes 0-31 and k = kc + 4 + t on lanes 32-63,
 //    which is legal because the MFMA sums over k;
 //  * global -> LDS goes through registers (one tile prefetched while the
-//    current one is multiplied), 16-byte loads when pointers/ld allow.
+//    current one is multiplied), 16-byte loads when pointers/ld allow;
+//  * two LDS stages, one barrier per K tile.
+//
+// Symmetric variants (the Grams of linear_HSIC are symmetric, and so are the
+// left factors of its gradient products):
+//  * SYM_RK  C = A A^T: only the tiles with tile_n <= tile_m are computed
+//    ("lower tile storage": element (i,j) is valid iff j < (i/BM + 1) * BM);
+//  * SYM_MM  C = S B with S in lower tile storage: for K tiles right of the
+//    diagonal tile the A operand is loaded transposed from S[k][m].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,22 +38,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_THREADS = 256;
+enum { SYM_NONE = 0, SYM_RK = 1, SYM_MM = 2 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC>
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
 struct GemmCfg {
   static constexpr int KPAD = 4;
-  // A tile in LDS: KC layout [BM][BK+KPAD] when !TA, XC layout [BK][BM] when TA
-  static constexpr int A_ROWS = TA ? BK : BM;
-  static constexpr int A_COLS = TA ? BM : BK;
-  static constexpr int A_LD = TA ? BM : BK + KPAD;
-  // B tile: XC layout [BK][BN] when !TB, KC layout [BN][BK+KPAD] when TB
-  static constexpr int B_ROWS = TB ? BN : BK;
-  static constexpr int B_COLS = TB ? BK : BN;
-  static constexpr int B_LD = TB ? BK + KPAD : BN;
-  static constexpr int A_ELEMS = A_ROWS * A_LD;
-  static constexpr int B_ELEMS = B_ROWS * B_LD;
-  static constexpr int A_V4 = A_ROWS * A_COLS / 4;  // float4 per tile
-  static constexpr int B_V4 = B_ROWS * B_COLS / 4;
+  // KC layout [rows][BK+KPAD]; XC layout [BK][cols]
+  static constexpr int A_LD_KC = BK + KPAD, A_LD_XC = BM;
+  static constexpr int B_LD_KC = BK + KPAD, B_LD_XC = BN;
+  static constexpr int A_ELEMS = (BM * A_LD_KC > BK * A_LD_XC) ? BM * A_LD_KC : BK * A_LD_XC;  // either layout fits
+  static constexpr int B_ELEMS = TB ? BN * B_LD_KC : BK * B_LD_XC;
+  static constexpr int A_V4 = BM * BK / 4;  // float4 per tile
+  static constexpr int B_V4 = BN * BK / 4;
   static constexpr int A_PER_T = (A_V4 + GEMM_THREADS - 1) / GEMM_THREADS;
   static constexpr int B_PER_T = (B_V4 + GEMM_THREADS - 1) / GEMM_THREADS;
   static constexpr int TM = WM / 32, TN = WN / 32;
@@ -73,37 +77,49 @@ __device__ __forceinline__ f32x4 load_v4(const float* __restrict__ base, int ld,
   return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC>
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, int NBUF, int SYM>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
     int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n) {
-  using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB, VEC>;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::A_ELEMS + Cfg::B_ELEMS];
+  using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STAGE = Cfg::A_ELEMS + Cfg::B_ELEMS;
   float* As = smem;
   float* Bs = smem + Cfg::A_ELEMS;
 
   // ---- block -> tile map: XCD-aware (blocks b and b+8 share an XCD's L2), then
   // GROUP_M-row panels so co-resident tiles share A row-panels and B col-panels.
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
+  int tile_m, tile_n;
   {
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (SYM == SYM_RK) {  // bid enumerates the lower triangle row by row: bid = tm (tm+1)/2 + tn
+      int tm = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
+      while ((tm + 1) * (tm + 2) / 2 <= bid) ++tm;
+      while (tm * (tm + 1) / 2 > bid) --tm;
+      tile_m = tm;
+      tile_n = bid - tm * (tm + 1) / 2;
+    } else {
+      constexpr int GROUP_M = 8;
+      const int group_sz = GROUP_M * tiles_n;
+      const int group_id = bid / group_sz;
+      const int first_m = group_id * GROUP_M;
+      const int gm = min(tiles_m - first_m, GROUP_M);
+      tile_m = first_m + (bid % group_sz) % gm;
+      tile_n = (bid % group_sz) / gm;
+    }
   }
-  constexpr int GROUP_M = 8;
-  const int group_sz = GROUP_M * tiles_n;
-  const int group_id = bid / group_sz;
-  const int first_m = group_id * GROUP_M;
-  const int gm = min(tiles_m - first_m, GROUP_M);
-  const int tile_m = first_m + (bid % group_sz) % gm;
-  const int tile_n = (bid % group_sz) / gm;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int kz = blockIdx.z;
   const int k_begin = kz * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
   C += (size_t)kz * c_split_stride;
+  // SYM_MM: K tiles at or beyond this column lie right of the diagonal tile of S
+  const int sym_split = (tile_m + 1) * BM;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -122,60 +138,78 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   f32x4 ra[Cfg::A_PER_T], rb[Cfg::B_PER_T];
 
+  // at = "A tile is read from global as [k][m]" (TA, or the mirrored half of a symmetric S)
+  auto a_transposed = [&](int k0) -> bool { return TA || (SYM == SYM_MM && k0 >= sym_split); };
+
   auto load_tiles = [&](int k0) {
+    const bool at = a_transposed(k0);
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
-      constexpr int V4R = Cfg::A_COLS / 4;
-      const int row = f / V4R, c4 = (f % V4R) * 4;
       if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
-        if (TA)  // global [k][m]
-          ra[i] = load_v4<VEC>(A, lda, k0 + row, m0 + c4, k_end, M);
-        else  // global [m][k]
-          ra[i] = load_v4<VEC>(A, lda, m0 + row, k0 + c4, M, k_end);
+        if (at) {  // global [k][m]
+          constexpr int V4R = BM / 4;
+          ra[i] = load_v4<VEC>(A, lda, k0 + f / V4R, m0 + (f % V4R) * 4, k_end, M);
+        } else {  // global [m][k]
+          constexpr int V4R = BK / 4;
+          ra[i] = load_v4<VEC>(A, lda, m0 + f / V4R, k0 + (f % V4R) * 4, M, k_end);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
-      constexpr int V4R = Cfg::B_COLS / 4;
-      const int row = f / V4R, c4 = (f % V4R) * 4;
       if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4) {
-        if (TB)  // global [n][k]
-          rb[i] = load_v4<VEC>(B, ldb, n0 + row, k0 + c4, N, k_end);
-        else  // global [k][n]
-          rb[i] = load_v4<VEC>(B, ldb, k0 + row, n0 + c4, k_end, N);
+        if (TB) {  // global [n][k]
+          constexpr int V4R = BK / 4;
+          rb[i] = load_v4<VEC>(B, ldb, n0 + f / V4R, k0 + (f % V4R) * 4, N, k_end);
+        } else {  // global [k][n]
+          constexpr int V4R = BN / 4;
+          rb[i] = load_v4<VEC>(B, ldb, k0 + f / V4R, n0 + (f % V4R) * 4, k_end, N);
+        }
       }
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](bool at) {
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
-      constexpr int V4R = Cfg::A_COLS / 4;
-      const int row = f / V4R, c4 = (f % V4R) * 4;
-      if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4)
-        *reinterpret_cast<f32x4*>(&As[row * Cfg::A_LD + c4]) = ra[i];
+      if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
+        if (at) {
+          constexpr int V4R = BM / 4;
+          *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_XC + (f % V4R) * 4]) = ra[i];
+        } else {
+          constexpr int V4R = BK / 4;
+          *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_KC + (f % V4R) * 4]) = ra[i];
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
-      constexpr int V4R = Cfg::B_COLS / 4;
-      const int row = f / V4R, c4 = (f % V4R) * 4;
-      if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4)
-        *reinterpret_cast<f32x4*>(&Bs[row * Cfg::B_LD + c4]) = rb[i];
+      if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4) {
+        if (TB) {
+          constexpr int V4R = BK / 4;
+          *reinterpret_cast<f32x4*>(&Bs[(f / V4R) * Cfg::B_LD_KC + (f % V4R) * 4]) = rb[i];
+        } else {
+          constexpr int V4R = BN / 4;
+          *reinterpret_cast<f32x4*>(&Bs[(f / V4R) * Cfg::B_LD_XC + (f % V4R) * 4]) = rb[i];
+        }
+      }
     }
   };
 
   if (k_begin < k_end) {
     load_tiles(k_begin);
-    store_tiles();
+    store_tiles(a_transposed(k_begin));
   }
   __syncthreads();
 
+  int cur = 0;
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const bool has_next = (k0 + BK) < k_end;
     if (has_next) load_tiles(k0 + BK);  // in flight while this tile is multiplied
+    const bool at = a_transposed(k0);
 
 #pragma unroll
     for (int kc = 0; kc < BK; kc += 8) {
@@ -183,23 +217,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         const int x = wm0 + i * 32 + l31;
-        if (!TA) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(&As[x * Cfg::A_LD + kc + 4 * lh]);
+        if (!at) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&As[x * Cfg::A_LD_KC + kc + 4 * lh]);
           af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
         } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) af[i][t] = As[(kc + 4 * lh + t) * Cfg::A_LD + x];
+          for (int t = 0; t < 4; ++t) af[i][t] = As[(kc + 4 * lh + t) * Cfg::A_LD_XC + x];
         }
       }
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
         const int x = wn0 + j * 32 + l31;
         if (TB) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[x * Cfg::B_LD + kc + 4 * lh]);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[x * Cfg::B_LD_KC + kc + 4 * lh]);
           bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
         } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bf[j][t] = Bs[(kc + 4 * lh + t) * Cfg::B_LD + x];
+          for (int t = 0; t < 4; ++t) bf[j][t] = Bs[(kc + 4 * lh + t) * Cfg::B_LD_XC + x];
         }
       }
 #pragma unroll
@@ -210,10 +244,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
           for (int j = 0; j < Cfg::TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    if (has_next) {
-      store_tiles();
+    if (NBUF == 2) {
+      if (has_next) {  // write the other stage, then flip
+        cur ^= 1;
+        As = smem + cur * STAGE;
+        Bs = As + Cfg::A_ELEMS;
+        store_tiles(a_transposed(k0 + BK));
+      }
       __syncthreads();
+    } else {
+      __syncthreads();
+      if (has_next) {
+        store_tiles(a_transposed(k0 + BK));
+        __syncthreads();
+      }
     }
   }
 
@@ -237,30 +281,49 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     }
 }
 
-// out[i] = sum_s slabs[s][i] (+ beta * out[i]) : deterministic split-K combine
+// slabs are [nsplit][M][N] contiguous; out is [M][N] with leading dimension ldc
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, size_t stride, int nsplit,
-                                 float* __restrict__ out, size_t count, float beta) {
+                                 float* __restrict__ out, size_t count, int N, int ldc, float beta) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < count; i += step) {
     float s = 0.f;
     for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * stride + i];
-    out[i] = beta != 0.f ? s + beta * out[i] : s;
+    const size_t o = (ldc == N) ? i : (i / N) * (size_t)ldc + (i % N);
+    out[o] = beta != 0.f ? s + beta * out[o] : s;
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int NBUF, int SYM>
 static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K,
                              float alpha, const float* A, int lda, const float* B, int ldb,
                              float beta, float* C, int ldc, int nsplit, int k_per_split,
                              size_t c_split_stride) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n, 1, nsplit), block(GEMM_THREADS);
-#define MCGRA_GEMM_LAUNCH(TA_, TB_, VEC_)                                                       \
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, TA_, TB_, VEC_>), grid, block, 0, st, \
-                     M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, k_per_split, c_split_stride, \
-                     tiles_m, tiles_n)
-  if (vec) {
+  const int nblk = (SYM == SYM_RK) ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+  dim3 grid(nblk, 1, nsplit), block(GEMM_THREADS);
+#define MCGRA_GEMM_LAUNCH(TA_, TB_, VEC_)                                                                \
+  do {                                                                                                   \
+    using Cfg_ = GemmCfg<BM, BN, BK, WM, WN, TA_, TB_>;                                                  \
+    constexpr size_t smem_ = sizeof(float) * NBUF * (Cfg_::A_ELEMS + Cfg_::B_ELEMS);                     \
+    auto kern_ = gemm_f32_kernel<BM, BN, BK, WM, WN, TA_, TB_, VEC_, NBUF, SYM>;                         \
+    if (smem_ > 64 * 1024) {                                                                             \
+      static bool done_ = false;                                                                         \
+      if (!done_) {                                                                                      \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)smem_);                                                 \
+        if (e_ != hipSuccess) return e_;                                                                 \
+        done_ = true;                                                                                    \
+      }                                                                                                  \
+    }                                                                                                    \
+    hipLaunchKernelGGL(kern_, grid, block, smem_, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,      \
+                       k_per_split, c_split_stride, tiles_m, tiles_n);                                   \
+  } while (0)
+  if (SYM == SYM_RK) {  // A A^T
+    if (vec) MCGRA_GEMM_LAUNCH(false, true, true); else MCGRA_GEMM_LAUNCH(false, true, false);
+  } else if (SYM == SYM_MM) {  // S B
+    if (vec) MCGRA_GEMM_LAUNCH(false, false, true); else MCGRA_GEMM_LAUNCH(false, false, false);
+  } else if (vec) {
     if (!ta && !tb) MCGRA_GEMM_LAUNCH(false, false, true);
     else if (!ta && tb) MCGRA_GEMM_LAUNCH(false, true, true);
     else if (ta && !tb) MCGRA_GEMM_LAUNCH(true, false, true);
@@ -275,8 +338,23 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
   return hipGetLastError();
 }
 
-// Workspace-free entry: no split-K.  `ws`/`ws_bytes` (optional) enable split-K
-// for skinny outputs whose tile grid cannot fill 256 CUs.
+// Tuning knob (mcgra_set_gemm_variant): 2 = double-buffered LDS (default), 1 = single stage.
+static int g_gemm_nbuf = 2;
+void set_gemm_variant(int v) { g_gemm_nbuf = (v == 1) ? 1 : 2; }
+
+template <int NBUF>
+static hipError_t launch_big(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K, float alpha,
+                             const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                             int nsplit, int k_per_split, size_t stride) {
+  return launch_cfg<128, 128, 32, 64, 64, NBUF, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
+                                                          ldc, nsplit, k_per_split, stride);
+}
+
+static inline bool vec_ok(const float* A, int lda, const float* B, int ldb) {
+  return (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0);
+}
+
+// `ws`/`ws_bytes` (optional) enable slab split-K for outputs whose tile grid cannot fill 256 CUs.
 hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha,
                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                  float* ws, size_t ws_bytes) {
@@ -287,7 +365,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     }
     K = 0;
   }
-  const bool vec = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0);
+  const bool vec = vec_ok(A, lda, B, ldb);
   const bool skinny = N <= 32;
   const int BM = 128, BN = skinny ? 32 : 128, BK = 32;
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -306,29 +384,38 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   if (nsplit > 1) {
     const size_t stride = (size_t)M * N;
     if (skinny)
-      e = launch_cfg<128, 32, 32, 32, 32>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
-                                          nsplit, k_per_split, stride);
+      e = launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
+                                                       nsplit, k_per_split, stride);
     else
-      e = launch_cfg<128, 128, 32, 64, 64>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
-                                           nsplit, k_per_split, stride);
+      e = (g_gemm_nbuf == 1 ? launch_big<1> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
+                                                             nsplit, k_per_split, stride);
     if (e != hipSuccess) return e;
-    if (ldc == N) {
-      const size_t cnt = stride;
-      int blocks = (int)min((size_t)2048, (cnt + 255) / 256);
-      hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, stride, nsplit, C, cnt, beta);
-    } else {
-      // strided C: combine row by row
-      for (int r = 0; r < M; ++r)
-        hipLaunchKernelGGL(sum_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws + (size_t)r * N,
-                           stride, nsplit, C + (size_t)r * ldc, (size_t)N, beta);
-    }
+    const int blocks = (int)min((size_t)2048, (stride + 255) / 256);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, stride, nsplit, C, stride, N, ldc, beta);
     return hipGetLastError();
   }
   if (skinny)
-    return launch_cfg<128, 32, 32, 32, 32>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 1,
-                                           K, 0);
-  return launch_cfg<128, 128, 32, 64, 64>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 1, K,
-                                          0);
+    return launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                                                        1, K, 0);
+  return (g_gemm_nbuf == 1 ? launch_big<1> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
+                                                            ldc, 1, K, 0);
+}
+
+// C = alpha A A^T + beta C on the lower tile storage (tiles of SYM_TILE = 128 with tile_n <= tile_m);
+// elements outside that region are not touched.  A is [n x k].
+hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A, int lda, float beta, float* C,
+                       int ldc) {
+  if (n <= 0) return hipSuccess;
+  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_RK>(st, false, true, vec_ok(A, lda, A, lda), n, n, k, alpha,
+                                                               A, lda, A, lda, beta, C, ldc, 1, k, 0);
+}
+
+// C[n x m] = alpha S B + beta C with S [n x n] symmetric in lower tile storage, B [n x m].
+hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
+                       float beta, float* C, int ldc) {
+  if (n <= 0 || m <= 0) return hipSuccess;
+  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM>(st, false, false, vec_ok(S, lds_, B, ldb), n, m, n, alpha,
+                                                               S, lds_, B, ldb, beta, C, ldc, 1, n, 0);
 }
 
 }  // namespace mcgra

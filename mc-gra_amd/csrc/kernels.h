@@ -20,7 +20,7 @@ void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows);
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total);
 void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out);
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
-                         double* rowvals);
+                         double* rowvals, bool lower);
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);

@@ -238,12 +238,17 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, cons
 // rowvals[0][i] = sum_j KFC_ij*KX_ij (c1), rowvals[1][i] = sum_j KX_ij*KY_ij (c2).
 __global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
     int n, int ld, float* __restrict__ KX, float* __restrict__ KY, const float* __restrict__ KFC,
-    float s1, float s2, double* __restrict__ rowvals) {
+    float s1, float s2, double* __restrict__ rowvals, int lower) {
   __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   double v1 = 0, v2 = 0;
-  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+  // lower != 0: KX / KY are in lower tile storage (common.h).  Only that region is read and
+  // written; tiles left of the diagonal tile stand for their mirror image too (weight 2).
+  const int jdiag = lower ? (i / SYM_TILE) * SYM_TILE : 0;
+  const int jend = lower ? min(n, jdiag + SYM_TILE) : n;
+  for (int j = threadIdx.x * 4; j < jend; j += ROW_THREADS * 4) {
+    const double wgt = (lower && j < jdiag) ? 2.0 : 1.0;
     f32x4 kx = *reinterpret_cast<f32x4*>(KX + base + j);
     f32x4 ky = {0, 0, 0, 0}, kf = {0, 0, 0, 0};
     if (s2 != 0.f) ky = *reinterpret_cast<f32x4*>(KY + base + j);
@@ -253,8 +258,8 @@ __global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
     for (int t = 0; t < 4; ++t) {
       float a = 0.f, b = 0.f;
       if (j + t < n) {
-        v1 += (double)kf[t] * kx[t];
-        v2 += (double)kx[t] * ky[t];
+        v1 += wgt * ((double)kf[t] * kx[t]);
+        v2 += wgt * ((double)kx[t] * ky[t]);
         a = 2.f * s2 * kx[t];
         b = 2.f * (s1 * kf[t] + s2 * ky[t]);
       }
@@ -593,8 +598,8 @@ void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const dou
   LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, rows, out);
 }
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
-                         double* rowvals) {
-  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals);
+                         double* rowvals, bool lower) {
+  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals, lower ? 1 : 0);
 }
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {

@@ -48,6 +48,26 @@ def sgemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
     return out
 
 
+def ssyrk_lower(A, out=None):
+    """C = A A^T on the lower tile storage (128 x 128 tiles on or below the diagonal); the rest of
+    `out` is left untouched (mcgra_ssyrk_lower)."""
+    n, k = A.shape
+    if out is None:
+        out = torch.zeros(n, n, device=A.device, dtype=torch.float32)
+    check(lib.mcgra_ssyrk_lower(_stream(), n, k, 1.0, _p(A), A.stride(0), 0.0, _p(out), out.stride(0)))
+    return out
+
+
+def ssymm_lower(S, B, beta=0.0, out=None):
+    """C = S B with symmetric S read from its lower tile storage only (mcgra_ssymm_lower)."""
+    n, m = S.shape[0], B.shape[1]
+    if out is None:
+        out = torch.zeros(n, m, device=S.device, dtype=torch.float32)
+    check(lib.mcgra_ssymm_lower(_stream(), n, m, 1.0, _p(S), S.stride(0), _p(B), B.stride(0), float(beta), _p(out),
+                                out.stride(0)))
+    return out
+
+
 def normalize_adj_tensor(adj):
     """utils.normalize_adj_tensor, dense branch (utils.py:211-230)."""
     out = torch.empty_like(adj)

@@ -82,7 +82,7 @@ def weights_of(victim):
 
 def run_reference_attack(adj, features, labels, victim, idx_attack, measure, weight_param,
                          weight_sup, lr, epochs, dataset, use, num_edges, eps=0.0,
-                         capture_steps=True):
+                         capture_steps=True, a0=None):
     """Drive topology_attack.PGDAttack.attack exactly as main.objective does
     (main.py:298-307) and capture per-step adj_changes / grads through a global
     optimizer post-hook."""
@@ -102,6 +102,8 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
                               w1=0, w2=0, w6=0, w7=0, w8=0, w9=0, w10=0)
     model = rta.PGDAttack(model=victim, embedding=embedding, H_A=H_A2, Y_A=Y_A, nnodes=n,
                           loss_type="CE", device=device).to(device)
+    if a0 is not None:      # start away from the origin: adj_changes is a public Parameter (topology_attack.py:77)
+        model.adj_changes.data = torch.tensor(np.asarray(a0, dtype=np.float32))
     steps_a, steps_g = [], []
 
     def hook(opt, a, k):
@@ -122,6 +124,11 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
     return dict(final=final, steps_a=steps_a, steps_g=steps_g, H_A2=H_A2.detach().numpy(),
                 Y_A=Y_A.detach().numpy(), feature_adj=feature_adj.numpy(),
                 auc=metric_pool(adj.numpy(), final, idx_attack))
+
+
+def init_adj_changes(n, seed, scale):
+    """Seeded non-zero start for adj_changes (tests regenerate it from the seed)."""
+    return (np.random.RandomState(seed).rand(n * (n - 1) // 2) * scale).astype(np.float32)
 
 
 def make_synth(n, f, c, hid, nlayer, seed, p_edge=0.08):
@@ -160,6 +167,10 @@ def gen_small(tmp):
         ("s80_mse_proj", 80, 40, 5, 16, 2, "MSELoss", (1, 0.1, 0, 0, 0, 100, 1, 0, 10, 10), 1.0, 0.1, 5, 30.0),
         ("s200_mse", 200, 64, 6, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
         ("s200_hsic", 200, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
+        # random (seeded) initial adj_changes: generic-sign gradients through every N x N term
+        ("s48_hsic_init", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 4, 1e12),
+        ("s200_hsic_init", 200, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 4, 1e12),
+        ("s200_mse_init", 200, 64, 6, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 0.01, 4, 1e12),
     ]
     for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:
         adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000)
@@ -167,9 +178,14 @@ def gen_small(tmp):
         np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
         random.seed(7)
         idx_attack = np.array(random.sample(range(n), n if "l3" not in name else int(n * 0.75)))
+        a0 = None
+        extra = {}
+        if name.endswith("_init"):
+            extra = dict(a0_seed=123, a0_scale=0.05)
+            a0 = init_adj_changes(n, 123, 0.05)
         res = run_reference_attack(adj, feats, labels, victim, idx_attack, measure, wp, wsup, lr,
-                                   epochs, "cora", (True, True, True), ne)
-        out = dict(adj=adj.numpy(), features=feats.numpy(), labels=lab, idx_attack=idx_attack,
+                                   epochs, "cora", (True, True, True), ne, a0=a0)
+        out = dict(adj=adj.numpy(), **extra, features=feats.numpy(), labels=lab, idx_attack=idx_attack,
                    measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup,
                    lr=lr, epochs=epochs, num_edges=ne, nlayer=nl, final=res["final"],
                    steps_a=np.stack(res["steps_a"]), steps_g=np.stack(res["steps_g"]),
@@ -278,17 +294,35 @@ def gen_cora(tmp):
     common = dict(idx_attack=idx_attack, idx_test=idx_test, num_edges=float(num_edges), sample_pos=samp,
                   features_bits=np.packbits(fx.astype(np.uint8), axis=1), nfeat=fx.shape[1],
                   adj_edges=ei, labels=lab, **weights_of(victim))
+    readme = (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000)
     runs = [
-        # README.md "K = {X, H_A, Y^, Y}" cora line: --w1=0.01 --w6=10 --w7=10 --w9=10 --w10=1000 --lr=-2 MSELoss
-        ("cora_mse_readme", "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 10 ** -2, 100),
-        ("cora_hsic", "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 10 ** -2, 12),
+        # README.md "K = {X, H_A, Y^, Y}" cora line: --w1=0.01 --w6=10 --w7=10 --w9=10 --w10=1000 --lr=-2 MSELoss.
+        # 100 epochs is the README horizon; Adam amplifies fp32 rounding noise on near-zero gradients, so the
+        # trajectory is only reproducible to ~1e-3 in AUC there (an fp64 run of the same algorithm differs from
+        # its fp32 run by 1e-7 / 4e-6 / 1.2e-4 / ~1e-3 at 10 / 20 / 40 / 100 epochs).  The 20-epoch run is the
+        # one held to 1e-4; the 100-epoch run is re-run with another thread count to record the reference's
+        # own spread under a changed summation order.
+        ("cora_mse_readme", "MSELoss", readme, 1.0, 10 ** -2, 100, None),
+        ("cora_mse_short", "MSELoss", readme, 1.0, 10 ** -2, 20, None),
+        # HSIC: at adj_changes == 0 every c1/c2 gradient is >= 0 (PSD Gram), the origin is a fixed point in exact
+        # arithmetic and the reference leaves it on rounding noise only; start from a seeded random adj_changes.
+        ("cora_hsic", "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 10 ** -2, 8, (123, 0.05)),
     ]
-    for name, measure, wp, wsup, lr, epochs in runs:
+    for name, measure, wp, wsup, lr, epochs, init in runs:
+        a0 = init_adj_changes(adj.shape[0], *init) if init else None
         res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs,
-                                   "cora", (True, True, True), num_edges)
+                                   "cora", (True, True, True), num_edges, a0=a0)
+        extra = dict(a0_seed=init[0], a0_scale=init[1]) if init else {}
+        if name == "cora_mse_readme":
+            torch.set_num_threads(3)
+            alt = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs,
+                                       "cora", (True, True, True), num_edges, capture_steps=False)
+            torch.set_num_threads(8)
+            extra["auc_alt_threads"] = alt["auc"]
+            print("  same run with 3 threads: auc", alt["auc"])
         sa = np.stack(res["steps_a"])
         out = dict(measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup, lr=lr,
-                   epochs=epochs, auc=res["auc"],
+                   epochs=epochs, auc=res["auc"], **extra,
                    final_sample=res["final"][samp[:, 0], samp[:, 1]],
                    final_sum=float(res["final"].astype(np.float64).sum()),
                    step_sum=sa.astype(np.float64).sum(1), step_sqsum=(sa.astype(np.float64) ** 2).sum(1),

@@ -29,10 +29,24 @@ def cfg_from(z):
                           num_edges=float(z["num_edges"]), eps=0.0, emb_nlayer=2)
 
 
+def init_adj_changes(n, seed, scale):
+    """Same generator as tests/golden/make_golden.py:init_adj_changes."""
+    return (np.random.RandomState(int(seed)).rand(n * (n - 1) // 2) * float(scale)).astype(np.float32)
+
+
+def a0_of(z):
+    if "a0_seed" in z:
+        return init_adj_changes(z["adj"].shape[0], z["a0_seed"], z["a0_scale"])
+    return None
+
+
 def oracle_from(z):
     n = z["adj"].shape[0]
-    return O.PGDAttackOracle(weights_from(z), z["features"], z["adj"], np.zeros((n, n), np.float32),
-                             z["feature_adj"], z["labels"], z["idx_attack"], cfg_from(z))
+    orc = O.PGDAttackOracle(weights_from(z), z["features"], z["adj"], np.zeros((n, n), np.float32),
+                            z["feature_adj"], z["labels"], z["idx_attack"], cfg_from(z))
+    if a0_of(z) is not None:
+        orc.set_adj_changes(a0_of(z))
+    return orc
 
 
 def load_cora(name):
@@ -68,6 +82,8 @@ def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None):
                            device=device)
     eng.set_model(w.W, w.b, w.Wlin, w.blin)
     eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
+    if a0_of(z) is not None:
+        eng.set_adj_changes(a0_of(z))
     return eng
 
 

@@ -126,3 +126,27 @@ def test_auc_matches_sklearn():
     pred = np.round(rng.rand(5000) + 0.3 * real, 2)      # many ties
     fpr, tpr, _ = roc_curve(real, pred)
     assert abs(O.auc_score(real, pred) - auc(fpr, tpr)) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["cora_mse_short", "cora_hsic"])
+def test_oracle_cora_auc(name):
+    """Cora through the reference's own data path / victim training (fixture), oracle vs reference AUC."""
+    z = H.load_cora(name)
+    w = O.GCNWeights([z["W0"], z["W1"]], [z["b0"], z["b1"]], z["Wlin"], z["blin"])
+    X, adj, lab = z["features"], z["adj"], z["labels"]
+    n = adj.shape[0]
+    cfg = O.AttackConfig(measure=str(z["measure"]), weight_sup=float(z["weight_sup"]),
+                         weight_param=tuple(z["weight_param"]), lr=float(z["lr"]), num_edges=float(z["num_edges"]))
+    orc = O.PGDAttackOracle(w, X, adj, np.zeros((n, n), np.float32), H.cora_feature_adj(X), lab, z["idx_attack"], cfg)
+    if H.a0_of(z) is not None:
+        orc.set_adj_changes(H.a0_of(z))
+    for t in range(int(z["epochs"])):
+        orc.step()
+        a = O.pack_tril(orc.M)[:: max(1, (n * (n - 1) // 2) // 4096)]
+        ref = np.clip(z["step_a_sample"][t], 0, 1)
+        assert np.mean(np.abs(a - ref) > 0.5 * float(z["lr"])) < 2e-3, t
+    _, Hs, _ = O.gcn_chain(orc.T0, adj, orc.w, 2)
+    _, YA = O.victim_head(Hs[-1], orc.w)
+    final = orc.finalize("cora", True, True, True, (lab[:, None] == lab[None, :]).astype(np.float32), Hs[-1], YA)
+    auc = O.metric_pool(adj, final, z["idx_attack"])
+    assert abs(auc - float(z["auc"])) <= 1e-4, (auc, float(z["auc"]))
