@@ -205,9 +205,18 @@ def main():
         if st["launches"]:
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (N x N x N products of linear_HSIC)",
+            # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
+            # (profiles/r01_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
+            # cannot be read from inside the timed process, so the committed profile value is reported.
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
+                ks = json.load(open(tp))["kernels"]
+                traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks))
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (N x N x N products of linear_HSIC: "
+                                                           "2 SYRK + 2 SYMM launches per step)",
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                                "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
                                "gemm_share_of_step": st["ms"] / (1e3 * dt)}
         else:

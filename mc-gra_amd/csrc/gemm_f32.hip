@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mcgra {
@@ -138,16 +140,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   f32x4 ra[Cfg::A_PER_T], rb[Cfg::B_PER_T];
 
-  // at = "A tile is read from global as [k][m]" (TA, or the mirrored half of a symmetric S)
-  auto a_transposed = [&](int k0) -> bool { return TA || (SYM == SYM_MM && k0 >= sym_split); };
+  // AT = "A tile is read from global as [k][m]" (TA, or the mirrored half of a symmetric S).  It is a
+  // compile-time property of each loop phase, so SYM_MM runs three specialised phases (lower tiles,
+  // the boundary tile, mirrored tiles) instead of branching per K tile.
+  using AtF = std::integral_constant<bool, false>;
+  using AtT = std::integral_constant<bool, true>;
 
-  auto load_tiles = [&](int k0) {
-    const bool at = a_transposed(k0);
+  auto load_tiles = [&](auto at_, int k0) {
+    constexpr bool AT = decltype(at_)::value;
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
       if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
-        if (at) {  // global [k][m]
+        if constexpr (AT) {  // global [k][m]
           constexpr int V4R = BM / 4;
           ra[i] = load_v4<VEC>(A, lda, k0 + f / V4R, m0 + (f % V4R) * 4, k_end, M);
         } else {  // global [m][k]
@@ -170,12 +175,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       }
     }
   };
-  auto store_tiles = [&](bool at) {
+  auto store_tiles = [&](auto at_) {
+    constexpr bool AT = decltype(at_)::value;
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
       if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
-        if (at) {
+        if constexpr (AT) {
           constexpr int V4R = BM / 4;
           *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_XC + (f % V4R) * 4]) = ra[i];
         } else {
@@ -199,25 +205,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     }
   };
 
-  if (k_begin < k_end) {
-    load_tiles(k_begin);
-    store_tiles(a_transposed(k_begin));
-  }
-  __syncthreads();
-
   int cur = 0;
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+  // one K tile: prefetch the next tile (layout at_n), multiply the staged one (layout at_c), stage the next
+  auto step = [&](auto at_c, auto at_n, int k0) {
+    constexpr bool ATC = decltype(at_c)::value;
     const bool has_next = (k0 + BK) < k_end;
-    if (has_next) load_tiles(k0 + BK);  // in flight while this tile is multiplied
-    const bool at = a_transposed(k0);
-
+    if (has_next) load_tiles(at_n, k0 + BK);  // in flight while this tile is multiplied
 #pragma unroll
     for (int kc = 0; kc < BK; kc += 8) {
       float af[Cfg::TM][4], bf[Cfg::TN][4];
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         const int x = wm0 + i * 32 + l31;
-        if (!at) {
+        if constexpr (!ATC) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(&As[x * Cfg::A_LD_KC + kc + 4 * lh]);
           af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
         } else {
@@ -249,16 +249,41 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         cur ^= 1;
         As = smem + cur * STAGE;
         Bs = As + Cfg::A_ELEMS;
-        store_tiles(a_transposed(k0 + BK));
+        store_tiles(at_n);
       }
       __syncthreads();
     } else {
       __syncthreads();
       if (has_next) {
-        store_tiles(a_transposed(k0 + BK));
+        store_tiles(at_n);
         __syncthreads();
       }
     }
+  };
+
+  if (SYM != SYM_MM) {
+    using At = std::integral_constant<bool, TA>;
+    if (k_begin < k_end) {
+      load_tiles(At{}, k_begin);
+      store_tiles(At{});
+    }
+    __syncthreads();
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) step(At{}, At{}, k0);
+  } else {
+    // K tiles with k0 < lower_end read S[m][k] (stored); the rest read the mirror S[k][m]
+    const int lower_end = min(k_end, max(k_begin, sym_split));
+    if (k_begin < k_end) {
+      if (k_begin < lower_end) { load_tiles(AtF{}, k_begin); store_tiles(AtF{}); }
+      else { load_tiles(AtT{}, k_begin); store_tiles(AtT{}); }
+    }
+    __syncthreads();
+    int k0 = k_begin;
+    for (; k0 + BK < lower_end; k0 += BK) step(AtF{}, AtF{}, k0);
+    if (k0 < lower_end) {  // last stored tile: its successor (if any) is mirrored
+      step(AtF{}, AtT{}, k0);
+      k0 += BK;
+    }
+    for (; k0 < k_end; k0 += BK) step(AtT{}, AtT{}, k0);
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
