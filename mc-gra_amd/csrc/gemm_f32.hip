@@ -79,8 +79,8 @@ __device__ __forceinline__ f32x4 load_v4(const float* __restrict__ base, int ld,
   return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, int NBUF, int SYM>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, int NBUF, int SYM, int PF>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
     int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n) {
@@ -138,26 +138,61 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[Cfg::A_PER_T], rb[Cfg::B_PER_T];
+  // register staging: PF sets, so that the global loads of tile t+PF are in flight while tile t is multiplied
+  f32x4 ra[PF][Cfg::A_PER_T], rb[PF][Cfg::B_PER_T];
 
   // AT = "A tile is read from global as [k][m]" (TA, or the mirrored half of a symmetric S).  It is a
-  // compile-time property of each loop phase, so SYM_MM runs three specialised phases (lower tiles,
-  // the boundary tile, mirrored tiles) instead of branching per K tile.
+  // compile-time property of each specialised step, so SYM_MM never branches inside a K tile.
   using AtF = std::integral_constant<bool, false>;
   using AtT = std::integral_constant<bool, true>;
+  using Rs0 = std::integral_constant<int, 0>;
+  using Rs1 = std::integral_constant<int, PF - 1>;
 
-  auto load_tiles = [&](auto at_, int k0) {
+  // Per-thread element offsets of its float4 slots inside a tile, hoisted out of the K loop.  Tiles that lie
+  // entirely inside the matrices (the common case) are loaded with plain 16-byte loads and no bounds checks.
+  // (32-bit offsets: the fast path is taken only when both operands span < 2^32 elements.)
+  constexpr bool A_NEEDS_KC = !TA, A_NEEDS_XC = TA || SYM == SYM_MM;
+  unsigned a_off_kc[Cfg::A_PER_T], a_off_xc[Cfg::A_PER_T], b_off[Cfg::B_PER_T];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_PER_T; ++i) {
+    const int f = tid + i * GEMM_THREADS;
+    a_off_kc[i] = A_NEEDS_KC ? (unsigned)(m0 + f / (BK / 4)) * (unsigned)lda + (f % (BK / 4)) * 4 : 0u;   // + k0
+    a_off_xc[i] = A_NEEDS_XC ? (unsigned)(f / (BM / 4)) * (unsigned)lda + m0 + (f % (BM / 4)) * 4 : 0u;    // + k0 * lda
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_PER_T; ++i) {
+    const int f = tid + i * GEMM_THREADS;
+    b_off[i] = TB ? (unsigned)(n0 + f / (BK / 4)) * (unsigned)ldb + (f % (BK / 4)) * 4       // + k0
+                  : (unsigned)(f / (BN / 4)) * (unsigned)ldb + n0 + (f % (BN / 4)) * 4;        // + k0 * ldb
+  }
+  const size_t span_a = (size_t)(TA || SYM == SYM_MM ? max(M, K) : M) * lda;
+  const size_t span_b = (size_t)(TB ? N : K) * ldb;
+  const bool interior = VEC && (m0 + BM <= M) && (n0 + BN <= N) && (Cfg::A_V4 % GEMM_THREADS == 0) &&
+                        (Cfg::B_V4 % GEMM_THREADS == 0) && span_a < (1ull << 32) && span_b < (1ull << 32);
+
+  auto load_tiles = [&](auto at_, auto rs_, int k0) {
     constexpr bool AT = decltype(at_)::value;
+    constexpr int RS = decltype(rs_)::value;
+    if (interior && k0 + BK <= k_end) {
+      const float* pa = AT ? A + (size_t)k0 * lda : A + k0;
+      const float* pb = TB ? B + k0 : B + (size_t)k0 * ldb;
+#pragma unroll
+      for (int i = 0; i < Cfg::A_PER_T; ++i)
+        ra[RS][i] = *reinterpret_cast<const f32x4*>(pa + (AT ? a_off_xc[i] : a_off_kc[i]));
+#pragma unroll
+      for (int i = 0; i < Cfg::B_PER_T; ++i) rb[RS][i] = *reinterpret_cast<const f32x4*>(pb + b_off[i]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
       if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
         if constexpr (AT) {  // global [k][m]
           constexpr int V4R = BM / 4;
-          ra[i] = load_v4<VEC>(A, lda, k0 + f / V4R, m0 + (f % V4R) * 4, k_end, M);
+          ra[RS][i] = load_v4<VEC>(A, lda, k0 + f / V4R, m0 + (f % V4R) * 4, k_end, M);
         } else {  // global [m][k]
           constexpr int V4R = BK / 4;
-          ra[i] = load_v4<VEC>(A, lda, m0 + f / V4R, k0 + (f % V4R) * 4, M, k_end);
+          ra[RS][i] = load_v4<VEC>(A, lda, m0 + f / V4R, k0 + (f % V4R) * 4, M, k_end);
         }
       }
     }
@@ -167,26 +202,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4) {
         if (TB) {  // global [n][k]
           constexpr int V4R = BK / 4;
-          rb[i] = load_v4<VEC>(B, ldb, n0 + f / V4R, k0 + (f % V4R) * 4, N, k_end);
+          rb[RS][i] = load_v4<VEC>(B, ldb, n0 + f / V4R, k0 + (f % V4R) * 4, N, k_end);
         } else {  // global [k][n]
           constexpr int V4R = BN / 4;
-          rb[i] = load_v4<VEC>(B, ldb, k0 + f / V4R, n0 + (f % V4R) * 4, k_end, N);
+          rb[RS][i] = load_v4<VEC>(B, ldb, k0 + f / V4R, n0 + (f % V4R) * 4, k_end, N);
         }
       }
     }
   };
-  auto store_tiles = [&](auto at_) {
+  auto store_tiles = [&](auto at_, auto rs_) {
     constexpr bool AT = decltype(at_)::value;
+    constexpr int RS = decltype(rs_)::value;
 #pragma unroll
     for (int i = 0; i < Cfg::A_PER_T; ++i) {
       const int f = tid + i * GEMM_THREADS;
       if (Cfg::A_V4 % GEMM_THREADS == 0 || f < Cfg::A_V4) {
         if constexpr (AT) {
           constexpr int V4R = BM / 4;
-          *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_XC + (f % V4R) * 4]) = ra[i];
+          *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_XC + (f % V4R) * 4]) = ra[RS][i];
         } else {
           constexpr int V4R = BK / 4;
-          *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_KC + (f % V4R) * 4]) = ra[i];
+          *reinterpret_cast<f32x4*>(&As[(f / V4R) * Cfg::A_LD_KC + (f % V4R) * 4]) = ra[RS][i];
         }
       }
     }
@@ -196,33 +232,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       if (Cfg::B_V4 % GEMM_THREADS == 0 || f < Cfg::B_V4) {
         if (TB) {
           constexpr int V4R = BK / 4;
-          *reinterpret_cast<f32x4*>(&Bs[(f / V4R) * Cfg::B_LD_KC + (f % V4R) * 4]) = rb[i];
+          *reinterpret_cast<f32x4*>(&Bs[(f / V4R) * Cfg::B_LD_KC + (f % V4R) * 4]) = rb[RS][i];
         } else {
           constexpr int V4R = BN / 4;
-          *reinterpret_cast<f32x4*>(&Bs[(f / V4R) * Cfg::B_LD_XC + (f % V4R) * 4]) = rb[i];
+          *reinterpret_cast<f32x4*>(&Bs[(f / V4R) * Cfg::B_LD_XC + (f % V4R) * 4]) = rb[RS][i];
         }
       }
     }
   };
 
   int cur = 0;
-  // one K tile: prefetch the next tile (layout at_n), multiply the staged one (layout at_c), stage the next
-  auto step = [&](auto at_c, auto at_n, int k0) {
+  // multiply the tile staged in LDS (layout at_c); fragment reads run one 8-deep chunk ahead of the MFMAs
+  auto multiply = [&](auto at_c) {
     constexpr bool ATC = decltype(at_c)::value;
-    const bool has_next = (k0 + BK) < k_end;
-    if (has_next) load_tiles(at_n, k0 + BK);  // in flight while this tile is multiplied
-#pragma unroll
-    for (int kc = 0; kc < BK; kc += 8) {
-      float af[Cfg::TM][4], bf[Cfg::TN][4];
+    float af[2][Cfg::TM][4], bf[2][Cfg::TN][4];
+    auto load_frags = [&](int buf, int kc) {
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         const int x = wm0 + i * 32 + l31;
         if constexpr (!ATC) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(&As[x * Cfg::A_LD_KC + kc + 4 * lh]);
-          af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
+          af[buf][i][0] = v[0]; af[buf][i][1] = v[1]; af[buf][i][2] = v[2]; af[buf][i][3] = v[3];
         } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) af[i][t] = As[(kc + 4 * lh + t) * Cfg::A_LD_XC + x];
+          for (int t = 0; t < 4; ++t) af[buf][i][t] = As[(kc + 4 * lh + t) * Cfg::A_LD_XC + x];
         }
       }
 #pragma unroll
@@ -230,11 +263,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         const int x = wn0 + j * 32 + l31;
         if (TB) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[x * Cfg::B_LD_KC + kc + 4 * lh]);
-          bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
+          bf[buf][j][0] = v[0]; bf[buf][j][1] = v[1]; bf[buf][j][2] = v[2]; bf[buf][j][3] = v[3];
         } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bf[j][t] = Bs[(kc + 4 * lh + t) * Cfg::B_LD_XC + x];
+          for (int t = 0; t < 4; ++t) bf[buf][j][t] = Bs[(kc + 4 * lh + t) * Cfg::B_LD_XC + x];
         }
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      if (c + 1 < BK / 8) {
+        load_frags((c + 1) & 1, (c + 1) * 8);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this chunk's MFMAs
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -242,20 +283,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
           for (int j = 0; j < Cfg::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][t], bf[c & 1][j][t], acc[i][j], 0, 0, 0);
     }
+  };
+  auto flip_stage = [&]() {
+    cur ^= 1;
+    As = smem + cur * STAGE;
+    Bs = As + Cfg::A_ELEMS;
+  };
+
+  // One K tile.  PF == 1: prefetch tile t+1 into the single register set, multiply tile t, stage t+1.
+  // PF == 2 (needs NBUF == 2): issue the loads of tile t+2 into register set rs (free: it held tile t, already
+  // staged), multiply tile t, stage tile t+1 from the other register set.
+  auto step = [&](auto at_c, auto at_n, auto at_n2, auto rs_, int k0) {
+    constexpr int RS = decltype(rs_)::value;
+    const bool has_next = (k0 + BK) < k_end;
+    if (PF == 1) {
+      if (has_next) load_tiles(at_n, Rs0{}, k0 + BK);
+    } else {
+      if (k0 + 2 * BK < k_end) load_tiles(at_n2, rs_, k0 + 2 * BK);
+    }
+    multiply(at_c);
+    using Other = std::integral_constant<int, (PF == 1) ? 0 : (RS ^ 1)>;
     if (NBUF == 2) {
-      if (has_next) {  // write the other stage, then flip
-        cur ^= 1;
-        As = smem + cur * STAGE;
-        Bs = As + Cfg::A_ELEMS;
-        store_tiles(at_n);
+      if (has_next) {
+        flip_stage();
+        store_tiles(at_n, Other{});
       }
       __syncthreads();
     } else {
       __syncthreads();
       if (has_next) {
-        store_tiles(at_n);
+        store_tiles(at_n, Other{});
         __syncthreads();
       }
     }
@@ -263,27 +322,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   if (SYM != SYM_MM) {
     using At = std::integral_constant<bool, TA>;
-    if (k_begin < k_end) {
-      load_tiles(At{}, k_begin);
-      store_tiles(At{});
+    if (k_begin < k_end) {  // prologue: stage tile 0, and with PF == 2 put tile 1 in flight
+      load_tiles(At{}, Rs0{}, k_begin);
+      store_tiles(At{}, Rs0{});
+      if (PF == 2 && k_begin + BK < k_end) load_tiles(At{}, Rs1{}, k_begin + BK);
     }
     __syncthreads();
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) step(At{}, At{}, k0);
+    for (int k0 = k_begin; k0 < k_end;) {
+      step(At{}, At{}, At{}, Rs0{}, k0);
+      k0 += BK;
+      if (PF == 2 && k0 < k_end) {
+        step(At{}, At{}, At{}, Rs1{}, k0);
+        k0 += BK;
+      }
+    }
   } else {
-    // K tiles with k0 < lower_end read S[m][k] (stored); the rest read the mirror S[k][m]
+    static_assert(SYM != SYM_MM || PF == 1, "SYM_MM runs with one-tile-ahead prefetch");
+    // K tiles with k0 < lower_end read S[m][k] (stored); the rest read the mirror S[k][m].  Three
+    // sequential specialised loops: stored tiles, the boundary tile, mirrored tiles.
     const int lower_end = min(k_end, max(k_begin, sym_split));
     if (k_begin < k_end) {
-      if (k_begin < lower_end) { load_tiles(AtF{}, k_begin); store_tiles(AtF{}); }
-      else { load_tiles(AtT{}, k_begin); store_tiles(AtT{}); }
+      if (k_begin < lower_end) { load_tiles(AtF{}, Rs0{}, k_begin); store_tiles(AtF{}, Rs0{}); }
+      else { load_tiles(AtT{}, Rs0{}, k_begin); store_tiles(AtT{}, Rs0{}); }
     }
     __syncthreads();
     int k0 = k_begin;
-    for (; k0 + BK < lower_end; k0 += BK) step(AtF{}, AtF{}, k0);
+    for (; k0 + BK < lower_end; k0 += BK) step(AtF{}, AtF{}, AtF{}, Rs0{}, k0);
     if (k0 < lower_end) {  // last stored tile: its successor (if any) is mirrored
-      step(AtF{}, AtT{}, k0);
+      step(AtF{}, AtT{}, AtT{}, Rs0{}, k0);
       k0 += BK;
     }
-    for (; k0 < k_end; k0 += BK) step(AtT{}, AtT{}, k0);
+    for (; k0 < k_end; k0 += BK) step(AtT{}, AtT{}, AtT{}, Rs0{}, k0);
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -319,7 +388,7 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, size_t stride,
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NBUF, int SYM>
+template <int BM, int BN, int BK, int WM, int WN, int NBUF, int SYM, int PF = 1>
 static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K,
                              float alpha, const float* A, int lda, const float* B, int ldb,
                              float beta, float* C, int ldc, int nsplit, int k_per_split,
@@ -331,7 +400,7 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
   do {                                                                                                   \
     using Cfg_ = GemmCfg<BM, BN, BK, WM, WN, TA_, TB_>;                                                  \
     constexpr size_t smem_ = sizeof(float) * NBUF * (Cfg_::A_ELEMS + Cfg_::B_ELEMS);                     \
-    auto kern_ = gemm_f32_kernel<BM, BN, BK, WM, WN, TA_, TB_, VEC_, NBUF, SYM>;                         \
+    auto kern_ = gemm_f32_kernel<BM, BN, BK, WM, WN, TA_, TB_, VEC_, NBUF, SYM, PF>;                         \
     if (smem_ > 64 * 1024) {                                                                             \
       static bool done_ = false;                                                                         \
       if (!done_) {                                                                                      \
@@ -363,16 +432,24 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
   return hipGetLastError();
 }
 
-// Tuning knob (mcgra_set_gemm_variant): 2 = double-buffered LDS (default), 1 = single stage.
+// Tuning knob (mcgra_set_gemm_variant), BK 32 unless stated:
+//   2 = two LDS stages, global loads one K tile ahead (default)    4 = two LDS stages, two tiles ahead
+//   1 = one LDS stage, one tile ahead                               3 = BK 16, two stages, one tile ahead
 static int g_gemm_nbuf = 2;
-void set_gemm_variant(int v) { g_gemm_nbuf = (v == 1) ? 1 : 2; }
+void set_gemm_variant(int v) { g_gemm_nbuf = (v == 1 || v == 3 || v == 4) ? v : 2; }
 
 template <int NBUF>
 static hipError_t launch_big(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K, float alpha,
                              const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                              int nsplit, int k_per_split, size_t stride) {
-  return launch_cfg<128, 128, 32, 64, 64, NBUF, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                                                          ldc, nsplit, k_per_split, stride);
+  if (NBUF == 3)
+    return launch_cfg<128, 128, 16, 64, 64, 2, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
+                                                         ldc, nsplit, k_per_split, stride);
+  if (NBUF == 4)
+    return launch_cfg<128, 128, 32, 64, 64, 2, SYM_NONE, 2>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
+                                                            ldc, nsplit, k_per_split, stride);
+  return launch_cfg<128, 128, 32, 64, 64, NBUF == 1 ? 1 : 2, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb,
+                                                                       beta, C, ldc, nsplit, k_per_split, stride);
 }
 
 static inline bool vec_ok(const float* A, int lda, const float* B, int ldb) {
@@ -412,7 +489,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
       e = launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
                                                        nsplit, k_per_split, stride);
     else
-      e = (g_gemm_nbuf == 1 ? launch_big<1> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
+      e = (g_gemm_nbuf == 1 ? launch_big<1> : g_gemm_nbuf == 3 ? launch_big<3> : g_gemm_nbuf == 4 ? launch_big<4> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
                                                              nsplit, k_per_split, stride);
     if (e != hipSuccess) return e;
     const int blocks = (int)min((size_t)2048, (stride + 255) / 256);
@@ -422,7 +499,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   if (skinny)
     return launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
                                                         1, K, 0);
-  return (g_gemm_nbuf == 1 ? launch_big<1> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
+  return (g_gemm_nbuf == 1 ? launch_big<1> : g_gemm_nbuf == 3 ? launch_big<3> : g_gemm_nbuf == 4 ? launch_big<4> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
                                                             ldc, 1, K, 0);
 }
 
@@ -431,7 +508,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
 hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A, int lda, float beta, float* C,
                        int ldc) {
   if (n <= 0) return hipSuccess;
-  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_RK>(st, false, true, vec_ok(A, lda, A, lda), n, n, k, alpha,
+  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_RK, 1>(st, false, true, vec_ok(A, lda, A, lda), n, n, k, alpha,
                                                                A, lda, A, lda, beta, C, ldc, 1, k, 0);
 }
 
@@ -439,7 +516,7 @@ hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A
 hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
                        float beta, float* C, int ldc) {
   if (n <= 0 || m <= 0) return hipSuccess;
-  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM>(st, false, false, vec_ok(S, lds_, B, ldb), n, m, n, alpha,
+  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM, 1>(st, false, false, vec_ok(S, lds_, B, ldb), n, m, n, alpha,
                                                                S, lds_, B, ldb, beta, C, ldc, 1, n, 0);
 }
 
