@@ -220,8 +220,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
               cfg->nclass, cfg->n_attack);
     return MCGRA_EINVAL;
   }
-  if (cfg->measure != MCGRA_MEASURE_HSIC && cfg->measure != MCGRA_MEASURE_MSE) {
-    set_error("measure %d (KL/CKA/DP) is not implemented on the HIP path yet", cfg->measure);
+  if (cfg->measure != MCGRA_MEASURE_HSIC && cfg->measure != MCGRA_MEASURE_MSE && cfg->measure != MCGRA_MEASURE_KL &&
+      cfg->measure != MCGRA_MEASURE_DP) {
+    set_error("measure %d (CKA) is not implemented on the HIP path yet", cfg->measure);
     return MCGRA_ENOSUP;
   }
   if (cfg->eps != 0.f) { set_error("eps != 0 (adding_noise) is not implemented on the HIP path yet"); return MCGRA_ENOSUP; }
@@ -254,6 +255,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn); A_(GSYM, nn);
   if (cfg->measure == MCGRA_MEASURE_HSIC) { A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn); }
+  if (cfg->measure == MCGRA_MEASURE_KL) { A_(XC, nn); }      // XC holds softmax(feature_adj) rows
+  if (cfg->measure == MCGRA_MEASURE_DP) { A_(KY, nn); A_(XC, nn); }
   A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
   A_(rowmin, ld); A_(rowmax, ld); A_(mm, 4);
   A_(rowsq, 2 * ld); h->rowsum = h->rowsq ? h->rowsq + n : nullptr;
@@ -338,6 +341,8 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
     launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
   }
+  if (h->cfg.measure == MCGRA_MEASURE_KL && h->cfg.w[0] != 0.f)
+    launch_row_softmax(st, n, ld, h->FADJ, h->XC);      // F.softmax(feature_adj) of calc_kl (:484), constant
   MCGRA_KERNEL_CHECK();
   // feature_adj.max() != feature_adj.min() (topology_attack.py:212) is evaluated by the host layer
   MCGRA_HIP(hipStreamSynchronize(st));
@@ -366,6 +371,16 @@ static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Y
   launch_gather_rows(st, na, width, Ysrc, ldy, h->idx, h->Yg, hm);
   if (h->cfg.measure == MCGRA_MEASURE_MSE) {
     launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot);   // sum of squares
+    launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
+  } else if (h->cfg.measure == MCGRA_MEASURE_DP) {   // |Y^T X|_F (:480-481): P = Yg^T Xg, d/dY = X P^T / |P|
+    MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
+    CHK(eg(h, st, true, false, width, width, na, 1.f, h->Yg, hm, Xg, hm, 0.f, h->Q, hm));
+    launch_sumsq(st, (size_t)width * hm, h->Q, h->scal + slot);
+    CHK(eg(h, st, false, true, na, width, width, 1.f, Xg, hm, h->Q, hm, 0.f, h->Gg, hm));
+    launch_scatter_add_rows_invnorm(st, na, width, h->Gg, hm, h->idx, h->scal + slot, (float)k_signed, G, ldg);
+  } else if (h->cfg.measure == MCGRA_MEASURE_KL) {   // calc_kl(X[idx], Y[idx]) (:483-487), X constant
+    launch_kl_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->rowvals + 7 * (size_t)h->ld);
+    launch_reduce_rows(st, h->rowvals + 7 * (size_t)h->ld, na, 1, h->scal + slot);
     launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
   } else {  // HSIC: value |Xc^T Yc|_F^2, gradient 2 Xc (Xc^T Yc)   (utils.py:1085-1089)
     // Y is centred explicitly: Xc^T Y == Xc^T Yc only in exact arithmetic, and with identical rows of Y
@@ -476,7 +491,37 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
 
   // ---- N x N loss terms (:212-236)
   const bool use1 = (w1 != 0), use2 = (w2 != 0);
-  if (!hsic) {
+  if (c.measure == MCGRA_MEASURE_DP) {
+    // dot_product(X, Y) = |Y^T X|_F (:480-481); d/dY = X P^T / |P|, d/dX = Y P / |P| with P = Y^T X
+    launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
+                     h->G_A1, h->rowvals);
+    launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
+    if (use1) {   // c1 = k1 dot_product(feature_adj, adj_norm): P = adj_norm^T Fadj
+      CHK(eg(h, st, true, false, n, n, n, 1.f, h->ADJN, ld, h->FADJ, ld, 0.f, h->KX, ld));
+      launch_rowsumsq(st, n, ld, h->KX, h->rowsx);
+      launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_H1);
+      CHK(eg(h, st, false, true, n, n, n, 1.f, h->FADJ, ld, h->KX, ld, 0.f, h->XC, ld));
+      launch_axpy_invnorm(st, n, ld, h->XC, h->scal + S_H1, (float)k1, h->G_ADJN);
+    }
+    if (use2) {   // c2 = k2 dot_product(adj_norm, A1): P = A1^T adj_norm
+      CHK(eg(h, st, true, false, n, n, n, 1.f, h->A1, ld, h->ADJN, ld, 0.f, h->KY, ld));
+      launch_rowsumsq(st, n, ld, h->KY, h->rowsy);
+      launch_reduce_rows(st, h->rowsy, n, 1, h->scal + S_H2);
+      CHK(eg(h, st, false, false, n, n, n, 1.f, h->A1, ld, h->KY, ld, 0.f, h->XC, ld));          // d/dX = Y P
+      launch_axpy_invnorm(st, n, ld, h->XC, h->scal + S_H2, (float)k2, h->G_ADJN);
+      CHK(eg(h, st, false, true, n, n, n, 1.f, h->ADJN, ld, h->KY, ld, 0.f, h->XC, ld));         // d/dY = X P^T
+      launch_axpy_invnorm(st, n, ld, h->XC, h->scal + S_H2, (float)k2, h->G_A1);
+    }
+  } else if (c.measure == MCGRA_MEASURE_KL) {
+    launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
+                     h->G_A1, h->rowvals);
+    launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);      // only the entropy slots are non-zero
+    if (use1 || use2) {
+      launch_kl_rows(st, n, ld, h->ADJN, h->A1, h->XC, use1 ? (float)k1 : 0.f, use2 ? (float)k2 : 0.f, h->G_ADJN,
+                     h->G_A1, h->rowvals + 4 * (size_t)ld);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+    }
+  } else if (!hsic) {
     launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, (float)(k1 * 2.0 / n2), (float)(k2 * 2.0 / n2),
                      (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN, h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
@@ -568,14 +613,16 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
     const double norm_a = sqrt(0.5 * s[S_SQ]);
     const double origin = nll + norm_a * 0.001;
     double c1v = 0, c2v = 0;
-    if (hsic) { c1v = k1 * s[S_H1]; c2v = k2 * s[S_H2]; }
+    const bool kl = c.measure == MCGRA_MEASURE_KL, dp = c.measure == MCGRA_MEASURE_DP;
+    if (dp) { c1v = k1 * sqrt(s[S_H1]); c2v = k2 * sqrt(s[S_H2]); }
+    else if (hsic || kl) { c1v = k1 * s[S_H1]; c2v = k2 * s[S_H2]; }
     else { c1v = k1 * s[S_V1] / n2; c2v = k2 * s[S_V2] / n2; }
     if (!use1) c1v = 0;
     if (!use2) c2v = 0;
     const double c6v = k6 * (-s[S_V6] / n2), c7v = k7 * (-s[S_V7] / n2);
     double c9v = 0, c10v = 0;
-    if (w9 != 0) c9v = hsic ? k9 * s[S_C9] : k9 * s[S_C9] / ((double)h->na * he);
-    if (w10 != 0) c10v = hsic ? k10 * s[S_C10] : k10 * s[S_C10] / ((double)h->na * C);
+    if (w9 != 0) c9v = dp ? k9 * sqrt(s[S_C9]) : (hsic || kl) ? k9 * s[S_C9] : k9 * s[S_C9] / ((double)h->na * he);
+    if (w10 != 0) c10v = dp ? k10 * sqrt(s[S_C10]) : (hsic || kl) ? k10 * s[S_C10] : k10 * s[S_C10] / ((double)h->na * C);
     scalars_out[0] = c.weight_sup * origin + sg * (c1v + c2v + c9v + c10v) + c6v + c7v;
     scalars_out[1] = origin; scalars_out[2] = c1v; scalars_out[3] = c2v; scalars_out[4] = c6v; scalars_out[5] = c7v;
     scalars_out[6] = c9v; scalars_out[7] = c10v; scalars_out[8] = 0.5 * s[S_CLAMPSUM]; scalars_out[9] = nll;

@@ -21,6 +21,11 @@ void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, 
 void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out);
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower);
+void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out);
+void launch_kl_rows(hipStream_t st, int n, int ld, const float* A, const float* B, const float* FS, float k1, float k2,
+                    float* GA, float* GB, double* rowvals);
+void launch_rowsumsq(hipStream_t st, int n, int ld, const float* P, double* rows);
+void launch_axpy_invnorm(hipStream_t st, int n, int ld, const float* T, const double* sumsq, float k, float* G);
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);
@@ -54,6 +59,8 @@ void launch_softmax_bwd(hipStream_t st, int n, int c, const float* sm, const flo
 void launch_gather_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float* dst, int ldd);
 void launch_scatter_add_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float scale,
                              float* dst, int ldd);
+void launch_scatter_add_rows_invnorm(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx,
+                                     const double* sumsq, float k, float* dst, int ldd);
 void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld);
 void launch_sumsq(hipStream_t st, size_t count, const float* X, double* out);
 void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* out);

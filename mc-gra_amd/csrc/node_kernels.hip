@@ -142,6 +142,18 @@ __global__ void k_scatter_add_rows(int m, int h, const float* __restrict__ src, 
   atomicAdd(&dst[(size_t)idx[i] * ldd + c], scale * src[(size_t)i * lds_ + c]);
 }
 
+// dst[idx[i]] += (k / sqrt(*sumsq)) * src[i]  (0 when *sumsq == 0)
+__global__ void k_scatter_add_rows_invnorm(int m, int h, const float* __restrict__ src, int lds_,
+                                           const int* __restrict__ idx, const double* __restrict__ sumsq, float k,
+                                           float* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * h) return;
+  const double sq = sumsq[0];
+  const float c = sq > 0.0 ? (float)(k / sqrt(sq)) : 0.f;
+  const int i = e / h, cc = e % h;
+  atomicAdd(&dst[(size_t)idx[i] * ldd + cc], c * src[(size_t)i * lds_ + cc]);
+}
+
 // column means of an [m x h] matrix, then centre in place (H X of CudaCKA.centering)
 __global__ void k_colmean_center(int m, int h, float* __restrict__ X, int ld) {
   __shared__ double shd[16];
@@ -259,6 +271,10 @@ void launch_gather_rows(hipStream_t st, int m, int h, const float* src, int lds_
 void launch_scatter_add_rows(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx, float scale,
                              float* dst, int ldd) {
   LAUNCH(k_scatter_add_rows, g1((size_t)m * h), dim3(256), st, m, h, src, lds_, idx, scale, dst, ldd);
+}
+void launch_scatter_add_rows_invnorm(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx,
+                                     const double* sumsq, float k, float* dst, int ldd) {
+  LAUNCH(k_scatter_add_rows_invnorm, g1((size_t)m * h), dim3(256), st, m, h, src, lds_, idx, sumsq, k, dst, ldd);
 }
 void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld) {
   LAUNCH(k_colmean_center, dim3(h), dim3(256), st, m, h, X, ld);

@@ -565,6 +565,123 @@ __global__ __launch_bounds__(ROW_THREADS) void k_ie_rows(int n, int ld, const fl
   if (threadIdx.x == 0) rows[i] = s;
 }
 
+
+// ---------------------------------------------------------------------------
+// PGDAttack.calc_kl on N x N operands (topology_attack.py:483-487):
+//   calc_kl(X, Y) = sum_ij softmax(X)_ij (log softmax(X)_ij - log_softmax(Y)_ij) / n   (rows = batch)
+//   c1 = k1 calc_kl(feature_adj, adj_norm)   c2 = k2 calc_kl(adj_norm, A1)
+// FS = row softmax of feature_adj (constant).  One block per row; the row (<= 160 KB) stays in L1/L2
+// across the passes.  Gradients are ACCUMULATED into GA (adj_norm) and GB (A1).
+//   d/dY = (softmax(Y) - softmax(X)) / n
+//   d/dX = xs * (g - <g, xs>),  g = (log xs + 1 - log_softmax(Y)) / n
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void k_row_softmax(int n, int ld, const float* __restrict__ X,
+                                                             float* __restrict__ out) {
+  __shared__ float shf[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) mx = fmaxf(mx, X[base + j]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) shf[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) s += expf(X[base + j] - mx);
+  s = block_sum(s, shf);
+  const float ls = logf(s);
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) out[base + j] = expf(X[base + j] - mx - ls);
+}
+
+__device__ __forceinline__ float block_max4(float v, float* sh) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void k_kl_rows(int n, int ld, const float* __restrict__ A,
+                                                         const float* __restrict__ B, const float* __restrict__ FS,
+                                                         float k1, float k2, float* __restrict__ GA,
+                                                         float* __restrict__ GB, double* __restrict__ rowvals) {
+  __shared__ float shf[16];
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const float invn = 1.f / (float)n;
+  float ma = -INFINITY, mb = -INFINITY;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) { ma = fmaxf(ma, A[base + j]); if (k2 != 0.f) mb = fmaxf(mb, B[base + j]); }
+  ma = block_max4(ma, shf);
+  if (k2 != 0.f) mb = block_max4(mb, shf);
+  float sa = 0.f, sb = 0.f;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) { sa += expf(A[base + j] - ma); if (k2 != 0.f) sb += expf(B[base + j] - mb); }
+  sa = block_sum(sa, shf);
+  if (k2 != 0.f) sb = block_sum(sb, shf);
+  const float lsa = ma + logf(sa), lsb = (k2 != 0.f) ? mb + logf(sb) : 0.f;
+  // <g, xs> of the c2 term and the two values
+  double v1 = 0, v2 = 0;
+  float dot = 0.f;
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) {
+    const float la = A[base + j] - lsa;
+    if (k1 != 0.f) { const float f = FS[base + j]; if (f > 0.f) v1 += (double)f * (logf(f) - la); }
+    if (k2 != 0.f) {
+      const float lb = B[base + j] - lsb, xs = expf(la);
+      if (xs > 0.f) v2 += (double)xs * (la - lb);
+      dot += (la + 1.f - lb) * invn * xs;
+    }
+  }
+  v1 = block_sum_d(v1, shd); v2 = block_sum_d(v2, shd);
+  if (k2 != 0.f) dot = block_sum(dot, shf);
+  for (int j = threadIdx.x; j < n; j += ROW_THREADS) {
+    const float la = A[base + j] - lsa, xs = expf(la);
+    float ga = 0.f;
+    if (k1 != 0.f) ga += k1 * invn * (xs - FS[base + j]);
+    if (k2 != 0.f) {
+      const float lb = B[base + j] - lsb;
+      ga += k2 * xs * ((la + 1.f - lb) * invn - dot);
+      GB[base + j] += k2 * invn * (expf(lb) - xs);
+    }
+    GA[base + j] += ga;
+  }
+  if (threadIdx.x == 0) { rowvals[i] = v1 * invn; rowvals[(size_t)n + i] = v2 * invn; }
+}
+
+
+// row sums of squares (double) - |P|_F^2 of PGDAttack.dot_product (:480-481)
+__global__ __launch_bounds__(ROW_THREADS) void k_rowsumsq(int n, int ld, const float* __restrict__ P,
+                                                          double* __restrict__ rows) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  double s = 0;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(P + base + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) if (j + t < n) s += (double)v[t] * v[t];
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) rows[i] = s;
+}
+
+// G += (k / sqrt(*sumsq)) * T   (0 when *sumsq == 0: torch.norm backward at the origin)
+__global__ __launch_bounds__(ROW_THREADS) void k_axpy_invnorm(int n, int ld, const float* __restrict__ T,
+                                                              const double* __restrict__ sumsq, float k,
+                                                              float* __restrict__ G) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const double sq = sumsq[0];
+  const float c = sq > 0.0 ? (float)(k / sqrt(sq)) : 0.f;
+  for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(T + base + j);
+    f32x4 g = *reinterpret_cast<f32x4*>(G + base + j);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (j + q < n) g[q] += c * t[q];
+    *reinterpret_cast<f32x4*>(G + base + j) = g;
+  }
+}
+
 // ---- host launchers ---------------------------------------------------------
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 
@@ -600,6 +717,19 @@ void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const dou
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower) {
   LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals, lower ? 1 : 0);
+}
+void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out) {
+  LAUNCH(k_row_softmax, dim3(n), dim3(ROW_THREADS), st, n, ld, X, out);
+}
+void launch_kl_rows(hipStream_t st, int n, int ld, const float* A, const float* B, const float* FS, float k1, float k2,
+                    float* GA, float* GB, double* rowvals) {
+  LAUNCH(k_kl_rows, dim3(n), dim3(ROW_THREADS), st, n, ld, A, B, FS, k1, k2, GA, GB, rowvals);
+}
+void launch_rowsumsq(hipStream_t st, int n, int ld, const float* P, double* rows) {
+  LAUNCH(k_rowsumsq, dim3(n), dim3(ROW_THREADS), st, n, ld, P, rows);
+}
+void launch_axpy_invnorm(hipStream_t st, int n, int ld, const float* T, const double* sumsq, float k, float* G) {
+  LAUNCH(k_axpy_invnorm, dim3(n), dim3(ROW_THREADS), st, n, ld, T, sumsq, k, G);
 }
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {

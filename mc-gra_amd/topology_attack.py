@@ -163,7 +163,7 @@ class PGDAttack(BaseAttack):
             w7 = args.w8
             w9, w10 = args.w9, args.w10
         measure = args.measure
-        if measure not in ("HSIC", "MSELoss"):
+        if measure not in ("HSIC", "MSELoss", "KL", "DP"):
             raise NotImplementedError(f"measure {measure!r} (topology_attack.py:197-208) is not on the HIP path yet")
         if float(getattr(args, "eps", 0) or 0) != 0:
             raise NotImplementedError("args.eps != 0 (adding_noise, topology_attack.py:474-478) is not on the HIP path yet")

@@ -172,7 +172,7 @@ def test_gcn_forward_matches_oracle(pkg, torch_):
 
 
 # ------------------------------------------------------------------ attack engine
-ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss")]
+ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss", "KL", "DP")]
 
 
 @pytest.mark.parametrize("name", ENGINE_CASES)
@@ -260,7 +260,7 @@ def test_engine_invariants_and_determinism(pkg, torch_):
 def test_unsupported_arguments_fail_loudly(pkg, torch_):
     z = H.load_case("s48_mse")
     with pytest.raises(NotImplementedError):
-        H.engine_from(pkg, z, measure="KL")
+        H.engine_from(pkg, z, measure="CKA")
     with pytest.raises(ValueError):
         H.engine_from(pkg, z, measure="KDE")
 
