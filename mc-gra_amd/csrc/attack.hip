@@ -45,7 +45,7 @@ static const double AP_C1 = 100, AP_C2 = 1000, AP_C6 = 10, AP_C7 = 10, AP_C9 = 1
 
 enum Scal {  // device scalar slots (double)
   S_SQ = 0, S_SUM, S_NLL, S_V1, S_V2, S_V6, S_V7, S_H1, S_H2, S_C9, S_C10, S_TOTX, S_TOTY, S_CLAMPSUM,
-  S_TMP, S_COUNT = 32
+  S_TMP, S_TMP2, S_CK0, S_CK1, S_CK2, S_CK3, S_COUNT = 32
 };
 
 struct GemmTimer {
@@ -81,6 +81,8 @@ struct mcgra_attack {
   float *Y = 0, *GT = 0, *Z = 0, *logp = 0, *sm = 0, *Z2 = 0, *sm2 = 0, *GZ = 0, *GZ2 = 0, *Gsm = 0;
   float *Zn = 0, *GZn = 0, *Gem = 0;
   float *HA = 0, *YA = 0, *HAg = 0, *HAc = 0, *YAg = 0, *YAc = 0, *Yg = 0, *Gg = 0, *Q = 0;
+  float *Q2 = 0, *Gg2 = 0, *coef = 0;
+  double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)
   float* ws = 0;
   size_t ws_bytes = 0;
   int nstrips = 32;
@@ -220,9 +222,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
               cfg->nclass, cfg->n_attack);
     return MCGRA_EINVAL;
   }
-  if (cfg->measure != MCGRA_MEASURE_HSIC && cfg->measure != MCGRA_MEASURE_MSE && cfg->measure != MCGRA_MEASURE_KL &&
-      cfg->measure != MCGRA_MEASURE_DP) {
-    set_error("measure %d (CKA) is not implemented on the HIP path yet", cfg->measure);
+  if (cfg->measure < MCGRA_MEASURE_HSIC || cfg->measure > MCGRA_MEASURE_DP) {
+    set_error("measure %d: only HSIC, MSELoss, KL, CKA, DP exist on this path (KDE needs cuda:0-only utils.py:991)",
+              cfg->measure);
     return MCGRA_ENOSUP;
   }
   if (cfg->eps != 0.f) { set_error("eps != 0 (adding_noise) is not implemented on the HIP path yet"); return MCGRA_ENOSUP; }
@@ -254,7 +256,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
 #define A_(p, cnt) if (!rc) rc = dalloc(h, &h->p, (cnt))
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn); A_(GSYM, nn);
-  if (cfg->measure == MCGRA_MEASURE_HSIC) { A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn); }
+  if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
+    A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn);
+  }
   if (cfg->measure == MCGRA_MEASURE_KL) { A_(XC, nn); }      // XC holds softmax(feature_adj) rows
   if (cfg->measure == MCGRA_MEASURE_DP) { A_(KY, nn); A_(XC, nn); }
   A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
@@ -273,7 +277,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(Zn, nm); A_(GZn, nm); A_(Gem, nm);
   const size_t am_ = (size_t)h->na * h->hmax;
   A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
-  A_(Q, (size_t)h->hmax * h->hmax);
+  A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
 #undef A_
@@ -335,11 +339,23 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   launch_gather_rows(st, h->na, h->C, h->YA, h->C, h->idx, h->YAg, h->hmax);
   launch_gather_rows(st, h->na, h->C, h->YA, h->C, h->idx, h->YAc, h->hmax);
   launch_colmean_center(st, h->na, h->C, h->YAc, h->hmax);
-  if (h->cfg.measure == MCGRA_MEASURE_HSIC && h->cfg.w[0] != 0.f) {
+  if (h->cfg.measure == MCGRA_MEASURE_CKA) {
+    // hsic(H_A, H_A), hsic(Y_A, Y_A) of linear_CKA's denominator (utils.py:1093): |Xc^T Xc|_F^2, constants
+    const int hm = h->hmax;
+    MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
+    CHK(eg(h, st, true, false, h->wdt[le], h->wdt[le], h->na, 1.f, h->HAc, hm, h->HAc, hm, 0.f, h->Q, hm));
+    launch_sumsq(st, (size_t)h->wdt[le] * hm, h->Q, h->cst + 1);
+    MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
+    CHK(eg(h, st, true, false, h->C, h->C, h->na, 1.f, h->YAc, hm, h->YAc, hm, 0.f, h->Q, hm));
+    launch_sumsq(st, (size_t)h->C * hm, h->Q, h->cst + 2);
+  }
+  if ((h->cfg.measure == MCGRA_MEASURE_HSIC || h->cfg.measure == MCGRA_MEASURE_CKA) && h->cfg.w[0] != 0.f) {
     // centred Gram of feature_adj: constant left factor of c1 (utils.py:1086,1089), from centred columns
     launch_rowsum(st, n, ld, h->FADJ, h->rowsx);
     launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
+    launch_rowsumsq(st, n, ld, h->KFC, h->rowsx);
+    launch_reduce_rows(st, h->rowsx, n, 1, h->cst + 0);      // hsic(feature_adj, feature_adj)
   }
   if (h->cfg.measure == MCGRA_MEASURE_KL && h->cfg.w[0] != 0.f)
     launch_row_softmax(st, n, ld, h->FADJ, h->XC);      // F.softmax(feature_adj) of calc_kl (:484), constant
@@ -372,6 +388,22 @@ static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Y
   if (h->cfg.measure == MCGRA_MEASURE_MSE) {
     launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot);   // sum of squares
     launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
+  } else if (h->cfg.measure == MCGRA_MEASURE_CKA) {
+    // linear_CKA(X, Y) (utils.py:1091-1096): value hxy / (sqrt(hxx) sqrt(hyy)); Q = Xc^T Yc, R = Yc^T Yc,
+    // d/dY = (2/den) Xc Q - (2 hxy / (den hyy)) Yc R.  hxx is the constant in cst[cst_slot].
+    launch_colmean_center(st, na, width, h->Yg, hm);
+    MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
+    MCGRA_HIP(hipMemsetAsync(h->Q2, 0, sizeof(float) * (size_t)hm * hm, st));
+    CHK(eg(h, st, true, false, width, width, na, 1.f, Xc, hm, h->Yg, hm, 0.f, h->Q, hm));
+    CHK(eg(h, st, true, false, width, width, na, 1.f, h->Yg, hm, h->Yg, hm, 0.f, h->Q2, hm));
+    launch_sumsq(st, (size_t)width * hm, h->Q, h->scal + S_TMP);
+    launch_sumsq(st, (size_t)width * hm, h->Q2, h->scal + S_TMP2);
+    float* ab = h->coef + (slot == S_C9 ? 8 : 12);
+    launch_cka_small_coef(st, h->cst + (slot == S_C9 ? 1 : 2), h->scal + S_TMP, h->scal + S_TMP2, (float)k_signed, ab,
+                          h->scal + slot);
+    CHK(eg(h, st, false, false, na, width, width, 1.f, Xc, hm, h->Q, hm, 0.f, h->Gg, hm));
+    CHK(eg(h, st, false, false, na, width, width, 1.f, h->Yg, hm, h->Q2, hm, 0.f, h->Gg2, hm));
+    launch_scatter_add2_rows(st, na, width, h->Gg, h->Gg2, hm, h->idx, ab, G, ldg);
   } else if (h->cfg.measure == MCGRA_MEASURE_DP) {   // |Y^T X|_F (:480-481): P = Yg^T Xg, d/dY = X P^T / |P|
     MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
     CHK(eg(h, st, true, false, width, width, na, 1.f, h->Yg, hm, Xg, hm, 0.f, h->Q, hm));
@@ -468,7 +500,8 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   const double k1 = w1 * 1000 * AP_C1, k2 = w2 * 100 * AP_C2, k6 = w6 * 100 * AP_C6, k7 = w7 * AP_C7;
   const double k9 = w9 * AP_C9, k10 = w10 * AP_C10;
   const double n2 = (double)n * n;
-  const bool hsic = c.measure == MCGRA_MEASURE_HSIC;
+  const bool cka = c.measure == MCGRA_MEASURE_CKA;
+  const bool hsic = c.measure == MCGRA_MEASURE_HSIC || cka;      // both run the centred-Gram path
   MCGRA_HIP(hipMemsetAsync(h->scal, 0, sizeof(double) * S_COUNT, st));
 
   // ---- forward: adjacency, normalisation (:164-166)
@@ -544,9 +577,16 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
         launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
         CHK(eg_syrk(h, st, sym, n, n, h->YC, ld, h->KY, ld));                                     // H Ky H
       }
-      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f,
-                          h->rowvals + 4 * (size_t)ld, sym);
-      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+      if (cka) {
+        launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, sym);
+        launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 4, h->scal + S_CK0);
+        launch_cka_coef(st, h->scal + S_CK0, h->cst + 0, use1 ? (float)k1 : 0.f, use2 ? (float)k2 : 0.f, h->coef);
+        launch_cka_lincomb(st, n, ld, h->KX, h->KY, h->KFC, h->coef, use1, use2, sym);
+      } else {
+        launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f,
+                            h->rowvals + 4 * (size_t)ld, sym);
+        launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+      }
       // G_adjn += 2 (s1 Kfc + s2 Kyc) @ Xc ;  G_A1 += 2 s2 Kxc @ Yc   (K 1 = 0, so Xc may replace X)
       CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
       if (use2) CHK(eg_symm(h, st, sym, n, n, h->KX, ld, h->YC, ld, 1.f, h->G_A1, ld));
@@ -614,7 +654,14 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
     const double origin = nll + norm_a * 0.001;
     double c1v = 0, c2v = 0;
     const bool kl = c.measure == MCGRA_MEASURE_KL, dp = c.measure == MCGRA_MEASURE_DP;
-    if (dp) { c1v = k1 * sqrt(s[S_H1]); c2v = k2 * sqrt(s[S_H2]); }
+    if (cka) {
+      double cst[8];
+      MCGRA_HIP(hipMemcpy(cst, h->cst, sizeof(cst), hipMemcpyDeviceToHost));
+      const double d1 = sqrt(cst[0]) * sqrt(s[S_CK1]), d2 = sqrt(s[S_CK1]) * sqrt(s[S_CK3]);
+      c1v = d1 > 0 ? k1 * s[S_CK0] / d1 : 0;
+      c2v = d2 > 0 ? k2 * s[S_CK2] / d2 : 0;
+    }
+    else if (dp) { c1v = k1 * sqrt(s[S_H1]); c2v = k2 * sqrt(s[S_H2]); }
     else if (hsic || kl) { c1v = k1 * s[S_H1]; c2v = k2 * s[S_H2]; }
     else { c1v = k1 * s[S_V1] / n2; c2v = k2 * s[S_V2] / n2; }
     if (!use1) c1v = 0;

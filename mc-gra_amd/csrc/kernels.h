@@ -26,6 +26,11 @@ void launch_kl_rows(hipStream_t st, int n, int ld, const float* A, const float* 
                     float* GA, float* GB, double* rowvals);
 void launch_rowsumsq(hipStream_t st, int n, int ld, const float* P, double* rows);
 void launch_axpy_invnorm(hipStream_t st, int n, int ld, const float* T, const double* sumsq, float k, float* G);
+void launch_cka_sums(hipStream_t st, int n, int ld, const float* KX, const float* KY, const float* KFC, bool use1,
+                     bool use2, double* rowvals, bool lower);
+void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float k1, float k2, float* coef);
+void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
+                        bool use1, bool use2, bool lower);
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);
@@ -61,6 +66,10 @@ void launch_scatter_add_rows(hipStream_t st, int m, int h, const float* src, int
                              float* dst, int ldd);
 void launch_scatter_add_rows_invnorm(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx,
                                      const double* sumsq, float k, float* dst, int ldd);
+void launch_cka_small_coef(hipStream_t st, const double* hxx, const double* hxy, const double* hyy, float k, float* ab,
+                           double* val);
+void launch_scatter_add2_rows(hipStream_t st, int m, int h, const float* S1, const float* S2, int lds_, const int* idx,
+                              const float* ab, float* dst, int ldd);
 void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld);
 void launch_sumsq(hipStream_t st, size_t count, const float* X, double* out);
 void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* out);

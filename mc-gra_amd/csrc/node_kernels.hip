@@ -154,6 +154,31 @@ __global__ void k_scatter_add_rows_invnorm(int m, int h, const float* __restrict
   atomicAdd(&dst[(size_t)idx[i] * ldd + cc], c * src[(size_t)i * lds_ + cc]);
 }
 
+// linear_CKA on small operands: coefficients of  d/dY = alpha Xc Q + beta Yc R  (Q = Xc^T Yc, R = Yc^T Yc)
+// in: hxx (constant), hxy = |Q|^2, hyy = |R|^2.  out: ab[0] = alpha, ab[1] = beta, ab[2] = value hxy/den.
+__global__ void k_cka_small_coef(const double* __restrict__ hxx, const double* __restrict__ hxy,
+                                 const double* __restrict__ hyy, float k, float* __restrict__ ab,
+                                 double* __restrict__ val) {
+  const double den = sqrt(hxx[0]) * sqrt(hyy[0]);
+  if (den > 0) {
+    ab[0] = (float)(k * 2.0 / den);
+    ab[1] = (float)(-k * 2.0 * hxy[0] / (den * hyy[0]));
+    val[0] = hxy[0] / den;
+  } else {          // 0/0 (identical rows): the documented degenerate case contributes nothing
+    ab[0] = 0.f; ab[1] = 0.f; val[0] = 0.0;
+  }
+}
+
+// dst[idx[i]] += ab[0] * S1[i] + ab[1] * S2[i]
+__global__ void k_scatter_add2_rows(int m, int h, const float* __restrict__ S1, const float* __restrict__ S2, int lds_,
+                                    const int* __restrict__ idx, const float* __restrict__ ab,
+                                    float* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * h) return;
+  const int i = e / h, c = e % h;
+  atomicAdd(&dst[(size_t)idx[i] * ldd + c], ab[0] * S1[(size_t)i * lds_ + c] + ab[1] * S2[(size_t)i * lds_ + c]);
+}
+
 // column means of an [m x h] matrix, then centre in place (H X of CudaCKA.centering)
 __global__ void k_colmean_center(int m, int h, float* __restrict__ X, int ld) {
   __shared__ double shd[16];
@@ -275,6 +300,14 @@ void launch_scatter_add_rows(hipStream_t st, int m, int h, const float* src, int
 void launch_scatter_add_rows_invnorm(hipStream_t st, int m, int h, const float* src, int lds_, const int* idx,
                                      const double* sumsq, float k, float* dst, int ldd) {
   LAUNCH(k_scatter_add_rows_invnorm, g1((size_t)m * h), dim3(256), st, m, h, src, lds_, idx, sumsq, k, dst, ldd);
+}
+void launch_cka_small_coef(hipStream_t st, const double* hxx, const double* hxy, const double* hyy, float k, float* ab,
+                           double* val) {
+  LAUNCH(k_cka_small_coef, dim3(1), dim3(1), st, hxx, hxy, hyy, k, ab, val);
+}
+void launch_scatter_add2_rows(hipStream_t st, int m, int h, const float* S1, const float* S2, int lds_, const int* idx,
+                              const float* ab, float* dst, int ldd) {
+  LAUNCH(k_scatter_add2_rows, g1((size_t)m * h), dim3(256), st, m, h, S1, S2, lds_, idx, ab, dst, ldd);
 }
 void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld) {
   LAUNCH(k_colmean_center, dim3(h), dim3(256), st, m, h, X, ld);

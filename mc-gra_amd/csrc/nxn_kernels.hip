@@ -682,6 +682,70 @@ __global__ __launch_bounds__(ROW_THREADS) void k_axpy_invnorm(int n, int ld, con
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// CudaCKA.linear_CKA on N x N operands (utils.py:1091-1096): hsic(X,Y) / (sqrt(hsic(X,X)) sqrt(hsic(Y,Y))).
+// KX, KY: centred Grams of adj_norm / A1 (lower tile storage when lower != 0), KFC: centred Gram of
+// feature_adj.  k_cka_sums gives per-row partials of <KFC,KX>, <KX,KX>, <KX,KY>, <KY,KY>;
+// k_cka_coef turns the five inner products into the coefficients of the gradient left factors
+//   L1 = af KFC + ax KX + ay KY  (G_adjn += L1 @ Xc),   L2 = bx KX + by KY  (G_A1 += L2 @ Yc)
+// and k_cka_lincomb writes L1 -> KY, L2 -> KX in place.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void k_cka_sums(int n, int ld, const float* __restrict__ KX,
+                                                          const float* __restrict__ KY, const float* __restrict__ KFC,
+                                                          int use1, int use2, double* __restrict__ rowvals, int lower) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const int jdiag = lower ? (i / SYM_TILE) * SYM_TILE : 0;
+  const int jend = lower ? min(n, jdiag + SYM_TILE) : n;
+  double fx = 0, xx = 0, xy = 0, yy = 0;
+  for (int j = threadIdx.x; j < jend; j += ROW_THREADS) {
+    const double w = (lower && j < jdiag) ? 2.0 : 1.0;
+    const double kx = KX[base + j];
+    xx += w * kx * kx;
+    if (use1) fx += w * kx * (double)KFC[base + j];
+    if (use2) { const double ky = KY[base + j]; xy += w * kx * ky; yy += w * ky * ky; }
+  }
+  fx = block_sum_d(fx, shd); xx = block_sum_d(xx, shd); xy = block_sum_d(xy, shd); yy = block_sum_d(yy, shd);
+  if (threadIdx.x == 0) {
+    rowvals[i] = fx; rowvals[(size_t)n + i] = xx; rowvals[2 * (size_t)n + i] = xy; rowvals[3 * (size_t)n + i] = yy;
+  }
+}
+
+// in: s[0..3] = hfx, hxx, hxy, hyy; hff; k1, k2 (0 = term off).  out: coef[0..4] = af, ax, ay, bx, by.
+// A vanishing denominator (identical rows) is the documented 0/0 case: that term contributes nothing.
+__global__ void k_cka_coef(const double* __restrict__ s, const double* __restrict__ hff, float k1, float k2,
+                           float* __restrict__ coef) {
+  const double hfx = s[0], hxx = s[1], hxy = s[2], hyy = s[3];
+  double af = 0, ax = 0, ay = 0, bx = 0, by = 0;
+  if (k1 != 0.f) {
+    const double den = sqrt(hff[0]) * sqrt(hxx);
+    if (den > 0) { af = k1 * 2.0 / den; ax += -k1 * 2.0 * hfx / (den * hxx); }
+  }
+  if (k2 != 0.f) {
+    const double den = sqrt(hxx) * sqrt(hyy);
+    if (den > 0) { ay = k2 * 2.0 / den; ax += -k2 * 2.0 * hxy / (den * hxx); bx = k2 * 2.0 / den; by = -k2 * 2.0 * hxy / (den * hyy); }
+  }
+  coef[0] = (float)af; coef[1] = (float)ax; coef[2] = (float)ay; coef[3] = (float)bx; coef[4] = (float)by;
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void k_cka_lincomb(int n, int ld, float* __restrict__ KX,
+                                                             float* __restrict__ KY, const float* __restrict__ KFC,
+                                                             const float* __restrict__ coef, int use1, int use2, int lower) {
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const int jend = lower ? min(n, (i / SYM_TILE + 1) * SYM_TILE) : n;
+  const float af = coef[0], ax = coef[1], ay = coef[2], bx = coef[3], by = coef[4];
+  for (int j = threadIdx.x; j < jend; j += ROW_THREADS) {
+    const float kx = KX[base + j];
+    const float ky = use2 ? KY[base + j] : 0.f;
+    const float kf = use1 ? KFC[base + j] : 0.f;
+    KY[base + j] = af * kf + ax * kx + ay * ky;
+    KX[base + j] = bx * kx + by * ky;
+  }
+}
+
 // ---- host launchers ---------------------------------------------------------
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 
@@ -730,6 +794,17 @@ void launch_rowsumsq(hipStream_t st, int n, int ld, const float* P, double* rows
 }
 void launch_axpy_invnorm(hipStream_t st, int n, int ld, const float* T, const double* sumsq, float k, float* G) {
   LAUNCH(k_axpy_invnorm, dim3(n), dim3(ROW_THREADS), st, n, ld, T, sumsq, k, G);
+}
+void launch_cka_sums(hipStream_t st, int n, int ld, const float* KX, const float* KY, const float* KFC, bool use1,
+                     bool use2, double* rowvals, bool lower) {
+  LAUNCH(k_cka_sums, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, use1 ? 1 : 0, use2 ? 1 : 0, rowvals, lower ? 1 : 0);
+}
+void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float k1, float k2, float* coef) {
+  LAUNCH(k_cka_coef, dim3(1), dim3(1), st, s4, hff, k1, k2, coef);
+}
+void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
+                        bool use1, bool use2, bool lower) {
+  LAUNCH(k_cka_lincomb, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, coef, use1 ? 1 : 0, use2 ? 1 : 0, lower ? 1 : 0);
 }
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {

@@ -9,9 +9,9 @@ to HBM and drives the engine.  There is no CPU path: without a HIP device or
 without libmcgra_hip.so it raises.
 
 Arguments the reference accepts but this path does not cover yet raise
-NotImplementedError naming the reference line (measure KL/CKA/DP/KDE,
-loss_type 'CW', args.eps != 0, a non-zero ori_adj, an embedding whose weights
-differ from victim_model.gc).
+NotImplementedError naming the reference line (measure KDE, loss_type 'CW',
+args.eps != 0, a non-zero ori_adj, an embedding whose weights differ from
+victim_model.gc).
 """
 import os
 
@@ -163,7 +163,7 @@ class PGDAttack(BaseAttack):
             w7 = args.w8
             w9, w10 = args.w9, args.w10
         measure = args.measure
-        if measure not in ("HSIC", "MSELoss", "KL", "DP"):
+        if measure not in ("HSIC", "MSELoss", "KL", "DP", "CKA"):
             raise NotImplementedError(f"measure {measure!r} (topology_attack.py:197-208) is not on the HIP path yet")
         if float(getattr(args, "eps", 0) or 0) != 0:
             raise NotImplementedError("args.eps != 0 (adding_noise, topology_attack.py:474-478) is not on the HIP path yet")

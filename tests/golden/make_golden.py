@@ -170,6 +170,8 @@ def gen_small(tmp):
         # random (seeded) initial adj_changes: generic-sign gradients through every N x N term
         ("s48_hsic_init", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 4, 1e12),
         ("s200_hsic_init", 200, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 4, 1e12),
+        # CKA with the small-operand terms: non-degenerate away from the origin (distinct em rows)
+        ("s48_cka_init", 48, 24, 4, 16, 2, "CKA", base_wp, 1.0, 0.01, 3, 1e12),
         ("s200_mse_init", 200, 64, 6, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 0.01, 4, 1e12),
     ]
     for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:

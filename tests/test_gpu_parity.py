@@ -172,7 +172,7 @@ def test_gcn_forward_matches_oracle(pkg, torch_):
 
 
 # ------------------------------------------------------------------ attack engine
-ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss", "KL", "DP")]
+ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss", "KL", "DP", "CKA")]
 
 
 @pytest.mark.parametrize("name", ENGINE_CASES)
@@ -193,7 +193,8 @@ def test_step_gradients_match_reference(pkg, torch_, name):
         g = O.pack_tril(eng.buffer("G_sym").cpu().numpy())
         g_ref = z["steps_g"][t]
         scale = np.abs(g_ref).max()
-        assert np.abs(g - g_ref).max() <= 3e-4 * scale, (name, t, np.abs(g - g_ref).max(), scale)
+        tol = 6e-4 if "cka" in name else 3e-4
+        assert np.abs(g - g_ref).max() <= tol * scale, (name, t, np.abs(g - g_ref).max(), scale)
         # intermediates against the oracle
         last = orc.last
         # the bisection case cannot be teacher-forced (state is not recoverable from the hook), so engine
@@ -259,8 +260,6 @@ def test_engine_invariants_and_determinism(pkg, torch_):
 
 def test_unsupported_arguments_fail_loudly(pkg, torch_):
     z = H.load_case("s48_mse")
-    with pytest.raises(NotImplementedError):
-        H.engine_from(pkg, z, measure="CKA")
     with pytest.raises(ValueError):
         H.engine_from(pkg, z, measure="KDE")
 
