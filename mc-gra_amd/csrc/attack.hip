@@ -82,6 +82,9 @@ struct mcgra_attack {
   float *Zn = 0, *GZn = 0, *Gem = 0;
   float *HA = 0, *YA = 0, *HAg = 0, *HAc = 0, *YAg = 0, *YAc = 0, *Yg = 0, *Gg = 0, *Q = 0;
   float *Q2 = 0, *Gg2 = 0, *coef = 0;
+  float* Abuf = 0;                 // modified_adj after adding_noise (only when eps != 0; otherwise it is M itself)
+  unsigned char* gate = 0;         // clamp pass-through mask of adding_noise's torch.clamp
+  double* colpart_d = 0;
   double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)
   float* ws = 0;
   size_t ws_bytes = 0;
@@ -227,7 +230,6 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
               cfg->measure);
     return MCGRA_ENOSUP;
   }
-  if (cfg->eps != 0.f) { set_error("eps != 0 (adding_noise) is not implemented on the HIP path yet"); return MCGRA_ENOSUP; }
   if (cfg->row_begin != 0 || (cfg->row_end != cfg->n && cfg->row_end != 0)) {
     set_error("row-block sharding is driven from the host layer; engine objects are full-range");
     return MCGRA_ENOSUP;
@@ -277,6 +279,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(Zn, nm); A_(GZn, nm); A_(Gem, nm);
   const size_t am_ = (size_t)h->na * h->hmax;
   A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
+  if (cfg->eps != 0.f) { A_(Abuf, nn); A_(gate, nn); A_(colpart_d, (size_t)h->nstrips * ld); }
   A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
@@ -428,12 +431,14 @@ static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Y
   return 0;
 }
 
-static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out) {
+// noise == NULL: modified_adj == M (monitoring forward :290-293 and eps == 0); otherwise adding_noise (:165)
+static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, const float* noise) {
   const int n = h->n, ld = h->ld;
-  launch_prep(st, false, n, ld, h->M, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum);
+  const bool general = noise != nullptr;
+  launch_prep(st, general, n, ld, h->M, nullptr, noise, h->cfg.eps, h->Abuf, h->gate, h->d, h->r, h->rowsq, h->rowsum);
   launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
   launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
-  launch_adjn(st, n, ld, h->M, h->r, adjn_out);
+  launch_adjn(st, n, ld, general ? h->Abuf : h->M, h->r, adjn_out);
   MCGRA_KERNEL_CHECK();
   return 0;
 }
@@ -491,7 +496,10 @@ static int project(mcgra_attack* h, hipStream_t st) {
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out) {
   if (!h) { set_error("null handle"); return MCGRA_EINVAL; }
   if (!h->graph_set) { set_error("mcgra_attack_set_graph must be called first"); return MCGRA_EINVAL; }
-  if (noise) { set_error("noise (eps != 0) is not implemented on the HIP path yet"); return MCGRA_ENOSUP; }
+  if ((h->cfg.eps != 0.f) != (noise != nullptr)) {
+    set_error("noise must be given exactly when eps != 0 (it stands for torch.randn_like at topology_attack.py:475)");
+    return MCGRA_EINVAL;
+  }
   hipStream_t st = (hipStream_t)stream;
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C;
@@ -505,8 +513,13 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   MCGRA_HIP(hipMemsetAsync(h->scal, 0, sizeof(double) * S_COUNT, st));
 
   // ---- forward: adjacency, normalisation (:164-166)
-  CHK(forward_common(h, st, h->ADJN));
-  const float* A = h->M;   // modified_adj == M when ori == 0, eps == 0
+  if (noise) {  // caller layout is [n][n]; the kernels use leading dimension ld.  G_A is free at this point.
+    MCGRA_HIP(hipMemcpy2DAsync(h->G_A, (size_t)ld * 4, noise, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+    noise = h->G_A;
+  }
+  CHK(forward_common(h, st, h->ADJN, noise));
+  const float* A = noise ? h->Abuf : h->M;   // modified_adj == M when ori == 0, eps == 0
+  const unsigned char* gate = noise ? h->gate : nullptr;
   // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
   CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
@@ -565,7 +578,8 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
     if (use1 || use2) {
       const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
       // adj_norm and A1 are symmetric here (ori == 0, eps == 0): column means == row means
-      launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
+      if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
+      else launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
       launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
       // Grams are symmetric: only the 128x128 tiles on or below the diagonal are computed (lower tile
       // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
@@ -637,7 +651,7 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
   // clamp(a,0,1).sum() <= n(n-1)/2, so a larger budget can never trigger the bisection (:339)
   const bool may_project = c.num_edges < 0.5 * n2;
-  launch_adam_sym(st, n, ld, h->G_A, nullptr, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
+  launch_adam_sym(st, n, ld, h->G_A, gate, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
                   (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->GSYM, may_project ? 0 : 1);
   MCGRA_KERNEL_CHECK();
   h->have_step = true;
@@ -681,7 +695,7 @@ int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, doubl
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   // adj_norm2 goes to the A1 buffer: ADJN must survive for the post-loop decode (:300)
-  CHK(forward_common(h, st, h->A1));
+  CHK(forward_common(h, st, h->A1, nullptr));
   CHK(chain_forward(h, st, h->A1, h->ld, h->L, h->Tv, h->Pv, h->Hv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, nullptr));
   if (out_logp)
@@ -718,7 +732,7 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   if (decode_mode < 0 || decode_mode > 6) { set_error("decode_mode %d", decode_mode); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
-  if (!h->have_step) CHK(forward_common(h, st, h->ADJN));   // epochs == 0: adj_norm of :142
+  if (!h->have_step) CHK(forward_common(h, st, h->ADJN, nullptr));   // epochs == 0: adj_norm of :142
   // em = embedding(features, adj_norm) ; adj_changes <- dot_product_decode(em) (:300-301)
   CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu));
   launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);

@@ -31,6 +31,7 @@ void launch_cka_sums(hipStream_t st, int n, int ld, const float* KX, const float
 void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float k1, float k2, float* coef);
 void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
                         bool use1, bool use2, bool lower);
+void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, int nstrips, double* cols);
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);

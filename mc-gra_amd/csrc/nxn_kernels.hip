@@ -746,6 +746,26 @@ __global__ __launch_bounds__(ROW_THREADS) void k_cka_lincomb(int n, int ld, floa
   }
 }
 
+
+// column sums of an n x n matrix (asymmetric adj_norm when eps != 0): strip partials then a fixed-order sum
+__global__ __launch_bounds__(256) void k_colsum_part(int n, int ld, const float* __restrict__ X, int rows_per_strip,
+                                                     double* __restrict__ part) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int strip = blockIdx.y;
+  const int i0 = strip * rows_per_strip, i1 = min(n, i0 + rows_per_strip);
+  if (j >= n) return;
+  double s = 0;
+  for (int i = i0; i < i1; ++i) s += X[(size_t)i * ld + j];
+  part[(size_t)strip * n + j] = s;
+}
+__global__ void k_colsum_fin(int n, const double* __restrict__ part, int nstrips, double* __restrict__ cols) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0;
+  for (int t = 0; t < nstrips; ++t) s += part[(size_t)t * n + j];
+  cols[j] = s;
+}
+
 // ---- host launchers ---------------------------------------------------------
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 
@@ -805,6 +825,11 @@ void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float 
 void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
                         bool use1, bool use2, bool lower) {
   LAUNCH(k_cka_lincomb, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, coef, use1 ? 1 : 0, use2 ? 1 : 0, lower ? 1 : 0);
+}
+void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, int nstrips, double* cols) {
+  const int rows_per_strip = (n + nstrips - 1) / nstrips;
+  LAUNCH(k_colsum_part, dim3((n + 255) / 256, nstrips), dim3(256), st, n, ld, X, rows_per_strip, part);
+  LAUNCH(k_colsum_fin, dim3((n + 255) / 256), dim3(256), st, n, part, nstrips, cols);
 }
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {

@@ -10,7 +10,7 @@ without libmcgra_hip.so it raises.
 
 Arguments the reference accepts but this path does not cover yet raise
 NotImplementedError naming the reference line (measure KDE, loss_type 'CW',
-args.eps != 0, a non-zero ori_adj, an embedding whose weights differ from
+a non-zero ori_adj, an embedding whose weights differ from
 victim_model.gc).
 """
 import os
@@ -165,8 +165,7 @@ class PGDAttack(BaseAttack):
         measure = args.measure
         if measure not in ("HSIC", "MSELoss", "KL", "DP", "CKA"):
             raise NotImplementedError(f"measure {measure!r} (topology_attack.py:197-208) is not on the HIP path yet")
-        if float(getattr(args, "eps", 0) or 0) != 0:
-            raise NotImplementedError("args.eps != 0 (adding_noise, topology_attack.py:474-478) is not on the HIP path yet")
+        eps = float(getattr(args, "eps", 0) or 0)
 
         n = self.nnodes
         adj_np = _dense_np(adj)
@@ -191,7 +190,7 @@ class PGDAttack(BaseAttack):
         if self.engine is not None:
             self.engine.close()
         eng = AttackEngine(n, dims, int(Wlin.shape[0]), emb_nlayer, measure, weight_supervised,
-                           (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=0.0, device=dev)
+                           (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev)
         eng.set_model(W, b, Wlin, blin)
         eng.set_graph(_dense_np(ori_features), adj_np, None, fadj, lab, idx)
         if self._adj_changes_init is not None:
@@ -204,7 +203,8 @@ class PGDAttack(BaseAttack):
             lab_t = torch.as_tensor(lab, device=dev)
         acc_test_list, sparsity_list = [], []
         for t in range(epochs):
-            eng.step()
+            # adding_noise (:474-478): torch.randn_like on the attack device, as the reference draws it
+            eng.step(noise=torch.randn(n, n, device=dev) if eps != 0 else None)
             if monitor:
                 out2, spars = eng.monitor(want_sparsity=False)       # (:290-296)
                 if idx_test_t is not None:

@@ -104,7 +104,13 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
                           loss_type="CE", device=device).to(device)
     if a0 is not None:      # start away from the origin: adj_changes is a public Parameter (topology_attack.py:77)
         model.adj_changes.data = torch.tensor(np.asarray(a0, dtype=np.float32))
-    steps_a, steps_g = [], []
+    steps_a, steps_g, noises = [], [], []
+    orig_randn_like = torch.randn_like
+
+    def rec_randn_like(t, *a_, **k_):      # adding_noise's torch.randn_like (topology_attack.py:475), recorded
+        z = orig_randn_like(t, *a_, **k_)
+        noises.append(z.detach().numpy().copy())
+        return z
 
     def hook(opt, a, k):
         p = opt.param_groups[0]["params"][0]
@@ -113,15 +119,18 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
 
     from torch.optim.optimizer import register_optimizer_step_post_hook
     handle = register_optimizer_step_post_hook(hook) if capture_steps else None
+    if eps != 0:
+        torch.randn_like = rec_randn_like
     try:
         model.attack(args, None, lr, 0, weight_sup, weight_param, feature_adj, 0, 0, 0,
                      None, None, np.arange(min(8, n)), adj, features, init_adj, labels, idx_attack,
                      num_edges, 0, epochs=epochs)
     finally:
+        torch.randn_like = orig_randn_like
         if handle is not None:
             handle.remove()
     final = model.modified_adj.detach().numpy().copy()
-    return dict(final=final, steps_a=steps_a, steps_g=steps_g, H_A2=H_A2.detach().numpy(),
+    return dict(final=final, steps_a=steps_a, steps_g=steps_g, noises=noises, H_A2=H_A2.detach().numpy(),
                 Y_A=Y_A.detach().numpy(), feature_adj=feature_adj.numpy(),
                 auc=metric_pool(adj.numpy(), final, idx_attack))
 
@@ -172,6 +181,10 @@ def gen_small(tmp):
         ("s200_hsic_init", 200, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 4, 1e12),
         # CKA with the small-operand terms: non-degenerate away from the origin (distinct em rows)
         ("s48_cka_init", 48, 24, 4, 16, 2, "CKA", base_wp, 1.0, 0.01, 3, 1e12),
+        # args.eps != 0: adding_noise (:474-478) makes modified_adj asymmetric and gates the gradient at the clamp
+        ("s48_hsic_eps", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_mse_eps", 48, 24, 4, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_kl_eps", 48, 24, 4, 16, 2, "KL", base_wp, 1.0, 0.01, 3, 1e12),
         ("s200_mse_init", 200, 64, 6, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 0.01, 4, 1e12),
     ]
     for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:
@@ -182,11 +195,16 @@ def gen_small(tmp):
         idx_attack = np.array(random.sample(range(n), n if "l3" not in name else int(n * 0.75)))
         a0 = None
         extra = {}
-        if name.endswith("_init"):
+        eps = 0.0
+        if name.endswith("_init") or name.endswith("_eps"):
             extra = dict(a0_seed=123, a0_scale=0.05)
             a0 = init_adj_changes(n, 123, 0.05)
+        if name.endswith("_eps"):
+            eps = 0.02
         res = run_reference_attack(adj, feats, labels, victim, idx_attack, measure, wp, wsup, lr,
-                                   epochs, "cora", (True, True, True), ne, a0=a0)
+                                   epochs, "cora", (True, True, True), ne, a0=a0, eps=eps)
+        if eps != 0:
+            extra.update(eps=eps, noise=np.stack(res["noises"]))
         out = dict(adj=adj.numpy(), **extra, features=feats.numpy(), labels=lab, idx_attack=idx_attack,
                    measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup,
                    lr=lr, epochs=epochs, num_edges=ne, nlayer=nl, final=res["final"],

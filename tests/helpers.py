@@ -26,7 +26,7 @@ def weights_from(z):
 def cfg_from(z):
     return O.AttackConfig(measure=str(z["measure"]), weight_sup=float(z["weight_sup"]),
                           weight_param=tuple(float(x) for x in z["weight_param"]), lr=float(z["lr"]),
-                          num_edges=float(z["num_edges"]), eps=0.0, emb_nlayer=2)
+                          num_edges=float(z["num_edges"]), eps=float(z["eps"]) if "eps" in z else 0.0, emb_nlayer=2)
 
 
 def init_adj_changes(n, seed, scale):
@@ -38,6 +38,11 @@ def a0_of(z):
     if "a0_seed" in z:
         return init_adj_changes(z["adj"].shape[0], z["a0_seed"], z["a0_scale"])
     return None
+
+
+def noise_of(z, t):
+    """Noise the reference drew at step t (recorded torch.randn_like), or None when eps == 0."""
+    return z["noise"][t] if "noise" in z else None
 
 
 def oracle_from(z):
@@ -79,7 +84,7 @@ def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None):
     dims = [w.W[0].shape[0]] + [x.shape[1] for x in w.W]
     eng = pkg.AttackEngine(z["adj"].shape[0], dims, w.Wlin.shape[0], 2, measure or cfg.measure, cfg.weight_sup,
                            weight_param or cfg.weight_param, cfg.lr, cfg.num_edges, len(z["idx_attack"]),
-                           device=device)
+                           eps=cfg.eps, device=device)
     eng.set_model(w.W, w.b, w.Wlin, w.blin)
     eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
     if a0_of(z) is not None:

@@ -188,8 +188,9 @@ def test_step_gradients_match_reference(pkg, torch_, name):
             a = np.clip(z["steps_a"][t - 1], 0, 1)
             eng.set_adj_changes(a)
             orc.set_adj_changes(a)
-        sc = eng.step(want_scalars=True)
-        orc.step()
+        nz = H.noise_of(z, t)
+        sc = eng.step(want_scalars=True, noise=None if nz is None else dev(torch_, nz))
+        orc.step(nz)
         g = O.pack_tril(eng.buffer("G_sym").cpu().numpy())
         g_ref = z["steps_g"][t]
         scale = np.abs(g_ref).max()
@@ -213,7 +214,8 @@ def test_free_run_final_matches_reference(pkg, torch_, name):
     z = H.load_case(name)
     eng = H.engine_from(pkg, z)
     for t in range(int(z["epochs"])):
-        eng.step()
+        nz = H.noise_of(z, t)
+        eng.step(noise=None if nz is None else dev(torch_, nz))
         a = eng.get_adj_changes().cpu().numpy()
         assert np.abs(a - np.clip(z["steps_a"][t], 0, 1)).max() < 0.05 * float(z["lr"]) + 1e-6 or float(z["num_edges"]) < 1e9
     lab = z["labels"]

@@ -88,7 +88,7 @@ def test_attack_steps_match_reference(name):
             # captured by the hook, then the clamp of topology_attack.py:282) so that each step's
             # gradient is checked on identical inputs instead of on an Adam-amplified drift
             orc.set_adj_changes(np.clip(z["steps_a"][t - 1], 0, 1))
-        orc.step()
+        orc.step(H.noise_of(z, t))
         g_ref = z["steps_g"][t]
         g = O.pack_tril(orc.last["G_sym"])
         scale = np.abs(g_ref).max()
