@@ -120,6 +120,36 @@ def cpu_baseline(workload, seed):
                 scaled_to_workload=v * scale)
 
 
+def timed_region(step_fn, steps, warmup, sync, world, dist=None, device=None, torch=None):
+    """The driver's timing contract: W untimed steps, then exactly K steps bracketed by barrier + device sync on
+    both sides; returns the MAX over ranks of the elapsed seconds.  `sync()` is torch.cuda.synchronize on GPU
+    (a no-op in the gloo CPU test that covers the N > 1 plumbing)."""
+    for _ in range(warmup):
+        step_fn()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def aggregate_value(world, steps, dt):
+    """Whole-job throughput of N independent replicas (weak scaling): every rank ran `steps` attack steps."""
+    return world * steps / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,22 +195,7 @@ def main():
     for _ in range(a.warmup):
         one_step()
     eng.profile(True); eng.gemm_stats(reset=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = timed_region(one_step, a.steps, 0, torch.cuda.synchronize, world, dist, dev, torch)
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
 
@@ -193,7 +208,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "attack-steps/sec", "value": world * a.steps / dt, "unit": "attack-steps/s",
+            "metric": "attack-steps/sec", "value": aggregate_value(world, a.steps, dt), "unit": "attack-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
