@@ -141,6 +141,15 @@ typedef struct mcgra_attack_config {
      uses [0, n).  The caller runs the collectives named in DESIGN.md between
      the phases of mcgra_attack_step_phase(). */
   int32_t row_begin, row_end;
+  /* victim family, unified layer form  P_l = adj @ (H W_l) + H Ws_l + b_l,  H_l = act(P_l):
+   *   GCN (models/gcn.py:35-46,164-174)        act 0 (relu), head_act 0, has_self 0
+   *   dense GAT (models/gat.py:36-50: the attention product is overwritten by adj @ h; heads concatenated into
+   *   W_l, zero bias; head elu(out_att(x)) :206)  act 1 (elu), head_act 1, has_self 0
+   *   GraphSAGE (models/graphsage.py:37-50: [x | adj@x] @ weight)   act 0, head_act 0, has_self 1 */
+  int32_t act, head_act, has_self;
+  /* depths of the H_A1 / H_A2 embedding forwards of the post-loop ensemble (topology_attack.py:304-307):
+     {1, 2}; embedding_gat.forward ignores set_layers (gat.py:170-174), so a GAT uses {nlayer, nlayer}. 0 = default */
+  int32_t fin_layers[2];
 } mcgra_attack_config_t;
 
 int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg);
@@ -149,7 +158,8 @@ int mcgra_attack_destroy(mcgra_attack_t* h);
 /* victim_model / embedding weights (models/gcn.py GCN.gc[l].weight/.bias,
  * GCN.linear1); device pointers, copied. */
 int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W,
-                           const float* const* b, const float* Wlin, const float* blin);
+                           const float* const* b, const float* Wlin, const float* blin,
+                           const float* const* Ws /* GraphSAGE self weights, NULL unless has_self */);
 
 /* constant inputs of PGDAttack.attack (topology_attack.py:95-98): ori_features
  * [n x nfeat], adj (true graph, used only for the H_A / Y_A priors :177-182),

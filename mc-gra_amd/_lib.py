@@ -39,6 +39,7 @@ class AttackConfig(C.Structure):
         ("emb_nlayer", C.c_int32), ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("measure", C.c_int32),
         ("n_attack", C.c_int32), ("weight_sup", C.c_float), ("w", C.c_float * 10), ("lr", C.c_float),
         ("eps", C.c_float), ("num_edges", C.c_double), ("row_begin", C.c_int32), ("row_end", C.c_int32),
+        ("act", C.c_int32), ("head_act", C.c_int32), ("has_self", C.c_int32), ("fin_layers", C.c_int32 * 2),
     ]
 
 
@@ -77,7 +78,7 @@ def _load():
                               C.POINTER(C.c_void_p), fp, fp, C.c_int, C.c_int, fp, fp],
         "mcgra_attack_create": [C.POINTER(C.c_void_p), C.POINTER(AttackConfig)],
         "mcgra_attack_destroy": [vp],
-        "mcgra_attack_set_model": [vp, vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), fp, fp],
+        "mcgra_attack_set_model": [vp, vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), fp, fp, C.POINTER(C.c_void_p)],
         "mcgra_attack_set_graph": [vp, vp, fp, fp, fp, fp, ip, ip],
         "mcgra_attack_set_adj_changes": [vp, vp, fp],
         "mcgra_attack_get_adj_changes": [vp, vp, fp],

@@ -75,6 +75,9 @@ struct mcgra_attack {
   float* W[MCGRA_MAX_LAYERS] = {0};
   float* b[MCGRA_MAX_LAYERS] = {0};
   float *Wlin = 0, *blin = 0;
+  float* Ws[MCGRA_MAX_LAYERS] = {0};   // GraphSAGE self weights (has_self), [dims[l] x dims[l+1]]
+  float *S0 = 0, *Sv = 0, *Su = 0;    // self terms X Ws_0 (constant) and H_{l-1} Ws_l of both chains
+  int act = 0, head_act = 0, has_self = 0, fin0 = 1, fin1 = 2;
   // node-level
   float *Tv = 0, *Pv = 0, *Hv = 0, *GPv = 0;   // victim(adj_norm) chain, [n x hsum]
   float *Tu = 0, *Pu = 0, *Hu = 0, *GPu = 0;   // victim/embedding(modified_adj) chain
@@ -166,14 +169,20 @@ static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, cons
 // x = relu(adj @ (x W_l) + b_l) for `depth` layers (models/gcn.py:71-76,164-172).
 // T[:, off[0]..] must already hold T_0 = X W_0.
 static int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int depth, float* T, float* P,
-                         float* H) {
+                         float* H, float* S) {
   const int n = h->n, hs = h->hsum;
   for (int l = 0; l < depth; ++l) {
     CHK(eg(h, st, false, false, n, h->wdt[l], n, 1.f, adj, adj_ld, T + h->off[l], hs, 0.f, h->Y, h->hmax));
-    launch_bias_relu(st, n, h->wdt[l], h->Y, h->hmax, h->b[l], P + h->off[l], H + h->off[l], hs);
-    if (l + 1 < h->L)
+    const float* self = !h->has_self ? nullptr : (l == 0 ? h->S0 : S + h->off[l]);
+    launch_bias_relu(st, n, h->wdt[l], h->Y, h->hmax, h->b[l], self, l == 0 ? h->hmax : hs, h->act, P + h->off[l],
+                     H + h->off[l], hs);
+    if (l + 1 < h->L) {
       launch_rowmat(st, n, h->wdt[l], h->wdt[l + 1], H + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr,
                     T + h->off[l + 1], hs);
+      if (h->has_self)   // x W_top of the next GraphSAGE layer (graphsage.py:44-45)
+        launch_rowmat(st, n, h->wdt[l], h->wdt[l + 1], H + h->off[l], hs, h->Ws[l + 1], h->wdt[l + 1], 1, nullptr,
+                      S + h->off[l + 1], hs);
+    }
   }
   MCGRA_KERNEL_CHECK();
   return 0;
@@ -183,7 +192,7 @@ static int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int 
 static int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, float* logp, float* sm) {
   const int l = h->L - 1;
   launch_rowmat(st, h->n, h->wdt[l], h->C, H + h->off[l], h->hsum, h->Wlin, 1, h->wdt[l], h->blin, Z, h->C);
-  launch_log_softmax(st, h->n, h->C, Z, h->C, logp, sm, h->C);
+  launch_log_softmax(st, h->n, h->C, Z, h->C, logp, sm, h->C, h->head_act);   // Z keeps the linear output
   MCGRA_KERNEL_CHECK();
   return 0;
 }
@@ -197,8 +206,10 @@ static int chain_backward(mcgra_attack* h, hipStream_t st, const float* adj, int
     // G_T_l = adj^T @ G_P_l
     CHK(eg(h, st, true, false, n, h->wdt[l], n, 1.f, adj, adj_ld, GP + h->off[l], hs, 0.f, h->GT, h->hmax));
     // G_P_{l-1} = (G_T_l @ W_l^T [+ Add]) * (P_{l-1} > 0)
-    launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], P + h->off[l - 1], hs,
-                       (l - 1 == add_at) ? Add : nullptr, add_ld, GP + h->off[l - 1], hs);
+    // (+ G_P_l @ Ws_l^T: the self path of a GraphSAGE layer)
+    launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l],
+                       h->has_self ? GP + h->off[l] : nullptr, hs, h->wdt[l], h->Ws[l], 1, h->wdt[l],
+                       P + h->off[l - 1], hs, h->act, (l - 1 == add_at) ? Add : nullptr, add_ld, GP + h->off[l - 1], hs);
   }
   MCGRA_KERNEL_CHECK();
   return 0;
@@ -237,6 +248,12 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   mcgra_attack* h = new mcgra_attack();
   h->cfg = *cfg;
   { const char* e = getenv("MCGRA_NO_SYM"); h->use_sym = !(e && e[0] == '1'); }
+  h->act = cfg->act; h->head_act = cfg->head_act; h->has_self = cfg->has_self;
+  h->fin0 = cfg->fin_layers[0] > 0 ? cfg->fin_layers[0] : 1;
+  h->fin1 = cfg->fin_layers[1] > 0 ? cfg->fin_layers[1] : 2;
+  if (h->fin0 > cfg->nlayer || h->fin1 > cfg->nlayer || cfg->act < 0 || cfg->act > 1) {
+    delete h; set_error("bad act / fin_layers"); return MCGRA_EINVAL;
+  }
   h->n = cfg->n;
   h->ld = (cfg->n + 3) & ~3;
   h->L = cfg->nlayer;
@@ -273,6 +290,10 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     if (!rc) rc = dalloc(h, &h->b[l], (size_t)cfg->dims[l + 1]);
   }
   A_(Wlin, (size_t)h->C * h->wdt[h->L - 1]); A_(blin, (size_t)h->C);
+  if (h->has_self) {
+    for (int l = 0; l < h->L && !rc; ++l) rc = dalloc(h, &h->Ws[l], (size_t)cfg->dims[l] * cfg->dims[l + 1]);
+    A_(S0, n * (size_t)h->hmax); A_(Sv, n * (size_t)h->hsum); A_(Su, n * (size_t)h->hsum);
+  }
   const size_t nh = n * h->hsum, nm = n * h->hmax, nc = n * h->C;
   A_(Tv, nh); A_(Pv, nh); A_(Hv, nh); A_(GPv, nh); A_(Tu, nh); A_(Pu, nh); A_(Hu, nh); A_(GPu, nh);
   A_(Y, nm); A_(GT, nm); A_(Z, nc); A_(logp, nc); A_(sm, nc); A_(Z2, nc); A_(sm2, nc); A_(GZ, nc); A_(GZ2, nc); A_(Gsm, nc);
@@ -298,10 +319,12 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
 }
 
 int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W, const float* const* b,
-                           const float* Wlin, const float* blin) {
+                           const float* Wlin, const float* blin, const float* const* Ws) {
   if (!h || !W || !b || !Wlin || !blin) { set_error("null argument"); return MCGRA_EINVAL; }
+  if ((h->has_self != 0) != (Ws != nullptr)) { set_error("Ws must be given exactly when has_self is set"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   for (int l = 0; l < h->L; ++l) {
+    if (Ws) MCGRA_HIP(hipMemcpyAsync(h->Ws[l], Ws[l], sizeof(float) * h->cfg.dims[l] * h->cfg.dims[l + 1], hipMemcpyDeviceToDevice, st));
     MCGRA_HIP(hipMemcpyAsync(h->W[l], W[l], sizeof(float) * h->cfg.dims[l] * h->cfg.dims[l + 1], hipMemcpyDeviceToDevice, st));
     MCGRA_HIP(hipMemcpyAsync(h->b[l], b[l], sizeof(float) * h->cfg.dims[l + 1], hipMemcpyDeviceToDevice, st));
   }
@@ -330,8 +353,11 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   // T0 = X @ W_0 : the only use of the features inside the loop (models/gcn.py:41)
   CHK(eg(h, st, false, false, n, h->wdt[0], h->cfg.dims[0], 1.f, features, h->cfg.dims[0], h->W[0], h->wdt[0], 0.f, h->Tv, hs));
   MCGRA_HIP(hipMemcpy2DAsync(h->Tu, (size_t)hs * 4, h->Tv, (size_t)hs * 4, (size_t)h->wdt[0] * 4, n, hipMemcpyDeviceToDevice, st));
+  if (h->has_self)   // S0 = X @ Ws_0: the self half of the first GraphSAGE layer, adjacency independent
+    CHK(eg(h, st, false, false, n, h->wdt[0], h->cfg.dims[0], 1.f, features, h->cfg.dims[0], h->Ws[0], h->wdt[0], 0.f, h->S0,
+           h->hmax));
   // priors on the TRUE, un-normalised adjacency (topology_attack.py:177-182, :243)
-  CHK(chain_forward(h, st, adj, n, h->L, h->Tu, h->Pu, h->Hu));
+  CHK(chain_forward(h, st, adj, n, h->L, h->Tu, h->Pu, h->Hu, h->Su));
   CHK(head_forward(h, st, h->Hu, h->Z2, h->YA, nullptr));                                  // Y_A (log-probs)
   const int le = h->Le - 1;
   MCGRA_HIP(hipMemcpy2DAsync(h->HA, (size_t)h->hmax * 4, h->Hu + h->off[le], (size_t)hs * 4, (size_t)h->wdt[le] * 4, n,
@@ -521,12 +547,12 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   const float* A = noise ? h->Abuf : h->M;   // modified_adj == M when ori == 0, eps == 0
   const unsigned char* gate = noise ? h->gate : nullptr;
   // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
-  CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv));
+  CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
   launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
   launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
   // ---- embedding(features, modified_adj - ori_adj) (:185) == first Le layers of victim(features, modified_adj) (:259)
-  CHK(chain_forward(h, st, A, ld, L, h->Tu, h->Pu, h->Hu));
+  CHK(chain_forward(h, st, A, ld, L, h->Tu, h->Pu, h->Hu, h->Su));
   CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
   const float* em = h->Hu + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
@@ -617,8 +643,9 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   }
 
   // ---- backward: victim(adj_norm) chain -> G_adjn
-  launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, h->Pv + h->off[L - 1], hs, nullptr, 0,
-                     h->GPv + h->off[L - 1], hs);
+  if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z, h->GZ);     // through elu(out_att(x)) (gat.py:206)
+  launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
+                     h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
   CHK(chain_backward(h, st, h->ADJN, ld, L - 1, h->Pv, h->GPv, -1, nullptr, 0));
   CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 1.f, h->G_ADJN, ld));   // sum_l G_P_l T_l^T
 
@@ -631,13 +658,15 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   int ltop;
   if (w10 != 0) {
     ltop = L - 1;
-    launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, h->Pu + h->off[L - 1], hs,
-                       (L - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[L - 1], hs);
+    if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z2, h->GZ2);
+    launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
+                       h->Pu + h->off[L - 1], hs, h->act, (L - 1 == Le - 1) ? h->Gem : nullptr, h->hmax,
+                       h->GPu + h->off[L - 1], hs);
   } else {
     ltop = Le - 1;
     if (L > Le) MCGRA_HIP(hipMemsetAsync(h->GPu, 0, sizeof(float) * (size_t)n * hs, st));
-    launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, h->Pu + h->off[Le - 1], hs, h->Gem, h->hmax,
-                       h->GPu + h->off[Le - 1], hs);
+    launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
+                       h->Pu + h->off[Le - 1], hs, h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
   }
   CHK(chain_backward(h, st, A, ld, ltop, h->Pu, h->GPu, Le - 1, h->Gem, h->hmax));
   // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
@@ -696,7 +725,7 @@ int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, doubl
   hipStream_t st = (hipStream_t)stream;
   // adj_norm2 goes to the A1 buffer: ADJN must survive for the post-loop decode (:300)
   CHK(forward_common(h, st, h->A1, nullptr));
-  CHK(chain_forward(h, st, h->A1, h->ld, h->L, h->Tv, h->Pv, h->Hv));
+  CHK(chain_forward(h, st, h->A1, h->ld, h->L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, nullptr));
   if (out_logp)
     MCGRA_HIP(hipMemcpyAsync(out_logp, h->logp, sizeof(float) * (size_t)h->n * h->C, hipMemcpyDeviceToDevice, st));
@@ -734,17 +763,17 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
   if (!h->have_step) CHK(forward_common(h, st, h->ADJN, nullptr));   // epochs == 0: adj_norm of :142
   // em = embedding(features, adj_norm) ; adj_changes <- dot_product_decode(em) (:300-301)
-  CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu));
+  CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu, h->Su));
   launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);
   CHK(eg(h, st, false, true, n, n, h->wdt[Le - 1], 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->M, ld));
   launch_decode_post(st, n, ld, h->M, nullptr);            // modified_adj = get_modified_adj (:302)
   // out = modified_adj + feature_adj (:314)
   launch_axpby2d(st, n, h->M, ld, 1.f, h->FADJ, ld, 1.f, out, n);
   // H_A1, H_A2 = embedding(features, modified_adj) with 1 / 2 layers; Y_A2 = victim (:304-308)
-  CHK(chain_forward(h, st, h->M, ld, L, h->Tu, h->Pu, h->Hu));
+  CHK(chain_forward(h, st, h->M, ld, L, h->Tu, h->Pu, h->Hu, h->Su));
   CHK(head_forward(h, st, h->Hu, h->Z2, h->logp, nullptr));
-  CHK(dd2(h, st, decode_mode, h->Hu + h->off[0], h->wdt[0], hs, out));
-  CHK(dd2(h, st, decode_mode, h->Hu + h->off[1], h->wdt[1], hs, out));
+  CHK(dd2(h, st, decode_mode, h->Hu + h->off[h->fin0 - 1], h->wdt[h->fin0 - 1], hs, out));   // H_A1 (:304-305)
+  CHK(dd2(h, st, decode_mode, h->Hu + h->off[h->fin1 - 1], h->wdt[h->fin1 - 1], hs, out));   // H_A2 (:306-307)
   CHK(dd2(h, st, decode_mode, h->logp, h->C, h->C, out));
   if (H_A) CHK(dd2(h, st, decode_mode, H_A, h->wdt[Le - 1], h->wdt[Le - 1], out));   // (:315-316)
   if (Y_A) CHK(dd2(h, st, decode_mode, Y_A, h->C, h->C, out));                        // (:317-318)

@@ -190,13 +190,13 @@ int mcgra_gcn_forward(void* stream, int n, int nfeat, int nlayer, const int32_t*
   for (int l = 0; l < nlayer; ++l) {
     const int w = dims[l + 1];
     MCGRA_HIP(sgemm(st, false, false, n, w, n, 1.f, adj, n, T, hm, 0.f, Yb, hm, ws, wsb));
-    launch_bias_relu(st, n, w, Yb, hm, b[l], P, H, hm);
+    launch_bias_relu(st, n, w, Yb, hm, b[l], nullptr, 0, 0, P, H, hm);
     if (emb_out && l + 1 == emb_nlayer)
       MCGRA_HIP(hipMemcpy2DAsync(emb_out, (size_t)w * 4, H, (size_t)hm * 4, (size_t)w * 4, n, hipMemcpyDeviceToDevice, st));
     if (l + 1 < nlayer) launch_rowmat(st, n, w, dims[l + 2], H, hm, W[l + 1], dims[l + 2], 1, nullptr, T, hm);
   }
   launch_rowmat(st, n, dims[nlayer], nclass, H, hm, Wlin, 1, dims[nlayer], blin, Z, nclass);
-  launch_log_softmax(st, n, nclass, Z, nclass, out, nullptr, nclass);
+  launch_log_softmax(st, n, nclass, Z, nclass, out, nullptr, nclass, 0);
   MCGRA_KERNEL_CHECK();
   MCGRA_HIP(hipStreamSynchronize(st));
   return 0;

@@ -50,12 +50,16 @@ void launch_sqdiff(hipStream_t st, size_t count, const float* X, const float* Y,
 void launch_ie_rows(hipStream_t st, int n, int ld, const float* P, double* rows);
 
 // ---- node_kernels.hip
-void launch_bias_relu(hipStream_t st, int n, int h, const float* Y, int ldy, const float* b, float* P, float* H, int ldo);
+void launch_bias_relu(hipStream_t st, int n, int h, const float* Y, int ldy, const float* b, const float* S, int lds_,
+                      int act, float* P, float* H, int ldo);
+void launch_elu_grad_mul(hipStream_t st, int n, int c, const float* Zlin, float* G);
 void launch_rowmat(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
                    int sc, const float* bias, float* Out, int ldo);
 void launch_rowmat_mask(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
-                        int sc, const float* P, int ldp, const float* Add, int lda, float* Out, int ldo);
-void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo);
+                        int sc, const float* In2, int ldi2, int k2dim, const float* W2, int sk2, int sc2, const float* P,
+                        int ldp, int act, const float* Add, int lda, float* Out, int ldo);
+void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo,
+                        int elu_in);
 void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,
                      const float* cnt, float scale, float* GZ, double* rownll);
 void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p);

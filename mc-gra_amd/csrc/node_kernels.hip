@@ -11,15 +11,26 @@ namespace mcgra {
 
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 
-// P = Y + b (+ self), H = relu(P)   (GraphConvolution.forward + F.relu, models/gcn.py:42-46,75)
+// act 0: relu (models/gcn.py:75, graphsage.py:82), act 1: elu (gat.py:48)
+__device__ __forceinline__ float act_fwd(float p, int act) {
+  return act == 0 ? fmaxf(p, 0.f) : (p > 0.f ? p : expm1f(p));
+}
+__device__ __forceinline__ float act_grad(float p, int act) {
+  return act == 0 ? (p > 0.f ? 1.f : 0.f) : (p > 0.f ? 1.f : expf(p));
+}
+
+// P = Y + b (+ S), H = act(P): GraphConvolution.forward + activation (models/gcn.py:42-46,75); S is the
+// self term x W_top of a GraphSAGE layer (graphsage.py:43-45)
 __global__ void k_bias_relu(int n, int h, const float* __restrict__ Y, int ldy, const float* __restrict__ b,
-                            float* __restrict__ P, float* __restrict__ H, int ldo) {
+                            const float* __restrict__ S, int lds_, int act, float* __restrict__ P,
+                            float* __restrict__ H, int ldo) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * h) return;
   const int i = e / h, c = e % h;
-  const float p = Y[(size_t)i * ldy + c] + b[c];
+  float p = Y[(size_t)i * ldy + c] + b[c];
+  if (S) p += S[(size_t)i * lds_ + c];
   P[(size_t)i * ldo + c] = p;
-  H[(size_t)i * ldo + c] = fmaxf(p, 0.f);
+  H[(size_t)i * ldo + c] = act_fwd(p, act);
 }
 
 // Out[i][c] = sum_k In[i][k] * W(k, c) (+ bias[c]);  W(k,c) = W[k*sk + c*sc]
@@ -35,32 +46,43 @@ __global__ void k_rowmat(int n, int kdim, int cdim, const float* __restrict__ In
   Out[(size_t)i * ldo + c] = s;
 }
 
-// Gout = (Gin @ W^T) * (P > 0):  relu backward fused with the linear backward
+// Gout = (Gin @ W^T [+ Gin2 @ W2^T] [+ Add]) * act'(P): activation backward fused with the linear backward(s)
 __global__ void k_rowmat_mask(int n, int kdim, int cdim, const float* __restrict__ In, int ldi,
-                              const float* __restrict__ W, int sk, int sc, const float* __restrict__ P,
-                              int ldp, const float* __restrict__ Add, int lda, float* __restrict__ Out, int ldo) {
+                              const float* __restrict__ W, int sk, int sc, const float* __restrict__ In2, int ldi2,
+                              int k2dim, const float* __restrict__ W2, int sk2, int sc2,
+                              const float* __restrict__ P, int ldp, int act, const float* __restrict__ Add, int lda,
+                              float* __restrict__ Out, int ldo) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * cdim) return;
   const int i = e / cdim, c = e % cdim;
   float s = 0.f;
   for (int k = 0; k < kdim; ++k) s = fmaf(In[(size_t)i * ldi + k], W[(size_t)k * sk + (size_t)c * sc], s);
+  if (In2)
+    for (int k = 0; k < k2dim; ++k) s = fmaf(In2[(size_t)i * ldi2 + k], W2[(size_t)k * sk2 + (size_t)c * sc2], s);
   if (Add) s += Add[(size_t)i * lda + c];
-  Out[(size_t)i * ldo + c] = P[(size_t)i * ldp + c] > 0.f ? s : 0.f;
+  Out[(size_t)i * ldo + c] = s * act_grad(P[(size_t)i * ldp + c], act);
+}
+
+// G *= elu'(Zlin): backward of the GAT head activation elu(out_att(x)) (gat.py:206)
+__global__ void k_elu_grad_mul(int n, int c, const float* __restrict__ Zlin, float* __restrict__ G) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * c) return;
+  G[e] *= act_grad(Zlin[e], 1);
 }
 
 // logp = log_softmax(Z), sm = softmax(Z) per row (models/gcn.py:174)
 __global__ void k_log_softmax(int n, int c, const float* __restrict__ Z, int ldz, float* __restrict__ logp,
-                              float* __restrict__ sm, int ldo) {
+                              float* __restrict__ sm, int ldo, int elu_in) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* z = Z + (size_t)i * ldz;
   float mx = -INFINITY;
-  for (int k = 0; k < c; ++k) mx = fmaxf(mx, z[k]);
+  for (int k = 0; k < c; ++k) mx = fmaxf(mx, elu_in ? act_fwd(z[k], 1) : z[k]);
   float s = 0.f;
-  for (int k = 0; k < c; ++k) s += expf(z[k] - mx);
+  for (int k = 0; k < c; ++k) s += expf((elu_in ? act_fwd(z[k], 1) : z[k]) - mx);
   const float ls = logf(s);
   for (int k = 0; k < c; ++k) {
-    const float l = z[k] - mx - ls;
+    const float l = (elu_in ? act_fwd(z[k], 1) : z[k]) - mx - ls;
     if (logp) logp[(size_t)i * ldo + k] = l;
     if (sm) sm[(size_t)i * ldo + k] = expf(l);
   }
@@ -262,19 +284,26 @@ __global__ void k_argmax_eq(int m, int c, const float* __restrict__ logp, int ld
 
 static inline dim3 g1(size_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
-void launch_bias_relu(hipStream_t st, int n, int h, const float* Y, int ldy, const float* b, float* P, float* H, int ldo) {
-  LAUNCH(k_bias_relu, g1((size_t)n * h), dim3(256), st, n, h, Y, ldy, b, P, H, ldo);
+void launch_bias_relu(hipStream_t st, int n, int h, const float* Y, int ldy, const float* b, const float* S, int lds_,
+                      int act, float* P, float* H, int ldo) {
+  LAUNCH(k_bias_relu, g1((size_t)n * h), dim3(256), st, n, h, Y, ldy, b, S, lds_, act, P, H, ldo);
+}
+void launch_elu_grad_mul(hipStream_t st, int n, int c, const float* Zlin, float* G) {
+  LAUNCH(k_elu_grad_mul, g1((size_t)n * c), dim3(256), st, n, c, Zlin, G);
 }
 void launch_rowmat(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
                    int sc, const float* bias, float* Out, int ldo) {
   LAUNCH(k_rowmat, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, bias, Out, ldo);
 }
 void launch_rowmat_mask(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
-                        int sc, const float* P, int ldp, const float* Add, int lda, float* Out, int ldo) {
-  LAUNCH(k_rowmat_mask, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, P, ldp, Add, lda, Out, ldo);
+                        int sc, const float* In2, int ldi2, int k2dim, const float* W2, int sk2, int sc2, const float* P,
+                        int ldp, int act, const float* Add, int lda, float* Out, int ldo) {
+  LAUNCH(k_rowmat_mask, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, In2, ldi2, k2dim, W2, sk2,
+         sc2, P, ldp, act, Add, lda, Out, ldo);
 }
-void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo) {
-  LAUNCH(k_log_softmax, g1(n), dim3(256), st, n, c, Z, ldz, logp, sm, ldo);
+void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo,
+                        int elu_in) {
+  LAUNCH(k_log_softmax, g1(n), dim3(256), st, n, c, Z, ldz, logp, sm, ldo, elu_in);
 }
 void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,
                      const float* cnt, float scale, float* GZ, double* rownll) {

@@ -127,7 +127,7 @@ class AttackEngine:
     topology_attack.py:161-298 (adj_changes + Adam moments) in HBM."""
 
     def __init__(self, n, dims, nclass, emb_nlayer, measure, weight_sup, weight_param, lr, num_edges,
-                 n_attack, eps=0.0, device="cuda:0"):
+                 n_attack, eps=0.0, device="cuda:0", act="relu", head_act="none", has_self=False, fin_layers=(1, 2)):
         _lib.require_device()
         self.device = torch.device(device)
         self.n, self.nclass, self.dims = int(n), int(nclass), list(int(d) for d in dims)
@@ -146,6 +146,10 @@ class AttackEngine:
         cfg.lr, cfg.eps = float(lr), float(eps)
         cfg.num_edges = float(min(num_edges, 1e300))
         cfg.row_begin, cfg.row_end = 0, self.n
+        cfg.act = {"relu": 0, "elu": 1}[act]
+        cfg.head_act = {"none": 0, "elu": 1}[head_act]
+        cfg.has_self = int(bool(has_self))
+        cfg.fin_layers[0], cfg.fin_layers[1] = int(fin_layers[0]), int(fin_layers[1])
         self._h = C.c_void_p(0)
         with torch.cuda.device(self.device):
             check(lib.mcgra_attack_create(C.byref(self._h), C.byref(cfg)))
@@ -163,16 +167,18 @@ class AttackEngine:
         except Exception:
             pass
 
-    def set_model(self, W, b, Wlin, blin):
+    def set_model(self, W, b, Wlin, blin, Ws=None):
         dev = self.device
+        Ws = [_dev_f32(w, dev) for w in Ws] if Ws is not None else None
         W = [_dev_f32(w, dev) for w in W]
         b = [_dev_f32(x, dev) for x in b]
         Wlin, blin = _dev_f32(Wlin, dev), _dev_f32(blin, dev)
         L = len(W)
         Wp = (C.c_void_p * L)(*[w.data_ptr() for w in W])
         bp = (C.c_void_p * L)(*[x.data_ptr() for x in b])
+        Wsp = (C.c_void_p * L)(*[w.data_ptr() for w in Ws]) if Ws is not None else None
         with torch.cuda.device(dev):
-            check(lib.mcgra_attack_set_model(self._h, _stream(), Wp, bp, _p(Wlin), _p(blin)))
+            check(lib.mcgra_attack_set_model(self._h, _stream(), Wp, bp, _p(Wlin), _p(blin), Wsp))
             torch.cuda.current_stream().synchronize()
 
     def set_graph(self, features, adj, ori_adj, feature_adj, labels, idx_attack):

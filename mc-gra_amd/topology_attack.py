@@ -101,19 +101,38 @@ class PGDAttack(BaseAttack):
     # ---- helpers ---------------------------------------------------------------
     @staticmethod
     def _weights(victim_model, embedding):
-        W = [l.weight.detach() for l in victim_model.gc]
-        b = []
-        for l in victim_model.gc:
-            if l.bias is None:
-                b.append(torch.zeros(l.weight.shape[1]))
-            else:
-                b.append(l.bias.detach())
+        """Victim weights in the engine's unified layer form  P_l = adj @ (H W_l) + H Ws_l + b_l, H_l = act(P_l).
+        Returns (W, b, Wlin, blin, Ws, act, head_act, emb_full): models/gcn.py GCN, the dense GAT of
+        models/gat.py (its attention product is overwritten by adj @ h, gat.py:44-45) and models/graphsage.py."""
+        if hasattr(victim_model, "attentions"):                       # GAT: heads concatenated, no bias, ELU
+            W = [torch.cat([a.W.detach() for a in heads], dim=1) for heads in victim_model.attentions]
+            b = [torch.zeros(w.shape[1]) for w in W]
+            Wlin, blin = victim_model.out_att.weight.detach(), victim_model.out_att.bias.detach()
+            emb_att = getattr(embedding, "attentions", None)
+            if emb_att is not None and emb_att is not victim_model.attentions:
+                for he, hv in zip(emb_att, victim_model.attentions):
+                    for ae, av in zip(he, hv):
+                        if not torch.equal(ae.W.detach().cpu(), av.W.detach().cpu()):
+                            raise NotImplementedError("embedding.attentions differs from victim_model.attentions "
+                                                      "(main.py:231 shares them)")
+            return W, b, Wlin, blin, None, "elu", "elu", True
+        gcs = victim_model.gc
+        sage = gcs[0].weight.shape[0] == 2 * victim_model.nfeat       # graphsage.py:20: weight is [2*in, out]
+        W, Ws, b = [], ([] if sage else None), []
+        for l in gcs:
+            w = l.weight.detach()
+            if sage:
+                half = w.shape[0] // 2
+                Ws.append(w[:half].contiguous())
+                w = w[half:].contiguous()
+            W.append(w)
+            b.append(torch.zeros(w.shape[1]) if l.bias is None else l.bias.detach())
         Wlin = victim_model.linear1.weight.detach()
         blin = (victim_model.linear1.bias.detach() if victim_model.linear1.bias is not None
                 else torch.zeros(Wlin.shape[0]))
         emb_gc = getattr(embedding, "gc", None)
         if emb_gc is not None:
-            for le, lv in zip(emb_gc, victim_model.gc):
+            for le, lv in zip(emb_gc, gcs):
                 same = torch.equal(le.weight.detach().cpu(), lv.weight.detach().cpu())
                 if le.bias is not None and lv.bias is not None:
                     same = same and torch.equal(le.bias.detach().cpu(), lv.bias.detach().cpu())
@@ -122,7 +141,7 @@ class PGDAttack(BaseAttack):
                         "embedding.gc differs from victim_model.gc; main.py:190 deep-copies them and the HIP path "
                         "shares one GCN chain between embedding(features, modified_adj) and victim(features, "
                         "modified_adj)")
-        return W, b, Wlin, blin
+        return W, b, Wlin, blin, Ws, "relu", "none", False
 
     def test(self, idx_attack, idx_val, idx_test, adj, features, labels, victim_model):
         """topology_attack.py:83-93 through mcgra_gcn_forward / mcgra_normalize_adj."""
@@ -130,7 +149,9 @@ class PGDAttack(BaseAttack):
         dev = torch.device(self.device)
         adj_t = torch.as_tensor(_dense_np(adj), device=dev)
         X = torch.as_tensor(_dense_np(features), device=dev)
-        W, b, Wlin, blin = self._weights(victim_model, None)
+        W, b, Wlin, blin, Ws, act, head_act, _ = self._weights(victim_model, None)
+        if Ws is not None or act != "relu":
+            raise NotImplementedError("PGDAttack.test() through mcgra_gcn_forward covers the GCN victim only")
         to = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         out, _ = E.gcn_forward(X, E.normalize_adj_tensor(adj_t), [to(w) for w in W], [to(x) for x in b], to(Wlin), to(blin))
         lab = torch.as_tensor(np.asarray(labels), device=dev)
@@ -177,9 +198,10 @@ class PGDAttack(BaseAttack):
             w1 = 0
         lab = np.asarray(labels.cpu() if isinstance(labels, torch.Tensor) else labels).astype(np.int64)
         idx = np.asarray(idx_attack).astype(np.int64)
-        W, b, Wlin, blin = self._weights(victim_model, self.embedding)
+        W, b, Wlin, blin, Ws, act, head_act, emb_full = self._weights(victim_model, self.embedding)
         dims = [W[0].shape[0]] + [w.shape[1] for w in W]
-        emb_nlayer = int(getattr(self.embedding, "nlayer", 2))
+        emb_nlayer = len(W) if emb_full else int(getattr(self.embedding, "nlayer", 2))
+        fin_layers = (len(W), len(W)) if emb_full else (1, 2)   # embedding_gat.forward ignores set_layers
         # inside the loop the reference ends every iteration with embedding.set_layers(2) (:179) or
         # set_layers(nlayer) (:240); both are 2 for main.py's flow
         label_adj = kwargs.get("label_adj", None)
@@ -190,8 +212,9 @@ class PGDAttack(BaseAttack):
         if self.engine is not None:
             self.engine.close()
         eng = AttackEngine(n, dims, int(Wlin.shape[0]), emb_nlayer, measure, weight_supervised,
-                           (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev)
-        eng.set_model(W, b, Wlin, blin)
+                           (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev,
+                           act=act, head_act=head_act, has_self=Ws is not None, fin_layers=fin_layers)
+        eng.set_model(W, b, Wlin, blin, Ws)
         eng.set_graph(_dense_np(ori_features), adj_np, None, fadj, lab, idx)
         if self._adj_changes_init is not None:
             eng.set_adj_changes(self._adj_changes_init)

@@ -243,32 +243,57 @@ def info_entropy_grad(prob: np.ndarray):
 # --------------------------------------------------------------------------
 @dataclass
 class GCNWeights:
-    """Weights of models/gcn.py GCN: gc[l].weight (in,out), gc[l].bias,
-    linear1.weight (nclass, hid), linear1.bias."""
+    """Weights of a victim in the unified layer form
+        P_l = adj @ (H_{l-1} W_l) + H_{l-1} Ws_l + b_l ,  H_l = act(P_l)
+    * models/gcn.py GCN: gc[l].weight (in,out), gc[l].bias, relu, no Ws; head linear1.
+    * models/gat.py GAT: the attention product is overwritten by ``torch.matmul(adj, h)`` (gat.py:44-45), so a
+      layer is elu(adj @ (x [W_1|...|W_heads])) without bias; head elu(out_att(x)) (gat.py:206).
+    * models/graphsage.py: [x | adj@x] @ weight (graphsage.py:43-45) = x W_top + adj @ (x W_bot): Ws = W_top."""
     W: List[np.ndarray]
     b: List[np.ndarray]
     Wlin: np.ndarray
     blin: np.ndarray
+    Ws: Optional[List[np.ndarray]] = None
+    act: str = "relu"
+    head_act: str = "none"
 
     def f32(self):
         return GCNWeights([w.astype(F32) for w in self.W], [x.astype(F32) for x in self.b],
-                          self.Wlin.astype(F32), self.blin.astype(F32))
+                          self.Wlin.astype(F32), self.blin.astype(F32),
+                          None if self.Ws is None else [w.astype(F32) for w in self.Ws], self.act, self.head_act)
 
 
-def gcn_chain(T0: np.ndarray, adj: np.ndarray, w: GCNWeights, nlayer: int):
-    """x = relu(adj @ (x @ W_l) + b_l) for l < nlayer
+def _act(p, kind):
+    if kind == "relu":
+        return np.maximum(p, 0).astype(F32)
+    return np.where(p > 0, p, np.expm1(np.minimum(p, 0))).astype(F32)        # F.elu
+
+
+def _act_grad(p, kind):
+    if kind == "relu":
+        return (p > 0).astype(F32)
+    return np.where(p > 0, 1.0, np.exp(np.minimum(p, 0))).astype(F32)
+
+
+def gcn_chain(T0: np.ndarray, adj: np.ndarray, w: GCNWeights, nlayer: int, S0: Optional[np.ndarray] = None):
+    """x = act(adj @ (x @ W_l) + x @ Ws_l + b_l) for l < nlayer
     (GraphConvolution.forward models/gcn.py:35-46; embedding_GCN.forward :71-76;
-    GCN.forward :164-172 in eval mode, dropout off).  T0 = X @ W_1 is passed in
-    because it does not depend on the adjacency.  Returns lists P (pre-act),
-    H (post-relu), T (H_l @ W_{l+1}; T[0] = T0)."""
+    GCN.forward :164-172 in eval mode, dropout off; gat.py:36-50; graphsage.py:37-50).
+    T0 = X @ W_0 and S0 = X @ Ws_0 are passed in because they do not depend on
+    the adjacency.  Returns lists P (pre-act), H (post-act), T (H_l @ W_{l+1};
+    T[0] = T0)."""
     P, H, T = [], [], [T0]
+    S = S0
     for l in range(nlayer):
         p = (adj @ T[l] + w.b[l][None, :]).astype(F32)
-        h = np.maximum(p, 0).astype(F32)
+        if S is not None:
+            p = (p + S).astype(F32)
+        h = _act(p, w.act)
         P.append(p)
         H.append(h)
         if l + 1 < nlayer:
             T.append((h @ w.W[l + 1]).astype(F32))
+            S = (h @ w.Ws[l + 1]).astype(F32) if w.Ws is not None else None
     return P, H, T
 
 
@@ -277,18 +302,30 @@ def gcn_chain_backward(gH_last: np.ndarray, adj: np.ndarray, P, T, w: GCNWeights
     g_adj = np.zeros_like(adj, dtype=F32)
     gH = gH_last
     for l in range(nlayer - 1, -1, -1):
-        gP = (gH * (P[l] > 0)).astype(F32)
+        gP = (gH * _act_grad(P[l], w.act)).astype(F32)
         g_adj += gP @ T[l].T
         if l > 0:
             gT = adj.T @ gP
             gH = (gT @ w.W[l].T).astype(F32)
+            if w.Ws is not None:
+                gH = (gH + gP @ w.Ws[l].T).astype(F32)
     return g_adj
 
 
 def victim_head(H_last: np.ndarray, w: GCNWeights):
-    """linear1 + log_softmax (models/gcn.py:173-174)."""
-    Z = (H_last @ w.Wlin.T + w.blin[None, :]).astype(F32)
+    """linear1 + log_softmax (models/gcn.py:173-174); GAT: elu(out_att(x)) first (gat.py:206-207).
+    Returns (Z fed to the softmax, log_softmax(Z))."""
+    Zl = (H_last @ w.Wlin.T + w.blin[None, :]).astype(F32)
+    Z = _act(Zl, "elu") if w.head_act == "elu" else Zl
     return Z, _log_softmax(Z)
+
+
+def victim_head_backward(G_Z: np.ndarray, H_last: np.ndarray, w: GCNWeights):
+    """d/dH_last given d/dZ (Z = the softmax input)."""
+    if w.head_act == "elu":
+        Zl = (H_last @ w.Wlin.T + w.blin[None, :]).astype(F32)
+        G_Z = (G_Z * _act_grad(Zl, "elu")).astype(F32)
+    return (G_Z @ w.Wlin).astype(F32)
 
 
 def dot_product_decode_dense(Z: np.ndarray):
@@ -406,7 +443,8 @@ class AttackConfig:
     lr: float = 0.01
     num_edges: float = float("inf")
     eps: float = 0.0
-    emb_nlayer: int = 2     # embedding.nlayer at loop entry (main.py:240 leaves 2)
+    emb_nlayer: int = 2     # embedding.nlayer at loop entry (main.py:240 leaves 2); GAT's embedding runs all layers
+    fin_layers: Sequence[int] = (1, 2)   # depths of H_A1 / H_A2 in the post-loop ensemble (:304-307)
 
 
 class PGDAttackOracle:
@@ -434,11 +472,12 @@ class PGDAttackOracle:
         self.M = np.zeros((n, n), dtype=F32)                     # Parameter zeros (:77-78)
         self.adam = AdamState(cfg.lr, np.zeros((n, n), F32), np.zeros((n, n), F32))
         self.T0 = (self.X @ self.w.W[0]).astype(F32)             # X @ W_1, adjacency independent
+        self.S0 = (self.X @ self.w.Ws[0]).astype(F32) if self.w.Ws is not None else None
         # priors from the true graph, constant over the loop (:177-182; unnormalised adj!)
         Le = cfg.emb_nlayer
-        _, Hh, _ = gcn_chain(self.T0, self.adj_true, self.w, Le)
+        _, Hh, _ = gcn_chain(self.T0, self.adj_true, self.w, Le, self.S0)
         self.HA = Hh[-1]                                          # H_A_cur (:243)
-        _, Hv, _ = gcn_chain(self.T0, self.adj_true, self.w, self.L)
+        _, Hv, _ = gcn_chain(self.T0, self.adj_true, self.w, self.L, self.S0)
         _, self.YA = victim_head(Hv[-1], self.w)                  # Y_A (:182), log-probs
         self.fadj_nonconst = bool(self.fadj.max() != self.fadj.min())   # (:212)
         self.adj_norm_last = None
@@ -465,7 +504,7 @@ class PGDAttackOracle:
         A, gate = adding_noise(mod, cfg.eps, noise)              # (:165)
         adj_norm, d, r = normalize_adj_tensor(A)                 # (:166)
         self.adj_norm_last = adj_norm
-        Pv, Hv, Tv = gcn_chain(self.T0, adj_norm, w, self.L)     # victim(features, adj_norm) (:167)
+        Pv, Hv, Tv = gcn_chain(self.T0, adj_norm, w, self.L, self.S0)     # victim(features, adj_norm) (:167)
         Z, logp = victim_head(Hv[-1], w)
         na = len(idx)
         nll = F32(-logp[idx, self.labels[idx]].mean(dtype=np.float64))      # _loss CE (:326-328)
@@ -476,7 +515,7 @@ class PGDAttackOracle:
 
         B = (A - self.ori).astype(F32)                           # modified_adj - ori_adj (:185)
         Le = cfg.emb_nlayer
-        Pe, He, Te = gcn_chain(self.T0, B, w, Le)                # embedding (:185)
+        Pe, He, Te = gcn_chain(self.T0, B, w, Le, self.S0)                # embedding (:185)
         em = He[-1]
         R_, S, Zn, nrm = dot_product_decode_dense(em)            # (:187)
         A1 = self.comp * sym_from_lower(R_) + self.ori           # get_modified_adj_after (:188)
@@ -513,7 +552,7 @@ class PGDAttackOracle:
             terms["c9"] = float(w9 * float(v) * AP["c9"]); loss += k * float(v)
             np.add.at(G_em, idx, F32(k) * gy)
         # output2 = victim(features, modified_adj) (:259)
-        Po, Ho, To = gcn_chain(self.T0, A, w, self.L)
+        Po, Ho, To = gcn_chain(self.T0, A, w, self.L, self.S0)
         Z2, _ = victim_head(Ho[-1], w)
         sm2 = _softmax(Z2)
         G_Ho = None
@@ -524,7 +563,7 @@ class PGDAttackOracle:
             G_sm = np.zeros_like(sm2)
             np.add.at(G_sm, idx, F32(k) * gy)
             G_Z2 = (sm2 * (G_sm - (G_sm * sm2).sum(1, keepdims=True))).astype(F32)
-            G_Ho = (G_Z2 @ w.Wlin).astype(F32)
+            G_Ho = victim_head_backward(G_Z2, Ho[-1], w)
 
         # backward --------------------------------------------------------
         # nll -> victim(adj_norm)
@@ -533,7 +572,7 @@ class PGDAttackOracle:
         cnt = np.zeros(n, F32); np.add.at(cnt, idx, 1)
         onehot = np.zeros_like(Z); onehot[np.arange(n), self.labels] = 1
         G_Z = (F32(cfg.weight_sup) * (sm - onehot) * (cnt / F32(na))[:, None]).astype(F32)
-        G_adjn += gcn_chain_backward((G_Z @ w.Wlin).astype(F32), adj_norm, Pv, Tv, w, self.L)
+        G_adjn += gcn_chain_backward(victim_head_backward(G_Z, Hv[-1], w), adj_norm, Pv, Tv, w, self.L)
 
         # decode backward: A1 = comp * sym_from_lower(relu(S)) + ori
         Gc = self.comp * G_A1
@@ -574,7 +613,7 @@ class PGDAttackOracle:
         # monitoring forward on the updated adjacency (:290-296)
         mod2 = self.comp * self.M + self.ori
         adj_norm2, _, _ = normalize_adj_tensor(mod2)
-        _, Hm, _ = gcn_chain(self.T0, adj_norm2, w, self.L)
+        _, Hm, _ = gcn_chain(self.T0, adj_norm2, w, self.L, self.S0)
         _, out2 = victim_head(Hm[-1], w)
         return dict(loss=loss, origin_loss=float(origin_loss), sparsity=float(mod2.mean()),
                     out_monitor=out2, **terms)
@@ -585,13 +624,13 @@ class PGDAttackOracle:
         w, n = self.w, self.n
         if self.adj_norm_last is None:               # epochs == 0: adj_norm from :142
             self.adj_norm_last, _, _ = normalize_adj_tensor(self.comp * self.M + self.ori)
-        _, He, _ = gcn_chain(self.T0, self.adj_norm_last, w, self.cfg.emb_nlayer)   # (:300)
+        _, He, _ = gcn_chain(self.T0, self.adj_norm_last, w, self.cfg.emb_nlayer, self.S0)   # (:300)
         R_, _, _, _ = dot_product_decode_dense(He[-1])
         self.M = sym_from_lower(R_)                                                  # (:301)
         mod = (self.comp * self.M + self.ori).astype(F32)                            # (:302)
-        _, H1, _ = gcn_chain(self.T0, mod, w, 1)                                     # (:304-305)
-        _, H2, _ = gcn_chain(self.T0, mod, w, 2)                                     # (:306-307)
-        _, Hv, _ = gcn_chain(self.T0, mod, w, self.L)
+        _, H1, _ = gcn_chain(self.T0, mod, w, self.cfg.fin_layers[0], self.S0)       # (:304-305)
+        _, H2, _ = gcn_chain(self.T0, mod, w, self.cfg.fin_layers[1], self.S0)       # (:306-307)
+        _, Hv, _ = gcn_chain(self.T0, mod, w, self.L, self.S0)
         _, Y2 = victim_head(Hv[-1], w)                                               # (:308)
         dd = lambda z: dot_product_decode2(z, dataset, useH_A, useY_A, useY)
         cur = mod + dd(H1[-1]) + dd(H2[-1]) + self.fadj + dd(Y2)                     # (:311-314)

@@ -71,12 +71,31 @@ def metric_pool(adj, inference_adj, idx):
 
 
 def weights_of(victim):
+    """Victim weights in the unified layer form of oracle.GCNWeights (W = neighbour part, Ws = self part)."""
     d = {}
+    if hasattr(victim, "attentions"):                       # models/gat.py GAT: heads concatenated, no bias
+        for l, heads in enumerate(victim.attentions):
+            W = torch.cat([a.W for a in heads], dim=1).detach().numpy().copy()
+            d[f"W{l}"] = W
+            d[f"b{l}"] = np.zeros(W.shape[1], np.float32)
+        d["Wlin"] = victim.out_att.weight.detach().numpy().copy()
+        d["blin"] = victim.out_att.bias.detach().numpy().copy()
+        d["act"], d["head_act"] = "elu", "elu"
+        return d
+    sage = victim.gc[0].weight.shape[0] == 2 * victim.nfeat     # models/graphsage.py: weight is [2*in, out]
     for l, layer in enumerate(victim.gc):
-        d[f"W{l}"] = layer.weight.detach().numpy().copy()
-        d[f"b{l}"] = layer.bias.detach().numpy().copy()
+        W = layer.weight.detach().numpy().copy()
+        if sage:
+            half = W.shape[0] // 2
+            d[f"Ws{l}"] = W[:half].copy()                   # rows that multiply `input` (graphsage.py:44)
+            W = W[half:].copy()                             # rows that multiply adj @ input
+        d[f"W{l}"] = W
+        d[f"b{l}"] = (layer.bias.detach().numpy().copy() if layer.bias is not None
+                      else np.zeros(W.shape[1], np.float32))
     d["Wlin"] = victim.linear1.weight.detach().numpy().copy()
-    d["blin"] = victim.linear1.bias.detach().numpy().copy()
+    d["blin"] = (victim.linear1.bias.detach().numpy().copy() if victim.linear1.bias is not None
+                 else np.zeros(d["Wlin"].shape[0], np.float32))
+    d["act"], d["head_act"] = "relu", "none"
     return d
 
 
@@ -88,9 +107,21 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
     optimizer post-hook."""
     device = torch.device("cpu")
     n = adj.shape[0]
-    nl = len(victim.gc)
-    embedding = embedding_GCN(nfeat=features.shape[1], nhid=victim.hidden_sizes[0], nlayer=nl, device=device)
-    embedding.gc = deepcopy(victim.gc)                                  # main.py:190
+    if hasattr(victim, "attentions"):                                   # main.py:213-231
+        from models.gat import embedding_gat
+        nl = len(victim.attentions)
+        embedding = embedding_gat(nfeat=features.shape[1], nclass=victim.nclass, nhid=victim.hidden_sizes[0],
+                                  nlayer=nl, dropout=0.5, alpha=0.1, nheads=len(victim.attentions[0]), device=device)
+        embedding.attentions = victim.attentions
+    elif victim.gc[0].weight.shape[0] == 2 * victim.nfeat:              # main.py:193-210
+        from models.graphsage import embedding_graphsage
+        nl = len(victim.gc)
+        embedding = embedding_graphsage(nfeat=features.shape[1], nhid=victim.hidden_sizes[0], nlayer=nl, device=device)
+        embedding.gc = deepcopy(victim.gc)
+    else:
+        nl = len(victim.gc)
+        embedding = embedding_GCN(nfeat=features.shape[1], nhid=victim.hidden_sizes[0], nlayer=nl, device=device)
+        embedding.gc = deepcopy(victim.gc)                              # main.py:190
     victim.eval()
     H_A = embedding(features, adj); Y_A = victim(features, adj)         # main.py:235-236
     embedding.set_layers(1); embedding(features, adj)
@@ -140,7 +171,7 @@ def init_adj_changes(n, seed, scale):
     return (np.random.RandomState(seed).rand(n * (n - 1) // 2) * scale).astype(np.float32)
 
 
-def make_synth(n, f, c, hid, nlayer, seed, p_edge=0.08):
+def make_synth(n, f, c, hid, nlayer, seed, p_edge=0.08, arch="gcn"):
     rng = np.random.RandomState(seed)
     torch.manual_seed(seed); random.seed(seed)
     labels = rng.randint(0, c, size=n)
@@ -153,8 +184,15 @@ def make_synth(n, f, c, hid, nlayer, seed, p_edge=0.08):
     up = np.triu(rng.rand(n, n) < prob, 1)
     adj = (up | up.T).astype(np.float32)
     device = torch.device("cpu")
-    victim = GCN(nfeat=f, nclass=c, nhid=hid, nlayer=nlayer, dropout=0.5, weight_decay=5e-4, device=device)
-    # reference GraphConvolution.reset_parameters init (models/gcn.py:28-33); no training
+    if arch == "gat":
+        from models.gat import GAT
+        victim = GAT(nfeat=f, nclass=c, nhid=hid, nlayer=nlayer, dropout=0.5, alpha=0.1, nheads=3, device=device)
+    elif arch == "sage":
+        from models.graphsage import graphsage
+        victim = graphsage(nfeat=f, nclass=c, nhid=hid, nlayer=nlayer, dropout=0.5, weight_decay=5e-4, device=device)
+    else:
+        victim = GCN(nfeat=f, nclass=c, nhid=hid, nlayer=nlayer, dropout=0.5, weight_decay=5e-4, device=device)
+    # reference reset_parameters / xavier init (models/gcn.py:28-33, gat.py:27-30); no training
     return torch.FloatTensor(adj), torch.FloatTensor(feats), torch.LongTensor(labels), victim
 
 
@@ -185,10 +223,16 @@ def gen_small(tmp):
         ("s48_hsic_eps", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
         ("s48_mse_eps", 48, 24, 4, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
         ("s48_kl_eps", 48, 24, 4, 16, 2, "KL", base_wp, 1.0, 0.01, 3, 1e12),
+        # other victims of main.py --arch: the dense "GAT" (gat.py:36-50) and GraphSAGE (graphsage.py:37-50)
+        ("s48_gat_hsic_init", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_gat_mse", 48, 24, 4, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_sage_hsic_init", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_sage_kl", 48, 24, 4, 16, 2, "KL", base_wp, 1.0, 0.01, 3, 1e12),
         ("s200_mse_init", 200, 64, 6, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 0.01, 4, 1e12),
     ]
     for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:
-        adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000)
+        arch = "gat" if "_gat_" in name else ("sage" if "_sage_" in name else "gcn")
+        adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000, arch=arch)
         lab = labels.numpy()
         np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
         random.seed(7)
@@ -196,8 +240,12 @@ def gen_small(tmp):
         a0 = None
         extra = {}
         eps = 0.0
+        if arch == "gat":      # embedding_gat.forward ignores set_layers (gat.py:170-174): every embedding is full depth
+            extra.update(arch=arch, emb_nlayer=nl, fin_layers=np.array([nl, nl]))
+        elif arch == "sage":
+            extra.update(arch=arch)
         if name.endswith("_init") or name.endswith("_eps"):
-            extra = dict(a0_seed=123, a0_scale=0.05)
+            extra.update(a0_seed=123, a0_scale=0.05)
             a0 = init_adj_changes(n, 123, 0.05)
         if name.endswith("_eps"):
             eps = 0.02

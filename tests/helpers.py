@@ -20,13 +20,17 @@ def load_case(name):
 
 def weights_from(z):
     L = int(z["nlayer"]) if "nlayer" in z else 2
-    return O.GCNWeights([z[f"W{l}"] for l in range(L)], [z[f"b{l}"] for l in range(L)], z["Wlin"], z["blin"])
+    Ws = [z[f"Ws{l}"] for l in range(L)] if "Ws0" in z else None
+    return O.GCNWeights([z[f"W{l}"] for l in range(L)], [z[f"b{l}"] for l in range(L)], z["Wlin"], z["blin"], Ws,
+                        str(z["act"]) if "act" in z else "relu", str(z["head_act"]) if "head_act" in z else "none")
 
 
 def cfg_from(z):
     return O.AttackConfig(measure=str(z["measure"]), weight_sup=float(z["weight_sup"]),
                           weight_param=tuple(float(x) for x in z["weight_param"]), lr=float(z["lr"]),
-                          num_edges=float(z["num_edges"]), eps=float(z["eps"]) if "eps" in z else 0.0, emb_nlayer=2)
+                          num_edges=float(z["num_edges"]), eps=float(z["eps"]) if "eps" in z else 0.0,
+                          emb_nlayer=int(z["emb_nlayer"]) if "emb_nlayer" in z else 2,
+                          fin_layers=tuple(int(x) for x in z["fin_layers"]) if "fin_layers" in z else (1, 2))
 
 
 def init_adj_changes(n, seed, scale):
@@ -82,10 +86,11 @@ def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None):
     cfg = cfg_from(z)
     w = weights_from(z)
     dims = [w.W[0].shape[0]] + [x.shape[1] for x in w.W]
-    eng = pkg.AttackEngine(z["adj"].shape[0], dims, w.Wlin.shape[0], 2, measure or cfg.measure, cfg.weight_sup,
-                           weight_param or cfg.weight_param, cfg.lr, cfg.num_edges, len(z["idx_attack"]),
-                           eps=cfg.eps, device=device)
-    eng.set_model(w.W, w.b, w.Wlin, w.blin)
+    eng = pkg.AttackEngine(z["adj"].shape[0], dims, w.Wlin.shape[0], cfg.emb_nlayer, measure or cfg.measure,
+                           cfg.weight_sup, weight_param or cfg.weight_param, cfg.lr, cfg.num_edges,
+                           len(z["idx_attack"]), eps=cfg.eps, device=device, act=w.act, head_act=w.head_act,
+                           has_self=w.Ws is not None, fin_layers=cfg.fin_layers)
+    eng.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
     eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
     if a0_of(z) is not None:
         eng.set_adj_changes(a0_of(z))
@@ -117,6 +122,50 @@ class FakeGCN:
         self.nfeat = w.W[0].shape[0]
         self.hidden_sizes = [w.W[0].shape[1]]
         self.nlayer = 2
+
+    def eval(self):
+        return self
+
+    def set_layers(self, n):
+        self.nlayer = n
+
+
+class _Att:
+    def __init__(self, W):
+        import torch
+        self.W = torch.tensor(np.asarray(W, np.float32))
+
+
+class FakeGAT:
+    """Duck-typed models/gat.py GAT / embedding_gat: attentions[l][head].W, out_att, nlayer."""
+
+    def __init__(self, w: O.GCNWeights, nhid=16):
+        self.attentions = [[_Att(W[:, k:k + nhid]) for k in range(0, W.shape[1], nhid)] for W in w.W]
+        self.out_att = _Lin(w.Wlin, w.blin)
+        self.nclass, self.nfeat, self.hidden_sizes, self.nlayer = w.Wlin.shape[0], w.W[0].shape[0], [nhid], len(w.W)
+
+    def eval(self):
+        return self
+
+    def set_layers(self, n):
+        self.nlayer = n
+
+
+class _SageLayer:
+    def __init__(self, Ws, Wn):
+        import torch
+        self.weight = torch.tensor(np.vstack([Ws, Wn]).astype(np.float32))      # graphsage.py:20, [2*in, out]
+        self.bias = None
+
+
+class FakeSAGE:
+    """Duck-typed models/graphsage.py graphsage / embedding_graphsage."""
+
+    def __init__(self, w: O.GCNWeights):
+        self.gc = [_SageLayer(a, b) for a, b in zip(w.Ws, w.W)]
+        self.linear1 = _Lin(w.Wlin, w.blin)
+        self.linear1.bias = None
+        self.nclass, self.nfeat, self.hidden_sizes, self.nlayer = w.Wlin.shape[0], w.W[0].shape[0], [w.W[0].shape[1]], 2
 
     def eval(self):
         return self

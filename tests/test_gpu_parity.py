@@ -221,7 +221,7 @@ def test_free_run_final_matches_reference(pkg, torch_, name):
     lab = z["labels"]
     label_adj = (lab[:, None] == lab[None, :]).astype(np.float32)
     final = eng.finalize(0, z["H_A2"], z["Y_A"], label_adj).cpu().numpy()
-    assert np.abs(final - z["final"]).max() < 1e-3
+    assert np.abs(final - z["final"]).max() < 1e-3 * max(1.0, np.abs(z["final"]).max())
     auc = O.metric_pool(z["adj"], final, z["idx_attack"])
     assert abs(auc - float(z["auc"])) < 1e-4
     eng.close()
@@ -290,6 +290,28 @@ def test_pgdattack_class_small(pkg, torch_):
     assert np.abs(final - z["final"]).max() < 1e-3
     assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
     assert len(model.history["acc_test"]) == int(z["epochs"])
+
+
+@pytest.mark.parametrize("name,fake", [("s48_gat_hsic_init", "FakeGAT"), ("s48_sage_kl", "FakeSAGE")])
+def test_pgdattack_class_other_victims(pkg, torch_, name, fake):
+    """main.py --arch gat / sage: PGDAttack reads the victim family off the model object."""
+    z = H.load_case(name)
+    w = H.weights_from(z)
+    victim, emb = getattr(H, fake)(w), getattr(H, fake)(w)
+    n = z["adj"].shape[0]
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=torch_.tensor(z["H_A2"]), Y_A=torch_.tensor(z["Y_A"]),
+                          nnodes=n, loss_type="CE", device="cuda:0")
+    if H.a0_of(z) is not None:
+        model.adj_changes = H.a0_of(z)
+    lab = z["labels"]
+    model.attack(_args(str(z["measure"])), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]),
+                 torch_.tensor(z["feature_adj"]), 0, 0, 0, None, None, np.arange(8), torch_.tensor(z["adj"]),
+                 torch_.tensor(z["features"]), torch_.zeros(n, n), torch_.tensor(lab), z["idx_attack"],
+                 float(z["num_edges"]), 0, epochs=int(z["epochs"]),
+                 label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    final = model.modified_adj.cpu().numpy()
+    assert np.abs(final - z["final"]).max() < 1e-3 * max(1.0, np.abs(z["final"]).max())
+    assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
 
 
 def _run_cora(pkg, t, name):
