@@ -1,0 +1,166 @@
+"""main.py entry with the reference's command line (/root/reference/MC-GRA/main.py:78-139) and its
+``--mode evaluate`` flow (:141-324, :392-409): load the graph, train the victim GCN, compute the priors
+H_A / Y_A, run PGDAttack on the MI355X hot path, report the recovered-adjacency AUC.
+
+    python -m mc_gra_amd.main --dataset cora --w1 0.01 --w6 10 --w7 10 --w9 10 --w10 1000 --lr -2 \
+        --useH_A --useY_A --useY --measure MSELoss            (after mcgra_loader.load())
+    python mc-gra_amd/main.py ...                             (stand-alone; bootstraps the loader itself)
+
+Not provided (each exits with a message naming the reference line): --arch gat/sage victim training
+(main.py:193-231; the attack itself accepts those victims), --mode search/baseline/gaussian/gcn_attack,
+--measure KDE.
+"""
+import argparse
+import os
+import random
+import sys
+from copy import deepcopy
+
+import numpy as np
+
+if __package__ in (None, ""):          # run as a script: load the hyphenated directory as package mc_gra_amd
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mcgra_loader
+    mcgra_loader.load()
+    from mc_gra_amd import utils
+    from mc_gra_amd.dataset import Dataset
+    from mc_gra_amd.models.gcn import GCN, embedding_GCN
+    from mc_gra_amd.topology_attack import PGDAttack
+else:
+    from . import utils
+    from .dataset import Dataset
+    from .models.gcn import GCN, embedding_GCN
+    from .topology_attack import PGDAttack
+
+import torch
+import torch.nn.functional as F
+from sklearn.metrics import auc, roc_curve
+
+
+def build_parser():
+    """Same flags and defaults as main.py:78-137 (+ --dataset_root, --saved_data for file locations)."""
+    p = argparse.ArgumentParser()
+    p.add_argument('--seed', type=int, default=15)
+    p.add_argument('--epochs', type=int, default=100)
+    p.add_argument('--lr', type=float, default=0.01)
+    p.add_argument('--weight_decay', type=float, default=5e-4)
+    p.add_argument('--hidden', type=int, default=16)
+    p.add_argument('--dropout', type=float, default=0.5)
+    p.add_argument('--nlayers', type=int, default=2)
+    p.add_argument('--arch', type=str, choices=["gcn", "gat", "sage"], default='gcn')
+    p.add_argument('--dataset', type=str, default='cora',
+                   choices=['cora', 'cora_ml', 'citeseer', 'polblogs', 'pubmed', 'AIDS', 'usair', 'brazil'])
+    p.add_argument('--density', type=float, default=10000000.0)
+    p.add_argument('--model', type=str, default='PGD', choices=['PGD', 'min-max'])
+    p.add_argument('--nlabel', type=float, default=1.0)
+    p.add_argument('--iter', type=int, default=1)
+    p.add_argument('--max_eval', type=int, default=100)
+    p.add_argument('--log_name', type=str, default="result.txt")
+    p.add_argument("--mode", type=str, default="evaluate", choices=["evaluate", "prepare", "notrain_test"])
+    p.add_argument("--measure", type=str, default="HSIC", choices=["HSIC", "MSELoss", "KL", "KDE", "CKA", "DP"])
+    p.add_argument("--measure2", type=str, default="HSIC")
+    p.add_argument("--nofeature", action='store_true')
+    p.add_argument('--weight_aux', type=float, default=0)
+    p.add_argument('--weight_sup', type=float, default=1)
+    for i in range(1, 11):
+        p.add_argument(f'--w{i}', type=float, default=0)
+    p.add_argument('--eps', type=float, default=0)
+    p.add_argument('--useH_A', action='store_true')
+    p.add_argument('--useY_A', action='store_true')
+    p.add_argument('--useY', action='store_true')
+    p.add_argument('--ensemble', action='store_true')
+    p.add_argument('--add_noise', action='store_true')
+    p.add_argument('--defense', action='store_true')
+    p.add_argument('--dataset_root', type=str, default='./dataset')
+    p.add_argument('--saved_data', type=str, default='./saved_data')
+    p.add_argument('--device', type=str, default='cuda:0')
+    return p
+
+
+def dot_product_decode(Z, dataset):
+    """main.dot_product_decode (main.py:44-55): feature_adj."""
+    if dataset in ('cora', 'citeseer', 'AIDS'):
+        Z = torch.matmul(Z, Z.t())
+        return torch.sigmoid(torch.relu(Z - torch.eye(Z.shape[0], device=Z.device)))
+    Z = F.normalize(Z, p=2, dim=1)
+    Z = torch.matmul(Z, Z.t())
+    return torch.relu(Z - torch.eye(Z.shape[0], device=Z.device))
+
+
+def metric_pool(ori_adj, inference_adj, idx):
+    """main.metric_pool (main.py:66-75)."""
+    real = ori_adj[idx, :][:, idx].reshape(-1).cpu()
+    pred = inference_adj[idx, :][:, idx].reshape(-1).cpu()
+    fpr, tpr, _ = roc_curve(real, pred)
+    return auc(fpr, tpr)
+
+
+def label_adjacency(labels):
+    """main.prepare (main.py:440-450): label_adj[i][j] = (labels[i] == labels[j])."""
+    lab = np.asarray(labels)
+    return (lab[:, None] == lab[None, :]).astype(np.float32)
+
+
+def run(args):
+    device = torch.device(args.device)
+    np.random.seed(args.seed); random.seed(args.seed); torch.manual_seed(args.seed)       # main.py:142-146
+    if args.measure == "KDE":
+        sys.exit("measure=KDE needs utils.MutualInformation (utils.py:980), which is cuda:0-only and not provided")
+    if args.arch != "gcn":
+        sys.exit(f"--arch {args.arch}: victim training of main.py:193-231 is not provided (the attack accepts such "
+                 "victims: pass model objects to PGDAttack)")
+    data = Dataset(root=args.dataset_root, name=args.dataset, setting='GCN')
+    adj, features, labels, init_adj = data.adj, data.features, data.labels, data.init_adj
+    idx_train, idx_val, idx_test = data.idx_train, data.idx_val, data.idx_test
+    random.sample(range(adj.shape[0]), int(adj.shape[0] * args.nlabel))                    # main.py:155 (consumes the RNG)
+    adj, features, labels = utils.preprocess(adj, features, labels, preprocess_adj=False, onehot_feature=False)
+    if args.mode == "prepare":
+        os.makedirs(args.saved_data, exist_ok=True)
+        np.save(os.path.join(args.saved_data, args.dataset + ".npy"), label_adjacency(labels))
+        return None
+    feature_adj = dot_product_decode(features, args.dataset)
+    if args.nofeature:
+        feature_adj = torch.eye(*feature_adj.size())
+    init_adj = torch.FloatTensor(init_adj.todense())
+
+    victim_model = GCN(nfeat=features.shape[1], nclass=labels.max().item() + 1, nhid=16, nlayer=args.nlayers,
+                       dropout=0.5, weight_decay=5e-4, device=device).to(device)           # main.py:175-183
+    victim_model.fit(features, adj, labels, idx_train, idx_val, verbose=False)
+    embedding = embedding_GCN(nfeat=features.shape[1], nhid=16, nlayer=args.nlayers, device=device)
+    embedding.gc = deepcopy(victim_model.gc)                                               # main.py:190
+    with torch.no_grad():
+        fd, ad = features.to(device), adj.to(device)
+        Y_A = victim_model(fd, ad)                                                         # main.py:236
+        embedding.set_layers(2)
+        H_A2 = embedding(fd, ad)                                                           # main.py:240-241
+        out = victim_model(fd, utils.normalize_adj_tensor(ad))
+        print("Test set results:", "accuracy= {:.4f}".format(utils.accuracy(out[idx_test], labels.to(device)[idx_test]).item()))
+    idx_attack = np.array(random.sample(range(adj.shape[0]), int(adj.shape[0] * args.nlabel)))   # main.py:244
+    num_edges = int(0.5 * args.density * adj.sum() / adj.shape[0] ** 2 * len(idx_attack) ** 2)
+
+    lr = 10 ** args.lr                                                                     # objective(): main.py:282-283
+    weight_param = tuple(getattr(args, f"w{i}") for i in range(1, 11))
+    lab_path = os.path.join(args.saved_data, args.dataset + ".npy")
+    label_adj = np.load(lab_path) if os.path.exists(lab_path) else label_adjacency(labels)
+    model = PGDAttack(model=victim_model, embedding=embedding, H_A=H_A2, Y_A=Y_A, nnodes=adj.shape[0],
+                      loss_type='CE', device=device)
+    model.attack(args, None, lr, 0, args.weight_sup, weight_param, feature_adj, 0, 0, 0, idx_train, idx_val,
+                 idx_test, adj, features, init_adj, labels, idx_attack, num_edges, 0, epochs=args.epochs,
+                 label_adj=label_adj)
+    inference_adj = model.modified_adj.cpu()
+    res = {"auc_attack": float(metric_pool(adj, inference_adj, idx_attack)),
+           "auc_train": float(metric_pool(adj, inference_adj, idx_train)),
+           "auc_all": float(metric_pool(adj, inference_adj, np.arange(adj.shape[0]))),
+           "density": float(inference_adj.mean())}
+    print(f"current auc={res['auc_all']}")
+    os.makedirs("./results/", exist_ok=True)
+    with open(os.path.join("./results", args.log_name), "a") as f:                         # main.py:314-323
+        f.write(f"current parameter: {args}\n")
+        f.write(f"In attack graph: AUC={res['auc_attack']}\tIn train graph: AUC={res['auc_train']}\t"
+                f"In Whole Graph: AUC={res['auc_all']}\n")
+        f.write(f"current density: {res['density']}\n")
+    return res
+
+
+if __name__ == '__main__':
+    run(build_parser().parse_args())
