@@ -103,6 +103,15 @@ int mcgra_dot_product_decode(void* stream, int n, int d, const float* Z, float* 
 int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X,
                       const float* Y, float* out);
 
+/* hsic.py (Gaussian-kernel HSIC; not called by the attack loop, named by the task's north_star):
+ * hsic_regular (hsic.py:117-124) = mean(Kxc * Kyc^T) with K = exp(-distmat / (2 sigma^2)) (:20-38), Kc = K H (:46);
+ * hsic_normalized (:127-135) = Pxy / (sqrt(Pxx) sqrt(Pyy)).  X [m x dx], Y [m x dy]; sigma > 0 (sigma=None, the
+ * median heuristic of :5-17, is not provided).  *out device scalar; synchronises. */
+int mcgra_hsic_regular(void* stream, int m, int dx, int dy, const float* X, const float* Y,
+                       float sigma, float* out);
+int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, const float* Y,
+                          float sigma, float* out);
+
 /* torch.nn.MSELoss()(X, Y) over `count` elements, *out device scalar. */
 int mcgra_mse(void* stream, int64_t count, const float* X, const float* Y, float* out);
 

@@ -24,7 +24,8 @@ SYMBOLS = [
     "mcgra_version", "mcgra_last_error", "mcgra_device_count", "mcgra_sgemm", "mcgra_set_gemm_variant",
     "mcgra_ssyrk_lower", "mcgra_ssymm_lower",
     "mcgra_get_modified_adj", "mcgra_pack_tril", "mcgra_normalize_adj", "mcgra_info_entropy",
-    "mcgra_dot_product_decode", "mcgra_linear_hsic", "mcgra_mse", "mcgra_gcn_forward",
+    "mcgra_dot_product_decode", "mcgra_linear_hsic", "mcgra_hsic_regular", "mcgra_hsic_normalized", "mcgra_mse",
+    "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
     "mcgra_attack_monitor", "mcgra_attack_finalize", "mcgra_attack_buffer", "mcgra_attack_copy_buffer",
@@ -73,6 +74,8 @@ def _load():
         "mcgra_info_entropy": [vp, C.c_int, fp, fp],
         "mcgra_dot_product_decode": [vp, C.c_int, C.c_int, fp, fp],
         "mcgra_linear_hsic": [vp, C.c_int, C.c_int, C.c_int, fp, fp, fp],
+        "mcgra_hsic_regular": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp],
+        "mcgra_hsic_normalized": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp],
         "mcgra_mse": [vp, C.c_int64, fp, fp, fp],
         "mcgra_gcn_forward": [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), fp, fp, C.POINTER(C.c_void_p),
                               C.POINTER(C.c_void_p), fp, fp, C.c_int, C.c_int, fp, fp],

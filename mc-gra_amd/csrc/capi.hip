@@ -150,6 +150,60 @@ int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X, const
   return 0;
 }
 
+// hsic.py hsic_regular (:117-124) with a given sigma; pair = 0: (x,y), used three times by hsic_normalized
+static int hsic_gauss(hipStream_t st, int m, int dx, int dy, const float* X, const float* Y, float sigma, double* out3,
+                      bool normalized) {
+  const int ld = (m + 3) & ~3;
+  Scratch s;
+  float* KX = s.get<float>((size_t)m * ld); NEED(KX);
+  float* KY = s.get<float>((size_t)m * ld); NEED(KY);
+  float* sx = s.get<float>(ld); float* sy = s.get<float>(ld); NEED(sx); NEED(sy);
+  double* rx = s.get<double>(ld); double* ry = s.get<double>(ld); double* rr = s.get<double>(ld); NEED(rx); NEED(ry); NEED(rr);
+  double* tot = s.get<double>(4); NEED(tot);
+  const float inv2s2 = 1.f / (2.f * sigma * sigma);
+  launch_row_sqnorm(st, m, dx, X, dx, sx);
+  launch_row_sqnorm(st, m, dy, Y, dy, sy);
+  MCGRA_HIP(sgemm(st, false, true, m, m, dx, 1.f, X, dx, X, dx, 0.f, KX, ld, nullptr, 0));     // X X^T (hsic.py:25)
+  MCGRA_HIP(sgemm(st, false, true, m, m, dy, 1.f, Y, dy, Y, dy, 0.f, KY, ld, nullptr, 0));
+  launch_gauss_kernel(st, m, ld, KX, sx, inv2s2, rx);
+  launch_gauss_kernel(st, m, ld, KY, sy, inv2s2, ry);
+  launch_hsic_gauss_rows(st, m, ld, KX, KY, rx, ry, rr);
+  launch_reduce_rows(st, rr, m, 1, tot + 0);
+  if (normalized) {
+    launch_hsic_gauss_rows(st, m, ld, KX, KX, rx, rx, rr);
+    launch_reduce_rows(st, rr, m, 1, tot + 1);
+    launch_hsic_gauss_rows(st, m, ld, KY, KY, ry, ry, rr);
+    launch_reduce_rows(st, rr, m, 1, tot + 2);
+  }
+  MCGRA_KERNEL_CHECK();
+  MCGRA_HIP(hipMemcpyAsync(out3, tot, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < 3; ++i) out3[i] /= (double)m * m;      // torch.mean
+  return 0;
+}
+
+int mcgra_hsic_regular(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma, float* out) {
+  if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  if (!(sigma > 0.f)) { set_error("sigma=None (median heuristic, hsic.py:5-17) is not provided"); return MCGRA_ENOSUP; }
+  double v[3];
+  int rc = hsic_gauss((hipStream_t)stream, m, dx, dy, X, Y, sigma, v, false);
+  if (rc) return rc;
+  const float f = (float)v[0];
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma, float* out) {
+  if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  if (!(sigma > 0.f)) { set_error("sigma=None (median heuristic, hsic.py:5-17) is not provided"); return MCGRA_ENOSUP; }
+  double v[3];
+  int rc = hsic_gauss((hipStream_t)stream, m, dx, dy, X, Y, sigma, v, true);
+  if (rc) return rc;
+  const float f = (float)(v[0] / (sqrt(v[1]) * sqrt(v[2])));       // Pxy / (Px * Py) (hsic.py:131-134)
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
 int mcgra_mse(void* stream, int64_t count, const float* X, const float* Y, float* out) {
   if (count < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;

@@ -32,6 +32,10 @@ void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float 
 void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
                         bool use1, bool use2, bool lower);
 void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, int nstrips, double* cols);
+void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows);
+void launch_hsic_gauss_rows(hipStream_t st, int m, int ld, const float* KX, const float* KY, const double* rowsx,
+                            const double* rowsy, double* rows);
+void launch_row_sqnorm(hipStream_t st, int m, int d, const float* X, int ldx, float* sq);
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);

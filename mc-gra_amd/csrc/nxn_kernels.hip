@@ -766,6 +766,58 @@ __global__ void k_colsum_fin(int n, const double* __restrict__ part, int nstrips
   cols[j] = s;
 }
 
+
+// ---------------------------------------------------------------------------
+// hsic.py (Gaussian-kernel HSIC): distmat (:20-27) + kernelmat (:30-47) + hsic_regular (:117-124).
+//   D_ij = r_i - 2 a_ij + r_j,  K = exp(-D / (2 sigma^2)),  Kc = K H  (row i minus its mean),
+//   hsic_regular = mean_ij Kxc_ij Kyc_ji.  K is symmetric, so Kyc_ji = Ky_ij - rowmean_y[j].
+// k_gauss_kernel turns the Gram a = X X^T into K in place and leaves row sums of K.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void k_gauss_kernel(int m, int ld, float* __restrict__ A,
+                                                              const float* __restrict__ sq, float inv2s2,
+                                                              double* __restrict__ rows) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const float ri = sq[i];
+  double s = 0;
+  for (int j = threadIdx.x; j < m; j += ROW_THREADS) {
+    const float d = ri - 2.f * A[base + j] + sq[j];
+    const float k = expf(-d * inv2s2);
+    A[base + j] = k;
+    s += k;
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) rows[i] = s;
+}
+
+// rows[i] = sum_j (Kx_ij - mx_i) (Ky_ij - my_j)
+__global__ __launch_bounds__(ROW_THREADS) void k_hsic_gauss_rows(int m, int ld, const float* __restrict__ KX,
+                                                                 const float* __restrict__ KY,
+                                                                 const double* __restrict__ rowsx,
+                                                                 const double* __restrict__ rowsy,
+                                                                 double* __restrict__ rows) {
+  __shared__ double shd[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const double inv = 1.0 / m;
+  const float mxi = (float)(rowsx[i] * inv);
+  double s = 0;
+  for (int j = threadIdx.x; j < m; j += ROW_THREADS)
+    s += (double)(KX[base + j] - mxi) * (double)(KY[base + j] - (float)(rowsy[j] * inv));
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) rows[i] = s;
+}
+
+// sq[i] = |X_i|^2 (torch.sum(X*X, 1), hsic.py:23)
+__global__ void k_row_sqnorm(int m, int d, const float* __restrict__ X, int ldx, float* __restrict__ sq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  float s = 0.f;
+  for (int k = 0; k < d; ++k) { const float v = X[(size_t)i * ldx + k]; s += v * v; }
+  sq[i] = s;
+}
+
 // ---- host launchers ---------------------------------------------------------
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 
@@ -830,6 +882,16 @@ void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, 
   const int rows_per_strip = (n + nstrips - 1) / nstrips;
   LAUNCH(k_colsum_part, dim3((n + 255) / 256, nstrips), dim3(256), st, n, ld, X, rows_per_strip, part);
   LAUNCH(k_colsum_fin, dim3((n + 255) / 256), dim3(256), st, n, part, nstrips, cols);
+}
+void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows) {
+  LAUNCH(k_gauss_kernel, dim3(m), dim3(ROW_THREADS), st, m, ld, A, sq, inv2s2, rows);
+}
+void launch_hsic_gauss_rows(hipStream_t st, int m, int ld, const float* KX, const float* KY, const double* rowsx,
+                            const double* rowsy, double* rows) {
+  LAUNCH(k_hsic_gauss_rows, dim3(m), dim3(ROW_THREADS), st, m, ld, KX, KY, rowsx, rowsy, rows);
+}
+void launch_row_sqnorm(hipStream_t st, int m, int d, const float* X, int ldx, float* sq) {
+  LAUNCH(k_row_sqnorm, dim3((m + 255) / 256), dim3(256), st, m, d, X, ldx, sq);
 }
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
                     const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA) {

@@ -100,6 +100,20 @@ def linear_hsic(X, Y):
     return out[0]
 
 
+def hsic_regular(x, y, sigma):
+    """hsic.hsic_regular (hsic.py:117-124) with a given sigma."""
+    out = torch.zeros(1, device=x.device, dtype=torch.float32)
+    check(lib.mcgra_hsic_regular(_stream(), x.shape[0], x.shape[1], y.shape[1], _p(x), _p(y), float(sigma), _p(out)))
+    return out[0]
+
+
+def hsic_normalized(x, y, sigma):
+    """hsic.hsic_normalized (hsic.py:127-135) with a given sigma."""
+    out = torch.zeros(1, device=x.device, dtype=torch.float32)
+    check(lib.mcgra_hsic_normalized(_stream(), x.shape[0], x.shape[1], y.shape[1], _p(x), _p(y), float(sigma), _p(out)))
+    return out[0]
+
+
 def mse(X, Y):
     out = torch.zeros(1, device=X.device, dtype=torch.float32)
     check(lib.mcgra_mse(_stream(), X.numel(), _p(X), _p(Y), _p(out)))

@@ -152,6 +152,29 @@ def linear_cka_grads(X, Y, need_x=True, need_y=True):
     return val, gX, gY
 
 
+def hsic_distmat(X):
+    """hsic.distmat (hsic.py:20-27)."""
+    X = X.astype(F32)
+    r = (X * X).sum(1, dtype=F32)
+    return (r[:, None] - F32(2) * (X @ X.T) + r[None, :]).astype(F32)
+
+
+def hsic_kernelmat(X, sigma):
+    """hsic.kernelmat with a given sigma (hsic.py:30-47): exp(-D / (2 sigma^2)) @ H."""
+    K = np.exp(-hsic_distmat(X) / F32(2.0 * sigma * sigma)).astype(F32)
+    return (K - K.mean(1, keepdims=True, dtype=np.float64)).astype(F32)          # K @ (I - 11^T/m)
+
+
+def hsic_regular(x, y, sigma) -> F32:
+    """hsic.hsic_regular (hsic.py:117-124)."""
+    return F32((hsic_kernelmat(x, sigma).astype(np.float64) * hsic_kernelmat(y, sigma).T).mean())
+
+
+def hsic_normalized(x, y, sigma) -> F32:
+    """hsic.hsic_normalized (hsic.py:127-135)."""
+    return F32(hsic_regular(x, y, sigma) / (np.sqrt(hsic_regular(x, x, sigma)) * np.sqrt(hsic_regular(y, y, sigma))))
+
+
 def mse_loss(X, Y) -> F32:
     """torch.nn.MSELoss()(X, Y) (topology_attack.py:194-195)."""
     return F32(np.mean((X.astype(np.float64) - Y) ** 2))

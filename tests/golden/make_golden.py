@@ -325,6 +325,13 @@ def gen_ops(tmp):
     # dot_product_decode packed (topology_attack.py:414-419)
     pm.nnodes = 19
     out["dd_out"] = pm.dot_product_decode(torch.tensor(Zr)).numpy()
+    # hsic.py (Gaussian-kernel HSIC) with explicit sigma
+    import hsic as rhsic
+    hx = rng.randn(45, 8).astype(np.float32); hy = (hx[:, :5] * 0.5 + rng.randn(45, 5) * 0.7).astype(np.float32)
+    out["ghsic_x"], out["ghsic_y"] = hx, hy
+    for sg in (1.0, 5.0):
+        out[f"ghsic_reg_{sg}"] = rhsic.hsic_regular(torch.tensor(hx), torch.tensor(hy), sigma=sg).item()
+        out[f"ghsic_norm_{sg}"] = rhsic.hsic_normalized(torch.tensor(hx), torch.tensor(hy), sigma=sg).item()
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
     print("ops.npz", len(out), "arrays")
 

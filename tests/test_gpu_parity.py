@@ -135,6 +135,18 @@ def test_ops_against_reference_goldens(pkg, torch_):
     assert np.array_equal(got, OPS["gma_out"])            # data movement: bit exact
 
 
+@pytest.mark.parametrize("sg", [1.0, 5.0])
+def test_gaussian_hsic_ops(pkg, torch_, sg):
+    """hsic.py hsic_regular / hsic_normalized against the reference's own values."""
+    from mc_gra_amd import engine as E
+    x, y = dev(torch_, OPS["ghsic_x"]), dev(torch_, OPS["ghsic_y"])
+    ref_r, ref_n = float(OPS[f"ghsic_reg_{sg}"]), float(OPS[f"ghsic_norm_{sg}"])
+    assert abs(float(E.hsic_regular(x, y, sg)) - ref_r) <= 5e-5 * abs(ref_r) + 1e-9
+    assert abs(float(E.hsic_normalized(x, y, sg)) - ref_n) <= 3e-4 * abs(ref_n)
+    with pytest.raises(NotImplementedError):
+        E.hsic_regular(x, y, 0.0)
+
+
 def test_ops_edge_cases(pkg, torch_):
     from mc_gra_amd import engine as E
     t = torch_

@@ -35,6 +35,14 @@ def test_linear_hsic_cka(tag):
     assert abs(O.linear_cka(X, Y) - v) < 1e-6
 
 
+@pytest.mark.parametrize("sg", [1.0, 5.0])
+def test_gaussian_hsic(sg):
+    """hsic.py hsic_regular / hsic_normalized with explicit sigma."""
+    x, y = OPS["ghsic_x"], OPS["ghsic_y"]
+    assert abs(O.hsic_regular(x, y, sg) - float(OPS[f"ghsic_reg_{sg}"])) <= 2e-5 * abs(float(OPS[f"ghsic_reg_{sg}"])) + 1e-9
+    assert abs(O.hsic_normalized(x, y, sg) - float(OPS[f"ghsic_norm_{sg}"])) <= 2e-4 * abs(float(OPS[f"ghsic_norm_{sg}"]))
+
+
 def test_info_entropy():
     v, g = O.info_entropy_grad(OPS["ie_in"])
     assert abs(v - OPS["ie_val"]) < 1e-6
