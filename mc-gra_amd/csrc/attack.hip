@@ -147,23 +147,33 @@ static int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, i
   MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws, h->ws_bytes));
   return timer_end(h, st, big, 2.0 * M * N * K);
 }
-// C = A A^T (A is [n x k]); sym: lower tile storage only
-static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, const float* A, int lda, float* C, int ldc) {
-  if (!sym) return eg(h, st, false, true, n, n, k, 1.f, A, lda, A, lda, 0.f, C, ldc);
+// C = A A^T (A is [n x k]); sym: lower tile storage only.  (A2, C2): second Gram in the same launch.
+static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, const float* A, int lda, float* C, int ldc,
+                   const float* A2 = nullptr, float* C2 = nullptr) {
+  if (!sym) {
+    CHK(eg(h, st, false, true, n, n, k, 1.f, A, lda, A, lda, 0.f, C, ldc));
+    if (C2) CHK(eg(h, st, false, true, n, n, k, 1.f, A2, lda, A2, lda, 0.f, C2, ldc));
+    return 0;
+  }
   const bool big = h->profile;
   CHK(timer_begin(h, st, big));
-  MCGRA_HIP(ssyrk_lower(st, n, k, 1.f, A, lda, 0.f, C, ldc));
+  MCGRA_HIP(ssyrk_lower(st, n, k, 1.f, A, lda, 0.f, C, ldc, A2, C2));
   const double t = (n + SYM_TILE - 1) / SYM_TILE;
-  return timer_end(h, st, big, 2.0 * (t * (t + 1) / 2) * SYM_TILE * SYM_TILE * k);
+  return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * (t * (t + 1) / 2) * SYM_TILE * SYM_TILE * k);
 }
 // C = S B + beta C (S symmetric [n x n], B [n x m]); sym: S is in lower tile storage
 static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, const float* S, int lds_, const float* B,
-                   int ldb, float beta, float* C, int ldc) {
-  if (!sym) return eg(h, st, false, false, n, m, n, 1.f, S, lds_, B, ldb, beta, C, ldc);
+                   int ldb, float beta, float* C, int ldc, const float* S2 = nullptr, const float* B2 = nullptr,
+                   float* C2 = nullptr) {
+  if (!sym) {
+    CHK(eg(h, st, false, false, n, m, n, 1.f, S, lds_, B, ldb, beta, C, ldc));
+    if (C2) CHK(eg(h, st, false, false, n, m, n, 1.f, S2, lds_, B2, ldb, beta, C2, ldc));
+    return 0;
+  }
   const bool big = h->profile;
   CHK(timer_begin(h, st, big));
-  MCGRA_HIP(ssymm_lower(st, n, m, 1.f, S, lds_, B, ldb, beta, C, ldc));
-  return timer_end(h, st, big, 2.0 * n * (double)m * n);
+  MCGRA_HIP(ssymm_lower(st, n, m, 1.f, S, lds_, B, ldb, beta, C, ldc, S2, B2, C2));
+  return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * n * (double)m * n);
 }
 
 // x = relu(adj @ (x W_l) + b_l) for `depth` layers (models/gcn.py:71-76,164-172).
@@ -611,11 +621,12 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
       // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
       // step instead of 4.
       const bool sym = h->use_sym;
-      CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld));                                       // H Kx H
       if (use2) {
         launch_rowsum(st, n, ld, h->A1, h->rowsy);
         launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
-        CHK(eg_syrk(h, st, sym, n, n, h->YC, ld, h->KY, ld));                                     // H Ky H
+        CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY));                       // H Kx H and H Ky H
+      } else {
+        CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld));                                     // H Kx H
       }
       if (cka) {
         launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, sym);
@@ -628,8 +639,8 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
         launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
       }
       // G_adjn += 2 (s1 Kfc + s2 Kyc) @ Xc ;  G_A1 += 2 s2 Kxc @ Yc   (K 1 = 0, so Xc may replace X)
-      CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
-      if (use2) CHK(eg_symm(h, st, sym, n, n, h->KX, ld, h->YC, ld, 1.f, h->G_A1, ld));
+      if (use2) CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld, h->KX, h->YC, h->G_A1));
+      else CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
     }
   }
 

@@ -83,8 +83,12 @@ template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, in
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
-    int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n) {
+    int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n,
+    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2) {
   using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB>;
+  // blockIdx.y == 1: the second, independent product of a batched pair (same shapes and leading dimensions);
+  // one launch instead of two lets the tail round of the first product overlap the head of the second
+  if (blockIdx.y == 1) { A = A2; B = B2; C = C2; }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int STAGE = Cfg::A_ELEMS + Cfg::B_ELEMS;
   float* As = smem;
@@ -355,24 +359,60 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     for (; k0 < k_end; k0 += BK) step(AtT{}, AtT{}, AtT{}, Rs0{}, k0);
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C/D layout of the MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // When the staging LDS is large enough, each wave parks its WM x WN tile there and writes whole rows with
+  // 16-byte stores (and 16-byte loads for beta); the rank-16/32 updates of the step are pure epilogue.
+  constexpr int CT_LD = WN + 4;
+  constexpr bool EPI_LDS = (NBUF * STAGE >= (GEMM_THREADS / 64) * WM * CT_LD);
+  const bool cvec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
+  if (EPI_LDS && cvec) {
+    float* Ct = smem + wave * (WM * CT_LD);
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      const int col = n0 + wn0 + j * 32 + l31;
-      if (col >= N) continue;
+      for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M) {
-          float* p = C + (size_t)row * ldc + col;
-          float v = alpha * acc[i][j][r];
-          if (beta != 0.f) v += beta * *p;
-          *p = v;
+        for (int r = 0; r < 16; ++r)
+          Ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CT_LD + j * 32 + l31] = alpha * acc[i][j][r];
+    __syncthreads();
+    constexpr int V4_PER_ROW = WN / 4;
+#pragma unroll
+    for (int it = 0; it < WM * V4_PER_ROW / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / V4_PER_ROW, c4 = (idx % V4_PER_ROW) * 4;
+      const int gr = m0 + wm0 + row, gc = n0 + wn0 + c4;
+      if (gr >= M || gc >= N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[row * CT_LD + c4]);
+      float* p = C + (size_t)gr * ldc + gc;
+      if (gc + 3 < N) {
+        if (beta != 0.f) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(p);
+          v[0] += beta * o[0]; v[1] += beta * o[1]; v[2] += beta * o[2]; v[3] += beta * o[3];
         }
+        *reinterpret_cast<f32x4*>(p) = v;
+      } else {
+        for (int q = 0; q < 4 && gc + q < N; ++q) p[q] = (beta != 0.f) ? v[q] + beta * p[q] : v[q];
       }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < M) {
+            float* p = C + (size_t)row * ldc + col;
+            float v = alpha * acc[i][j][r];
+            if (beta != 0.f) v += beta * *p;
+            *p = v;
+          }
+        }
+      }
+  }
 }
 
 // slabs are [nsplit][M][N] contiguous; out is [M][N] with leading dimension ldc
@@ -392,10 +432,11 @@ template <int BM, int BN, int BK, int WM, int WN, int NBUF, int SYM, int PF = 1>
 static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K,
                              float alpha, const float* A, int lda, const float* B, int ldb,
                              float beta, float* C, int ldc, int nsplit, int k_per_split,
-                             size_t c_split_stride) {
+                             size_t c_split_stride, const float* A2 = nullptr, const float* B2 = nullptr,
+                             float* C2 = nullptr) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nblk = (SYM == SYM_RK) ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-  dim3 grid(nblk, 1, nsplit), block(GEMM_THREADS);
+  dim3 grid(nblk, C2 ? 2 : 1, nsplit), block(GEMM_THREADS);
 #define MCGRA_GEMM_LAUNCH(TA_, TB_, VEC_)                                                                \
   do {                                                                                                   \
     using Cfg_ = GemmCfg<BM, BN, BK, WM, WN, TA_, TB_>;                                                  \
@@ -411,7 +452,7 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
       }                                                                                                  \
     }                                                                                                    \
     hipLaunchKernelGGL(kern_, grid, block, smem_, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,      \
-                       k_per_split, c_split_stride, tiles_m, tiles_n);                                   \
+                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2);                       \
   } while (0)
   if (SYM == SYM_RK) {  // A A^T
     if (vec) MCGRA_GEMM_LAUNCH(false, true, true); else MCGRA_GEMM_LAUNCH(false, true, false);
@@ -504,20 +545,23 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
 }
 
 // C = alpha A A^T + beta C on the lower tile storage (tiles of SYM_TILE = 128 with tile_n <= tile_m);
-// elements outside that region are not touched.  A is [n x k].
+// elements outside that region are not touched.  A is [n x k].  (A2, C2): optional second product of the
+// same shape in the same launch.
 hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A, int lda, float beta, float* C,
-                       int ldc) {
+                       int ldc, const float* A2, float* C2) {
   if (n <= 0) return hipSuccess;
-  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_RK, 1>(st, false, true, vec_ok(A, lda, A, lda), n, n, k, alpha,
-                                                               A, lda, A, lda, beta, C, ldc, 1, k, 0);
+  const bool vec = vec_ok(A, lda, A2 ? A2 : A, lda);
+  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_RK, 1>(st, false, true, vec, n, n, k, alpha, A, lda, A, lda, beta,
+                                                                  C, ldc, 1, k, 0, A2, A2, C2);
 }
 
 // C[n x m] = alpha S B + beta C with S [n x n] symmetric in lower tile storage, B [n x m].
 hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
-                       float beta, float* C, int ldc) {
+                       float beta, float* C, int ldc, const float* S2, const float* B2, float* C2) {
   if (n <= 0 || m <= 0) return hipSuccess;
-  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM, 1>(st, false, false, vec_ok(S, lds_, B, ldb), n, m, n, alpha,
-                                                               S, lds_, B, ldb, beta, C, ldc, 1, n, 0);
+  const bool vec = vec_ok(S, lds_, B, ldb) && (!C2 || vec_ok(S2, lds_, B2, ldb));
+  return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM, 1>(st, false, false, vec, n, m, n, alpha, S, lds_, B, ldb,
+                                                                  beta, C, ldc, 1, n, 0, S2, B2, C2);
 }
 
 }  // namespace mcgra
