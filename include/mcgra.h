@@ -193,6 +193,22 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
                       double* scalars_out);
 
+/* Row-block sharding over ranks (one process per GPU).  A step is four phases; the host layer runs the
+ * collectives between them (mc-gra_amd/sharded.py):
+ *   phase 0  replicated   forward, losses, centred operands
+ *   phase 1  sharded      centred Grams KX, KY: tile rows of [cfg.row_begin, cfg.row_end) only
+ *            -> all-gather the row blocks of "KX", "KY"
+ *   phase 2  sharded      gradient products into rows [row_begin, row_end) of "G_adjn", "G_A1"
+ *            -> all-gather the row blocks of "G_adjn", "G_A1"
+ *   phase 3  replicated   small-operand terms, backward chains, Adam, projection (scalars_out as in mcgra_attack_step)
+ * mcgra_attack_step == phases 0..3 with the full row range.  Measures without N x N x N products (MSELoss, KL) do
+ * all their work in phases 0 and 3. */
+int mcgra_attack_step_phase(mcgra_attack_t* h, void* stream, int phase, const float* noise,
+                            double* scalars_out);
+/* Use caller-owned device memory ([>= n rows][ld] fp32, ld from mcgra_attack_buffer) for one of the exchanged
+ * buffers "KX", "KY", "G_adjn", "G_A1", so that the host layer can hand it to its collective library. */
+int mcgra_attack_bind_buffer(mcgra_attack_t* h, const char* name, float* ptr);
+
 /* Monitoring forward of topology_attack.py:290-296 on the current adjacency:
  * out_logp [n x nclass] = victim(features, normalize(get_modified_adj)),
  * *sparsity (host) = mean(modified_adj).  Synchronises if sparsity != NULL. */

@@ -149,7 +149,7 @@ static int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, i
 }
 // C = A A^T (A is [n x k]); sym: lower tile storage only.  (A2, C2): second Gram in the same launch.
 static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, const float* A, int lda, float* C, int ldc,
-                   const float* A2 = nullptr, float* C2 = nullptr) {
+                   const float* A2 = nullptr, float* C2 = nullptr, int t0 = 0, int trows = -1) {
   if (!sym) {
     CHK(eg(h, st, false, true, n, n, k, 1.f, A, lda, A, lda, 0.f, C, ldc));
     if (C2) CHK(eg(h, st, false, true, n, n, k, 1.f, A2, lda, A2, lda, 0.f, C2, ldc));
@@ -157,14 +157,14 @@ static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, cons
   }
   const bool big = h->profile;
   CHK(timer_begin(h, st, big));
-  MCGRA_HIP(ssyrk_lower(st, n, k, 1.f, A, lda, 0.f, C, ldc, A2, C2));
-  const double t = (n + SYM_TILE - 1) / SYM_TILE;
-  return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * (t * (t + 1) / 2) * SYM_TILE * SYM_TILE * k);
+  MCGRA_HIP(ssyrk_lower(st, n, k, 1.f, A, lda, 0.f, C, ldc, A2, C2, t0, trows));
+  const double ta = t0, tb = trows >= 0 ? t0 + trows : (n + SYM_TILE - 1) / SYM_TILE;
+  return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * (tb * (tb + 1) / 2 - ta * (ta + 1) / 2) * SYM_TILE * SYM_TILE * k);
 }
 // C = S B + beta C (S symmetric [n x n], B [n x m]); sym: S is in lower tile storage
 static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, const float* S, int lds_, const float* B,
                    int ldb, float beta, float* C, int ldc, const float* S2 = nullptr, const float* B2 = nullptr,
-                   float* C2 = nullptr) {
+                   float* C2 = nullptr, int t0 = 0, int trows = -1) {
   if (!sym) {
     CHK(eg(h, st, false, false, n, m, n, 1.f, S, lds_, B, ldb, beta, C, ldc));
     if (C2) CHK(eg(h, st, false, false, n, m, n, 1.f, S2, lds_, B2, ldb, beta, C2, ldc));
@@ -172,8 +172,9 @@ static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, cons
   }
   const bool big = h->profile;
   CHK(timer_begin(h, st, big));
-  MCGRA_HIP(ssymm_lower(st, n, m, 1.f, S, lds_, B, ldb, beta, C, ldc, S2, B2, C2));
-  return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * n * (double)m * n);
+  MCGRA_HIP(ssymm_lower(st, n, m, 1.f, S, lds_, B, ldb, beta, C, ldc, S2, B2, C2, t0, trows));
+  const double rows = trows >= 0 ? fmin((double)trows * SYM_TILE, (double)n - (double)t0 * SYM_TILE) : n;
+  return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * rows * (double)m * n);
 }
 
 // x = relu(adj @ (x W_l) + b_l) for `depth` layers (models/gcn.py:71-76,164-172).
@@ -251,9 +252,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
               cfg->measure);
     return MCGRA_ENOSUP;
   }
-  if (cfg->row_begin != 0 || (cfg->row_end != cfg->n && cfg->row_end != 0)) {
-    set_error("row-block sharding is driven from the host layer; engine objects are full-range");
-    return MCGRA_ENOSUP;
+  if (cfg->row_begin < 0 || cfg->row_begin % 128 != 0 || (cfg->row_end != 0 && cfg->row_end <= cfg->row_begin)) {
+    set_error("row block [%d, %d): row_begin must be a multiple of 128 and row_end > row_begin", cfg->row_begin, cfg->row_end);
+    return MCGRA_EINVAL;
   }
   mcgra_attack* h = new mcgra_attack();
   h->cfg = *cfg;
@@ -529,7 +530,15 @@ static int project(mcgra_attack* h, hipStream_t st) {
   return 0;
 }
 
-int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out) {
+// Phases of one step (bit k of `phases`), for row-block sharding over ranks:
+//   0  replicated: forward, losses, centred operands Xc / Yc (every measure other than HSIC / CKA finishes its
+//      N x N terms here)
+//   1  sharded:    centred Grams, tile rows [row_begin, row_end) only           -> exchange KX, KY row blocks
+//   2  sharded:    combine (replicated, cheap) + gradient products, rows [row_begin, row_end) only
+//                                                                              -> exchange G_adjn, G_A1 row blocks
+//   3  replicated: small-operand terms, backward chains, normalisation backward, Adam, projection
+static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out, int phases) {
+#define PH(k) ((phases >> (k)) & 1)
   if (!h) { set_error("null handle"); return MCGRA_EINVAL; }
   if (!h->graph_set) { set_error("mcgra_attack_set_graph must be called first"); return MCGRA_EINVAL; }
   if ((h->cfg.eps != 0.f) != (noise != nullptr)) {
@@ -546,16 +555,28 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   const double n2 = (double)n * n;
   const bool cka = c.measure == MCGRA_MEASURE_CKA;
   const bool hsic = c.measure == MCGRA_MEASURE_HSIC || cka;      // both run the centred-Gram path
-  MCGRA_HIP(hipMemsetAsync(h->scal, 0, sizeof(double) * S_COUNT, st));
-
-  // ---- forward: adjacency, normalisation (:164-166)
-  if (noise) {  // caller layout is [n][n]; the kernels use leading dimension ld.  G_A is free at this point.
-    MCGRA_HIP(hipMemcpy2DAsync(h->G_A, (size_t)ld * 4, noise, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
-    noise = h->G_A;
-  }
-  CHK(forward_common(h, st, h->ADJN, noise));
   const float* A = noise ? h->Abuf : h->M;   // modified_adj == M when ori == 0, eps == 0
   const unsigned char* gate = noise ? h->gate : nullptr;
+  const float* em = h->Hu + h->off[Le - 1];
+  const int he = h->wdt[Le - 1];
+  const bool use1 = (w1 != 0), use2 = (w2 != 0);
+  const bool sym = h->use_sym;
+  // tile rows of this rank (single GPU: all of them)
+  const int t_all = (n + SYM_TILE - 1) / SYM_TILE;
+  // (a trailing rank of a padded plan may own no tile rows at all: t0 == t1 == t_all)
+  const int t0 = c.row_begin / SYM_TILE < t_all ? c.row_begin / SYM_TILE : t_all;
+  const int t1 = (c.row_end >= n || c.row_end <= 0) ? t_all : (c.row_end + SYM_TILE - 1) / SYM_TILE;
+  const bool sharded = (t0 != 0 || t1 != t_all);
+
+  if (PH(0)) {
+  MCGRA_HIP(hipMemsetAsync(h->scal, 0, sizeof(double) * S_COUNT, st));
+  // ---- forward: adjacency, normalisation (:164-166)
+  const float* noise_ld = nullptr;
+  if (noise) {  // caller layout is [n][n]; the kernels use leading dimension ld.  G_A is free at this point.
+    MCGRA_HIP(hipMemcpy2DAsync(h->G_A, (size_t)ld * 4, noise, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+    noise_ld = h->G_A;
+  }
+  CHK(forward_common(h, st, h->ADJN, noise_ld));
   // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
   CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
@@ -564,15 +585,12 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
   // ---- embedding(features, modified_adj - ori_adj) (:185) == first Le layers of victim(features, modified_adj) (:259)
   CHK(chain_forward(h, st, A, ld, L, h->Tu, h->Pu, h->Hu, h->Su));
   CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
-  const float* em = h->Hu + h->off[Le - 1];
-  const int he = h->wdt[Le - 1];
   // ---- dot_product_decode + get_modified_adj_after (:187-188)
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
   CHK(eg(h, st, false, true, n, n, he, 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->A1, ld));
   launch_decode_post(st, n, ld, h->A1, nullptr);
 
   // ---- N x N loss terms (:212-236)
-  const bool use1 = (w1 != 0), use2 = (w2 != 0);
   if (c.measure == MCGRA_MEASURE_DP) {
     // dot_product(X, Y) = |Y^T X|_F (:480-481); d/dY = X P^T / |P|, d/dX = Y P / |P| with P = Y^T X
     launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
@@ -612,38 +630,47 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
                      h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
     if (use1 || use2) {
-      const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
       // adj_norm and A1 are symmetric here (ori == 0, eps == 0): column means == row means
       if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
       else launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
       launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
-      // Grams are symmetric: only the 128x128 tiles on or below the diagonal are computed (lower tile
-      // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
-      // step instead of 4.
-      const bool sym = h->use_sym;
       if (use2) {
         launch_rowsum(st, n, ld, h->A1, h->rowsy);
         launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
-        CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY));                       // H Kx H and H Ky H
-      } else {
-        CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld));                                     // H Kx H
       }
-      if (cka) {
-        launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, sym);
-        launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 4, h->scal + S_CK0);
-        launch_cka_coef(st, h->scal + S_CK0, h->cst + 0, use1 ? (float)k1 : 0.f, use2 ? (float)k2 : 0.f, h->coef);
-        launch_cka_lincomb(st, n, ld, h->KX, h->KY, h->KFC, h->coef, use1, use2, sym);
-      } else {
-        launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f,
-                            h->rowvals + 4 * (size_t)ld, sym);
-        launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
-      }
-      // G_adjn += 2 (s1 Kfc + s2 Kyc) @ Xc ;  G_A1 += 2 s2 Kxc @ Yc   (K 1 = 0, so Xc may replace X)
-      if (use2) CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld, h->KX, h->YC, h->G_A1));
-      else CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld));
     }
   }
+  MCGRA_KERNEL_CHECK();
+  }  // phase 0
 
+  if (PH(1) && hsic && (use1 || use2)) {
+    // Grams are symmetric: only the 128x128 tiles on or below the diagonal are computed (lower tile
+    // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
+    // step instead of 4.  Sharded: tile rows [t0, t1) of this rank.
+    if (sharded && !sym) { set_error("row-block sharding needs the symmetric GEMM path"); return MCGRA_EINVAL; }
+    if (use2) CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY, t0, t1 - t0));   // H Kx H and H Ky H
+    else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
+  }
+
+  if (PH(2) && hsic && (use1 || use2)) {
+    const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
+    if (cka) {
+      launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, sym);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 4, h->scal + S_CK0);
+      launch_cka_coef(st, h->scal + S_CK0, h->cst + 0, use1 ? (float)k1 : 0.f, use2 ? (float)k2 : 0.f, h->coef);
+      launch_cka_lincomb(st, n, ld, h->KX, h->KY, h->KFC, h->coef, use1, use2, sym);
+    } else {
+      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f,
+                          h->rowvals + 4 * (size_t)ld, sym);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+    }
+    // G_adjn += 2 (s1 Kfc + s2 Kyc) @ Xc ;  G_A1 += 2 s2 Kxc @ Yc   (K 1 = 0, so Xc may replace X)
+    if (use2) CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld, h->KX, h->YC, h->G_A1, t0, t1 - t0));
+    else CHK(eg_symm(h, st, sym, n, n, h->KY, ld, h->XC, ld, 1.f, h->G_ADJN, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
+    MCGRA_KERNEL_CHECK();
+  }
+
+  if (PH(3)) {
   // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
   MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
   if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
@@ -728,6 +755,29 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, doubl
     scalars_out[1] = origin; scalars_out[2] = c1v; scalars_out[3] = c2v; scalars_out[4] = c6v; scalars_out[5] = c7v;
     scalars_out[6] = c9v; scalars_out[7] = c10v; scalars_out[8] = 0.5 * s[S_CLAMPSUM]; scalars_out[9] = nll;
   }
+  }  // phase 3
+  return 0;
+#undef PH
+}
+
+int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out) {
+  return step_impl(h, stream, noise, scalars_out, 0xF);
+}
+
+int mcgra_attack_step_phase(mcgra_attack_t* h, void* stream, int phase, const float* noise, double* scalars_out) {
+  if (phase < 0 || phase > 3) { set_error("phase %d", phase); return MCGRA_EINVAL; }
+  return step_impl(h, stream, noise, phase == 3 ? scalars_out : nullptr, 1 << phase);
+}
+
+int mcgra_attack_bind_buffer(mcgra_attack_t* h, const char* name, float* ptr) {
+  if (!h || !name || !ptr) { set_error("null argument"); return MCGRA_EINVAL; }
+  float** slot = nullptr;
+  if (!strcmp(name, "KX")) slot = &h->KX;
+  else if (!strcmp(name, "KY")) slot = &h->KY;
+  else if (!strcmp(name, "G_adjn")) slot = &h->G_ADJN;
+  else if (!strcmp(name, "G_A1")) slot = &h->G_A1;
+  if (!slot) { set_error("buffer '%s' cannot be bound", name); return MCGRA_EINVAL; }
+  *slot = ptr;     // [>= n rows][ld] fp32, caller-owned (exchanged between ranks by the host layer)
   return 0;
 }
 

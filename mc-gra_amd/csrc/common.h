@@ -31,10 +31,10 @@ void set_gemm_variant(int v);
 // j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.
 constexpr int SYM_TILE = 128;
 hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A, int lda, float beta, float* C,
-                       int ldc, const float* A2 = nullptr, float* C2 = nullptr);
+                       int ldc, const float* A2 = nullptr, float* C2 = nullptr, int tile_off = 0, int tile_rows = -1);
 hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
                        float beta, float* C, int ldc, const float* S2 = nullptr, const float* B2 = nullptr,
-                       float* C2 = nullptr);
+                       float* C2 = nullptr, int tile_off = 0, int tile_rows = -1);
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
     int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n,
-    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2) {
+    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2, int tile_off) {
   using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB>;
   // blockIdx.y == 1: the second, independent product of a batched pair (same shapes and leading dimensions);
   // one launch instead of two lets the tail round of the first product overlap the head of the second
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     if (SYM == SYM_RK) {  // bid enumerates the lower triangle row by row: bid = tm (tm+1)/2 + tn
+      bid += tile_off * (tile_off + 1) / 2;   // row-block sharding: this launch starts at tile row tile_off
       int tm = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
       while ((tm + 1) * (tm + 2) / 2 <= bid) ++tm;
       while (tm * (tm + 1) / 2 > bid) --tm;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
       const int gm = min(tiles_m - first_m, GROUP_M);
       tile_m = first_m + (bid % group_sz) % gm;
       tile_n = (bid % group_sz) / gm;
+      if (SYM == SYM_MM) tile_m += tile_off;   // row-block sharding: rows [tile_off * BM, ...) of C = S B
     }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -433,9 +435,13 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
                              float alpha, const float* A, int lda, const float* B, int ldb,
                              float beta, float* C, int ldc, int nsplit, int k_per_split,
                              size_t c_split_stride, const float* A2 = nullptr, const float* B2 = nullptr,
-                             float* C2 = nullptr) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int nblk = (SYM == SYM_RK) ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+                             float* C2 = nullptr, int tile_off = 0, int tile_rows = -1) {
+  // tile_off / tile_rows: restrict a symmetric launch to tile rows [tile_off, tile_off + tile_rows)
+  const int tiles_all = (M + BM - 1) / BM;
+  const int tiles_m = tile_rows >= 0 ? tile_rows : tiles_all, tiles_n = (N + BN - 1) / BN;
+  const int t1 = tile_off + tiles_m;
+  const int nblk = (SYM == SYM_RK) ? t1 * (t1 + 1) / 2 - tile_off * (tile_off + 1) / 2 : tiles_m * tiles_n;
+  if (nblk <= 0) return hipSuccess;
   dim3 grid(nblk, C2 ? 2 : 1, nsplit), block(GEMM_THREADS);
 #define MCGRA_GEMM_LAUNCH(TA_, TB_, VEC_)                                                                \
   do {                                                                                                   \
@@ -452,7 +458,7 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
       }                                                                                                  \
     }                                                                                                    \
     hipLaunchKernelGGL(kern_, grid, block, smem_, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,      \
-                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2);                       \
+                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2, tile_off);             \
   } while (0)
   if (SYM == SYM_RK) {  // A A^T
     if (vec) MCGRA_GEMM_LAUNCH(false, true, true); else MCGRA_GEMM_LAUNCH(false, true, false);
@@ -548,20 +554,21 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
 // elements outside that region are not touched.  A is [n x k].  (A2, C2): optional second product of the
 // same shape in the same launch.
 hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A, int lda, float beta, float* C,
-                       int ldc, const float* A2, float* C2) {
+                       int ldc, const float* A2, float* C2, int tile_off, int tile_rows) {
   if (n <= 0) return hipSuccess;
   const bool vec = vec_ok(A, lda, A2 ? A2 : A, lda);
   return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_RK, 1>(st, false, true, vec, n, n, k, alpha, A, lda, A, lda, beta,
-                                                                  C, ldc, 1, k, 0, A2, A2, C2);
+                                                                  C, ldc, 1, k, 0, A2, A2, C2, tile_off, tile_rows);
 }
 
 // C[n x m] = alpha S B + beta C with S [n x n] symmetric in lower tile storage, B [n x m].
 hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
-                       float beta, float* C, int ldc, const float* S2, const float* B2, float* C2) {
+                       float beta, float* C, int ldc, const float* S2, const float* B2, float* C2, int tile_off,
+                       int tile_rows) {
   if (n <= 0 || m <= 0) return hipSuccess;
   const bool vec = vec_ok(S, lds_, B, ldb) && (!C2 || vec_ok(S2, lds_, B2, ldb));
   return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM, 1>(st, false, false, vec, n, m, n, alpha, S, lds_, B, ldb,
-                                                                  beta, C, ldc, 1, n, 0, S2, B2, C2);
+                                                                  beta, C, ldc, 1, n, 0, S2, B2, C2, tile_off, tile_rows);
 }
 
 }  // namespace mcgra

@@ -141,7 +141,8 @@ class AttackEngine:
     topology_attack.py:161-298 (adj_changes + Adam moments) in HBM."""
 
     def __init__(self, n, dims, nclass, emb_nlayer, measure, weight_sup, weight_param, lr, num_edges,
-                 n_attack, eps=0.0, device="cuda:0", act="relu", head_act="none", has_self=False, fin_layers=(1, 2)):
+                 n_attack, eps=0.0, device="cuda:0", act="relu", head_act="none", has_self=False, fin_layers=(1, 2),
+                 row_begin=0, row_end=None):
         _lib.require_device()
         self.device = torch.device(device)
         self.n, self.nclass, self.dims = int(n), int(nclass), list(int(d) for d in dims)
@@ -159,7 +160,7 @@ class AttackEngine:
             cfg.w[i] = float(weight_param[i])
         cfg.lr, cfg.eps = float(lr), float(eps)
         cfg.num_edges = float(min(num_edges, 1e300))
-        cfg.row_begin, cfg.row_end = 0, self.n
+        cfg.row_begin, cfg.row_end = int(row_begin), int(self.n if row_end is None else row_end)
         cfg.act = {"relu": 0, "elu": 1}[act]
         cfg.head_act = {"none": 0, "elu": 1}[head_act]
         cfg.has_self = int(bool(has_self))
@@ -232,6 +233,29 @@ class AttackEngine:
                 return dict(zip(keys, list(buf)))
             check(lib.mcgra_attack_step(self._h, _stream(), _p(noise), None))
         return None
+
+    def step_phase(self, phase, noise=None, want_scalars=False):
+        """One phase of a row-block sharded step (mcgra_attack_step_phase)."""
+        with torch.cuda.device(self.device):
+            if want_scalars and phase == 3:
+                buf = (C.c_double * 10)()
+                check(lib.mcgra_attack_step_phase(self._h, _stream(), int(phase), _p(noise), buf))
+                keys = ("loss", "origin_loss", "c1", "c2", "c6", "c7", "c9", "c10", "clamp_sum", "nll")
+                return dict(zip(keys, list(buf)))
+            check(lib.mcgra_attack_step_phase(self._h, _stream(), int(phase), _p(noise), None))
+        return None
+
+    def leading_dim(self):
+        ptr, r, c, ld = C.c_void_p(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib.mcgra_attack_buffer(self._h, b"M", C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))
+        return ld.value
+
+    def bind_buffer(self, name, tensor):
+        """Hand one of the exchanged buffers (KX, KY, G_adjn, G_A1) to the engine as caller-owned memory."""
+        assert tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous()
+        assert tensor.shape[0] >= self.n and tensor.shape[1] == self.leading_dim()
+        self._keep.append(tensor)
+        check(lib.mcgra_attack_bind_buffer(self._h, name.encode(), _p(tensor)))
 
     def monitor(self, want_sparsity=False):
         out = torch.empty(self.n, self.nclass, device=self.device, dtype=torch.float32)

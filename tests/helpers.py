@@ -80,7 +80,7 @@ def cora_feature_adj(feats):
 
 
 # ---------------------------------------------------------------- GPU-side helpers
-def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None):
+def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None, **kw):
     """AttackEngine (C-ABI handle) set up from a golden attack case."""
     import torch  # noqa: F401
     cfg = cfg_from(z)
@@ -89,7 +89,7 @@ def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None):
     eng = pkg.AttackEngine(z["adj"].shape[0], dims, w.Wlin.shape[0], cfg.emb_nlayer, measure or cfg.measure,
                            cfg.weight_sup, weight_param or cfg.weight_param, cfg.lr, cfg.num_edges,
                            len(z["idx_attack"]), eps=cfg.eps, device=device, act=w.act, head_act=w.head_act,
-                           has_self=w.Ws is not None, fin_layers=cfg.fin_layers)
+                           has_self=w.Ws is not None, fin_layers=cfg.fin_layers, **kw)
     eng.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
     eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
     if a0_of(z) is not None:
