@@ -150,6 +150,50 @@ def aggregate_value(world, steps, dt):
     return world * steps / dt
 
 
+def build_engine(pkg, torch, dev, workload, seed, **kw):
+    """Engine + inputs of one workload, seeded: the same seed gives bit-identical state on every rank."""
+    n, f, c, hid, nl, measure, wp = WORKLOADS[workload]
+    inp = make_inputs(n, f, c, hid, nl, seed)
+    X = torch.as_tensor(inp["features"], device=dev)
+    fadj = feature_adj_cora(X, torch)
+    eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, 1.0, wp, 0.01, 1e30, n, device=dev, **kw)
+    eng.set_model(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
+    adj_dev = torch.as_tensor(inp["adj"], device=dev)
+    eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
+    # seeded non-zero start: with measure=HSIC the origin is a fixed point of the exact dynamics
+    # (DESIGN.md section 5, fact 2), so a zero start would time a run that optimises nothing
+    g = torch.Generator(device=dev); g.manual_seed(seed + 1000)
+    eng.set_adj_changes(torch.rand(n * (n - 1) // 2, device=dev, generator=g) * 0.05)
+    return eng, inp, adj_dev
+
+
+def sharded_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, monitor):
+    """ONE attack row-block sharded over all ranks, timed like the main region.  Reported
+    beside the replica throughput at N > 1; never the headline value."""
+    from mc_gra_amd.sharded import RowBlockPlan, ShardedStepper, HipShardBackend
+    n = WORKLOADS[workload][0]
+    plan = RowBlockPlan(n, world, rank)
+    eng, _, _ = build_engine(pkg, torch, dev, workload, seed, row_begin=plan.row_begin, row_end=plan.row_end)
+    st = ShardedStepper(HipShardBackend(eng, plan), plan, dist=dist)
+
+    def one_step():
+        st.step()
+        if monitor:
+            eng.monitor()
+
+    dt = timed_region(one_step, steps, 2, torch.cuda.synchronize, world, dist, dev, torch)
+    a = eng.get_adj_changes()
+    diff = torch.zeros(1, device=dev)
+    if world > 1:
+        ref = a.clone()
+        dist.broadcast(ref, src=0)
+        diff = (a - ref).abs().max().reshape(1)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+    return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "row_blocks": world,
+            "rows_per_rank": plan.rows_per_rank, "max_abs_diff_across_ranks": float(diff.item()),
+            "exchange": "2 x all_gather_into_tensor of 2 row-block buffers per step (RCCL)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +203,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-monitor", action="store_true", help="skip the per-step monitoring forward (:290-296)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-shard-probe", action="store_true",
+                    help="N > 1: skip the extra (untimed-for-value) run of one attack row-block sharded over the ranks")
+    ap.add_argument("--force-shard-probe", action="store_true", help="run the probe at N = 1 too (phase API, one row block)")
     a = ap.parse_args()
 
     import torch
@@ -174,17 +221,7 @@ def main():
     pkg = mcgra_loader.load()
 
     n, f, c, hid, nl, measure, wp = WORKLOADS[a.workload]
-    inp = make_inputs(n, f, c, hid, nl, a.seed + rank)          # replicas: every rank its own graph
-    X = torch.as_tensor(inp["features"], device=dev)
-    fadj = feature_adj_cora(X, torch)
-    eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, 1.0, wp, 0.01, 1e30, n, device=dev)
-    eng.set_model(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
-    adj_dev = torch.as_tensor(inp["adj"], device=dev)
-    eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
-    # seeded non-zero start: with measure=HSIC the origin is a fixed point of the exact dynamics
-    # (DESIGN.md section 5, fact 2), so a zero start would time a run that optimises nothing
-    g = torch.Generator(device=dev); g.manual_seed(a.seed + 1000 + rank)
-    eng.set_adj_changes(torch.rand(n * (n - 1) // 2, device=dev, generator=g) * 0.05)
+    eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed + rank)     # replicas: every rank its own graph
     monitor = not a.no_monitor
 
     def one_step():
@@ -206,6 +243,16 @@ def main():
     final = eng.finalize(0, H_A, Y_A, label_adj)
     auc = gpu_auc(adj_dev, final, torch)
 
+    shard = None
+    if (world > 1 or a.force_shard_probe) and not a.no_shard_probe and os.environ.get("MCGRA_BENCH_NO_SHARD_PROBE") != "1":
+        del eng, final, H_A, Y_A, label_adj
+        torch.cuda.empty_cache()
+        try:
+            shard = sharded_probe(pkg, torch, dist, dev, rank, world, a.workload, a.seed, min(a.steps, 10), monitor)
+            shard["speedup_vs_one_gpu_step"] = (dt / a.steps) / (shard["ms_per_step"] * 1e-3)
+        except Exception as e:                       # never lose the headline line to the probe
+            shard = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         out = {
             "metric": "attack-steps/sec", "value": aggregate_value(world, a.steps, dt), "unit": "attack-steps/s",
@@ -217,6 +264,8 @@ def main():
                        "monitor_forward": monitor, "parallelism": "replicas" if world > 1 else "single"},
             "auc": auc,
         }
+        if shard is not None:
+            out["sharded_probe"] = shard
         if st["launches"]:
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12
@@ -228,8 +277,8 @@ def main():
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
                 ks = json.load(open(tp))["kernels"]
                 traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks))
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (N x N x N products of linear_HSIC: "
-                                                           "2 SYRK + 2 SYMM launches per step)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (N x N x N products of linear_HSIC: one batched "
+                                                           "SYRK pair + one batched SYMM pair launch per step)",
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                                "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,

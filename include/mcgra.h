@@ -205,6 +205,17 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
  * all their work in phases 0 and 3. */
 int mcgra_attack_step_phase(mcgra_attack_t* h, void* stream, int phase, const float* noise,
                             double* scalars_out);
+/* Which of the exchanged buffers the step in flight needs gathered (valid after phase 0; the choice between the
+ * low-rank and the Gram evaluation of linear_HSIC(adj_norm, modified_adj1) is data dependent).
+ * After phase 1: the KX / KY bits; after phase 2: the G_ADJN / G_A1 bits. */
+#define MCGRA_EXCHANGE_KX 1
+#define MCGRA_EXCHANGE_KY 2
+#define MCGRA_EXCHANGE_G_ADJN 4
+#define MCGRA_EXCHANGE_G_A1 8
+int mcgra_attack_exchange_mask(mcgra_attack_t* h);
+/* Steps that took the low-rank / the Gram (general) evaluation of the N x N linear_HSIC terms since creation. */
+int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps);
+
 /* Use caller-owned device memory ([>= n rows][ld] fp32, ld from mcgra_attack_buffer) for one of the exchanged
  * buffers "KX", "KY", "G_adjn", "G_A1", so that the host layer can hand it to its collective library. */
 int mcgra_attack_bind_buffer(mcgra_attack_t* h, const char* name, float* ptr);

@@ -94,6 +94,14 @@ struct mcgra_attack {
   int nstrips = 32;
   bool profile = false;
   bool use_sym = true;             // SYRK / SYMM on lower tile storage for the linear_HSIC Grams (MCGRA_NO_SYM=1 disables)
+  // low-rank linear_HSIC(adj_norm, modified_adj1) (lowrank_kernels.hip); MCGRA_NO_LOWRANK=1 disables
+  bool lr_ok = false;              // configuration allows it (HSIC, ReLU embedding, width <= 32)
+  bool lr_step = false;            // the step in flight takes it (no relu-masked pair in the decode)
+  int lr_ldv = 0;
+  float *lrL = 0, *lrV = 0, *lrT = 0, *lrR = 0, *lrQ = 0, *lrDelta = 0, *lrC = 0;
+  double* lrStats = 0;
+  unsigned int* nmask = 0;
+  int64_t lr_steps = 0, general_steps = 0;
   GemmTimer timer;
 };
 
@@ -313,6 +321,17 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
   if (cfg->eps != 0.f) { A_(Abuf, nn); A_(gate, nn); A_(colpart_d, (size_t)h->nstrips * ld); }
   A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
+  {
+    const char* e = getenv("MCGRA_NO_LOWRANK");
+    const int he = h->wdt[h->Le - 1];
+    h->lr_ok = cfg->measure == MCGRA_MEASURE_HSIC && h->act == 0 && he <= 32 && !(e && e[0] == '1') && h->use_sym;
+    if (h->lr_ok) {
+      h->lr_ldv = (2 * he + 1 + 3) & ~3;
+      A_(lrL, n * 2 * he); A_(lrR, n * 2 * he); A_(lrQ, n * 2 * he); A_(lrV, n * (size_t)h->lr_ldv);
+      A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, (size_t)2 * he + (size_t)he * he);
+    }
+    A_(nmask, 4);
+  }
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
 #undef A_
@@ -588,7 +607,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // ---- dot_product_decode + get_modified_adj_after (:187-188)
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
   CHK(eg(h, st, false, true, n, n, he, 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->A1, ld));
-  launch_decode_post(st, n, ld, h->A1, nullptr);
+  MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+  launch_decode_post(st, n, ld, h->A1, nullptr, h->nmask);
+  h->lr_step = false;
 
   // ---- N x N loss terms (:212-236)
   if (c.measure == MCGRA_MEASURE_DP) {
@@ -634,9 +655,31 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
       else launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
       launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
-      if (use2) {
-        launch_rowsum(st, n, ld, h->A1, h->rowsy);
-        launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
+      if (h->lr_ok && !cka) {
+        // Low-rank path for c2 needs every off-diagonal pair active in the decode's relu (relu'(0) = 0 would
+        // mask a pair in the backward); that is data dependent, so the count is read back once per step.
+        unsigned int masked = 0;
+        if (use2) {
+          MCGRA_HIP(hipMemcpyAsync(&masked, h->nmask, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+          MCGRA_HIP(hipStreamSynchronize(st));
+        }
+        h->lr_step = (masked == 0);
+      }
+      if (h->lr_step) {
+        ++h->lr_steps;
+        if (use2) {
+          launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
+          launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
+          // T = Xc^T [U | D Z | delta^2]: W, W2 and t3 from one pass over Xc
+          CHK(eg(h, st, true, false, n, h->lr_ldv, n, 1.f, h->XC, ld, h->lrV, h->lr_ldv, 0.f, h->lrT, h->lr_ldv));
+          launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
+        }
+      } else {
+        ++h->general_steps;
+        if (use2) {
+          launch_rowsum(st, n, ld, h->A1, h->rowsy);
+          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
+        }
       }
     }
   }
@@ -648,11 +691,15 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
     // step instead of 4.  Sharded: tile rows [t0, t1) of this rank.
     if (sharded && !sym) { set_error("row-block sharding needs the symmetric GEMM path"); return MCGRA_EINVAL; }
+    if (h->lr_step) {
+      // the one N x N x N product left: P1 = (H Kf H) Xc, for both the value and the gradient of c1
+      if (use1) CHK(eg_symm(h, st, true, n, n, h->KFC, ld, h->XC, ld, 0.f, h->KX, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
+    } else
     if (use2) CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY, t0, t1 - t0));   // H Kx H and H Ky H
     else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
   }
 
-  if (PH(2) && hsic && (use1 || use2)) {
+  if (PH(2) && hsic && (use1 || use2) && !h->lr_step) {
     const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
     if (cka) {
       launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, sym);
@@ -671,6 +718,20 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
 
   if (PH(3)) {
+  if (hsic && h->lr_step && (use1 || use2)) {
+    const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
+    // G_adjn += 2 s1 P1 + 2 s2 (D^2 Xc + 1 c^T);  v1 = sum P1 o Xc
+    launch_lr_elem(st, n, ld, h->XC, use1 ? h->KX : nullptr, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
+                   2.f * s1, 2.f * s2, h->G_ADJN, h->rowvals + 4 * (size_t)ld);
+    launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
+    if (use2) {
+      CHK(eg(h, st, false, true, n, n, 2 * he, 2.f * s2, h->lrL, 2 * he, h->lrR, 2 * he, 1.f, h->G_ADJN, ld));  // U M1^T - D Z W^T
+      CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->XC, ld, h->lrT, h->lr_ldv, 0.f, h->lrQ, 2 * he));       // [Q | Q2]
+      launch_rowsumsq(st, n, ld, h->XC, h->rowsy);                                                              // diag(KX)
+      CHK(eg(h, st, false, true, n, n, he, 2.f * s2, h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));         // Q Z^T
+    }
+    MCGRA_KERNEL_CHECK();
+  }
   // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
   MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
   if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
@@ -690,6 +751,11 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // ---- backward: decode (S = Zn Zn^T, A1 = offdiag relu(S))
   launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
   CHK(eg(h, st, false, false, n, he, n, 1.f, h->G_A, ld, h->Zn, h->hmax, 0.f, h->GZn, h->hmax));
+  if (hsic && h->lr_step && use2) {   // the -2 s2 KX D part of d c2 / d A1, applied to Zn directly
+    launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->rowsy, -2.f * (float)(sg * k2), h->GZn, h->hmax,
+                    h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld);
+    launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
+  }
   launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
 
   // ---- backward: modified_adj chain (embedding + output2) -> G_A
@@ -778,6 +844,23 @@ int mcgra_attack_bind_buffer(mcgra_attack_t* h, const char* name, float* ptr) {
   else if (!strcmp(name, "G_A1")) slot = &h->G_A1;
   if (!slot) { set_error("buffer '%s' cannot be bound", name); return MCGRA_EINVAL; }
   *slot = ptr;     // [>= n rows][ld] fp32, caller-owned (exchanged between ranks by the host layer)
+  return 0;
+}
+
+int mcgra_attack_exchange_mask(mcgra_attack_t* h) {
+  if (!h) return 0;
+  const int m = h->cfg.measure;
+  if (m != MCGRA_MEASURE_HSIC && m != MCGRA_MEASURE_CKA) return 0;
+  const bool use1 = h->cfg.w[0] != 0, use2 = h->cfg.w[1] != 0;
+  if (!use1 && !use2) return 0;
+  if (h->lr_step) return use1 ? MCGRA_EXCHANGE_KX : 0;
+  return MCGRA_EXCHANGE_KX | (use2 ? MCGRA_EXCHANGE_KY : 0) | MCGRA_EXCHANGE_G_ADJN | (use2 ? MCGRA_EXCHANGE_G_A1 : 0);
+}
+
+int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps) {
+  if (!h) { set_error("null handle"); return MCGRA_EINVAL; }
+  if (lowrank_steps) *lowrank_steps = h->lr_steps;
+  if (general_steps) *general_steps = h->general_steps;
   return 0;
 }
 

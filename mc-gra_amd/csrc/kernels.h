@@ -11,7 +11,7 @@ void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, co
                  const float* noise, float eps, float* A, unsigned char* gate, float* d, float* r,
                  double* rowsq, double* rowsum);
 void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out);
-void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori);
+void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori, unsigned int* nmask = nullptr);
 void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float* Y, const float* F,
                       float kmse1, float kmse2, float kie6, float kie7, float* GX, float* GY,
                       double* rowvals);
@@ -87,5 +87,16 @@ void launch_fill(hipStream_t st, size_t count, float* p, float v);
 void launch_scale(hipStream_t st, size_t count, float* p, float v);
 void launch_count_idx(hipStream_t st, int m, const int* idx, float* cnt);
 void launch_argmax_eq(hipStream_t st, int m, int c, const float* logp, int ld, const int* idx, const int* labels, int* correct);
+
+// ---- lowrank_kernels.hip (low-rank linear_HSIC(adj_norm, modified_adj1))
+void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats);
+void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
+                    int ldv, float* delta);
+void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,
+                    double* rowval);
+void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
+                    const float* cvec, float a1, float a2, float* G, double* rowval);
+void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
+                     const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval);
 
 }  // namespace mcgra

@@ -1,0 +1,166 @@
+// Low-rank evaluation of linear_HSIC(adj_norm, modified_adj1) and of its two gradients.
+//
+// With a ReLU embedding em >= 0, so Zn >= 0 and S = Zn Zn^T >= 0: the relu of dot_product_decode (:414-419) is
+// the identity and modified_adj1 = Z Z^T - D with Z = Zn [n x h], D = diag(|z_i|^2).  Then, with Xc = H adj_norm,
+// U = H Z, W = Xc^T U, W2 = Xc^T D Z, R = Yc^T Xc = Z W^T - D Xc:
+//   linear_HSIC(X, Y) = |R|_F^2                                       (utils.py:1085-1089)
+//   d/dX              = 2 Yc R = 2 (U M1^T - D Z W^T + D^2 Xc + 1 c^T),  M1 = W (Z^T Z) - W2,  c = delta^T R / n
+//   d/dY              = 2 (Q Z^T - KX D),  Q = Xc W   -- the KX D part is only ever consumed through the decode
+//                       backward, where ((KX D + D KX) offdiag) Z = Q2 + D Q - 2 diag(KX) D Z,  Q2 = Xc W2,
+// all O(n^2 h).  The engine takes this path only on steps where no off-diagonal S_ij is <= 0 (k_decode_post
+// counts them), because relu'(0) = 0 masks such pairs in the reference's backward.
+#include "common.h"
+#include "kernels.h"
+
+namespace mcgra {
+
+#define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
+constexpr int LR_HMAX = 32;
+
+// stats (double): zbar[h] | zeta[h] | ZtZ[h*h].  grid = h + 2 blocks of 256:
+//   block k < h : column k of Z^T Z;  block h : column means;  block h+1 : zeta = sum_i delta_i z_i
+__global__ __launch_bounds__(256) void k_lr_colstats(int n, int h, const float* __restrict__ Z, int ldz,
+                                                     double* __restrict__ stats) {
+  __shared__ double sh[16];
+  const int b = blockIdx.x;
+  double acc[LR_HMAX];
+#pragma unroll
+  for (int k = 0; k < LR_HMAX; ++k) acc[k] = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float* z = Z + (size_t)i * ldz;
+    double wgt;
+    if (b < h) wgt = (double)z[b];
+    else if (b == h) wgt = 1.0;
+    else {
+      float d = 0.f;
+      for (int k = 0; k < h; ++k) d += z[k] * z[k];
+      wgt = (double)d;
+    }
+#pragma unroll
+    for (int k = 0; k < LR_HMAX; ++k)
+      if (k < h) acc[k] += wgt * (double)z[k];
+  }
+  for (int k = 0; k < h; ++k) {
+    const double t = block_sum_d(acc[k], sh);
+    if (threadIdx.x == 0) {
+      if (b < h) stats[2 * h + (size_t)b * h + k] = t;
+      else if (b == h) stats[k] = t / (double)n;
+      else stats[h + k] = t;
+    }
+  }
+}
+
+// per node i: delta_i = |z_i|^2;  Lf = [U | -delta z] (ld 2h);  V = [U | delta z | delta^2 | 0...] (ld ldv)
+__global__ void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, const double* __restrict__ stats,
+                          float* __restrict__ Lf, float* __restrict__ V, int ldv, float* __restrict__ delta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* z = Z + (size_t)i * ldz;
+  float d = 0.f;
+  for (int k = 0; k < h; ++k) d += z[k] * z[k];
+  delta[i] = d;
+  for (int k = 0; k < h; ++k) {
+    const float u = z[k] - (float)stats[k];
+    Lf[(size_t)i * 2 * h + k] = u;
+    Lf[(size_t)i * 2 * h + h + k] = -d * z[k];
+    V[(size_t)i * ldv + k] = u;
+    V[(size_t)i * ldv + h + k] = d * z[k];
+  }
+  V[(size_t)i * ldv + 2 * h] = d * d;
+  for (int k = 2 * h + 1; k < ldv; ++k) V[(size_t)i * ldv + k] = 0.f;
+}
+
+// per column index j, from T = Xc^T V (ld ldv): W = T[:, :h], W2 = T[:, h:2h], t3 = T[:, 2h]
+//   c_j = (W_j . zeta - t3_j) / n;  M1_j = W_j (Z^T Z) - W2_j;  Rm = [M1 | W] (ld 2h)
+//   rowval_j = W_j . (Z^T Z) W_j   (its sum is |Z W^T|_F^2)
+__global__ void k_lr_post(int n, int h, const float* __restrict__ T, int ldv, const double* __restrict__ stats,
+                          float* __restrict__ Rm, float* __restrict__ cvec, double* __restrict__ rowval) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float* w = T + (size_t)j * ldv;
+  double cz = 0.0, quad = 0.0;
+  for (int k = 0; k < h; ++k) cz += (double)w[k] * stats[h + k];
+  cvec[j] = (float)((cz - (double)w[2 * h]) / (double)n);
+  for (int l = 0; l < h; ++l) {
+    double m = 0.0;
+    for (int k = 0; k < h; ++k) m += (double)w[k] * stats[2 * h + (size_t)k * h + l];
+    quad += m * (double)w[l];
+    Rm[(size_t)j * 2 * h + l] = (float)(m - (double)w[h + l]);
+    Rm[(size_t)j * 2 * h + h + l] = w[l];
+  }
+  rowval[j] = quad;
+}
+
+// N x N pass: G_ij += a2 (delta_i^2 Xc_ij + c_j) + a1 P1_ij ;  rowval_i = sum_j P1_ij Xc_ij  (linear_HSIC(Fadj, X))
+__global__ __launch_bounds__(256) void k_lr_elem(int n, int ld, const float* __restrict__ Xc,
+                                                 const float* __restrict__ P1, const float* __restrict__ delta,
+                                                 const float* __restrict__ cvec, float a1, float a2,
+                                                 float* __restrict__ G, double* __restrict__ rowval) {
+  __shared__ double sh[16];
+  const int i = blockIdx.x;
+  const size_t base = (size_t)i * ld;
+  const float d2 = delta ? delta[i] * delta[i] : 0.f;
+  double acc = 0.0;
+  for (int j = threadIdx.x * 4; j < n; j += 256 * 4) {
+    const float4 x = *reinterpret_cast<const float4*>(Xc + base + j);
+    float4 g = *reinterpret_cast<const float4*>(G + base + j);
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P1) p = *reinterpret_cast<const float4*>(P1 + base + j);
+    if (cvec) c = *reinterpret_cast<const float4*>(cvec + j);      // cvec is padded to ld
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ps[4] = {p.x, p.y, p.z, p.w}, cs[4] = {c.x, c.y, c.z, c.w};
+    float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (j + t < n) {
+        gs[t] += a2 * (d2 * xs[t] + cs[t]) + a1 * ps[t];
+        acc += (double)ps[t] * (double)xs[t];
+      }
+    }
+    *reinterpret_cast<float4*>(G + base + j) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+  }
+  const double t = block_sum_d(acc, sh);
+  if (threadIdx.x == 0 && rowval) rowval[i] = t;
+}
+
+// per node i, after QQ = Xc [W | W2] (ld 2h) and rs_i = |xc_i|^2:
+//   G_Zn_i += kk (Q2_i + delta_i Q_i - 2 rs_i delta_i z_i)          (kk = -2 s2)
+//   rowval_i = quad_i - 2 delta_i z_i . Q_i + delta_i^2 rs_i       (quad from k_lr_post; the sum is |R|_F^2)
+__global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const float* __restrict__ Z, int ldz,
+                           const float* __restrict__ delta, const double* __restrict__ rs, float kk,
+                           float* __restrict__ GZn, int ldg, const double* __restrict__ quad,
+                           double* __restrict__ rowval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = delta[i];
+  const float r = (float)rs[i];
+  const float* q = QQ + (size_t)i * 2 * h;
+  const float* z = Z + (size_t)i * ldz;
+  double zq = 0.0;
+  for (int k = 0; k < h; ++k) {
+    zq += (double)z[k] * (double)q[k];
+    GZn[(size_t)i * ldg + k] += kk * (q[h + k] + d * q[k] - 2.f * r * d * z[k]);
+  }
+  rowval[i] = quad[i] - 2.0 * (double)d * zq + (double)d * (double)d * rs[i];
+}
+
+void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats) {
+  LAUNCH(k_lr_colstats, dim3(h + 2), dim3(256), st, n, h, Z, ldz, stats);
+}
+void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
+                    int ldv, float* delta) {
+  LAUNCH(k_lr_prep, dim3((n + 255) / 256), dim3(256), st, n, h, Z, ldz, stats, Lf, V, ldv, delta);
+}
+void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,
+                    double* rowval) {
+  LAUNCH(k_lr_post, dim3((n + 255) / 256), dim3(256), st, n, h, T, ldv, stats, Rm, cvec, rowval);
+}
+void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
+                    const float* cvec, float a1, float a2, float* G, double* rowval) {
+  LAUNCH(k_lr_elem, dim3(n), dim3(256), st, n, ld, Xc, P1, delta, cvec, a1, a2, G, rowval);
+}
+void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
+                     const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval) {
+  LAUNCH(k_lr_part2, dim3((n + 255) / 256), dim3(256), st, n, h, QQ, Z, ldz, delta, rs, kk, GZn, ldg, quad, rowval);
+}
+
+}  // namespace mcgra

@@ -96,20 +96,30 @@ __global__ __launch_bounds__(ROW_THREADS) void k_adjn(int n, int ld, const float
 }
 
 // modified_adj1 = (1-I) * relu(Zn Zn^T) (+ ori)   (:187-188), in place on S.
+// nmask (optional): number of off-diagonal pairs with S_ij <= 0, i.e. pairs the relu masks in the backward
+// (integer atomics: order-independent, so still deterministic).
 __global__ __launch_bounds__(ROW_THREADS) void k_decode_post(int n, int ld, float* __restrict__ S,
-                                                             const float* __restrict__ ori) {
+                                                             const float* __restrict__ ori,
+                                                             unsigned int* __restrict__ nmask) {
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
+  int masked = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     f32x4 s = *reinterpret_cast<f32x4*>(S + base + j);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int jj = j + t;
+      if (jj != i && jj < n && !(s[t] > 0.f)) ++masked;
       float v = (jj != i && jj < n) ? fmaxf(s[t], 0.f) : 0.f;
       if (ori && jj < n) v += ori[base + jj];
       s[t] = v;
     }
     *reinterpret_cast<f32x4*>(S + base + j) = s;
+  }
+  if (nmask) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o, 64);
+    if ((threadIdx.x & 63) == 0 && masked) atomicAdd(nmask, (unsigned int)masked);
   }
 }
 
@@ -830,8 +840,8 @@ void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, co
 void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out) {
   LAUNCH(k_adjn, dim3(n), dim3(ROW_THREADS), st, n, ld, A, r, out);
 }
-void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori) {
-  LAUNCH(k_decode_post, dim3(n), dim3(ROW_THREADS), st, n, ld, S, ori);
+void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori, unsigned int* nmask) {
+  LAUNCH(k_decode_post, dim3(n), dim3(ROW_THREADS), st, n, ld, S, ori, nmask);
 }
 void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float* Y, const float* F,
                       float kmse1, float kmse2, float kie6, float kie7, float* GX, float* GY,

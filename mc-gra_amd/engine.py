@@ -245,6 +245,15 @@ class AttackEngine:
             check(lib.mcgra_attack_step_phase(self._h, _stream(), int(phase), _p(noise), None))
         return None
 
+    def exchange_mask(self):
+        """Bit mask (KX=1, KY=2, G_adjn=4, G_A1=8) of the buffers the step in flight needs gathered."""
+        return int(lib.mcgra_attack_exchange_mask(self._h))
+
+    def path_stats(self):
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        check(lib.mcgra_attack_path_stats(self._h, C.byref(a), C.byref(b)))
+        return {"lowrank_steps": a.value, "general_steps": b.value}
+
     def leading_dim(self):
         ptr, r, c, ld = C.c_void_p(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib.mcgra_attack_buffer(self._h, b"M", C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))

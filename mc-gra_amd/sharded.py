@@ -11,6 +11,7 @@ import torch
 
 TILE = 128          # SYM_TILE of csrc/common.h: row blocks are whole 128-row tiles
 EXCHANGED_AFTER_PHASE = {1: ("KX", "KY"), 2: ("G_adjn", "G_A1")}
+EXCHANGE_BIT = {"KX": 1, "KY": 2, "G_adjn": 4, "G_A1": 8}          # MCGRA_EXCHANGE_* of include/mcgra.h
 
 
 class RowBlockPlan:
@@ -50,7 +51,7 @@ class ShardedStepper:
             if k == 3:
                 out = r
             if self.b.needs_exchange:
-                for name in EXCHANGED_AFTER_PHASE.get(k, ()):
+                for name in self.b.exchange_names(k):
                     self._all_gather_rows(self.b.exchanged[name])
         return out
 
@@ -72,3 +73,9 @@ class HipShardBackend:
 
     def phase(self, k, noise=None, want_scalars=False):
         return self.eng.step_phase(k, noise=noise, want_scalars=want_scalars)
+
+    def exchange_names(self, k):
+        """Buffers to gather after phase k of the step in flight: the engine picks, per step, between the
+        low-rank evaluation (one product: only KX rows travel) and the Gram evaluation (all four)."""
+        mask = self.eng.exchange_mask()
+        return [nm for nm in EXCHANGED_AFTER_PHASE.get(k, ()) if mask & EXCHANGE_BIT[nm]]

@@ -1,0 +1,67 @@
+"""Turn the rocprofv3 outputs of a bench.py run (gpurun_out/<tag>_{stats,fetch,write}/...) into the committed
+summaries under profiles/: kernel stats CSV, per-kernel PMC summary, GEMM traffic JSON.
+
+    python scripts/profile_summary.py r01          (after the three rocprofv3 passes listed in profiles/README.md)
+
+FETCH_SIZE / WRITE_SIZE are in KiB-ish units of 1 KB as rocprofv3 prints them; FETCH_SIZE under-reports by 2x on
+gfx950 (calibrated on k_rowsum: one 400 MB read shows 200 MB), so HBM-side bytes = 2 * FETCH + WRITE.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    fs = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
+    if not fs:
+        sys.exit(f"missing {pattern}")
+    return fs[-1]
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+shutil.copy(one(f"{tag}_stats/**/*_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+per = defaultdict(lambda: {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "ns": 0.0})
+for ctr, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    src = one(f"{tag}_{d}/**/*_counter_collection.csv")
+    shutil.copy(src, os.path.join(P, f"{tag}_pmc_{d}_size.csv"))
+    for row in csv.DictReader(open(src)):
+        if row["Counter_Name"] != ctr:
+            continue
+        k = short(row["Kernel_Name"]) + f" grid={row['Grid_Size']}"
+        per[k][ctr] += float(row["Counter_Value"])
+        if ctr == "FETCH_SIZE":
+            per[k]["n"] += 1
+            per[k]["ns"] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+rows = []
+for k, v in per.items():
+    n = max(v["n"], 1)
+    hbm = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) / n * 1024
+    rows.append((v["ns"], k, n, v["FETCH_SIZE"] / n, v["WRITE_SIZE"] / n, hbm, v["ns"] / n / 1e6))
+rows.sort(reverse=True)
+with open(os.path.join(P, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "fetch_size_kb_per_launch", "write_size_kb_per_launch",
+                "hbm_bytes_per_launch_corrected", "avg_ms_under_pmc", "corrected_GBps"])
+    for _, k, n, fe, wr, hbm, ms in rows:
+        w.writerow([k, n, f"{fe:.1f}", f"{wr:.1f}", f"{hbm:.0f}", f"{ms:.4f}", f"{hbm / (ms * 1e-3) / 1e9:.1f}" if ms else ""])
+gem = [r for r in rows if "gemm_f32_kernel<128, 128" in r[1] and r[5] > 5e9]
+out = {"note": "HBM-side bytes per launch of the N x N x N fp32 MFMA GEMM launches (synthetic-10k-hsic; one launch = a batched "
+               "pair of products), from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the "
+               "gfx950 correction (calibrated on k_rowsum: 2 x FETCH_SIZE = 400.7 MB for a 400 MB read)",
+       "kernels": [{"kernel": k, "launches": n, "fetch_size_kb": fe, "write_size_kb": wr, "hbm_bytes_corrected": hbm,
+                    "avg_ms": ms} for _, k, n, fe, wr, hbm, ms in gem]}
+json.dump(out, open(os.path.join(P, f"{tag}_gemm_traffic.json"), "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))

@@ -24,6 +24,9 @@ class OracleShardBackend:
         orc.shard, orc.exchanged = (plan.row_begin, plan.row_end), self.np_ex
         self.it = None
 
+    def exchange_names(self, k):
+        return {1: ("KX", "KY"), 2: ("G_adjn", "G_A1")}.get(k, ())
+
     def phase(self, k, noise=None, want_scalars=False):
         if k == 0:
             for v in self.np_ex.values():

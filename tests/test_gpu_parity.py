@@ -413,7 +413,7 @@ def test_sharded_phases_match_monolithic_step(pkg, case, world):
             for r, b in enumerate(bks):
                 outs[r] = b.phase(k, noise, want_scalars=True) if k == 3 else b.phase(k, noise)
             if bks[0].needs_exchange:
-                for name in EXCHANGED_AFTER_PHASE.get(k, ()):
+                for name in bks[0].exchange_names(k):
                     for src, p in zip(bks, plans):                       # emulated all_gather of equal row blocks
                         blk = slice(p.rank * p.rows_per_rank, (p.rank + 1) * p.rows_per_rank)
                         for dst in bks:
@@ -426,3 +426,55 @@ def test_sharded_phases_match_monolithic_step(pkg, case, world):
             # row-range launches run the same tiles with the same k order as the full launch: bit-identical
             assert torch.equal(a, a_ref), f"sharded != monolithic at step {t}: {(a - a_ref).abs().max().item():.3e}"
             assert outs[r]["loss"] == pytest.approx(ref["loss"], rel=1e-6)
+
+
+# ---- low-rank evaluation of linear_HSIC(adj_norm, modified_adj1) -------------------------
+@pytest.mark.parametrize("case", ["s200_hsic_init", "s48_hsic_eps", "s80_hsic_l3", "s48_sage_hsic_init", "s200_hsic"])
+def test_lowrank_hsic_matches_gram_path(pkg, case, monkeypatch):
+    """Same steps through the low-rank path (default for a ReLU embedding) and through the Gram path
+    (MCGRA_NO_LOWRANK=1): gradients agree to fp32 rounding and the fast path is the one that ran."""
+    import torch
+    z = H.load_case(case)
+    fast = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    gram = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    for t in range(3):
+        noise = H.noise_of(z, t)
+        noise = None if noise is None else torch.tensor(noise, device="cuda")
+        a = fast.step(want_scalars=True, noise=noise)
+        b = gram.step(want_scalars=True, noise=noise)
+        gf, gg = fast.buffer("G_sym").cpu().numpy(), gram.buffer("G_sym").cpu().numpy()
+        assert np.abs(gf - gg).max() <= 2e-5 * np.abs(gg).max(), (t, np.abs(gf - gg).max(), np.abs(gg).max())
+        for k in ("loss", "c1", "c2"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-7), (t, k)
+        gram.set_adj_changes(fast.get_adj_changes())          # keep both on the same trajectory
+    assert fast.path_stats() == {"lowrank_steps": 3, "general_steps": 0}
+    assert gram.path_stats() == {"lowrank_steps": 0, "general_steps": 3}
+
+
+def test_lowrank_falls_back_when_decode_masks_a_pair(pkg):
+    """Orthogonal or dead embedding rows make S_ij = 0: relu'(0) = 0 masks those pairs in the reference's
+    backward, so the engine must take the Gram path on such a step (and still match the oracle)."""
+    z = H.load_case("s48_hsic_init")
+    w = H.weights_from(z)
+    le = H.cfg_from(z).emb_nlayer - 1
+    probe = H.oracle_from(z)
+    probe.step()
+    pre = probe.last["em"]                                     # relu output with the golden bias
+    w.b = [b.copy() for b in w.b]
+    w.b[le] = (w.b[le] - np.quantile(pre, 0.5, axis=0)).astype(np.float32)      # about half of the entries die
+    orc = O.PGDAttackOracle(w, z["features"], z["adj"], np.zeros_like(z["adj"]), z["feature_adj"], z["labels"],
+                            z["idx_attack"], H.cfg_from(z))
+    orc.set_adj_changes(H.a0_of(z))
+    eng = H.engine_from(pkg, z)
+    eng.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
+    eng.step()
+    orc.step()
+    S = orc.last["S"]
+    off = ~np.eye(S.shape[0], dtype=bool)
+    assert ((S <= 0) & off).sum() > 0, "test precondition: some decode pairs must be masked"
+    assert eng.path_stats() == {"lowrank_steps": 0, "general_steps": 1}
+    g = O.pack_tril(eng.buffer("G_sym").cpu().numpy())
+    gr = O.pack_tril(orc.last["G_sym"])
+    assert np.abs(g - gr).max() <= 3e-4 * max(np.abs(gr).max(), 1e-30)
