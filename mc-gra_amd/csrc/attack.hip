@@ -102,6 +102,12 @@ struct mcgra_attack {
   double* lrStats = 0;
   unsigned int* nmask = 0;
   int64_t lr_steps = 0, general_steps = 0;
+  // second stream: the one N x N x N product of the low-rank path depends only on adj_norm, so it is forked
+  // right after the normalisation and runs (MFMA-bound) under the HBM-bound rest of the step
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool p1_inflight = false;
+  bool overlap = true;             // MCGRA_NO_OVERLAP=1 keeps everything on the caller's stream
   GemmTimer timer;
 };
 
@@ -331,6 +337,15 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, (size_t)2 * he + (size_t)he * he);
     }
     A_(nmask, 4);
+    const char* eo = getenv("MCGRA_NO_OVERLAP");
+    h->overlap = !(eo && eo[0] == '1');
+    if (!rc && h->lr_ok) {
+      if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        set_error("stream / event creation failed"); rc = MCGRA_EHIP;
+      }
+    }
   }
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
@@ -344,6 +359,9 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (!h) return 0;
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->timer.ev) (void)hipEventDestroy(e);
+  if (h->st2) { (void)hipStreamSynchronize(h->st2); (void)hipStreamDestroy(h->st2); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
   return 0;
 }
@@ -596,6 +614,25 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     noise_ld = h->G_A;
   }
   CHK(forward_common(h, st, h->ADJN, noise_ld));
+  h->p1_inflight = false;
+  if (hsic && (use1 || use2)) {
+    // Xc = H adj_norm.  adj_norm is symmetric when eps == 0 (ori == 0): column means == row means
+    if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
+    else launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
+    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
+    if (h->lr_ok && !cka && use1) {
+      // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
+      // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
+      hipStream_t sp = h->overlap ? h->st2 : st;
+      if (h->overlap) {
+        MCGRA_HIP(hipEventRecord(h->ev_fork, st));
+        MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+      }
+      CHK(eg_symm(h, sp, true, n, n, h->KFC, ld, h->XC, ld, 0.f, h->KX, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
+      if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
+      h->p1_inflight = true;
+    }
+  }
   // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
   CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
@@ -651,10 +688,6 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                      h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
     if (use1 || use2) {
-      // adj_norm and A1 are symmetric here (ori == 0, eps == 0): column means == row means
-      if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
-      else launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
-      launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
       if (h->lr_ok && !cka) {
         // Low-rank path for c2 needs every off-diagonal pair active in the decode's relu (relu'(0) = 0 would
         // mask a pair in the backward); that is data dependent, so the count is read back once per step.
@@ -691,9 +724,11 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
     // step instead of 4.  Sharded: tile rows [t0, t1) of this rank.
     if (sharded && !sym) { set_error("row-block sharding needs the symmetric GEMM path"); return MCGRA_EINVAL; }
+    if (h->p1_inflight) {        // join the forked P1 product (also before the Gram path may overwrite KX)
+      if (h->overlap) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+      h->p1_inflight = false;
+    }
     if (h->lr_step) {
-      // the one N x N x N product left: P1 = (H Kf H) Xc, for both the value and the gradient of c1
-      if (use1) CHK(eg_symm(h, st, true, n, n, h->KFC, ld, h->XC, ld, 0.f, h->KX, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
     } else
     if (use2) CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY, t0, t1 - t0));   // H Kx H and H Ky H
     else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
@@ -725,7 +760,6 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                    2.f * s1, 2.f * s2, h->G_ADJN, h->rowvals + 4 * (size_t)ld);
     launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
     if (use2) {
-      CHK(eg(h, st, false, true, n, n, 2 * he, 2.f * s2, h->lrL, 2 * he, h->lrR, 2 * he, 1.f, h->G_ADJN, ld));  // U M1^T - D Z W^T
       CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->XC, ld, h->lrT, h->lr_ldv, 0.f, h->lrQ, 2 * he));       // [Q | Q2]
       launch_rowsumsq(st, n, ld, h->XC, h->rowsy);                                                              // diag(KX)
       CHK(eg(h, st, false, true, n, n, he, 2.f * s2, h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));         // Q Z^T
@@ -746,7 +780,15 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
                      h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
   CHK(chain_backward(h, st, h->ADJN, ld, L - 1, h->Pv, h->GPv, -1, nullptr, 0));
-  CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 1.f, h->G_ADJN, ld));   // sum_l G_P_l T_l^T
+  if (hsic && h->lr_step && use2 && rankk_nt_supported(n, n, hs, 2 * he)) {
+    // sum_l G_P_l T_l^T and the low-rank 2 s2 (U M1^T - D Z W^T) in one pass over G_adjn
+    MCGRA_HIP(rankk_nt(st, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 2 * he, 2.f * (float)(sg * k2), h->lrL, 2 * he, h->lrR,
+                       2 * he, 1.f, h->G_ADJN, ld));
+  } else {
+    if (hsic && h->lr_step && use2)
+      CHK(eg(h, st, false, true, n, n, 2 * he, 2.f * (float)(sg * k2), h->lrL, 2 * he, h->lrR, 2 * he, 1.f, h->G_ADJN, ld));
+    CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 1.f, h->G_ADJN, ld));   // sum_l G_P_l T_l^T
+  }
 
   // ---- backward: decode (S = Zn Zn^T, A1 = offdiag relu(S))
   launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]

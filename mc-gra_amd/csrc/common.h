@@ -27,6 +27,12 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
 
 void set_gemm_variant(int v);
 
+// rankk_f32.hip: C = beta C + alpha1 A1 B1^T (+ alpha2 A2 B2^T), K1, K2 <= 64 (HBM-bound rank-k updates)
+bool rankk_nt_supported(int M, int N, int K1, int K2);
+hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const float* A1, int lda1, const float* B1,
+                    int ldb1, int K2, float alpha2, const float* A2, int lda2, const float* B2, int ldb2, float beta,
+                    float* C, int ldc);
+
 // "Lower tile storage" of a symmetric n x n matrix: element (i, j) is valid iff
 // j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.
 constexpr int SYM_TILE = 128;

@@ -79,12 +79,14 @@ __device__ __forceinline__ f32x4 load_v4(const float* __restrict__ base, int ld,
   return v;
 }
 
+static int g_gemm_sched = 0;   // block-schedule experiment knob (set_gemm_variant bits 8..15)
+
 template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, int NBUF, int SYM, int PF>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
+__global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
     int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n,
-    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2, int tile_off) {
+    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2, int tile_off, int sched) {
   using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB>;
   // blockIdx.y == 1: the second, independent product of a batched pair (same shapes and leading dimensions);
   // one launch instead of two lets the tail round of the first product overlap the head of the second
@@ -100,8 +102,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
   {
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (!(sched & 1)) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     if (SYM == SYM_RK) {  // bid enumerates the lower triangle row by row: bid = tm (tm+1)/2 + tn
       bid += tile_off * (tile_off + 1) / 2;   // row-block sharding: this launch starts at tile row tile_off
       int tm = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
       tile_m = tm;
       tile_n = bid - tm * (tm + 1) / 2;
     } else {
-      constexpr int GROUP_M = 8;
+      const int GROUP_M = ((sched >> 1) & 0x7f) ? ((sched >> 1) & 0x7f) : 8;
       const int group_sz = GROUP_M * tiles_n;
       const int group_id = bid / group_sz;
       const int first_m = group_id * GROUP_M;
@@ -121,6 +125,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // Two blocks share a CU, i.e. two waves share each SIMD's MFMA pipe.  Left alone they drift into phase (both
+  // reach the ds_write / barrier / first-fragment bubble of a K tile together) and the pipe idles ~17 %.  Giving
+  // the wave in the odd hardware wave slot a higher issue priority keeps them out of phase: it runs its MFMA
+  // clusters uninterrupted and the other wave fills its bubbles.
+  if (sched & (1 << 16)) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID.WAVE_ID
+    if (wave_slot & 1) __builtin_amdgcn_s_setprio(1);
+  }
 
   const int kz = blockIdx.z;
   const int k_begin = kz * k_per_split;
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
       }
     }
   };
-  auto store_tiles = [&](auto at_, auto rs_) {
+  auto store_tiles_to = [&](auto at_, auto rs_, float* As, float* Bs) {
     constexpr bool AT = decltype(at_)::value;
     constexpr int RS = decltype(rs_)::value;
 #pragma unroll
@@ -247,9 +260,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
   };
 
+  auto store_tiles = [&](auto at_, auto rs_) { store_tiles_to(at_, rs_, As, Bs); };
+
   int cur = 0;
-  // multiply the tile staged in LDS (layout at_c); fragment reads run one 8-deep chunk ahead of the MFMAs
-  auto multiply = [&](auto at_c) {
+  // multiply the tile staged in LDS (layout at_c); fragment reads run one 8-deep chunk ahead of the MFMAs.
+  // `mid` runs before the last chunk's MFMAs: the ds_writes of the next tile go there, so that their issue, the
+  // vmcnt wait in front of them and their completion overlap this wave's own MFMAs instead of sitting between
+  // the MFMA burst and the barrier (measured: staging at the end costs 14 % of the loop).
+  auto multiply = [&](auto at_c, auto&& mid) {
     constexpr bool ATC = decltype(at_c)::value;
     float af[2][Cfg::TM][4], bf[2][Cfg::TN][4];
     auto load_frags = [&](int buf, int kc) {
@@ -283,6 +301,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
         load_frags((c + 1) & 1, (c + 1) * 8);
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this chunk's MFMAs
       }
+      if (c == BK / 8 - 1) {
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -303,21 +325,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
   // staged), multiply tile t, stage tile t+1 from the other register set.
   auto step = [&](auto at_c, auto at_n, auto at_n2, auto rs_, int k0) {
     constexpr int RS = decltype(rs_)::value;
-    const bool has_next = (k0 + BK) < k_end;
+    const bool has_next = (k0 + BK) < k_end && !(sched & (1 << 17));   // bit 17: timing experiment, no staging
     if (PF == 1) {
-      if (has_next) load_tiles(at_n, Rs0{}, k0 + BK);
+      if (has_next && !(sched & (1 << 19))) load_tiles(at_n, Rs0{}, k0 + BK);   // bit 19: timing experiment, stale registers
     } else {
       if (k0 + 2 * BK < k_end) load_tiles(at_n2, rs_, k0 + 2 * BK);
     }
-    multiply(at_c);
     using Other = std::integral_constant<int, (PF == 1) ? 0 : (RS ^ 1)>;
     if (NBUF == 2) {
-      if (has_next) {
-        flip_stage();
-        store_tiles(at_n, Other{});
-      }
-      __syncthreads();
+      float* An = smem + (cur ^ 1) * STAGE;
+      multiply(at_c, [&]() { if (has_next) store_tiles_to(at_n, Other{}, An, An + Cfg::A_ELEMS); });
+      if (has_next) flip_stage();
+      if (!(sched & (1 << 18))) __syncthreads();                          // bit 18: timing experiment, no barrier
     } else {
+      multiply(at_c, []() {});
       __syncthreads();
       if (has_next) {
         store_tiles(at_n, Other{});
@@ -458,7 +479,7 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
       }                                                                                                  \
     }                                                                                                    \
     hipLaunchKernelGGL(kern_, grid, block, smem_, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,      \
-                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2, tile_off);             \
+                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2, tile_off, g_gemm_sched);             \
   } while (0)
   if (SYM == SYM_RK) {  // A A^T
     if (vec) MCGRA_GEMM_LAUNCH(false, true, true); else MCGRA_GEMM_LAUNCH(false, true, false);
@@ -483,7 +504,13 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
 //   2 = two LDS stages, global loads one K tile ahead (default)    4 = two LDS stages, two tiles ahead
 //   1 = one LDS stage, one tile ahead                               3 = BK 16, two stages, one tile ahead
 static int g_gemm_nbuf = 2;
-void set_gemm_variant(int v) { g_gemm_nbuf = (v == 1 || v == 3 || v == 4) ? v : 2; }
+static bool g_gemm_rankk = true;   // variant 16 routes rank-k updates through the MFMA kernel again (A/B measurements)
+void set_gemm_variant(int v) {
+  g_gemm_rankk = !(v & 16);
+  g_gemm_sched = ((v >> 8) & 0xff) | (((v >> 5) & 7) << 16) | (((v >> 16) & 1) << 19);     // bit 0: no XCD remap; bits 1..7: GROUP_M (0 = 8); bit 16: slot priority
+  v &= 15;
+  g_gemm_nbuf = (v == 1 || v == 3 || v == 4) ? v : 2;
+}
 
 template <int NBUF>
 static hipError_t launch_big(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K, float alpha,
@@ -514,6 +541,8 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     }
     K = 0;
   }
+  if (!ta && tb && K > 0 && g_gemm_rankk && rankk_nt_supported(M, N, K, 0))   // rank-k update: HBM-bound, not MFMA work
+    return rankk_nt(st, M, N, K, alpha, A, lda, B, ldb, 0, 0.f, nullptr, 0, nullptr, 0, beta, C, ldc);
   const bool vec = vec_ok(A, lda, B, ldb);
   const bool skinny = N <= 32;
   const int BM = 128, BN = skinny ? 32 : 128, BK = 32;
@@ -567,6 +596,9 @@ hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S
                        int tile_rows) {
   if (n <= 0 || m <= 0) return hipSuccess;
   const bool vec = vec_ok(S, lds_, B, ldb) && (!C2 || vec_ok(S2, lds_, B2, ldb));
+  if (g_gemm_nbuf == 3)   // experiment: BK = 16, three blocks per CU
+    return launch_cfg<SYM_TILE, SYM_TILE, 16, 64, 64, 2, SYM_MM, 1>(st, false, false, vec, n, m, n, alpha, S, lds_, B, ldb,
+                                                                    beta, C, ldc, 1, n, 0, S2, B2, C2, tile_off, tile_rows);
   return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM, 1>(st, false, false, vec, n, m, n, alpha, S, lds_, B, ldb,
                                                                   beta, C, ldc, 1, n, 0, S2, B2, C2, tile_off, tile_rows);
 }

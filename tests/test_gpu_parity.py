@@ -53,6 +53,24 @@ def test_sgemm_matches_fp64(pkg, torch_, ta, tb, m, n, k):
     assert np.all(np.abs(C - ref) <= bound + 1e-30)
 
 
+@pytest.mark.parametrize("m,n,k,beta", [(256, 256, 16, 0.0), (1000, 777, 33, 1.0), (300, 2708, 64, -0.5),
+                                        (515, 301, 7, 2.0), (2708, 2708, 32, 1.0)])
+def test_rank_k_update_path(pkg, torch_, m, n, k, beta):
+    """C = beta C + alpha A B^T with K <= 64 goes through the HBM-bound rank-k kernel (rankk_f32.hip);
+    odd K / odd N exercise its scalar staging and tail stores; operands with a leading dimension > K too."""
+    from mc_gra_amd import engine as E
+    rng = np.random.RandomState(m + n + k)
+    Abig = rng.randn(m, k + 5).astype(np.float32)
+    A = Abig[:, :k]
+    B = rng.randn(n, k).astype(np.float32)
+    C0 = rng.randn(m, n).astype(np.float32)
+    got = E.sgemm(dev(torch_, Abig)[:, :k], dev(torch_, B), tb=True, alpha=1.5, beta=beta,
+                  out=dev(torch_, C0).clone()).cpu().numpy()
+    ref = 1.5 * (A.astype(np.float64) @ B.astype(np.float64).T) + beta * C0
+    bound = 4e-7 * (1.5 * np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T + abs(beta) * np.abs(C0)) + 1e-30
+    assert np.all(np.abs(got - ref) <= bound)
+
+
 def test_sgemm_identity_asymmetric_and_beta(pkg, torch_):
     from mc_gra_amd import engine as E
     n = 200
