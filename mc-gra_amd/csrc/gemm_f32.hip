@@ -82,7 +82,7 @@ __device__ __forceinline__ f32x4 load_v4(const float* __restrict__ base, int ld,
 static int g_gemm_sched = 0;   // block-schedule experiment knob (set_gemm_variant bits 8..15)
 
 template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, int NBUF, int SYM, int PF>
-__global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) void gemm_f32_kernel(
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
     int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n,
@@ -125,15 +125,6 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
     }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // Two blocks share a CU, i.e. two waves share each SIMD's MFMA pipe.  Left alone they drift into phase (both
-  // reach the ds_write / barrier / first-fragment bubble of a K tile together) and the pipe idles ~17 %.  Giving
-  // the wave in the odd hardware wave slot a higher issue priority keeps them out of phase: it runs its MFMA
-  // clusters uninterrupted and the other wave fills its bubbles.
-  if (sched & (1 << 16)) {
-    const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID.WAVE_ID
-    if (wave_slot & 1) __builtin_amdgcn_s_setprio(1);
-  }
 
   const int kz = blockIdx.z;
   const int k_begin = kz * k_per_split;
@@ -189,17 +180,23 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
   const bool interior = VEC && (m0 + BM <= M) && (n0 + BN <= N) && (Cfg::A_V4 % GEMM_THREADS == 0) &&
                         (Cfg::B_V4 % GEMM_THREADS == 0) && span_a < (1ull << 32) && span_b < (1ull << 32);
 
+  // interior tile, full K tile: plain 16-byte loads, no conditions (the steady-state loops use only this)
+  auto load_tiles_fast = [&](auto at_, auto rs_, int k0) {
+    constexpr bool AT = decltype(at_)::value;
+    constexpr int RS = decltype(rs_)::value;
+    const float* pa = AT ? A + (size_t)k0 * lda : A + k0;
+    const float* pb = TB ? B + k0 : B + (size_t)k0 * ldb;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_T; ++i)
+      ra[RS][i] = *reinterpret_cast<const f32x4*>(pa + (AT ? a_off_xc[i] : a_off_kc[i]));
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PER_T; ++i) rb[RS][i] = *reinterpret_cast<const f32x4*>(pb + b_off[i]);
+  };
   auto load_tiles = [&](auto at_, auto rs_, int k0) {
     constexpr bool AT = decltype(at_)::value;
     constexpr int RS = decltype(rs_)::value;
     if (interior && k0 + BK <= k_end) {
-      const float* pa = AT ? A + (size_t)k0 * lda : A + k0;
-      const float* pb = TB ? B + k0 : B + (size_t)k0 * ldb;
-#pragma unroll
-      for (int i = 0; i < Cfg::A_PER_T; ++i)
-        ra[RS][i] = *reinterpret_cast<const f32x4*>(pa + (AT ? a_off_xc[i] : a_off_kc[i]));
-#pragma unroll
-      for (int i = 0; i < Cfg::B_PER_T; ++i) rb[RS][i] = *reinterpret_cast<const f32x4*>(pb + b_off[i]);
+      load_tiles_fast(at_, rs_, k0);
       return;
     }
 #pragma unroll
@@ -325,9 +322,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
   // staged), multiply tile t, stage tile t+1 from the other register set.
   auto step = [&](auto at_c, auto at_n, auto at_n2, auto rs_, int k0) {
     constexpr int RS = decltype(rs_)::value;
-    const bool has_next = (k0 + BK) < k_end && !(sched & (1 << 17));   // bit 17: timing experiment, no staging
+    const bool has_next = (k0 + BK) < k_end;
     if (PF == 1) {
-      if (has_next && !(sched & (1 << 19))) load_tiles(at_n, Rs0{}, k0 + BK);   // bit 19: timing experiment, stale registers
+      if (has_next) load_tiles(at_n, Rs0{}, k0 + BK);
     } else {
       if (k0 + 2 * BK < k_end) load_tiles(at_n2, rs_, k0 + 2 * BK);
     }
@@ -336,7 +333,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
       float* An = smem + (cur ^ 1) * STAGE;
       multiply(at_c, [&]() { if (has_next) store_tiles_to(at_n, Other{}, An, An + Cfg::A_ELEMS); });
       if (has_next) flip_stage();
-      if (!(sched & (1 << 18))) __syncthreads();                          // bit 18: timing experiment, no barrier
+      __syncthreads();
     } else {
       multiply(at_c, []() {});
       __syncthreads();
@@ -347,6 +344,20 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
     }
   };
 
+  // PF == 2 steady state: a pair of steps (register sets 0, 1) with no condition inside, so that the compiler
+  // can keep the loads of tile t+2 in flight across the barrier (counted vmcnt, never 0): the general `step`
+  // merges a fast and a bounds-checked load path and the waitcnt insertion then drains everything at the top.
+  // Valid while tiles t .. t+3 are full interior tiles of one layout.
+  auto step_fast = [&](auto at_, auto rs_, int k0) {
+    constexpr int RS = decltype(rs_)::value;
+    load_tiles_fast(at_, rs_, k0 + 2 * BK);
+    float* An = smem + (cur ^ 1) * STAGE;
+    multiply(at_, [&]() { store_tiles_to(at_, std::integral_constant<int, RS ^ 1>{}, An, An + Cfg::A_ELEMS); });
+    flip_stage();
+    __syncthreads();
+  };
+  constexpr bool FASTPAIR = (PF == 2 && NBUF == 2);
+
   if (SYM != SYM_MM) {
     using At = std::integral_constant<bool, TA>;
     if (k_begin < k_end) {  // prologue: stage tile 0, and with PF == 2 put tile 1 in flight
@@ -355,7 +366,14 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
       if (PF == 2 && k_begin + BK < k_end) load_tiles(At{}, Rs1{}, k_begin + BK);
     }
     __syncthreads();
-    for (int k0 = k_begin; k0 < k_end;) {
+    int k0 = k_begin;
+    if (FASTPAIR && interior) {
+      for (; k0 + 4 * BK <= k_end; k0 += 2 * BK) {
+        step_fast(At{}, Rs0{}, k0);
+        step_fast(At{}, Rs1{}, k0 + BK);
+      }
+    }
+    while (k0 < k_end) {
       step(At{}, At{}, At{}, Rs0{}, k0);
       k0 += BK;
       if (PF == 2 && k0 < k_end) {
@@ -363,8 +381,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
         k0 += BK;
       }
     }
-  } else {
-    static_assert(SYM != SYM_MM || PF == 1, "SYM_MM runs with one-tile-ahead prefetch");
+  } else if (PF == 1) {
     // K tiles with k0 < lower_end read S[m][k] (stored); the rest read the mirror S[k][m].  Three
     // sequential specialised loops: stored tiles, the boundary tile, mirrored tiles.
     const int lower_end = min(k_end, max(k_begin, sym_split));
@@ -380,6 +397,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (BK == 16 && SYM == SYM_MM) ? 3 : 2) 
       k0 += BK;
     }
     for (; k0 < k_end; k0 += BK) step(AtT{}, AtT{}, AtT{}, Rs0{}, k0);
+  } else {
+    static_assert(SYM != SYM_MM || PF == 1, "SYM_MM runs with one-tile-ahead prefetch (two-ahead needs 12 step bodies and spills)");
   }
 
   // ---- epilogue.  C/D layout of the MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -507,7 +526,7 @@ static int g_gemm_nbuf = 2;
 static bool g_gemm_rankk = true;   // variant 16 routes rank-k updates through the MFMA kernel again (A/B measurements)
 void set_gemm_variant(int v) {
   g_gemm_rankk = !(v & 16);
-  g_gemm_sched = ((v >> 8) & 0xff) | (((v >> 5) & 7) << 16) | (((v >> 16) & 1) << 19);     // bit 0: no XCD remap; bits 1..7: GROUP_M (0 = 8); bit 16: slot priority
+  g_gemm_sched = (v >> 8) & 0xff;     // bit 0: no XCD remap; bits 1..7: GROUP_M (0 = 8)
   v &= 15;
   g_gemm_nbuf = (v == 1 || v == 3 || v == 4) ? v : 2;
 }
@@ -596,9 +615,6 @@ hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S
                        int tile_rows) {
   if (n <= 0 || m <= 0) return hipSuccess;
   const bool vec = vec_ok(S, lds_, B, ldb) && (!C2 || vec_ok(S2, lds_, B2, ldb));
-  if (g_gemm_nbuf == 3)   // experiment: BK = 16, three blocks per CU
-    return launch_cfg<SYM_TILE, SYM_TILE, 16, 64, 64, 2, SYM_MM, 1>(st, false, false, vec, n, m, n, alpha, S, lds_, B, ldb,
-                                                                    beta, C, ldc, 1, n, 0, S2, B2, C2, tile_off, tile_rows);
   return launch_cfg<SYM_TILE, SYM_TILE, 32, 64, 64, 2, SYM_MM, 1>(st, false, false, vec, n, m, n, alpha, S, lds_, B, ldb,
                                                                   beta, C, ldc, 1, n, 0, S2, B2, C2, tile_off, tile_rows);
 }
