@@ -563,7 +563,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   if (!ta && tb && K > 0 && g_gemm_rankk && rankk_nt_supported(M, N, K, 0))   // rank-k update: HBM-bound, not MFMA work
     return rankk_nt(st, M, N, K, alpha, A, lda, B, ldb, 0, 0.f, nullptr, 0, nullptr, 0, beta, C, ldc);
   const bool vec = vec_ok(A, lda, B, ldb);
-  const bool skinny = N <= 32;
+  const bool skinny = N <= 64;   // up to two 32-wide column tiles: re-reading the N x N operand twice beats a 128-wide tile
   const int BM = 128, BN = skinny ? 32 : 128, BK = 32;
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nsplit = 1;
