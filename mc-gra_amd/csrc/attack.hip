@@ -340,7 +340,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const char* eo = getenv("MCGRA_NO_OVERLAP");
     h->overlap = !(eo && eo[0] == '1');
     if (!rc && h->lr_ok) {
-      if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess ||
+      // lowest priority: blocks of the caller's (HBM-bound) kernels take freed CU slots ahead of new tiles of
+      // the forked MFMA-bound product, which otherwise fills every slot and starves them until it ends
+      int pr_least = 0, pr_greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+      if (hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, pr_least) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         set_error("stream / event creation failed"); rc = MCGRA_EHIP;
@@ -724,7 +728,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     // storage), and the gradient products read the mirrored half transposed (SYMM): 3 n^3 MACs per
     // step instead of 4.  Sharded: tile rows [t0, t1) of this rank.
     if (sharded && !sym) { set_error("row-block sharding needs the symmetric GEMM path"); return MCGRA_EINVAL; }
-    if (h->p1_inflight) {        // join the forked P1 product (also before the Gram path may overwrite KX)
+    // Join the forked P1 product: always before the Gram path may overwrite KX; on a low-rank step only when
+    // the caller runs phases separately (the KX rows are exchanged after this phase).  A monolithic low-rank
+    // step joins as late as possible (phase 3, in front of the only consumer).
+    if (h->p1_inflight && (!h->lr_step || phases != 0xF)) {
       if (h->overlap) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
       h->p1_inflight = false;
     }
@@ -755,10 +762,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (PH(3)) {
   if (hsic && h->lr_step && (use1 || use2)) {
     const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
-    // G_adjn += 2 s1 P1 + 2 s2 (D^2 Xc + 1 c^T);  v1 = sum P1 o Xc
-    launch_lr_elem(st, n, ld, h->XC, use1 ? h->KX : nullptr, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
-                   2.f * s1, 2.f * s2, h->G_ADJN, h->rowvals + 4 * (size_t)ld);
-    launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
+    (void)s1;
     if (use2) {
       CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->XC, ld, h->lrT, h->lr_ldv, 0.f, h->lrQ, 2 * he));       // [Q | Q2]
       launch_rowsumsq(st, n, ld, h->XC, h->rowsy);                                                              // diag(KX)
@@ -815,6 +819,17 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                        h->Pu + h->off[Le - 1], hs, h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
   }
   CHK(chain_backward(h, st, A, ld, ltop, h->Pu, h->GPu, Le - 1, h->Gem, h->hmax));
+  if (hsic && h->lr_step && (use1 || use2)) {
+    // Last contribution to G_adjn, and the only consumer of P1: everything above ran beside the forked product.
+    // G_adjn += 2 s1 P1 + 2 s2 (D^2 Xc + 1 c^T);  v1 = sum P1 o Xc
+    if (h->p1_inflight) {
+      if (h->overlap) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+      h->p1_inflight = false;
+    }
+    launch_lr_elem(st, n, ld, h->XC, use1 ? h->KX : nullptr, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
+                   2.f * (float)(sg * k1), 2.f * (float)(sg * k2), h->G_ADJN, h->rowvals + 4 * (size_t)ld);
+    launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
+  }
   // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
   launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, h->G_A);
   CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 1.f, h->G_A, ld));
