@@ -235,6 +235,7 @@ def main():
     dt = timed_region(one_step, a.steps, 0, torch.cuda.synchronize, world, dist, dev, torch)
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
+    eng_path = eng.path_stats()
 
     # recovered-adjacency AUC of the run (post-loop ensemble, topology_attack.py:300-324), untimed
     lab = torch.as_tensor(inp["labels"], device=dev)
@@ -273,12 +274,16 @@ def main():
             # (profiles/r01_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
             # cannot be read from inside the timed process, so the committed profile value is reported.
             traffic = None
+            ps = eng_path
+            lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
             tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
-                ks = json.load(open(tp))["kernels"]
+                ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == "symm" or not lowrank]
                 traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks))
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (N x N x N products of linear_HSIC: one batched "
-                                                           "SYRK pair + one batched SYMM pair launch per step)",
+            what = ("P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step: SYMM on lower tile storage, "
+                    "one launch per step") if lowrank else ("N x N x N products of the Gram evaluation of linear_HSIC: one "
+                    "batched SYRK pair + one batched SYMM pair launch per step")
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (" + what + ")",
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                                "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,

@@ -99,7 +99,7 @@ struct mcgra_attack {
   bool lr_step = false;            // the step in flight takes it (no relu-masked pair in the decode)
   int lr_ldv = 0;
   float *lrL = 0, *lrV = 0, *lrT = 0, *lrR = 0, *lrQ = 0, *lrDelta = 0, *lrC = 0;
-  double* lrStats = 0;
+  double *lrStats = 0, *lrRs = 0;
   unsigned int* nmask = 0;
   int64_t lr_steps = 0, general_steps = 0;
   // second stream: the one N x N x N product of the low-rank path depends only on adj_norm, so it is forked
@@ -334,7 +334,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     if (h->lr_ok) {
       h->lr_ldv = (2 * he + 1 + 3) & ~3;
       A_(lrL, n * 2 * he); A_(lrR, n * 2 * he); A_(lrQ, n * 2 * he); A_(lrV, n * (size_t)h->lr_ldv);
-      A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, (size_t)2 * he + (size_t)he * he);
+      A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, lr_stats_doubles(he)); A_(lrRs, ld);
     }
     A_(nmask, 4);
     const char* eo = getenv("MCGRA_NO_OVERLAP");
@@ -510,13 +510,14 @@ static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Y
 }
 
 // noise == NULL: modified_adj == M (monitoring forward :290-293 and eps == 0); otherwise adding_noise (:165)
-static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, const float* noise) {
+static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, const float* noise,
+                          double* adjn_rowsum = nullptr) {
   const int n = h->n, ld = h->ld;
   const bool general = noise != nullptr;
   launch_prep(st, general, n, ld, h->M, nullptr, noise, h->cfg.eps, h->Abuf, h->gate, h->d, h->r, h->rowsq, h->rowsum);
   launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
   launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
-  launch_adjn(st, n, ld, general ? h->Abuf : h->M, h->r, adjn_out);
+  launch_adjn(st, n, ld, general ? h->Abuf : h->M, h->r, adjn_out, adjn_rowsum);
   MCGRA_KERNEL_CHECK();
   return 0;
 }
@@ -617,13 +618,14 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     MCGRA_HIP(hipMemcpy2DAsync(h->G_A, (size_t)ld * 4, noise, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
     noise_ld = h->G_A;
   }
-  CHK(forward_common(h, st, h->ADJN, noise_ld));
+  const bool want_xc = hsic && (use1 || use2);
+  // adj_norm is symmetric when eps == 0 (ori == 0): its column means are its row sums / n, which k_adjn emits
+  CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !noise) ? h->rowsx : nullptr));
   h->p1_inflight = false;
-  if (hsic && (use1 || use2)) {
-    // Xc = H adj_norm.  adj_norm is symmetric when eps == 0 (ori == 0): column means == row means
+  if (want_xc) {
+    // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
     if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
-    else launch_rowsum(st, n, ld, h->ADJN, h->rowsx);
-    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC);
+    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr);
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
@@ -688,20 +690,22 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                      (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN, h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
   } else {
-    launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
-                     h->G_A1, h->rowvals);
+    if ((use1 || use2) && h->lr_ok && !cka) {
+      // Low-rank path for c2 needs every off-diagonal pair active in the decode's relu (relu'(0) = 0 would
+      // mask a pair in the backward); that is data dependent, so the count is read back once per step.
+      unsigned int masked = 0;
+      if (use2) {
+        MCGRA_HIP(hipMemcpyAsync(&masked, h->nmask, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        MCGRA_HIP(hipStreamSynchronize(st));
+      }
+      h->lr_step = (masked == 0);
+    }
+    // on a low-rank step with c2 the modified_adj1 side (c7 value and gradient) is folded into k_lr_decode_bwd
+    const bool y_fused = h->lr_step && use2 && lr_decode_supported(he);
+    launch_loss_elem(st, n, ld, h->ADJN, y_fused ? nullptr : h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2),
+                     h->G_ADJN, y_fused ? nullptr : h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
     if (use1 || use2) {
-      if (h->lr_ok && !cka) {
-        // Low-rank path for c2 needs every off-diagonal pair active in the decode's relu (relu'(0) = 0 would
-        // mask a pair in the backward); that is data dependent, so the count is read back once per step.
-        unsigned int masked = 0;
-        if (use2) {
-          MCGRA_HIP(hipMemcpyAsync(&masked, h->nmask, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-          MCGRA_HIP(hipStreamSynchronize(st));
-        }
-        h->lr_step = (masked == 0);
-      }
       if (h->lr_step) {
         ++h->lr_steps;
         if (use2) {
@@ -762,11 +766,11 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (PH(3)) {
   if (hsic && h->lr_step && (use1 || use2)) {
     const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
-    (void)s1;
+    (void)s1; (void)s2;
     if (use2) {
       CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->XC, ld, h->lrT, h->lr_ldv, 0.f, h->lrQ, 2 * he));       // [Q | Q2]
-      launch_rowsumsq(st, n, ld, h->XC, h->rowsy);                                                              // diag(KX)
-      CHK(eg(h, st, false, true, n, n, he, 2.f * s2, h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));         // Q Z^T
+      if (!lr_decode_supported(he))
+        CHK(eg(h, st, false, true, n, n, he, 2.f * s2, h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));       // Q Z^T
     }
     MCGRA_KERNEL_CHECK();
   }
@@ -795,10 +799,17 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
 
   // ---- backward: decode (S = Zn Zn^T, A1 = offdiag relu(S))
-  launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
-  CHK(eg(h, st, false, false, n, he, n, 1.f, h->G_A, ld, h->Zn, h->hmax, 0.f, h->GZn, h->hmax));
+  if (hsic && h->lr_step && use2 && lr_decode_supported(he)) {
+    // ((G + G^T) o [S > 0]) Zn for G = ie'(A1) + 2 s2 Q Z^T, without materialising G (c7 value from the same pass)
+    const int np = launch_lr_decode_bwd(st, n, ld, he, h->A1, h->Zn, h->hmax, h->lrQ, (float)(k7 / n2),
+                                        2.f * (float)(sg * k2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax);
+    launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, np, 1, h->scal + S_V7);
+  } else {
+    launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
+    CHK(eg(h, st, false, false, n, he, n, 1.f, h->G_A, ld, h->Zn, h->hmax, 0.f, h->GZn, h->hmax));
+  }
   if (hsic && h->lr_step && use2) {   // the -2 s2 KX D part of d c2 / d A1, applied to Zn directly
-    launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->rowsy, -2.f * (float)(sg * k2), h->GZn, h->hmax,
+    launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->lrRs, -2.f * (float)(sg * k2), h->GZn, h->hmax,
                     h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld);
     launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
   }

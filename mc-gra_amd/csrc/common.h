@@ -76,4 +76,14 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return t;
 }
 
+// Info_entropy term (topology_attack.py:44-52): q = clamp(p, 1e-4, 1 - 1e-4), value q log2 q, gradient
+// -k (log2 q + 1/ln 2) inside the clamp range and 0 outside.
+__device__ __forceinline__ void ie_term(float p, float k, float& val, float& grad) {
+  const float lo = 1e-4f, hi = 1.f - 1e-4f;
+  const float q = fminf(fmaxf(p, lo), hi);
+  const float l2 = log2f(q);
+  val = q * l2;
+  grad = (p >= lo && p <= hi) ? -k * (l2 + 1.4426950408889634f) : 0.f;
+}
+
 }  // namespace mcgra

@@ -10,7 +10,7 @@ namespace mcgra {
 void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, const float* ori,
                  const float* noise, float eps, float* A, unsigned char* gate, float* d, float* r,
                  double* rowsq, double* rowsum);
-void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out);
+void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out, double* rowsum = nullptr);
 void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori, unsigned int* nmask = nullptr);
 void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float* Y, const float* F,
                       float kmse1, float kmse2, float kie6, float kie7, float* GX, float* GY,
@@ -18,7 +18,8 @@ void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float
 void launch_reduce_rows(hipStream_t st, const double* rowvals, int n, int nvec, double* out);
 void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows);
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total);
-void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out);
+void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out,
+                        double* rowsq = nullptr);
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower);
 void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out);
@@ -89,6 +90,11 @@ void launch_count_idx(hipStream_t st, int m, const int* idx, float* cnt);
 void launch_argmax_eq(hipStream_t st, int m, int c, const float* logp, int ld, const int* idx, const int* labels, int* correct);
 
 // ---- lowrank_kernels.hip (low-rank linear_HSIC(adj_norm, modified_adj1))
+size_t lr_stats_doubles(int h);
+int lr_decode_slabs(int n);
+bool lr_decode_supported(int h);
+int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
+                         float kie7, float a2, float* slabs, double* v7part, float* GZn, int ldg);
 void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats);
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta);

@@ -17,16 +17,19 @@ namespace mcgra {
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 constexpr int LR_HMAX = 32;
 
-// stats (double): zbar[h] | zeta[h] | ZtZ[h*h].  grid = h + 2 blocks of 256:
-//   block k < h : column k of Z^T Z;  block h : column means;  block h+1 : zeta = sum_i delta_i z_i
-__global__ __launch_bounds__(256) void k_lr_colstats(int n, int h, const float* __restrict__ Z, int ldz,
-                                                     double* __restrict__ stats) {
+// stats (double): zbar[h] | zeta[h] | ZtZ[h*h].  Two deterministic stages: grid (h + 2, LR_PARTS) partial sums
+// over row slices (block x = k < h : column k of Z^T Z;  x = h : column sums;  x = h+1 : zeta = sum_i delta_i z_i),
+// then a fixed-order combine.
+constexpr int LR_PARTS = 16;
+__global__ __launch_bounds__(256) void k_lr_colstats_part(int n, int h, const float* __restrict__ Z, int ldz,
+                                                          double* __restrict__ part) {
   __shared__ double sh[16];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, pz = blockIdx.y;
+  const int per = (n + LR_PARTS - 1) / LR_PARTS, i0 = pz * per, i1 = min(n, i0 + per);
   double acc[LR_HMAX];
 #pragma unroll
   for (int k = 0; k < LR_HMAX; ++k) acc[k] = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     const float* z = Z + (size_t)i * ldz;
     double wgt;
     if (b < h) wgt = (double)z[b];
@@ -42,12 +45,17 @@ __global__ __launch_bounds__(256) void k_lr_colstats(int n, int h, const float* 
   }
   for (int k = 0; k < h; ++k) {
     const double t = block_sum_d(acc[k], sh);
-    if (threadIdx.x == 0) {
-      if (b < h) stats[2 * h + (size_t)b * h + k] = t;
-      else if (b == h) stats[k] = t / (double)n;
-      else stats[h + k] = t;
-    }
+    if (threadIdx.x == 0) part[((size_t)b * LR_PARTS + pz) * h + k] = t;
   }
+}
+__global__ void k_lr_colstats_fin(int n, int h, const double* __restrict__ part, double* __restrict__ stats) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= h) return;
+  double t = 0.0;
+  for (int pz = 0; pz < LR_PARTS; ++pz) t += part[((size_t)b * LR_PARTS + pz) * h + k];
+  if (b < h) stats[2 * h + (size_t)b * h + k] = t;
+  else if (b == h) stats[k] = t / (double)n;
+  else stats[h + k] = t;
 }
 
 // per node i: delta_i = |z_i|^2;  Lf = [U | -delta z] (ld 2h);  V = [U | delta z | delta^2 | 0...] (ld ldv)
@@ -143,8 +151,109 @@ __global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const flo
   rowval[i] = quad[i] - 2.0 * (double)d * zq + (double)d * (double)d * rs[i];
 }
 
+// stats needs 2h + h^2 doubles followed by (h + 2) * LR_PARTS * h doubles of scratch
+size_t lr_stats_doubles(int h) { return (size_t)2 * h + (size_t)h * h + (size_t)(h + 2) * LR_PARTS * h; }
+// Decode backward of a low-rank step without materialising d loss / d modified_adj1:
+//   G_Zn_i = sum_{j != i, A1_ij > 0} [ 2 ie'(A1_ij) + a2 (q_i.z_j + q_j.z_i) ] z_j
+// i.e. ((G + G^T) o [S > 0]) Zn for G = ie'(A1) + a2 Q Z^T (c7's entropy gradient and the Q Z^T part of c2), which
+// replaces an elementwise write, a rank-k update, the mirror/mask pass and a skinny product over N x N buffers.
+// A1 is symmetric (bit-exactly: both halves are the same fmaf chain), so thread i reads A1[j][i]: coalesced in i,
+// with z_j, q_j wave-uniform.  The j range is split over blockIdx.y into slabs that are summed in fixed order.
+// v7part: per-block partial of sum ie_value(A1) (c7's value).
+template <int H>
+__global__ __launch_bounds__(256) void k_lr_decode_bwd(int n, int ld, const float* __restrict__ A1,
+                                                       const float* __restrict__ Z, int ldz,
+                                                       const float* __restrict__ QQ, float kie7, float a2, int jper,
+                                                       float* __restrict__ slabs, double* __restrict__ v7part) {
+  constexpr int JC = 64;                       // columns staged per chunk: z_j | q_j, read back as LDS broadcasts
+  __shared__ __attribute__((aligned(16))) float zq[JC][2 * H];
+  __shared__ double sh[16];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < n;
+  const int j0 = blockIdx.y * jper, j1 = min(n, j0 + jper);
+  float zi[H], qi[H], acc[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f;
+    qi[k] = valid ? QQ[(size_t)i * 2 * H + k] : 0.f;
+    acc[k] = 0.f;
+  }
+  double v7 = 0.0;
+  for (int jc = j0; jc < j1; jc += JC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < JC * 2 * H; e += 256) {
+      const int jj = e / (2 * H), c = e - jj * 2 * H, j = jc + jj;
+      float v = 0.f;
+      if (j < j1) v = c < H ? Z[(size_t)j * ldz + c] : QQ[(size_t)j * 2 * H + (c - H)];
+      zq[jj][c] = v;
+    }
+    __syncthreads();
+    const int jn = min(JC, j1 - jc);
+    float a_next = valid ? A1[(size_t)jc * ld + i] : 0.f;
+    for (int jj = 0; jj < jn; ++jj) {
+      const int j = jc + jj;
+      const float a = a_next;
+      if (jj + 1 < jn) a_next = valid ? A1[(size_t)(j + 1) * ld + i] : 0.f;
+      float zj[H], qj[H];
+#pragma unroll
+      for (int k = 0; k < H; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&zq[jj][k]);
+        zj[k] = t.x; zj[k + 1] = t.y; zj[k + 2] = t.z; zj[k + 3] = t.w;
+        const float4 u = *reinterpret_cast<const float4*>(&zq[jj][H + k]);
+        qj[k] = u.x; qj[k + 1] = u.y; qj[k + 2] = u.z; qj[k + 3] = u.w;
+      }
+      float dq = 0.f, dz = 0.f;
+#pragma unroll
+      for (int k = 0; k < H; ++k) { dq = fmaf(qi[k], zj[k], dq); dz = fmaf(qj[k], zi[k], dz); }
+      float val = 0.f, g = 0.f;
+      if (kie7 != 0.f) ie_term(a, kie7, val, g);
+      v7 += (double)val;
+      const float w = (i != j && a > 0.f) ? 2.f * g + a2 * (dq + dz) : 0.f;
+#pragma unroll
+      for (int k = 0; k < H; ++k) acc[k] = fmaf(w, zj[k], acc[k]);
+    }
+  }
+  if (valid) {
+    float* o = slabs + ((size_t)blockIdx.y * n + i) * H;
+#pragma unroll
+    for (int k = 0; k < H; ++k) o[k] = acc[k];
+  }
+  const double t = block_sum_d(valid ? v7 : 0.0, sh);
+  if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+__global__ void k_lr_sum_slabs(int n, int h, int nslab, const float* __restrict__ slabs, float* __restrict__ out,
+                               int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * h) return;
+  float t = 0.f;
+  for (int s = 0; s < nslab; ++s) t += slabs[(size_t)s * n * h + e];
+  out[(size_t)(e / h) * ldo + (e % h)] = t;
+}
+// returns the number of v7 partials written; slabs must hold nslab * n * h floats (nslab = lr_decode_slabs(n))
+bool lr_decode_supported(int h) { return h == 8 || h == 16 || h == 32; }
+int lr_decode_slabs(int n) {
+  const int nb = (n + 255) / 256;
+  int js = (512 + nb - 1) / nb;
+  if (js > 64) js = 64;
+  if (js > n / 64) js = n / 64;        // keeps nb * js partials <= n and the j slices >= 64 long
+  return js < 1 ? 1 : js;
+}
+int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
+                         float kie7, float a2, float* slabs, double* v7part, float* GZn, int ldg) {
+  const int nb = (n + 255) / 256, js = lr_decode_slabs(n), jper = (n + js - 1) / js;
+  // embedding widths are padded to the next supported H; Z / QQ columns beyond h must then be zero, which holds for
+  // widths that are themselves 8, 16 or 32 (others: see lr_decode_supported)
+  if (h == 8) LAUNCH(k_lr_decode_bwd<8>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, QQ, kie7, a2, jper, slabs, v7part);
+  else if (h == 16) LAUNCH(k_lr_decode_bwd<16>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, QQ, kie7, a2, jper, slabs, v7part);
+  else LAUNCH(k_lr_decode_bwd<32>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, QQ, kie7, a2, jper, slabs, v7part);
+  LAUNCH(k_lr_sum_slabs, dim3((n * h + 255) / 256), dim3(256), st, n, h, js, slabs, GZn, ldg);
+  return nb * js;
+}
+
 void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats) {
-  LAUNCH(k_lr_colstats, dim3(h + 2), dim3(256), st, n, h, Z, ldz, stats);
+  double* part = stats + (size_t)2 * h + (size_t)h * h;
+  LAUNCH(k_lr_colstats_part, dim3(h + 2, LR_PARTS), dim3(256), st, n, h, Z, ldz, part);
+  LAUNCH(k_lr_colstats_fin, dim3(h + 2), dim3(64), st, n, h, part, stats);
 }
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta) {

@@ -76,11 +76,16 @@ __global__ __launch_bounds__(ROW_THREADS) void k_prep(int n, int ld, const float
 }
 
 // adj_norm = (r_i * (A + I)_ij) * r_j   (utils.py:226-228)
+// rowsum (optional): row sums of the result in fp64 (same per-thread order as k_rowsum) -- the column means of the
+// symmetric adj_norm for the centring of linear_HSIC, saving a pass over the matrix.
 __global__ __launch_bounds__(ROW_THREADS) void k_adjn(int n, int ld, const float* __restrict__ A,
-                                                      const float* __restrict__ r, float* __restrict__ out) {
+                                                      const float* __restrict__ r, float* __restrict__ out,
+                                                      double* __restrict__ rowsum) {
+  __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   const float ri = r[i];
+  double s = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     f32x4 a = *reinterpret_cast<const f32x4*>(A + base + j);
     f32x4 rj = *reinterpret_cast<const f32x4*>(r + j);
@@ -90,8 +95,13 @@ __global__ __launch_bounds__(ROW_THREADS) void k_adjn(int n, int ld, const float
       const int jj = j + t;
       const float mx = a[t] + (jj == i ? 1.f : 0.f);
       o[t] = jj < n ? (ri * mx) * rj[t] : 0.f;
+      s += (double)o[t];
     }
     *reinterpret_cast<f32x4*>(out + base + j) = o;
+  }
+  if (rowsum) {
+    s = block_sum_d(s, shd);
+    if (threadIdx.x == 0) rowsum[i] = s;
   }
 }
 
@@ -132,14 +142,6 @@ __global__ __launch_bounds__(ROW_THREADS) void k_decode_post(int n, int ld, floa
 // kmse1/kmse2 are the full scalar multipliers (w * align * 2/n^2), 0 to skip.
 // rowvals[4][n]: per-row partials of sum (f-x)^2, (x-y)^2, q log2 q (x), (y).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void ie_term(float p, float k, float& val, float& grad) {
-  const float lo = 1e-4f, hi = 1.f - 1e-4f;
-  const float q = fminf(fmaxf(p, lo), hi);
-  const float l2 = log2f(q);
-  val = q * l2;
-  grad = (p >= lo && p <= hi) ? -k * (l2 + 1.4426950408889634f) : 0.f;
-}
-
 __global__ __launch_bounds__(ROW_THREADS) void k_loss_elem(
     int n, int ld, const float* __restrict__ X, const float* __restrict__ Y,
     const float* __restrict__ F, float kmse1, float kmse2, float kie6, float kie7,
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(ROW_THREADS) void k_loss_elem(
   double v1 = 0, v2 = 0, v6 = 0, v7 = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(X + base + j);
-    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + base + j);
+    f32x4 y = {0, 0, 0, 0};
+    if (Y) y = *reinterpret_cast<const f32x4*>(Y + base + j);      // Y == nullptr: X-side terms only
     f32x4 f = {0, 0, 0, 0};
     if (kmse1 != 0.f) f = *reinterpret_cast<const f32x4*>(F + base + j);
     f32x4 gx, gy;
@@ -161,12 +164,12 @@ __global__ __launch_bounds__(ROW_THREADS) void k_loss_elem(
         if (kmse1 != 0.f) { const float e = f[t] - x[t]; v1 += (double)e * e; a -= kmse1 * e; }
         if (kmse2 != 0.f) { const float e = x[t] - y[t]; v2 += (double)e * e; a += kmse2 * e; b -= kmse2 * e; }
         if (kie6 != 0.f) { float v, g; ie_term(x[t], kie6, v, g); v6 += v; a += g; }
-        if (kie7 != 0.f) { float v, g; ie_term(y[t], kie7, v, g); v7 += v; b += g; }
+        if (kie7 != 0.f && Y) { float v, g; ie_term(y[t], kie7, v, g); v7 += v; b += g; }
       }
       gx[t] = a; gy[t] = b;
     }
     *reinterpret_cast<f32x4*>(GX + base + j) = gx;
-    *reinterpret_cast<f32x4*>(GY + base + j) = gy;
+    if (GY) *reinterpret_cast<f32x4*>(GY + base + j) = gy;
   }
   v1 = block_sum_d(v1, shd); v2 = block_sum_d(v2, shd);
   v6 = block_sum_d(v6, shd); v7 = block_sum_d(v7, shd);
@@ -226,17 +229,27 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center(int n, int ld, float* __
 // H X X^T H = (H X)(H X)^T, so the centred Gram is formed from centred operands.  This is the
 // same matrix as centring the Gram afterwards, but the fp32 GEMM then sums zero-mean products
 // instead of cancelling an O(n) mean (measured on Cora's feature_adj: 3e-7 vs 2e-4 relative).
+// rowsq (optional): |row|^2 of the centred result in fp64 (diag of the centred Gram, lowrank_kernels.hip).
 __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, const float* __restrict__ X,
                                                              const double* __restrict__ rows,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, double* __restrict__ rowsq) {
+  __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   const double inv = 1.0 / n;
+  double s = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     f32x4 x = *reinterpret_cast<const f32x4*>(X + base + j);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = (j + t < n) ? (float)((double)x[t] - rows[j + t] * inv) : 0.f;
+    for (int t = 0; t < 4; ++t) {
+      x[t] = (j + t < n) ? (float)((double)x[t] - rows[j + t] * inv) : 0.f;
+      s += (double)x[t] * (double)x[t];
+    }
     *reinterpret_cast<f32x4*>(out + base + j) = x;
+  }
+  if (rowsq) {
+    s = block_sum_d(s, shd);
+    if (threadIdx.x == 0) rowsq[i] = s;
   }
 }
 
@@ -837,8 +850,8 @@ void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, co
   if (general) LAUNCH(k_prep<true>, dim3(n), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum);
   else LAUNCH(k_prep<false>, dim3(n), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum);
 }
-void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out) {
-  LAUNCH(k_adjn, dim3(n), dim3(ROW_THREADS), st, n, ld, A, r, out);
+void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out, double* rowsum) {
+  LAUNCH(k_adjn, dim3(n), dim3(ROW_THREADS), st, n, ld, A, r, out, rowsum);
 }
 void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori, unsigned int* nmask) {
   LAUNCH(k_decode_post, dim3(n), dim3(ROW_THREADS), st, n, ld, S, ori, nmask);
@@ -857,8 +870,8 @@ void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows) 
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total) {
   LAUNCH(k_center, dim3(n), dim3(ROW_THREADS), st, n, ld, K, rows, total);
 }
-void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out) {
-  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, rows, out);
+void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out, double* rowsq) {
+  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, rows, out, rowsq);
 }
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower) {
