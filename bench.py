@@ -220,6 +220,8 @@ def main():
     import mcgra_loader
     pkg = mcgra_loader.load()
 
+    if os.environ.get("MCGRA_GEMM_VARIANT"):          # A/B runs of kernel variants (mcgra_set_gemm_variant)
+        pkg._lib.lib.mcgra_set_gemm_variant(int(os.environ["MCGRA_GEMM_VARIANT"]))
     n, f, c, hid, nl, measure, wp = WORKLOADS[a.workload]
     eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed + rank)     # replicas: every rank its own graph
     monitor = not a.no_monitor
