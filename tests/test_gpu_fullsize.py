@@ -1,0 +1,124 @@
+"""BASELINE.json's full size (synthetic N = 10 000, d = 128, 2-layer GCN, HSIC, priors H_A+Y_A+Y) on the GPU: the
+oracle cannot run there in seconds, so parity is carried by size-independent properties -- state invariants,
+bit-determinism, agreement of the two independent evaluations of linear_HSIC (low-rank vs Gram),
+bit-identity of the row-block sharded phases, and gradient linearity in the loss weights."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+WL = "synthetic-10k-hsic"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import mcgra_loader
+    pkg = mcgra_loader.load()
+    import bench
+    return pkg, torch, bench, torch.device("cuda:0")
+
+
+def _engine(ctx, seed=0, **kw):
+    pkg, torch, bench, dev = ctx
+    return bench.build_engine(pkg, torch, dev, WL, seed, **kw)
+
+
+def test_state_invariants_and_determinism_at_10k(ctx):
+    pkg, torch, bench, dev = ctx
+    outs = []
+    for _ in range(2):
+        eng, inp, _ = _engine(ctx)
+        sc = [eng.step(want_scalars=True) for _ in range(3)]
+        outs.append((eng.get_adj_changes().clone(), [s["loss"] for s in sc]))
+        M = eng.buffer("M")
+        assert torch.equal(M, M.t()), "learnable adjacency must stay symmetric"
+        assert float(M.diagonal().abs().max()) == 0.0
+        assert float(M.min()) >= 0.0 and float(M.max()) <= 1.0          # clamp of :283
+        assert eng.path_stats() == {"lowrank_steps": 3, "general_steps": 0}
+        assert all(np.isfinite(s["loss"]) for s in sc)
+        del eng
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0][0], outs[1][0]), "two runs must give identical bits"
+    assert outs[0][1] == outs[1][1]
+
+
+def test_lowrank_and_gram_evaluations_agree_at_10k(ctx, monkeypatch):
+    pkg, torch, bench, dev = ctx
+    fast, _, _ = _engine(ctx)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    gram, _, _ = _engine(ctx)
+    monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    for t in range(2):
+        a = fast.step(want_scalars=True)
+        b = gram.step(want_scalars=True)
+        gf, gg = fast.buffer("G_sym"), gram.buffer("G_sym")
+        err = float((gf - gg).abs().max()) / float(gg.abs().max())
+        assert err < 5e-5, (t, err)
+        # the scalar values differ more than the gradients: the Gram evaluation sums 10^8 products of fp32 Gram entries
+        # (measured ~5e-5 relative at this size; the low-rank value is the one closer to an fp64 evaluation)
+        for k in ("loss", "c1", "c2", "c6", "c7"):
+            assert a[k] == pytest.approx(b[k], rel=3e-4, abs=1e-6), (t, k)
+        gram.set_adj_changes(fast.get_adj_changes())
+    assert gram.path_stats()["general_steps"] == 2
+
+
+def test_sharded_phases_bit_identical_at_10k(ctx):
+    pkg, torch, bench, dev = ctx
+    from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend
+    n = bench.WORKLOADS[WL][0]
+    full, _, _ = _engine(ctx)
+    plans = [RowBlockPlan(n, 2, r) for r in range(2)]
+    bks = [HipShardBackend(_engine(ctx, row_begin=p.row_begin, row_end=p.row_end)[0], p) for p in plans]
+    for t in range(2):
+        full.step()
+        for k in range(4):
+            for b in bks:
+                b.phase(k)
+            for name in bks[0].exchange_names(k):
+                for src, p in zip(bks, plans):
+                    blk = slice(p.rank * p.rows_per_rank, (p.rank + 1) * p.rows_per_rank)
+                    for dst in bks:
+                        if dst is not src:
+                            dst.exchanged[name][blk].copy_(src.exchanged[name][blk])
+        ref = full.get_adj_changes()
+        for b in bks:
+            assert torch.equal(b.eng.get_adj_changes(), ref), f"step {t}"
+    assert bks[0].exchange_names(1) == ["KX"] and bks[0].exchange_names(2) == []      # low-rank step: one buffer travels
+
+
+def test_gradient_is_linear_in_the_loss_weights_at_10k(ctx):
+    """d loss / d adj_changes is linear in (weight_sup, w1, w2, w6, w7, w9, w10): G(w_a + w_b) = G(w_a) + G(w_b) with
+    the norm term of :173 attributed to weight_sup.  Checked with the N x N terms split from the rest."""
+    pkg, torch, bench, dev = ctx
+    n, f, c, hid, nl, measure, wp = bench.WORKLOADS[WL]
+    inp = bench.make_inputs(n, f, c, hid, nl, 0)
+    X = torch.as_tensor(inp["features"], device=dev)
+    fadj = bench.feature_adj_cora(X, torch)
+    adj_dev = torch.as_tensor(inp["adj"], device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(1000)
+    a0 = torch.rand(n * (n - 1) // 2, device=dev, generator=g) * 0.05
+
+    def grad(weight_sup, weights):
+        eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, weight_sup, weights, 0.01, 1e30, n, device=dev)
+        eng.set_model(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
+        eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
+        eng.set_adj_changes(a0)
+        eng.step()
+        out = eng.buffer("G_sym").clone()
+        del eng
+        torch.cuda.empty_cache()
+        return out
+
+    wa = (wp[0], wp[1], 0, 0, 0, 0, 0, 0, 0, 0)                  # the N x N HSIC terms
+    wb = (0, 0, 0, 0, 0, wp[5], wp[6], 0, wp[8], wp[9])          # entropy and small-operand terms
+    g_all = grad(1.0, wp)
+    g_sum = grad(0.0, wa) + grad(1.0, wb)
+    err = float((g_all - g_sum).abs().max()) / float(g_all.abs().max())
+    assert err < 2e-5, err
