@@ -496,3 +496,63 @@ def test_lowrank_falls_back_when_decode_masks_a_pair(pkg):
     g = O.pack_tril(eng.buffer("G_sym").cpu().numpy())
     gr = O.pack_tril(orc.last["G_sym"])
     assert np.abs(g - gr).max() <= 3e-4 * max(np.abs(gr).max(), 1e-30)
+
+
+# ---- synthetic problems checked against the oracle directly (shapes the goldens do not cover) ------------------
+def _synthetic_case(n, nfeat, widths, nclass, seed, measure="HSIC", weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)):
+    rng = np.random.RandomState(seed)
+    dims = [nfeat] + list(widths)
+    z = {"measure": np.array(measure), "weight_sup": np.array(1.0), "weight_param": np.array(weight_param, np.float64),
+         "lr": np.array(0.01), "num_edges": np.array(1e30), "nlayer": np.array(len(widths)),
+         "emb_nlayer": np.array(min(2, len(widths))), "a0_seed": np.array(7), "a0_scale": np.array(0.05)}
+    for l in range(len(widths)):
+        s = 1.0 / np.sqrt(dims[l + 1])
+        z[f"W{l}"] = rng.uniform(-s, s, (dims[l], dims[l + 1])).astype(np.float32)
+        z[f"b{l}"] = rng.uniform(0, s, dims[l + 1]).astype(np.float32)
+    s = 1.0 / np.sqrt(widths[-1])
+    z["Wlin"] = rng.uniform(-s, s, (nclass, widths[-1])).astype(np.float32)
+    z["blin"] = rng.uniform(-s, s, nclass).astype(np.float32)
+    z["features"] = (rng.rand(n, nfeat) < 0.3).astype(np.float32)
+    a = (rng.rand(n, n) < 0.08).astype(np.float32)
+    a = np.triu(a, 1); z["adj"] = a + a.T
+    z["feature_adj"] = H.cora_feature_adj(z["features"])
+    z["labels"] = rng.randint(0, nclass, n)
+    z["idx_attack"] = rng.permutation(n)[: n - 5]
+    return z
+
+
+@pytest.mark.parametrize("n,widths,expect", [(97, (12, 12), "lowrank"), (130, (24, 8), "lowrank"),
+                                             (96, (40, 40), "general"), (150, (16, 16, 16), "lowrank")])
+def test_engine_matches_oracle_on_odd_shapes(pkg, n, widths, expect):
+    """n not a multiple of 4 / 128, embedding widths outside {8, 16, 32} (unfused decode backward) and > 32 (Gram
+    evaluation): teacher-forced per-step gradient against the oracle."""
+    z = _synthetic_case(n, 11, widths, 4, seed=n)
+    orc = H.oracle_from(z)
+    eng = H.engine_from(pkg, z)
+    for t in range(3):
+        orc.step()
+        eng.step()
+        g = O.pack_tril(eng.buffer("G_sym").cpu().numpy())
+        gr = O.pack_tril(orc.last["G_sym"])
+        assert np.abs(g - gr).max() <= 3e-4 * np.abs(gr).max(), (t, np.abs(g - gr).max(), np.abs(gr).max())
+        eng.set_adj_changes(O.pack_tril(orc.M))           # teacher forcing
+    ps = eng.path_stats()
+    assert (ps["lowrank_steps"], ps["general_steps"]) == ((3, 0) if expect == "lowrank" else (0, 3))
+
+
+@pytest.mark.parametrize("wp", [(0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000),
+                                (0.01, 0.01, 0, 0, 0, 0, 0, 0, 0, 0)])
+def test_lowrank_with_single_terms(pkg, wp, monkeypatch):
+    """c1 only (no mask readback), c2 only (no N x N x N product at all), no entropy terms: low-rank == Gram."""
+    z = H.load_case("s200_hsic_init")
+    fast = H.engine_from(pkg, z, weight_param=wp)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    gram = H.engine_from(pkg, z, weight_param=wp)
+    monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    for t in range(2):
+        a, b = fast.step(want_scalars=True), gram.step(want_scalars=True)
+        gf, gg = fast.buffer("G_sym").cpu().numpy(), gram.buffer("G_sym").cpu().numpy()
+        assert np.abs(gf - gg).max() <= 2e-5 * np.abs(gg).max()
+        assert a["loss"] == pytest.approx(b["loss"], rel=2e-5, abs=1e-7)
+        gram.set_adj_changes(fast.get_adj_changes())
+    assert fast.path_stats()["lowrank_steps"] == 2
