@@ -33,6 +33,9 @@ WORKLOADS = {
     "cora-shape-hsic": (2708, 1433, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "cora-shape-mse": (2708, 1433, 7, 16, 2, "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-4k-hsic": (4096, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    # BASELINE.json configs[4] shape on ONE GPU (54 GB of N x N buffers; ~0.5 s per step)
+    "synthetic-20k-hsic-3layer": (20000, 256, 7, 16, 3, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    "synthetic-30k-hsic-3layer": (30000, 256, 7, 16, 3, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
 }
 
 
