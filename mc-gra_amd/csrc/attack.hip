@@ -68,6 +68,7 @@ struct mcgra_attack {
   float *M = 0, *am = 0, *av = 0, *ADJN = 0, *A1 = 0, *G_ADJN = 0, *G_A1 = 0, *G_A = 0;
   float *KX = 0, *KY = 0, *KFC = 0, *FADJ = 0, *GSYM = 0, *XC = 0, *YC = 0;
   // vectors
+  float *cmean = 0;                // fp32 column means for the centring passes
   float *d = 0, *r = 0, *rowpart = 0, *colpart = 0, *gd = 0, *nrm = 0, *cnt = 0, *rowmin = 0, *rowmax = 0, *mm = 0;
   double *rowsq = 0, *rowsum = 0, *rowvals = 0, *rowsx = 0, *rowsy = 0, *scal = 0;
   int *labels = 0, *idx = 0, *correct = 0;
@@ -305,7 +306,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   }
   if (cfg->measure == MCGRA_MEASURE_KL) { A_(XC, nn); }      // XC holds softmax(feature_adj) rows
   if (cfg->measure == MCGRA_MEASURE_DP) { A_(KY, nn); A_(XC, nn); }
-  A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
+  A_(cmean, ld); A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
   A_(rowmin, ld); A_(rowmax, ld); A_(mm, 4);
   A_(rowsq, 2 * ld); h->rowsum = h->rowsq ? h->rowsq + n : nullptr;
   A_(rowvals, 8 * ld); A_(rowsx, ld); A_(rowsy, ld); A_(scal, S_COUNT);
@@ -433,7 +434,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   if ((h->cfg.measure == MCGRA_MEASURE_HSIC || h->cfg.measure == MCGRA_MEASURE_CKA) && h->cfg.w[0] != 0.f) {
     // centred Gram of feature_adj: constant left factor of c1 (utils.py:1086,1089), from centred columns
     launch_rowsum(st, n, ld, h->FADJ, h->rowsx);
-    launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->XC);
+    launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->cmean, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
     launch_rowsumsq(st, n, ld, h->KFC, h->rowsx);
     launch_reduce_rows(st, h->rowsx, n, 1, h->cst + 0);      // hsic(feature_adj, feature_adj)
@@ -625,7 +626,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (want_xc) {
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
     if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
-    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr);
+    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr);
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
@@ -719,7 +720,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         ++h->general_steps;
         if (use2) {
           launch_rowsum(st, n, ld, h->A1, h->rowsy);
-          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->YC);
+          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC);
         }
       }
     }

@@ -35,7 +35,18 @@ extern "C" {
 int mcgra_sgemm(void* stream, int ta, int tb, int m, int n, int k, float alpha, const float* A, int lda,
                 const float* B, int ldb, float beta, float* C, int ldc) {
   if (m < 0 || n < 0 || k < 0 || !A || !B || !C) { set_error("bad sgemm argument"); return MCGRA_EINVAL; }
-  MCGRA_HIP(sgemm((hipStream_t)stream, ta != 0, tb != 0, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0));
+  // Split-K slabs for products with few output tiles (skinny A.T): one lazily allocated workspace per device,
+  // shared by all calls -- callers that overlap such products on several streams must serialise them.
+  static float* ws[16] = {nullptr};
+  constexpr size_t WS_BYTES = (size_t)64 << 20;
+  int dev = 0;
+  MCGRA_HIP(hipGetDevice(&dev));
+  float* w = nullptr;
+  if (dev >= 0 && dev < 16 && (size_t)m * n * 4 * 2 <= WS_BYTES) {
+    if (!ws[dev] && hipMalloc(&ws[dev], WS_BYTES) != hipSuccess) ws[dev] = nullptr;
+    w = ws[dev];
+  }
+  MCGRA_HIP(sgemm((hipStream_t)stream, ta != 0, tb != 0, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, w, w ? WS_BYTES : 0));
   return 0;
 }
 

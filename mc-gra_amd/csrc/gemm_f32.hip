@@ -523,9 +523,11 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
 //   2 = two LDS stages, global loads one K tile ahead (default)    4 = two LDS stages, two tiles ahead
 //   1 = one LDS stage, one tile ahead                               3 = BK 16, two stages, one tile ahead
 static int g_gemm_nbuf = 2;
+static int g_skinny_blocks = 0;      // set_gemm_variant bits 20..27: experiment override (x 256)
 static bool g_gemm_rankk = true;   // variant 16 routes rank-k updates through the MFMA kernel again (A/B measurements)
 void set_gemm_variant(int v) {
   g_gemm_rankk = !(v & 16);
+  g_skinny_blocks = ((v >> 20) & 0xff) * 256;
   g_gemm_sched = (v >> 8) & 0xff;     // bit 0: no XCD remap; bits 1..7: GROUP_M (0 = 8)
   v &= 15;
   g_gemm_nbuf = (v == 1 || v == 3 || v == 4) ? v : 2;
@@ -568,7 +570,13 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nsplit = 1;
   if (ws && tiles < 256 && K >= 4 * BK) {
-    nsplit = min(min(64, (512 + tiles - 1) / tiles), K / (2 * BK));
+    // skinny products stream the big operand once: they need ~16 MB of loads in flight (16-20 KB per block),
+    // i.e. >= 1000 blocks; the square-ish ones only need every CU busy
+    // (measured at N = 10 000: 1024 blocks 117 us vs 147 us at 512 for a 16-wide product; two column tiles want 2048;
+    //  at N = 2708 more slabs only add combine work)
+    const bool big = (double)M * K >= 33554432.0 || (double)N * K >= 33554432.0 * 2;
+    const int target = (skinny && big) ? (g_skinny_blocks ? g_skinny_blocks : (N > BN ? 2048 : 1024)) : 512;
+    nsplit = min(min(64, (target + tiles - 1) / tiles), K / (2 * BK));
     while (nsplit > 1 && (size_t)nsplit * M * N * sizeof(float) > ws_bytes) --nsplit;
     if (nsplit < 1) nsplit = 1;
   }

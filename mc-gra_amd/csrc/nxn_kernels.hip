@@ -230,24 +230,29 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center(int n, int ld, float* __
 // same matrix as centring the Gram afterwards, but the fp32 GEMM then sums zero-mean products
 // instead of cancelling an O(n) mean (measured on Cora's feature_adj: 3e-7 vs 2e-4 relative).
 // rowsq (optional): |row|^2 of the centred result in fp64 (diag of the centred Gram, lowrank_kernels.hip).
+// The column means arrive as fp32 (k_colmean_f32: fp64 sum / n rounded once), so the pass is pure fp32 streaming.
+__global__ void k_colmean_f32(int n, int ld, const double* __restrict__ colsum, float* __restrict__ mean) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ld) mean[j] = j < n ? (float)(colsum[j] / (double)n) : 0.f;
+}
 __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, const float* __restrict__ X,
-                                                             const double* __restrict__ rows,
+                                                             const float* __restrict__ mean,
                                                              float* __restrict__ out, double* __restrict__ rowsq) {
   __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
-  const double inv = 1.0 / n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   double s = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     f32x4 x = *reinterpret_cast<const f32x4*>(X + base + j);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + j);      // padded with zeros to ld
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      x[t] = (j + t < n) ? (float)((double)x[t] - rows[j + t] * inv) : 0.f;
-      s += (double)x[t] * (double)x[t];
-    }
+    for (int t = 0; t < 4; ++t) x[t] = (j + t < n) ? x[t] - mu[t] : 0.f;
+    s0 = fmaf(x[0], x[0], s0); s1 = fmaf(x[1], x[1], s1); s2 = fmaf(x[2], x[2], s2); s3 = fmaf(x[3], x[3], s3);
     *reinterpret_cast<f32x4*>(out + base + j) = x;
   }
-  if (rowsq) {
+  if (rowsq) {      // <= ceil(n / 1024) fp32 terms per partial, then fp64
+    s = (double)s0 + (double)s1 + (double)s2 + (double)s3;
     s = block_sum_d(s, shd);
     if (threadIdx.x == 0) rowsq[i] = s;
   }
@@ -870,8 +875,10 @@ void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows) 
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total) {
   LAUNCH(k_center, dim3(n), dim3(ROW_THREADS), st, n, ld, K, rows, total);
 }
-void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* out, double* rowsq) {
-  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, rows, out, rowsq);
+void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* mean_scratch,
+                        float* out, double* rowsq) {
+  LAUNCH(k_colmean_f32, dim3((ld + 255) / 256), dim3(256), st, n, ld, rows, mean_scratch);
+  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, mean_scratch, out, rowsq);
 }
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower) {
