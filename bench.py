@@ -197,6 +197,40 @@ def sharded_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, mon
             "exchange": "2 x all_gather_into_tensor of 2 row-block buffers per step (RCCL)"}
 
 
+def split_bf16_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor):
+    """The same workload with the opt-in 3-plane bf16 split of the one N x N x N product (MCGRA_SPLIT_BF16=1,
+    csrc/split_bf16.hip: fp32-level error, the six plane products as one hipBLASLt bf16 GEMM).  Reported beside the
+    fp32 MFMA headline, never as `value`."""
+    os.environ["MCGRA_SPLIT_BF16"] = "1"
+    try:
+        eng, inp, adj_dev = build_engine(pkg, torch, dev, workload, seed)
+    finally:
+        del os.environ["MCGRA_SPLIT_BF16"]
+
+    def one_step():
+        eng.step()
+        if monitor:
+            eng.monitor()
+
+    for _ in range(warmup):
+        one_step()
+    eng.profile(True); eng.gemm_stats(reset=True)
+    dt = timed_region(one_step, steps, 0, torch.cuda.synchronize, 1, None, dev, torch)
+    st = eng.gemm_stats(reset=True)
+    eng.profile(False)
+    lab = torch.as_tensor(inp["labels"], device=dev)
+    final = eng.finalize(0, eng.buffer("HA"), eng.buffer("YA"), (lab[:, None] == lab[None, :]).float())
+    n = WORKLOADS[workload][0]
+    out = {"value": steps / dt, "unit": "attack-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "auc": gpu_auc(adj_dev, final, torch), "dtype": "f32 operands as 3 bf16 planes, 6 plane products, fp32 accumulate"}
+    if st["launches"]:
+        ms = st["ms"] / st["launches"]
+        out["product"] = {"kernel": "hipBLASLt bf16 GEMM n x n x 6n (planes concatenated along K)", "avg_launch_ms": ms,
+                          "bf16_tflops_issued": 12.0 * n ** 3 / (ms * 1e-3) / 1e12, "peak_bf16_dense": 2500.0,
+                          "fp32_equivalent_tflops": 2.0 * n ** 3 / (ms * 1e-3) / 1e12}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +243,7 @@ def main():
     ap.add_argument("--no-shard-probe", action="store_true",
                     help="N > 1: skip the extra (untimed-for-value) run of one attack row-block sharded over the ranks")
     ap.add_argument("--force-shard-probe", action="store_true", help="run the probe at N = 1 too (phase API, one row block)")
+    ap.add_argument("--no-split-probe", action="store_true", help="skip the extra run with MCGRA_SPLIT_BF16=1 (N = 1, HSIC)")
     a = ap.parse_args()
 
     import torch
@@ -266,6 +301,16 @@ def main():
     final = eng.finalize(0, H_A, Y_A, label_adj)
     auc = gpu_auc(adj_dev, final, torch)
 
+    split = None
+    if world == 1 and measure == "HSIC" and not a.no_split_probe and os.environ.get("MCGRA_SPLIT_BF16") != "1":
+        try:
+            # same warmup and step count as the main run, so that the two recovered-adjacency AUCs are comparable
+            split = split_bf16_probe(pkg, torch, dev, a.workload, a.seed + rank, a.steps, a.warmup, monitor)
+            split["auc_fp32_path"] = auc
+            split["speedup_vs_fp32_path"] = split["value"] / aggregate_value(world, a.steps, dt)
+        except Exception as e:
+            split = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     shard = None
     if (world > 1 or a.force_shard_probe) and not a.no_shard_probe and os.environ.get("MCGRA_BENCH_NO_SHARD_PROBE") != "1":
         del eng, final, H_A, Y_A, label_adj
@@ -289,6 +334,8 @@ def main():
         }
         if shard is not None:
             out["sharded_probe"] = shard
+        if split is not None:
+            out["split_bf16_probe"] = split
         if st["launches"]:
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12

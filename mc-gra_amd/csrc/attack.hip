@@ -109,6 +109,10 @@ struct mcgra_attack {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool p1_inflight = false;
   bool overlap = true;             // MCGRA_NO_OVERLAP=1 keeps everything on the caller's stream
+  // opt-in (MCGRA_SPLIT_BF16=1): P1 through the 3-plane bf16 split of split_bf16.hip instead of the fp32 MFMA SYMM
+  bool split_on = false;
+  unsigned short *Acat = 0, *Bcat = 0;
+  int64_t split_steps = 0;
   GemmTimer timer;
 };
 
@@ -338,6 +342,15 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, lr_stats_doubles(he)); A_(lrRs, ld);
     }
     A_(nmask, 4);
+    const char* es = getenv("MCGRA_SPLIT_BF16");
+    if (!rc && h->lr_ok && cfg->eps == 0.f && es && es[0] == '1') {
+      if (!split_bf16_available()) { rc = MCGRA_ENOSUP; }
+      else {
+        const size_t cat = (size_t)n * 6 * split_bf16_kpad((int)n);
+        A_(Acat, cat); A_(Bcat, cat);
+        h->split_on = (rc == 0);
+      }
+    }
     const char* eo = getenv("MCGRA_NO_OVERLAP");
     h->overlap = !(eo && eo[0] == '1');
     if (!rc && h->lr_ok) {
@@ -436,6 +449,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
     launch_rowsum(st, n, ld, h->FADJ, h->rowsx);
     launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->cmean, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
+    if (h->split_on) split3_planes_sym(st, n, ld, h->KFC, h->Acat);     // bf16 planes of the constant Gram, once
     launch_rowsumsq(st, n, ld, h->KFC, h->rowsx);
     launch_reduce_rows(st, h->rowsx, n, 1, h->cst + 0);      // hsic(feature_adj, feature_adj)
   }
@@ -631,10 +645,21 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
       hipStream_t sp = h->overlap ? h->st2 : st;
+      // bf16 planes of Xc^T (opt-in split path) on the caller's stream, ahead of the fork: cmean is reused later
+      if (h->split_on && !noise) split3_planes_rows(st, n, ld, h->ADJN, h->cmean, h->Bcat);
       if (h->overlap) {
         MCGRA_HIP(hipEventRecord(h->ev_fork, st));
         MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
       }
+      if (h->split_on && !noise) {
+        // planes of Xc^T from the rows of the (symmetric) adj_norm, then one bf16 library GEMM (split_bf16.hip)
+        const int row0 = t0 * SYM_TILE, row1 = t1 * SYM_TILE < n ? t1 * SYM_TILE : n;
+        const bool big = h->profile;
+        CHK(timer_begin(h, sp, big));
+        CHK(split_bf16_gemm(sp, n, row0, row1 - row0, h->Acat, h->Bcat, h->KX, ld));
+        CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
+        ++h->split_steps;
+      } else
       CHK(eg_symm(h, sp, true, n, n, h->KFC, ld, h->XC, ld, 0.f, h->KX, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
       if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
       h->p1_inflight = true;

@@ -42,6 +42,13 @@ hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S
                        float beta, float* C, int ldc, const float* S2 = nullptr, const float* B2 = nullptr,
                        float* C2 = nullptr, int tile_off = 0, int tile_rows = -1);
 
+// split_bf16.hip (opt-in): P1 = S B as a 3-plane bf16 split through one library GEMM
+bool split_bf16_available();
+int split_bf16_kpad(int n);
+void split3_planes_sym(hipStream_t st, int n, int ld, const float* S_lower, void* Acat);
+void split3_planes_rows(hipStream_t st, int n, int ld, const float* X, const float* mean, void* Bcat);
+int split_bf16_gemm(hipStream_t st, int n, int row0, int nrows, const void* Acat, const void* Bcat, float* C, int ldc);
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
