@@ -790,14 +790,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
 
   if (PH(3)) {
-  if (hsic && h->lr_step && (use1 || use2)) {
-    const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
-    (void)s1; (void)s2;
-    if (use2) {
-      CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->XC, ld, h->lrT, h->lr_ldv, 0.f, h->lrQ, 2 * he));       // [Q | Q2]
-      if (!lr_decode_supported(he))
-        CHK(eg(h, st, false, true, n, n, he, 2.f * s2, h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));       // Q Z^T
-    }
+  if (hsic && h->lr_step && use2) {
+    CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->XC, ld, h->lrT, h->lr_ldv, 0.f, h->lrQ, 2 * he));         // [Q | Q2] = Xc [W | W2]
+    if (!lr_decode_supported(he))     // widths without a fused decode backward: d c2 / d A1 += 2 s2 Q Z^T, materialised
+      CHK(eg(h, st, false, true, n, n, he, 2.f * (float)(sg * k2), h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));
     MCGRA_KERNEL_CHECK();
   }
   // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
