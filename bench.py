@@ -311,6 +311,24 @@ def main():
         except Exception as e:
             split = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # BASELINE.json configs[1] (Cora-sized dense GCN + HSIC, fp32) beside the 10k headline: same engine, same timing
+    extra = None
+    if world == 1 and a.workload == "synthetic-10k-hsic" and not a.no_split_probe:
+        try:
+            e2, _, _ = build_engine(pkg, torch, dev, "cora-shape-hsic", a.seed)
+
+            def cora_step():
+                e2.step()
+                if monitor:
+                    e2.monitor()
+
+            dt2 = timed_region(cora_step, 100, 10, torch.cuda.synchronize, 1, None, dev, torch)
+            extra = {"cora-shape-hsic": {"value": 100 / dt2, "unit": "attack-steps/s", "ms_per_step": 10.0 * dt2,
+                                         "nodes": WORKLOADS["cora-shape-hsic"][0], "steps": 100}}
+            del e2
+        except Exception as e:
+            extra = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     shard = None
     if (world > 1 or a.force_shard_probe) and not a.no_shard_probe and os.environ.get("MCGRA_BENCH_NO_SHARD_PROBE") != "1":
         del eng, final, H_A, Y_A, label_adj
@@ -329,13 +347,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": a.workload, "nodes": n, "features": f, "gcn_layers": nl, "hidden": hid,
                        "classes": c, "measure": measure, "priors": "H_A+Y_A+Y", "weight_param": list(wp),
-                       "monitor_forward": monitor, "parallelism": "replicas" if world > 1 else "single"},
+                       "monitor_forward": monitor,
+                       "forward_reuse": bool(monitor and os.environ.get("MCGRA_NO_FWD_REUSE") != "1"),
+                       "parallelism": "replicas" if world > 1 else "single"},
             "auc": auc,
         }
         if shard is not None:
             out["sharded_probe"] = shard
         if split is not None:
             out["split_bf16_probe"] = split
+        if extra is not None:
+            out["other_workloads"] = extra
         if st["launches"]:
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12

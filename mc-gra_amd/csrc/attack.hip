@@ -62,6 +62,12 @@ struct mcgra_attack {
   int wdt[MCGRA_MAX_LAYERS + 1];   // width of layer l output (dims[l+1])
   int64_t t = 0;                   // Adam step count
   bool have_step = false;
+  // The monitoring forward of :290-296 (victim on the updated adjacency) is exactly the first forward of the next
+  // iteration (:164-167) when eps == 0: mcgra_attack_monitor leaves its adj_norm, degree vectors, chain and
+  // log-probs in place and the next step adopts them instead of recomputing (bit-identical, one N x N pass and two
+  // skinny products less per step).  MCGRA_NO_FWD_REUSE=1 disables.
+  bool fwd_cached = false, fwd_reuse = true;
+  float* ADJN_next = 0;
   bool graph_set = false, model_set = false;
   std::vector<void*> allocs;
   // N x N
@@ -331,6 +337,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   const size_t am_ = (size_t)h->na * h->hmax;
   A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
   if (cfg->eps != 0.f) { A_(Abuf, nn); A_(gate, nn); A_(colpart_d, (size_t)h->nstrips * ld); }
+  { const char* e = getenv("MCGRA_NO_FWD_REUSE"); h->fwd_reuse = cfg->eps == 0.f && !(e && e[0] == '1'); }
+  if (h->fwd_reuse) { A_(ADJN_next, nn); }
   A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
   {
     const char* e = getenv("MCGRA_NO_LOWRANK");
@@ -386,6 +394,7 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
 
 int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W, const float* const* b,
                            const float* Wlin, const float* blin, const float* const* Ws) {
+  if (h) h->fwd_cached = false;      // whatever the last monitor call left is stale now
   if (!h || !W || !b || !Wlin || !blin) { set_error("null argument"); return MCGRA_EINVAL; }
   if ((h->has_self != 0) != (Ws != nullptr)) { set_error("Ws must be given exactly when has_self is set"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
@@ -403,6 +412,7 @@ int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* 
 int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* features, const float* adj,
                            const float* ori_adj, const float* feature_adj, const int32_t* labels,
                            const int32_t* idx_attack) {
+  if (h) h->fwd_cached = false;      // whatever the last monitor call left is stale now
   if (!h || !features || !adj || !feature_adj || !labels || !idx_attack) { set_error("null argument"); return MCGRA_EINVAL; }
   if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
   if (ori_adj) {
@@ -463,6 +473,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
 }
 
 int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed) {
+  if (h) h->fwd_cached = false;      // whatever the last monitor call left is stale now
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
@@ -626,7 +637,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const bool sharded = (t0 != 0 || t1 != t_all);
 
   if (PH(0)) {
-  MCGRA_HIP(hipMemsetAsync(h->scal, 0, sizeof(double) * S_COUNT, st));
+  const bool adopt = h->fwd_cached && !noise;       // forward of this iteration already done by the last monitor call
+  h->fwd_cached = false;
+  // (S_SQ, S_SUM are the first two slots: written by forward_common, kept when its results are adopted)
+  MCGRA_HIP(hipMemsetAsync(h->scal + (adopt ? 2 : 0), 0, sizeof(double) * (S_COUNT - (adopt ? 2 : 0)), st));
   // ---- forward: adjacency, normalisation (:164-166)
   const float* noise_ld = nullptr;
   if (noise) {  // caller layout is [n][n]; the kernels use leading dimension ld.  G_A is free at this point.
@@ -635,7 +649,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
   const bool want_xc = hsic && (use1 || use2);
   // adj_norm is symmetric when eps == 0 (ori == 0): its column means are its row sums / n, which k_adjn emits
-  CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !noise) ? h->rowsx : nullptr));
+  if (adopt) { float* t = h->ADJN; h->ADJN = h->ADJN_next; h->ADJN_next = t; }
+  else CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !noise) ? h->rowsx : nullptr));
   h->p1_inflight = false;
   if (want_xc) {
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
@@ -666,8 +681,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     }
   }
   // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
-  CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv, h->Sv));
-  CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
+  if (!adopt) {
+    CHK(chain_forward(h, st, h->ADJN, ld, L, h->Tv, h->Pv, h->Hv, h->Sv));
+    CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
+  }
   launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
   launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
   // ---- embedding(features, modified_adj - ori_adj) (:185) == first Le layers of victim(features, modified_adj) (:259)
@@ -957,10 +974,15 @@ int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long lo
 int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, double* sparsity) {
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  // adj_norm2 goes to the A1 buffer: ADJN must survive for the post-loop decode (:300)
-  CHK(forward_common(h, st, h->A1, nullptr));
-  CHK(chain_forward(h, st, h->A1, h->ld, h->L, h->Tv, h->Pv, h->Hv, h->Sv));
-  CHK(head_forward(h, st, h->Hv, h->Z, h->logp, nullptr));
+  // adj_norm2 must not overwrite ADJN, which has to survive for the post-loop decode (:300): it goes to ADJN_next
+  // (adopted by the next step, see fwd_cached) or, without reuse, to the A1 buffer.
+  const bool want_xc = (h->cfg.measure == MCGRA_MEASURE_HSIC || h->cfg.measure == MCGRA_MEASURE_CKA) &&
+                       (h->cfg.w[0] != 0 || h->cfg.w[1] != 0);
+  float* dst = h->fwd_reuse ? h->ADJN_next : h->A1;
+  CHK(forward_common(h, st, dst, nullptr, (h->fwd_reuse && want_xc) ? h->rowsx : nullptr));
+  CHK(chain_forward(h, st, dst, h->ld, h->L, h->Tv, h->Pv, h->Hv, h->Sv));
+  CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->fwd_reuse ? h->sm : nullptr));
+  h->fwd_cached = h->fwd_reuse;
   if (out_logp)
     MCGRA_HIP(hipMemcpyAsync(out_logp, h->logp, sizeof(float) * (size_t)h->n * h->C, hipMemcpyDeviceToDevice, st));
   if (sparsity) {

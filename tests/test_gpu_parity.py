@@ -585,3 +585,28 @@ def test_split_bf16_matches_fp32_path(pkg, case, monkeypatch):
         e1.step(); e2.step()
     import torch
     assert torch.equal(e1.get_adj_changes(), e2.get_adj_changes())
+
+
+@pytest.mark.parametrize("case", ["s200_hsic_init", "s200_mse", "s48_kl", "s48_gat_hsic_init"])
+def test_monitor_forward_reuse_is_bit_identical(pkg, case, monkeypatch):
+    """The next step adopts the monitoring forward of :290-296 instead of recomputing it: same bits as without reuse,
+    with or without a monitor call between steps, and set_adj_changes in between invalidates it."""
+    import torch
+    z = H.load_case(case)
+    a = H.engine_from(pkg, z)                       # reuse on, monitor between steps
+    monkeypatch.setenv("MCGRA_NO_FWD_REUSE", "1")
+    b = H.engine_from(pkg, z)                       # reuse off, monitor between steps
+    monkeypatch.delenv("MCGRA_NO_FWD_REUSE")
+    c = H.engine_from(pkg, z)                       # reuse on, no monitor calls at all
+    for t in range(4):
+        ra, rb = a.step(want_scalars=True), b.step(want_scalars=True)
+        c.step()
+        (la, sa), (lb, sb) = a.monitor(want_sparsity=True), b.monitor(want_sparsity=True)
+        assert ra == rb, t
+        assert torch.equal(a.get_adj_changes(), b.get_adj_changes()) and torch.equal(a.get_adj_changes(), c.get_adj_changes())
+        assert torch.equal(la, lb) and sa == sb
+        if t == 1:                                   # stale cache must not survive a state change
+            x = a.get_adj_changes() * 0.5
+            for e in (a, b, c):
+                e.set_adj_changes(x)
+    assert torch.equal(a.buffer("adj_norm"), b.buffer("adj_norm"))      # what finalize (:300) decodes from
