@@ -610,3 +610,17 @@ def test_monitor_forward_reuse_is_bit_identical(pkg, case, monkeypatch):
             for e in (a, b, c):
                 e.set_adj_changes(x)
     assert torch.equal(a.buffer("adj_norm"), b.buffer("adj_norm"))      # what finalize (:300) decodes from
+
+
+def test_side_stream_overlap_is_bit_identical(pkg, monkeypatch):
+    """MCGRA_OVERLAP=1 only moves the N x N x N product onto the engine's own stream: same bits."""
+    import torch
+    z = H.load_case("s200_hsic_init")
+    a = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_OVERLAP", "1")
+    b = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_OVERLAP")
+    for t in range(3):
+        ra, rb = a.step(want_scalars=True), b.step(want_scalars=True)
+        a.monitor(); b.monitor()
+        assert ra == rb and torch.equal(a.get_adj_changes(), b.get_adj_changes())
