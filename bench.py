@@ -201,7 +201,7 @@ def split_bf16_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor):
     """The same workload with the opt-in 3-plane bf16 split of the one N x N x N product (MCGRA_SPLIT_BF16=1,
     csrc/split_bf16.hip: fp32-level error, the six plane products as one hipBLASLt bf16 GEMM).  Reported beside the
     fp32 MFMA headline, never as `value`."""
-    os.environ["MCGRA_SPLIT_BF16"] = "1"
+    os.environ["MCGRA_SPLIT_BF16"] = os.environ.get("MCGRA_SPLIT_PROBE_MODE", "1")
     try:
         eng, inp, adj_dev = build_engine(pkg, torch, dev, workload, seed)
     finally:

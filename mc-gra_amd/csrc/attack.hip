@@ -117,6 +117,8 @@ struct mcgra_attack {
   bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
   // opt-in (MCGRA_SPLIT_BF16=1): P1 through the 3-plane bf16 split of split_bf16.hip instead of the fp32 MFMA SYMM
   bool split_on = false;
+  int split_mode = 0;              // 1: planes concatenated along K through hipBLASLt; 2: hand-written kernel on packed planes
+  unsigned char *Apack = 0, *Bpack = 0;
   unsigned short *Acat = 0, *Bcat = 0;
   int64_t split_steps = 0;
   GemmTimer timer;
@@ -357,7 +359,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         const size_t cat = (size_t)n * 6 * split_bf16_kpad((int)n);
         A_(Acat, cat); A_(Bcat, cat);
         h->split_on = (rc == 0);
+        h->split_mode = 1;
       }
+    }
+    if (!rc && h->lr_ok && cfg->eps == 0.f && es && es[0] == '2') {
+      A_(Apack, split3_pack_bytes((int)n)); A_(Bpack, split3_pack_bytes((int)n));
+      h->split_on = (rc == 0);
+      h->split_mode = 2;
     }
     // Off by default: the product holds every CU's LDS and registers, so what runs beside it crawls and slows it
     // by about as much as it hides (measured: 21.2-21.5 ms with the side stream, 21.6 without).  MCGRA_OVERLAP=1.
@@ -461,7 +469,8 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
     launch_rowsum(st, n, ld, h->FADJ, h->rowsx);
     launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->cmean, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
-    if (h->split_on) split3_planes_sym(st, n, ld, h->KFC, h->Acat);     // bf16 planes of the constant Gram, once
+    if (h->split_mode == 1) split3_planes_sym(st, n, ld, h->KFC, h->Acat);     // bf16 planes of the constant Gram, once
+    if (h->split_mode == 2) split3_pack(st, n, ld, h->KFC, nullptr, true, h->Apack);
     launch_rowsumsq(st, n, ld, h->KFC, h->rowsx);
     launch_reduce_rows(st, h->rowsx, n, 1, h->cst + 0);      // hsic(feature_adj, feature_adj)
   }
@@ -663,17 +672,21 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
       hipStream_t sp = h->overlap ? h->st2 : st;
       // bf16 planes of Xc^T (opt-in split path) on the caller's stream, ahead of the fork: cmean is reused later
-      if (h->split_on && !noise) split3_planes_rows(st, n, ld, h->ADJN, h->cmean, h->Bcat);
+      const bool split_now = h->split_on && !noise && (h->split_mode == 1 || !sharded);
+      if (split_now && h->split_mode == 1) split3_planes_rows(st, n, ld, h->ADJN, h->cmean, h->Bcat);
+      if (split_now && h->split_mode == 2) split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack);
       if (h->overlap) {
         MCGRA_HIP(hipEventRecord(h->ev_fork, st));
         MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
       }
-      if (h->split_on && !noise) {
-        // planes of Xc^T from the rows of the (symmetric) adj_norm, then one bf16 library GEMM (split_bf16.hip)
+      if (split_now) {
+        // planes of Xc^T from the rows of the (symmetric) adj_norm, then the split product: one bf16 library GEMM
+        // (split_bf16.hip) or the hand-written plane-reusing kernel (split_symm_bf16.hip)
         const int row0 = t0 * SYM_TILE, row1 = t1 * SYM_TILE < n ? t1 * SYM_TILE : n;
         const bool big = h->profile;
         CHK(timer_begin(h, sp, big));
-        CHK(split_bf16_gemm(sp, n, row0, row1 - row0, h->Acat, h->Bcat, h->KX, ld));
+        if (h->split_mode == 1) CHK(split_bf16_gemm(sp, n, row0, row1 - row0, h->Acat, h->Bcat, h->KX, ld));
+        else MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld));
         CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
         ++h->split_steps;
       } else

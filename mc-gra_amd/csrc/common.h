@@ -49,6 +49,11 @@ void split3_planes_sym(hipStream_t st, int n, int ld, const float* S_lower, void
 void split3_planes_rows(hipStream_t st, int n, int ld, const float* X, const float* mean, void* Bcat);
 int split_bf16_gemm(hipStream_t st, int n, int row0, int nrows, const void* Acat, const void* Bcat, float* C, int ldc);
 
+// split_symm_bf16.hip (opt-in, MCGRA_SPLIT_BF16=2): the same split as a hand-written kernel on packed planes
+size_t split3_pack_bytes(int n);
+void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out);
+hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc);
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,0 +1,232 @@
+// OPT-IN (MCGRA_SPLIT_BF16=2): hand-written kernel for the 3-plane bf16 split of P1 = (H Kf H) Xc
+// (see split_bf16.hip for the arithmetic: x = x0 + x1 + x2 in bf16, the six plane products with i + j <= 2 summed
+// in the MFMA's fp32 accumulator, fp32-level error).
+//
+// What a library GEMM on K-concatenated planes cannot do is REUSE planes: here one K step stages the three planes
+// of both operands once (48 KB) and every fragment read from LDS feeds up to three MFMAs (a0 with b0, b1, b2; a1
+// with b0, b1; a2 with b0), so a 256 x 256 block tile needs 16 B/clk/CU from L2 and 48 B/clk/CU from LDS for 48
+// v_mfma_f32_32x32x16_bf16 per wave and K step -- MFMA-bound -- where the concatenated form moves twice the bytes.
+//
+// Operands are pre-packed in HBM in exactly the LDS image of a K step, [panel of 256 rows][k chunk of 16][plane]
+// [row][16 k] (8 KB per plane, 24 KB per operand and step, zero padded), so staging is a linear 16-byte copy and
+// the fragment of lane (r = l & 31, h = l >> 5) -- row r, k = 8h .. 8h+7 -- is one conflict-free ds_read_b128.
+// A is packed once per graph (constant Gram), B per step from the rows of adj_norm (Xc^T[j][k] = adj_norm[j][k] -
+// mean_j by symmetry, eps == 0 only).  512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA
+// tiles = 128 accumulator registers; two LDS stages of 48 KB, next step's tile in registers during the multiply,
+// one barrier per step; one block per CU.
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/mcgra.h"
+#include "common.h"
+
+namespace mcgra {
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: arrays of it stay in scratch)
+
+constexpr int TB = 256;                       // block tile (rows of A' and of B'^T)
+constexpr int KC = 16;                        // k per step = one MFMA K
+constexpr int PLANE = TB * KC * 2;            // 8192 bytes: one plane of one operand for one step
+constexpr int OPB = 3 * PLANE;                // 24576 bytes per operand and step
+constexpr int STAGE = 2 * OPB;                // 49152
+constexpr int THREADS = 512;
+constexpr int LD_PER_T = STAGE / THREADS / 16;  // 6 x 16 B per thread and step
+
+__device__ __forceinline__ void split3(float x, __hip_bfloat16& p0, __hip_bfloat16& p1, __hip_bfloat16& p2) {
+  p0 = __float2bfloat16(x);
+  const float r1 = x - __bfloat162float(p0);
+  p1 = __float2bfloat16(r1);
+  const float r2 = r1 - __bfloat162float(p1);
+  p2 = __float2bfloat16(r2);
+}
+
+// pack rows of a [n x n] fp32 matrix (value(row, k) = X[row][k] - sub[row], or the symmetric S given in lower tile
+// storage when sub == nullptr and sym != 0) into [panel][kchunk][plane][row][16].  One thread: 8 consecutive k of a row.
+__global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
+                                               int sym, int nkc, __hip_bfloat16* __restrict__ out) {
+  // block: 32 rows x 8 (k chunk pairs of 8): thread (r, c): row = blockIdx.y * 32 + r, k0 = (blockIdx.x * 8 + c) * 8
+  const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+  const int row = blockIdx.y * 32 + r;
+  const int k0 = (blockIdx.x * 8 + c) * 8;
+  if (k0 >= nkc * KC) return;
+  float v[8];
+  const float mu = (sub && row < n) ? sub[row] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    float x = 0.f;
+    if (row < n && k < n) {
+      if (sym) {
+        const int lim = (row / SYM_TILE + 1) * SYM_TILE;
+        x = k < lim ? X[(size_t)row * ld + k] : X[(size_t)k * ld + row];
+      } else {
+        x = X[(size_t)row * ld + k] - mu;
+      }
+    }
+    v[j] = x;
+  }
+  __hip_bfloat16 p[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
+  const int panel = row / TB, rin = row % TB, kc = k0 / KC, half = (k0 % KC) / 8;
+  char* base = reinterpret_cast<char*>(out) + ((size_t)panel * nkc + kc) * OPB + (size_t)rin * 32 + half * 16;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(base + q * PLANE) = *reinterpret_cast<const uint4*>(p[q]);
+}
+
+__global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
+                                                                 float* __restrict__ C, int n, int ldc, int nkc,
+                                                                 int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, tile_n;
+  {  // XCD-aware bijective remap, then 4-panel groups (gemm_f32.hip)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GROUP_M = 4;
+    const int group_sz = GROUP_M * tiles_n;
+    const int group_id = bid / group_sz;
+    const int first_m = group_id * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    tile_m = first_m + (bid % group_sz) % gm;
+    tile_n = (bid % group_sz) / gm;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, wave tile 128 x 64
+  const int l31 = lane & 31, lh = lane >> 5;
+  const char* ga = Ap + (size_t)tile_m * nkc * OPB + (size_t)tid * 16;
+  const char* gb = Bp + (size_t)tile_n * nkc * OPB + (size_t)tid * 16;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // two register sets: the tile two steps ahead is in flight while the tile one step ahead is stored to LDS
+  u32x4 rg[2][LD_PER_T];
+  auto gload = [&](auto rs_, int kc) {
+    constexpr int RS = decltype(rs_)::value;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rg[RS][i] = *reinterpret_cast<const u32x4*>(ga + (size_t)kc * OPB + i * PLANE);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rg[RS][3 + i] = *reinterpret_cast<const u32x4*>(gb + (size_t)kc * OPB + i * PLANE);
+  };
+  auto lstore = [&](auto rs_, int stage) {
+    constexpr int RS = decltype(rs_)::value;
+    char* s = smem + stage * STAGE + tid * 16;
+#pragma unroll
+    for (int i = 0; i < LD_PER_T; ++i) *reinterpret_cast<u32x4*>(s + i * PLANE) = rg[RS][i];
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  const int a_off = (wm * 128 + l31) * 32 + lh * 16;        // + i * 1024 (row tile) + plane * PLANE
+  const int b_off = OPB + (wn * 64 + l31) * 32 + lh * 16;   // + j * 1024 + plane * PLANE
+  auto frag = [&](const char* s, int off) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + off)); };
+  auto multiply = [&](int stage) {
+    const char* s = smem + stage * STAGE;
+    bf16x8 b0[2], b1[2], b2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      b0[j] = frag(s, b_off + j * 1024);
+      b1[j] = frag(s, b_off + j * 1024 + PLANE);
+      b2[j] = frag(s, b_off + j * 1024 + 2 * PLANE);
+    }
+    bf16x8 a0 = frag(s, a_off), a1 = frag(s, a_off + PLANE), a2 = frag(s, a_off + 2 * PLANE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8 n0 = a0, n1 = a1, n2 = a2;
+      if (i + 1 < 4) {      // next row tile's fragments in flight during this one's 12 MFMAs
+        n0 = frag(s, a_off + (i + 1) * 1024);
+        n1 = frag(s, a_off + (i + 1) * 1024 + PLANE);
+        n2 = frag(s, a_off + (i + 1) * 1024 + 2 * PLANE);
+      }
+      // The six plane products of a tile, smallest terms first (they meet an accumulator that has not yet absorbed
+      // this step's leading product), alternating between the two column tiles so that consecutive MFMAs never
+      // depend on each other's accumulator.
+#define MCGRA_P(A_, B_)                                                                   \
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[0], acc[i][0], 0, 0, 0); \
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[1], acc[i][1], 0, 0, 0);
+      MCGRA_P(a2, b0) MCGRA_P(a1, b1) MCGRA_P(a0, b2) MCGRA_P(a1, b0) MCGRA_P(a0, b1) MCGRA_P(a0, b0)
+#undef MCGRA_P
+      a0 = n0; a1 = n1; a2 = n2;
+    }
+  };
+
+  gload(R0{}, 0);
+  lstore(R0{}, 0);
+  if (nkc > 1) gload(R1{}, 1);
+  __syncthreads();
+  int kc = 0;
+  for (; kc + 3 < nkc; kc += 2) {          // steady state, no conditions: tiles kc+2, kc+3 exist
+    gload(R0{}, kc + 2);
+    multiply(0);
+    lstore(R1{}, 1);
+    __syncthreads();
+    gload(R1{}, kc + 3);
+    multiply(1);
+    lstore(R0{}, 0);
+    __syncthreads();
+  }
+  for (; kc < nkc; kc += 2) {              // last one to three steps
+    if (kc + 2 < nkc) gload(R0{}, kc + 2);
+    multiply(0);
+    if (kc + 1 < nkc) lstore(R1{}, 1);
+    __syncthreads();
+    if (kc + 1 < nkc) {
+      if (kc + 3 < nkc) gload(R1{}, kc + 3);
+      multiply(1);
+      if (kc + 2 < nkc) lstore(R0{}, 0);
+      __syncthreads();
+    }
+  }
+
+  // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): 128-byte row segments per instruction
+  const int m0 = tile_m * TB + wm * 128, n0 = tile_n * TB + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < n && col < n) C[(size_t)row * ldc + col] = acc[i][j][r];
+      }
+    }
+}
+}  // namespace
+
+size_t split3_pack_bytes(int n) {
+  const size_t panels = (n + TB - 1) / TB, nkc = (n + KC - 1) / KC;
+  return panels * nkc * OPB;
+}
+void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out) {
+  const int nkc = (n + KC - 1) / KC, panels = (n + TB - 1) / TB;
+  dim3 grid((nkc * 2 + 7) / 8, panels * (TB / 32));
+  hipLaunchKernelGGL(k_pack3, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (__hip_bfloat16*)out);
+}
+// C[n x n] (row-major, ldc) = A' B'^T from the packed planes
+hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc) {
+  const int nkc = (n + KC - 1) / KC, tiles = (n + TB - 1) / TB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(split3_symm_kernel, dim3(tiles * tiles), dim3(THREADS), 2 * STAGE, st, (const char*)Apack,
+                     (const char*)Bpack, C, n, ldc, nkc, tiles, tiles);
+  return hipGetLastError();
+}
+
+}  // namespace mcgra

@@ -559,12 +559,13 @@ def test_lowrank_with_single_terms(pkg, wp, monkeypatch):
 
 
 # ---- opt-in 3-plane bf16 split of the P1 product (split_bf16.hip) ------------------------------------------------
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("case", ["s200_hsic_init", "s48_hsic"])
-def test_split_bf16_matches_fp32_path(pkg, case, monkeypatch):
+def test_split_bf16_matches_fp32_path(pkg, case, mode, monkeypatch):
     """MCGRA_SPLIT_BF16=1: same gradients as the fp32 MFMA path to fp32 rounding (the split keeps 24 mantissa bits)."""
     z = H.load_case(case)
     ref = H.engine_from(pkg, z)
-    monkeypatch.setenv("MCGRA_SPLIT_BF16", "1")
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", mode)      # 1: hipBLASLt on concatenated planes, 2: hand-written kernel
     try:
         spl = H.engine_from(pkg, z)
     except Exception as e:                       # hipBLASLt missing on the box: the option refuses loudly
@@ -577,8 +578,8 @@ def test_split_bf16_matches_fp32_path(pkg, case, monkeypatch):
         assert np.abs(gs - gr).max() <= 2e-5 * np.abs(gr).max(), (t, np.abs(gs - gr).max(), np.abs(gr).max())
         assert b["loss"] == pytest.approx(a["loss"], rel=2e-5, abs=1e-7)
         spl.set_adj_changes(ref.get_adj_changes())
-    # the library GEMM must be run-to-run deterministic as well (no atomics in the chosen algorithm)
-    monkeypatch.setenv("MCGRA_SPLIT_BF16", "1")
+    # run-to-run determinism (for the library GEMM: no atomics in the chosen algorithm)
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", mode)
     e1, e2 = H.engine_from(pkg, z), H.engine_from(pkg, z)
     monkeypatch.delenv("MCGRA_SPLIT_BF16")
     for t in range(2):
