@@ -24,7 +24,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 WORKLOADS = {
     # name: (N, nfeat, nclass, hidden, nlayer, measure, weight_param)
@@ -197,15 +198,23 @@ def sharded_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, mon
             "exchange": "2 x all_gather_into_tensor of 2 row-block buffers per step (RCCL)"}
 
 
-def split_bf16_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor):
-    """The same workload with the opt-in 3-plane bf16 split of the one N x N x N product (MCGRA_SPLIT_BF16=1,
-    csrc/split_bf16.hip: fp32-level error, the six plane products as one hipBLASLt bf16 GEMM).  Reported beside the
-    fp32 MFMA headline, never as `value`."""
-    os.environ["MCGRA_SPLIT_BF16"] = os.environ.get("MCGRA_SPLIT_PROBE_MODE", "1")
+PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
+                 1: "3-plane bf16 split, hipBLASLt bf16 GEMM n x n x 6n on K-concatenated planes",
+                 2: "3-plane bf16 split, hand-written split3_symm_kernel on packed planes (256 x 256 tiles)"}
+
+
+def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode):
+    """The same workload with another evaluation of the one N x N x N product (MCGRA_SPLIT_BF16=mode): the pure fp32
+    MFMA path beside a split-bf16 headline, or the other way round.  Never the reported `value`."""
+    old = os.environ.get("MCGRA_SPLIT_BF16")
+    os.environ["MCGRA_SPLIT_BF16"] = str(mode)
     try:
         eng, inp, adj_dev = build_engine(pkg, torch, dev, workload, seed)
     finally:
-        del os.environ["MCGRA_SPLIT_BF16"]
+        if old is None:
+            del os.environ["MCGRA_SPLIT_BF16"]
+        else:
+            os.environ["MCGRA_SPLIT_BF16"] = old
 
     def one_step():
         eng.step()
@@ -221,13 +230,15 @@ def split_bf16_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor):
     lab = torch.as_tensor(inp["labels"], device=dev)
     final = eng.finalize(0, eng.buffer("HA"), eng.buffer("YA"), (lab[:, None] == lab[None, :]).float())
     n = WORKLOADS[workload][0]
+    pm = eng.product_mode()
     out = {"value": steps / dt, "unit": "attack-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-           "auc": gpu_auc(adj_dev, final, torch), "dtype": "f32 operands as 3 bf16 planes, 6 plane products, fp32 accumulate"}
+           "auc": gpu_auc(adj_dev, final, torch), "product": PRODUCT_MODES[pm]}
     if st["launches"]:
         ms = st["ms"] / st["launches"]
-        out["product"] = {"kernel": "hipBLASLt bf16 GEMM n x n x 6n (planes concatenated along K)", "avg_launch_ms": ms,
-                          "bf16_tflops_issued": 12.0 * n ** 3 / (ms * 1e-3) / 1e12, "peak_bf16_dense": 2500.0,
-                          "fp32_equivalent_tflops": 2.0 * n ** 3 / (ms * 1e-3) / 1e12}
+        out["product_avg_launch_ms"] = ms
+        out["product_fp32_equivalent_tflops"] = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
+        if pm:
+            out["product_bf16_tflops_issued"] = 12.0 * n ** 3 / (ms * 1e-3) / 1e12
     return out
 
 
@@ -243,7 +254,8 @@ def main():
     ap.add_argument("--no-shard-probe", action="store_true",
                     help="N > 1: skip the extra (untimed-for-value) run of one attack row-block sharded over the ranks")
     ap.add_argument("--force-shard-probe", action="store_true", help="run the probe at N = 1 too (phase API, one row block)")
-    ap.add_argument("--no-split-probe", action="store_true", help="skip the extra run with MCGRA_SPLIT_BF16=1 (N = 1, HSIC)")
+    ap.add_argument("--no-split-probe", action="store_true",
+                    help="skip the extra runs at N = 1 (other evaluation of the N x N x N product, Cora-shape workload)")
     a = ap.parse_args()
 
     import torch
@@ -279,7 +291,7 @@ def main():
 
     # the same N x N x N product alone on the chip (no side-stream company), for the roofline's "alone" figure
     alone_ms = None
-    if st["launches"] and eng_path["lowrank_steps"] > 0 and measure == "HSIC":
+    if st["launches"] and eng_path["lowrank_steps"] > 0 and measure == "HSIC" and eng.product_mode() == 0:
         from mc_gra_amd import engine as E
         KFC, Bop = eng.buffer("KFC"), eng.buffer("adj_norm")
         out_s = torch.empty_like(Bop)
@@ -301,13 +313,15 @@ def main():
     final = eng.finalize(0, H_A, Y_A, label_adj)
     auc = gpu_auc(adj_dev, final, torch)
 
+    # the other evaluation of the N x N x N product beside the headline: pure fp32 MFMA when the default (bf16 split,
+    # fp32-level error) ran, the split when MCGRA_SPLIT_BF16=0 was given
+    pmode = eng.product_mode()
     split = None
-    if world == 1 and measure == "HSIC" and not a.no_split_probe and os.environ.get("MCGRA_SPLIT_BF16") != "1":
+    if world == 1 and measure == "HSIC" and not a.no_split_probe:
         try:
-            # same warmup and step count as the main run, so that the two recovered-adjacency AUCs are comparable
-            split = split_bf16_probe(pkg, torch, dev, a.workload, a.seed + rank, a.steps, a.warmup, monitor)
-            split["auc_fp32_path"] = auc
-            split["speedup_vs_fp32_path"] = split["value"] / aggregate_value(world, a.steps, dt)
+            split = product_probe(pkg, torch, dev, a.workload, a.seed + rank, a.steps, a.warmup, monitor, 0 if pmode else 2)
+            split["headline_auc"] = auc
+            split["headline_over_this"] = aggregate_value(world, a.steps, dt) / split["value"]
         except Exception as e:
             split = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -343,7 +357,8 @@ def main():
         out = {
             "metric": "attack-steps/sec", "value": aggregate_value(world, a.steps, dt), "unit": "attack-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not pmode else "f32 (the N x N x N product: operands as 3 bf16 planes, 6 MFMA products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": a.workload, "nodes": n, "features": f, "gcn_layers": nl, "hidden": hid,
                        "classes": c, "measure": measure, "priors": "H_A+Y_A+Y", "weight_param": list(wp),
@@ -355,7 +370,7 @@ def main():
         if shard is not None:
             out["sharded_probe"] = shard
         if split is not None:
-            out["split_bf16_probe"] = split
+            out["fp32_mfma_probe" if pmode else "split_bf16_probe"] = split
         if extra is not None:
             out["other_workloads"] = extra
         if st["launches"]:
@@ -368,20 +383,37 @@ def main():
             ps = eng_path
             lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
             tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            role = "split" if (lowrank and pmode == 2) else "symm"
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
-                ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == "symm" or not lowrank]
-                traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks))
-            what = ("P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step: SYMM on lower tile storage, "
-                    "one launch per step") if lowrank else ("N x N x N products of the Gram evaluation of linear_HSIC: one "
-                    "batched SYRK pair + one batched SYMM pair launch per step")
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (" + what + ")",
-                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                               "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
-                               "gemm_share_of_step": st["ms"] / (1e3 * dt)}
-            if alone_ms:     # achieved / frac above are measured inside the step, where the product shares the chip
-                out["roofline"]["alone"] = {"avg_launch_ms": alone_ms, "achieved": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12,
-                                            "frac": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == role or not lowrank]
+                traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks)) if ks else None
+            if lowrank and pmode:
+                # the bf16 matrix cores issue 6 plane products per fp32-equivalent product: 12 n^3 flop per launch
+                issued = 6.0 * ach
+                out["roofline"] = {"bound": "mfma",
+                                   "kernel": ("split3_symm_kernel" if pmode == 2 else "hipBLASLt bf16 GEMM") +
+                                             " (P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step, as a "
+                                             "3-plane bf16 split: 6 plane products per product, fp32 accumulate, fp32-level "
+                                             "error; one launch per step)",
+                                   "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": issued / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent_tflops": ach,
+                                   "algorithmic_flop_per_launch": 12.0 * n ** 3,
+                                   "traffic": traffic, "traffic_unit": "bytes/launch",
+                                   "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
+                                   "gemm_share_of_step": st["ms"] / (1e3 * dt)}
+            else:
+                what = ("P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step: SYMM on lower tile "
+                        "storage, one launch per step") if lowrank else ("N x N x N products of the Gram evaluation of "
+                        "linear_HSIC: one batched SYRK pair + one batched SYMM pair launch per step")
+                out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,32> (" + what + ")",
+                                   "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                                   "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
+                                   "gemm_share_of_step": st["ms"] / (1e3 * dt)}
+                if alone_ms:     # the same SYMM by itself right after the timed region
+                    out["roofline"]["alone"] = {"avg_launch_ms": alone_ms,
+                                                "achieved": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12,
+                                                "frac": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         else:
             out["roofline"] = None
         if not a.no_cpu_baseline:

@@ -213,6 +213,10 @@ int mcgra_attack_step_phase(mcgra_attack_t* h, void* stream, int phase, const fl
 #define MCGRA_EXCHANGE_G_ADJN 4
 #define MCGRA_EXCHANGE_G_A1 8
 int mcgra_attack_exchange_mask(mcgra_attack_t* h);
+/* How the one N x N x N product of a low-rank step is evaluated by this engine: 0 = fp32 MFMA SYMM, 1 = 3-plane bf16
+ * split through a hipBLASLt GEMM, 2 = 3-plane bf16 split, hand-written kernel (the default for n >= 1024; fp32-level
+ * error).  Chosen at create from MCGRA_SPLIT_BF16. */
+int mcgra_attack_product_mode(mcgra_attack_t* h);
 /* Steps that took the low-rank / the Gram (general) evaluation of the N x N linear_HSIC terms since creation. */
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps);
 

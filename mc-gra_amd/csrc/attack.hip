@@ -352,7 +352,12 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, lr_stats_doubles(he)); A_(lrRs, ld);
     }
     A_(nmask, 4);
+    // The one N x N x N product of a low-rank step.  Default for n >= 1024: the 3-plane bf16 split on the bf16 matrix
+    // cores (split_symm_bf16.hip: fp32-level error, 1.7x the fp32 MFMA SYMM).  MCGRA_SPLIT_BF16=0: fp32 MFMA SYMM;
+    // =1: the split through a hipBLASLt GEMM on K-concatenated planes; =2: the split kernel at any size.
     const char* es = getenv("MCGRA_SPLIT_BF16");
+    const char auto_mode[2] = {n >= 1024 ? '2' : '0', 0};
+    if (!es || !es[0]) es = auto_mode;
     if (!rc && h->lr_ok && cfg->eps == 0.f && es && es[0] == '1') {
       if (!split_bf16_available()) { rc = MCGRA_ENOSUP; }
       else {
@@ -672,7 +677,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
       hipStream_t sp = h->overlap ? h->st2 : st;
       // bf16 planes of Xc^T (opt-in split path) on the caller's stream, ahead of the fork: cmean is reused later
-      const bool split_now = h->split_on && !noise && (h->split_mode == 1 || !sharded);
+      // (row blocks of a sharded step must start on a 256-row panel for the split kernel; otherwise fp32 SYMM)
+      const bool split_now = h->split_on && !noise && (h->split_mode == 1 || (c.row_begin % split3_panel()) == 0);
       if (split_now && h->split_mode == 1) split3_planes_rows(st, n, ld, h->ADJN, h->cmean, h->Bcat);
       if (split_now && h->split_mode == 2) split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack);
       if (h->overlap) {
@@ -686,7 +692,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         const bool big = h->profile;
         CHK(timer_begin(h, sp, big));
         if (h->split_mode == 1) CHK(split_bf16_gemm(sp, n, row0, row1 - row0, h->Acat, h->Bcat, h->KX, ld));
-        else MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld));
+        else {
+          const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
+          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0));
+        }
         CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
         ++h->split_steps;
       } else
@@ -978,6 +987,8 @@ int mcgra_attack_exchange_mask(mcgra_attack_t* h) {
   if (h->lr_step) return use1 ? MCGRA_EXCHANGE_KX : 0;
   return MCGRA_EXCHANGE_KX | (use2 ? MCGRA_EXCHANGE_KY : 0) | MCGRA_EXCHANGE_G_ADJN | (use2 ? MCGRA_EXCHANGE_G_A1 : 0);
 }
+
+int mcgra_attack_product_mode(mcgra_attack_t* h) { return h ? h->split_mode : 0; }
 
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps) {
   if (!h) { set_error("null handle"); return MCGRA_EINVAL; }

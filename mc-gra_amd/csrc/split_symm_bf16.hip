@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __res
 
 __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
                                                                  float* __restrict__ C, int n, int ldc, int nkc,
-                                                                 int tiles_m, int tiles_n) {
+                                                                 int tiles_m, int tiles_n, int panel_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tile_m, tile_n;
   {  // XCD-aware bijective remap, then 4-panel groups (gemm_f32.hip)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
     const int group_id = bid / group_sz;
     const int first_m = group_id * GROUP_M;
     const int gm = min(tiles_m - first_m, GROUP_M);
-    tile_m = first_m + (bid % group_sz) % gm;
+    tile_m = first_m + (bid % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
     tile_n = (bid % group_sz) / gm;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,18 +215,23 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
   dim3 grid((nkc * 2 + 7) / 8, panels * (TB / 32));
   hipLaunchKernelGGL(k_pack3, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (__hip_bfloat16*)out);
 }
-// C[n x n] (row-major, ldc) = A' B'^T from the packed planes
-hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc) {
+// C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
+// (panel_rows < 0: all panels).  Tiles are independent, so a row range gives the same bits as the full launch.
+hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
+                       int panel_rows) {
   const int nkc = (n + KC - 1) / KC, tiles = (n + TB - 1) / TB;
+  const int tm = panel_rows >= 0 ? panel_rows : tiles;
+  if (tm <= 0) return hipSuccess;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(split3_symm_kernel, dim3(tiles * tiles), dim3(THREADS), 2 * STAGE, st, (const char*)Apack,
-                     (const char*)Bpack, C, n, ldc, nkc, tiles, tiles);
+  hipLaunchKernelGGL(split3_symm_kernel, dim3(tm * tiles), dim3(THREADS), 2 * STAGE, st, (const char*)Apack,
+                     (const char*)Bpack, C, n, ldc, nkc, tm, tiles, panel_off);
   return hipGetLastError();
 }
+int split3_panel() { return TB; }
 
 }  // namespace mcgra

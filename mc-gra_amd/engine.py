@@ -249,6 +249,10 @@ class AttackEngine:
         """Bit mask (KX=1, KY=2, G_adjn=4, G_A1=8) of the buffers the step in flight needs gathered."""
         return int(lib.mcgra_attack_exchange_mask(self._h))
 
+    def product_mode(self):
+        """0: fp32 MFMA SYMM, 1: bf16 split through hipBLASLt, 2: bf16 split, hand-written kernel (mcgra_attack_product_mode)."""
+        return int(lib.mcgra_attack_product_mode(self._h))
+
     def path_stats(self):
         a, b = C.c_longlong(0), C.c_longlong(0)
         check(lib.mcgra_attack_path_stats(self._h, C.byref(a), C.byref(b)))

@@ -9,7 +9,7 @@ tests, on a numpy stand-in supplied by the test.
 """
 import torch
 
-TILE = 128          # SYM_TILE of csrc/common.h: row blocks are whole 128-row tiles
+TILE = 256          # row blocks are whole 256-row panels (2 x SYM_TILE of csrc/common.h; panel of split_symm_bf16.hip)
 EXCHANGED_AFTER_PHASE = {1: ("KX", "KY"), 2: ("G_adjn", "G_A1")}
 EXCHANGE_BIT = {"KX": 1, "KY": 2, "G_adjn": 4, "G_A1": 8}          # MCGRA_EXCHANGE_* of include/mcgra.h
 

@@ -99,5 +99,5 @@ def test_row_block_plan():
     assert all(q.rows_per_rank == 1280 and q.n_pad == 10240 for q in p)
     assert [q.row_begin for q in p] == [1280 * r for r in range(8)] and p[7].row_end == 10240 and p[7].has_rows
     q = RowBlockPlan(200, 4, 3)
-    assert q.rows_per_rank == 128 and q.n_pad == 512 and not q.has_rows
+    assert q.rows_per_rank == 256 and q.n_pad == 1024 and not q.has_rows
     assert RowBlockPlan(2708, 1, 0).row_end == 2816

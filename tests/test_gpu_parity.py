@@ -411,13 +411,14 @@ def test_main_entry_end_to_end(pkg, torch_, tmp_path, monkeypatch):
 
 # ---- row-block sharded step (scope row (e)) -------------------------------------------------------------------
 @pytest.mark.parametrize("case,world", [("s200_hsic_init", 1), ("s200_hsic_init", 2), ("s200_hsic_init", 3),
-                                        ("s200_hsic", 2), ("s48_cka_init", 1), ("s200_mse", 2)])
+                                        ("s200_hsic", 2), ("s48_cka_init", 1), ("s200_mse", 2), ("synthetic600", 2),
+                                        ("synthetic600", 3)])
 def test_sharded_phases_match_monolithic_step(pkg, case, world):
     """`world` engines on one GPU, each restricted to its row block, driven by the product's ShardedStepper
     phase protocol with the all-gather emulated by device copies: same adjacency as mcgra_attack_step."""
     import torch
     from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend, EXCHANGED_AFTER_PHASE
-    z = H.load_case(case)
+    z = _synthetic_case(600, 11, (16, 16), 4, seed=5) if case == "synthetic600" else H.load_case(case)
     n = z["adj"].shape[0]
     full = H.engine_from(pkg, z)
     plans = [RowBlockPlan(n, world, r) for r in range(world)]
