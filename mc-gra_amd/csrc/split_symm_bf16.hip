@@ -8,8 +8,10 @@
 // v_mfma_f32_32x32x16_bf16 per wave and K step -- MFMA-bound -- where the concatenated form moves twice the bytes.
 //
 // Operands are pre-packed in HBM in exactly the LDS image of a K step, [panel of 256 rows][k chunk of 16][plane]
-// [row][16 k] (8 KB per plane, 24 KB per operand and step, zero padded), so staging is a linear 16-byte copy and
-// the fragment of lane (r = l & 31, h = l >> 5) -- row r, k = 8h .. 8h+7 -- is one conflict-free ds_read_b128.
+// [k half][row][8 k] (8 KB per plane, 24 KB per operand and step, zero padded), so staging is a linear 16-byte copy
+// and the fragment of lane (r = l & 31, h = l >> 5) -- row r, k = 8h .. 8h+7 -- is one ds_read_b128 whose 32 lanes of
+// a half read 512 contiguous bytes (rows 16 B apart: no bank conflicts; a [row][16 k] image has them 32 B apart and
+// measured one conflict cycle per LDS instruction).
 // A is packed once per graph (constant Gram), B per step from the rows of adj_norm (Xc^T[j][k] = adj_norm[j][k] -
 // mean_j by symmetry, eps == 0 only).  512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA
 // tiles = 128 accumulator registers; two LDS stages of 48 KB, next step's tile in registers during the multiply,
@@ -47,7 +49,7 @@ __device__ __forceinline__ void split3(float x, __hip_bfloat16& p0, __hip_bfloat
 }
 
 // pack rows of a [n x n] fp32 matrix (value(row, k) = X[row][k] - sub[row], or the symmetric S given in lower tile
-// storage when sub == nullptr and sym != 0) into [panel][kchunk][plane][row][16].  One thread: 8 consecutive k of a row.
+// storage when sub == nullptr and sym != 0) into [panel][kchunk][plane][k half][row][8].  One thread: 8 consecutive k of a row.
 __global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
                                                int sym, int nkc, __hip_bfloat16* __restrict__ out) {
   // block: 32 rows x 8 (k chunk pairs of 8): thread (r, c): row = blockIdx.y * 32 + r, k0 = (blockIdx.x * 8 + c) * 8
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __res
 #pragma unroll
   for (int j = 0; j < 8; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
   const int panel = row / TB, rin = row % TB, kc = k0 / KC, half = (k0 % KC) / 8;
-  char* base = reinterpret_cast<char*>(out) + ((size_t)panel * nkc + kc) * OPB + (size_t)rin * 32 + half * 16;
+  char* base = reinterpret_cast<char*>(out) + ((size_t)panel * nkc + kc) * OPB + (size_t)half * (PLANE / 2) + (size_t)rin * 16;
 #pragma unroll
   for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(base + q * PLANE) = *reinterpret_cast<const uint4*>(p[q]);
 }
@@ -129,26 +131,27 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
   };
   using R0 = std::integral_constant<int, 0>;
   using R1 = std::integral_constant<int, 1>;
-  const int a_off = (wm * 128 + l31) * 32 + lh * 16;        // + i * 1024 (row tile) + plane * PLANE
-  const int b_off = OPB + (wn * 64 + l31) * 32 + lh * 16;   // + j * 1024 + plane * PLANE
+  const int a_off = lh * (PLANE / 2) + (wm * 128 + l31) * 16;        // + i * 512 (row tile) + plane * PLANE
+  const int b_off = OPB + lh * (PLANE / 2) + (wn * 64 + l31) * 16;   // + j * 512 + plane * PLANE
   auto frag = [&](const char* s, int off) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + off)); };
-  auto multiply = [&](int stage) {
+  auto multiply = [&](int stage, auto&& after_first_reads) {
     const char* s = smem + stage * STAGE;
     bf16x8 b0[2], b1[2], b2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      b0[j] = frag(s, b_off + j * 1024);
-      b1[j] = frag(s, b_off + j * 1024 + PLANE);
-      b2[j] = frag(s, b_off + j * 1024 + 2 * PLANE);
+      b0[j] = frag(s, b_off + j * 512);
+      b1[j] = frag(s, b_off + j * 512 + PLANE);
+      b2[j] = frag(s, b_off + j * 512 + 2 * PLANE);
     }
     bf16x8 a0 = frag(s, a_off), a1 = frag(s, a_off + PLANE), a2 = frag(s, a_off + 2 * PLANE);
+    after_first_reads();     // staging of later tiles queues behind this step's first fragment reads
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bf16x8 n0 = a0, n1 = a1, n2 = a2;
       if (i + 1 < 4) {      // next row tile's fragments in flight during this one's 12 MFMAs
-        n0 = frag(s, a_off + (i + 1) * 1024);
-        n1 = frag(s, a_off + (i + 1) * 1024 + PLANE);
-        n2 = frag(s, a_off + (i + 1) * 1024 + 2 * PLANE);
+        n0 = frag(s, a_off + (i + 1) * 512);
+        n1 = frag(s, a_off + (i + 1) * 512 + PLANE);
+        n2 = frag(s, a_off + (i + 1) * 512 + 2 * PLANE);
       }
       // The six plane products of a tile, smallest terms first (they meet an accumulator that has not yet absorbed
       // this step's leading product), alternating between the two column tiles so that consecutive MFMAs never
@@ -162,30 +165,27 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
     }
   };
 
+  // Step t multiplies stage t & 1.  At its top (behind the first fragment reads) the tile for step t+1, in flight
+  // since the top of step t-1, is written to the other stage -- free since the barrier that ended step t-1 -- and the
+  // same registers are reloaded with the tile for step t+3; the other register set holds tile t+2.  So every global
+  // load has two full steps to land and the end of a step is only a barrier.
   gload(R0{}, 0);
   lstore(R0{}, 0);
   if (nkc > 1) gload(R1{}, 1);
+  if (nkc > 2) gload(R0{}, 2);
   __syncthreads();
   int kc = 0;
-  for (; kc + 3 < nkc; kc += 2) {          // steady state, no conditions: tiles kc+2, kc+3 exist
-    gload(R0{}, kc + 2);
-    multiply(0);
-    lstore(R1{}, 1);
+  for (; kc + 4 < nkc; kc += 2) {          // steady state, no conditions: tiles up to kc+4 exist
+    multiply(0, [&]() { lstore(R1{}, 1); gload(R1{}, kc + 3); });
     __syncthreads();
-    gload(R1{}, kc + 3);
-    multiply(1);
-    lstore(R0{}, 0);
+    multiply(1, [&]() { lstore(R0{}, 0); gload(R0{}, kc + 4); });
     __syncthreads();
   }
-  for (; kc < nkc; kc += 2) {              // last one to three steps
-    if (kc + 2 < nkc) gload(R0{}, kc + 2);
-    multiply(0);
-    if (kc + 1 < nkc) lstore(R1{}, 1);
+  for (; kc < nkc; kc += 2) {              // last steps
+    multiply(0, [&]() { if (kc + 1 < nkc) lstore(R1{}, 1); if (kc + 3 < nkc) gload(R1{}, kc + 3); });
     __syncthreads();
     if (kc + 1 < nkc) {
-      if (kc + 3 < nkc) gload(R1{}, kc + 3);
-      multiply(1);
-      if (kc + 2 < nkc) lstore(R0{}, 0);
+      multiply(1, [&]() { if (kc + 2 < nkc) lstore(R0{}, 0); if (kc + 4 < nkc) gload(R0{}, kc + 4); });
       __syncthreads();
     }
   }
