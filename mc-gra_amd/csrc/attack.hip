@@ -694,7 +694,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         if (h->split_mode == 1) CHK(split_bf16_gemm(sp, n, row0, row1 - row0, h->Acat, h->Bcat, h->KX, ld));
         else {
           const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
-          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0));
+          // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
+          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld));
         }
         CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
         ++h->split_steps;

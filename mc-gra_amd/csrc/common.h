@@ -52,8 +52,8 @@ int split_bf16_gemm(hipStream_t st, int n, int row0, int nrows, const void* Acat
 // split_symm_bf16.hip (opt-in, MCGRA_SPLIT_BF16=2): the same split as a hand-written kernel on packed planes
 size_t split3_pack_bytes(int n);
 void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out);
-hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off = 0,
-                       int panel_rows = -1);
+hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
+                       int panel_rows, float* slab, size_t slab_bytes);
 int split3_panel();
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------

@@ -82,29 +82,38 @@ __global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __res
   for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(base + q * PLANE) = *reinterpret_cast<const uint4*>(p[q]);
 }
 
+// One launch covers the linear tile ids [tile_base, tile_base + gridDim.x / ksplit) of the tiles_m x tiles_n tile grid.
+// ksplit > 1 (the ragged last round of a launch, split3_symm): each tile's K range is cut into ksplit parts whose
+// partial tiles go to `slab` ([part][tile - tile_base][256][256]) and are summed in fixed order by k_split3_reduce.
 __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
                                                                  float* __restrict__ C, int n, int ldc, int nkc,
-                                                                 int tiles_m, int tiles_n, int panel_off) {
+                                                                 int tiles_m, int tiles_n, int panel_off, int tile_base,
+                                                                 int ksplit, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tile_m, tile_n;
-  {  // XCD-aware bijective remap, then 4-panel groups (gemm_f32.hip)
+  int tile_m, tile_n, lin, part;
+  {  // XCD-aware bijective remap of this launch's blocks, then 4-panel groups over the whole tile grid (gemm_f32.hip)
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    part = bid % ksplit;
+    lin = tile_base + bid / ksplit;
     constexpr int GROUP_M = 4;
     const int group_sz = GROUP_M * tiles_n;
-    const int group_id = bid / group_sz;
+    const int group_id = lin / group_sz;
     const int first_m = group_id * GROUP_M;
     const int gm = min(tiles_m - first_m, GROUP_M);
-    tile_m = first_m + (bid % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
-    tile_n = (bid % group_sz) / gm;
+    tile_m = first_m + (lin % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
+    tile_n = (lin % group_sz) / gm;
   }
+  const int kper = (nkc + ksplit - 1) / ksplit;
+  const int kc_begin = part * kper;
+  const int nk = max(0, min(nkc, kc_begin + kper) - kc_begin);          // K steps of this block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, wave tile 128 x 64
   const int l31 = lane & 31, lh = lane >> 5;
-  const char* ga = Ap + (size_t)tile_m * nkc * OPB + (size_t)tid * 16;
-  const char* gb = Bp + (size_t)tile_n * nkc * OPB + (size_t)tid * 16;
+  const char* ga = Ap + ((size_t)tile_m * nkc + kc_begin) * OPB + (size_t)tid * 16;
+  const char* gb = Bp + ((size_t)tile_n * nkc + kc_begin) * OPB + (size_t)tid * 16;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -169,28 +178,41 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
   // since the top of step t-1, is written to the other stage -- free since the barrier that ended step t-1 -- and the
   // same registers are reloaded with the tile for step t+3; the other register set holds tile t+2.  So every global
   // load has two full steps to land and the end of a step is only a barrier.
+  if (nk > 0) {
   gload(R0{}, 0);
   lstore(R0{}, 0);
-  if (nkc > 1) gload(R1{}, 1);
-  if (nkc > 2) gload(R0{}, 2);
+  if (nk > 1) gload(R1{}, 1);
+  if (nk > 2) gload(R0{}, 2);
   __syncthreads();
   int kc = 0;
-  for (; kc + 4 < nkc; kc += 2) {          // steady state, no conditions: tiles up to kc+4 exist
+  for (; kc + 4 < nk; kc += 2) {          // steady state, no conditions: tiles up to kc+4 exist
     multiply(0, [&]() { lstore(R1{}, 1); gload(R1{}, kc + 3); });
     __syncthreads();
     multiply(1, [&]() { lstore(R0{}, 0); gload(R0{}, kc + 4); });
     __syncthreads();
   }
-  for (; kc < nkc; kc += 2) {              // last steps
-    multiply(0, [&]() { if (kc + 1 < nkc) lstore(R1{}, 1); if (kc + 3 < nkc) gload(R1{}, kc + 3); });
+  for (; kc < nk; kc += 2) {              // last steps
+    multiply(0, [&]() { if (kc + 1 < nk) lstore(R1{}, 1); if (kc + 3 < nk) gload(R1{}, kc + 3); });
     __syncthreads();
-    if (kc + 1 < nkc) {
-      multiply(1, [&]() { if (kc + 2 < nkc) lstore(R0{}, 0); if (kc + 4 < nkc) gload(R0{}, kc + 4); });
+    if (kc + 1 < nk) {
+      multiply(1, [&]() { if (kc + 2 < nk) lstore(R0{}, 0); if (kc + 4 < nk) gload(R0{}, kc + 4); });
       __syncthreads();
     }
   }
+  }
 
   // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): 128-byte row segments per instruction
+  if (ksplit > 1) {
+    float* o = slab + ((size_t)part * (gridDim.x / ksplit) + (lin - tile_base)) * (TB * TB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TB + wn * 64 + j * 32 + l31] = acc[i][j][r];
+    return;
+  }
   const int m0 = tile_m * TB + wm * 128, n0 = tile_n * TB + wn * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -203,6 +225,31 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
         if (row < n && col < n) C[(size_t)row * ldc + col] = acc[i][j][r];
       }
     }
+}
+
+// C tile = sum over parts of the partial tiles of the split-K tail (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__ slab, int ntile, int ksplit, float* __restrict__ C,
+                                                       int n, int ldc, int tiles_m, int tiles_n, int panel_off, int tile_base) {
+  const int t = blockIdx.x, lin = tile_base + t;
+  constexpr int GROUP_M = 4;
+  const int group_sz = GROUP_M * tiles_n, group_id = lin / group_sz, first_m = group_id * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (lin % group_sz) % gm + panel_off, tile_n = (lin % group_sz) / gm;
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < TB * TB / 4; e += gridDim.y * 256) {
+    const int row = e / (TB / 4), c4 = (e % (TB / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < ksplit; ++p) {
+      const float4 x = *reinterpret_cast<const float4*>(slab + ((size_t)p * ntile + t) * (TB * TB) + (size_t)row * TB + c4);
+      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    const int gr = tile_m * TB + row, gc = tile_n * TB + c4;
+    if (gr >= n) continue;
+    float* o = C + (size_t)gr * ldc + gc;
+    if (gc + 0 < n) o[0] = v.x;
+    if (gc + 1 < n) o[1] = v.y;
+    if (gc + 2 < n) o[2] = v.z;
+    if (gc + 3 < n) o[3] = v.w;
+  }
 }
 }  // namespace
 
@@ -218,18 +265,39 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
 // C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
 // (panel_rows < 0: all panels).  Tiles are independent, so a row range gives the same bits as the full launch.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
-                       int panel_rows) {
+                       int panel_rows, float* slab, size_t slab_bytes) {
   const int nkc = (n + KC - 1) / KC, tiles = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles;
   if (tm <= 0) return hipSuccess;
   static bool attr_done = false;
+  static int slots = 256;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     if (e != hipSuccess) return e;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        cus > 0)
+      slots = cus;               // one block per CU
     attr_done = true;
   }
-  hipLaunchKernelGGL(split3_symm_kernel, dim3(tm * tiles), dim3(THREADS), 2 * STAGE, st, (const char*)Apack,
-                     (const char*)Bpack, C, n, ldc, nkc, tm, tiles, panel_off);
+  // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so
+  // that it fills the chip too (tiles are 256 x 256 x n: 1600 of them on 256 CUs would otherwise take 7 rounds for 6.25).
+  const int total = tm * tiles;
+  int full = (total / slots) * slots, rem = total - full, ksplit = 1;
+  if (rem > 0 && rem * 2 <= slots && slab) {
+    ksplit = slots / rem;
+    if (ksplit > 8) ksplit = 8;
+    while (ksplit > 1 && (size_t)ksplit * rem * TB * TB * sizeof(float) > slab_bytes) --ksplit;
+  }
+  if (ksplit <= 1) { full = total; rem = 0; }
+  if (full > 0)
+    hipLaunchKernelGGL(split3_symm_kernel, dim3(full), dim3(THREADS), 2 * STAGE, st, (const char*)Apack, (const char*)Bpack, C,
+                       n, ldc, nkc, tm, tiles, panel_off, 0, 1, nullptr);
+  if (rem > 0) {
+    hipLaunchKernelGGL(split3_symm_kernel, dim3(rem * ksplit), dim3(THREADS), 2 * STAGE, st, (const char*)Apack,
+                       (const char*)Bpack, C, n, ldc, nkc, tm, tiles, panel_off, full, ksplit, slab);
+    hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, full);
+  }
   return hipGetLastError();
 }
 int split3_panel() { return TB; }
