@@ -69,6 +69,15 @@ int mcgra_ssyrk_lower(void* stream, int n, int k, float alpha, const float* A, i
 int mcgra_ssymm_lower(void* stream, int n, int m, float alpha, const float* S, int lds,
                       const float* B, int ldb, float beta, float* C, int ldc);
 
+/* C[n x n] = S (X - rowsub 1^T)^T for a symmetric S given in lower tile storage (or in full), i.e. C[m][j] = sum_k
+ * S[m][k] (X[j][k] - rowsub[j]) (rowsub may be NULL), evaluated as the 3-plane bf16 split of DESIGN.md section 3:
+ * operands as x0 + x1 + x2 in bf16, the six plane products with i + j <= 2 in the fp32 accumulator of the bf16 MFMA
+ * (fp32-level error).  With X = adj_norm (symmetric) and rowsub its column means this is (H Kf H) Xc, the N x N x N
+ * product torch.mm performs inside CudaCKA.linear_HSIC's backward (utils.py:1085-1089).  Synchronous; packs both
+ * operands itself (the engine keeps S packed across steps). */
+int mcgra_ssymm_split_bf16(void* stream, int n, const float* S, int lds, const float* X, int ldx, const float* rowsub,
+                           float* C, int ldc);
+
 /* Tuning knob for A/B measurements in one process: 2 = double-buffered LDS K loop
  * (default), 1 = single LDS stage with two barriers per K tile.  Same results bit for bit. */
 int mcgra_set_gemm_variant(int v);

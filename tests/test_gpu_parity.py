@@ -626,3 +626,31 @@ def test_side_stream_overlap_is_bit_identical(pkg, monkeypatch):
         ra, rb = a.step(want_scalars=True), b.step(want_scalars=True)
         a.monitor(); b.monitor()
         assert ra == rb and torch.equal(a.get_adj_changes(), b.get_adj_changes())
+
+
+@pytest.mark.parametrize("n", [33, 256, 257, 511, 1000, 1537, 2708, 4100])
+def test_split_bf16_product_against_fp64(pkg, torch_, n):
+    """mcgra_ssymm_split_bf16 at sizes around the 256-row panels, the 16-wide K steps and the split-K tail: error against
+    fp64 within the fp32-product class (<= 1e-6 of |S||B|), asymmetric B exposes any transposition, repeat runs are
+    bit-identical (the barrier structure of a new kernel is screened over several runs and sizes)."""
+    import torch
+    from mc_gra_amd import engine as E
+    rng = np.random.RandomState(n)
+    F = rng.randn(n, 24).astype(np.float32)
+    S = (F @ F.T).astype(np.float32)
+    S = (S + S.T) * 0.5
+    X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1            # NOT symmetric
+    sub = rng.rand(n).astype(np.float32) * 0.05
+    Sd, Xd, sd = dev(torch_, S), dev(torch_, X), dev(torch_, sub)
+    outs = [E.ssymm_split_bf16(Sd, Xd, sd).clone() for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    B = (X.astype(np.float64) - sub.astype(np.float64)[:, None])
+    ref = S.astype(np.float64) @ B.T
+    scale = np.abs(S).astype(np.float64) @ np.abs(B).T
+    err = np.abs(outs[0].cpu().numpy().astype(np.float64) - ref) / scale
+    assert err.max() <= 1e-6, err.max()
+    # the fp32 MFMA SYMM on the same operands (lower tile storage) for comparison of the error class
+    Bt = torch.tensor(np.ascontiguousarray(B.T.astype(np.float32)), device="cuda")
+    f32 = E.ssymm_lower(Sd, Bt).cpu().numpy().astype(np.float64)
+    assert err.max() <= 4 * (np.abs(f32 - ref) / scale).max() + 2e-7
