@@ -28,7 +28,7 @@ def one(pattern):
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
