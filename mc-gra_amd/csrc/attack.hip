@@ -67,6 +67,7 @@ struct mcgra_attack {
   // log-probs in place and the next step adopts them instead of recomputing (bit-identical, one N x N pass and two
   // skinny products less per step).  MCGRA_NO_FWD_REUSE=1 disables.
   bool fwd_cached = false, fwd_reuse = true;
+  bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
   float* ADJN_next = 0;
   bool graph_set = false, model_set = false;
   std::vector<void*> allocs;
@@ -312,7 +313,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   int rc = 0;
 #define A_(p, cnt) if (!rc) rc = dalloc(h, &h->p, (cnt))
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
-  A_(KX, nn); A_(FADJ, nn); A_(GSYM, nn);
+  A_(KX, nn); A_(FADJ, nn);
+  { const char* e = getenv("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
+  if (h->keep_gsym) { A_(GSYM, nn); }
   if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
     A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn);
   }
@@ -917,7 +920,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // clamp(a,0,1).sum() <= n(n-1)/2, so a larger budget can never trigger the bisection (:339)
   const bool may_project = c.num_edges < 0.5 * n2;
   launch_adam_sym(st, n, ld, h->G_A, gate, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
-                  (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->GSYM, may_project ? 0 : 1);
+                  (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->keep_gsym ? h->GSYM : nullptr,
+                  may_project ? 0 : 1);
   MCGRA_KERNEL_CHECK();
   h->have_step = true;
   if (may_project) CHK(project(h, st));
@@ -1081,6 +1085,10 @@ int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr, int* r
   };
   for (const E& e : tab)
     if (strcmp(e.nm, name) == 0) {
+      if (!e.p) {
+        set_error("buffer '%s' is not kept by this engine (G_sym needs MCGRA_KEEP_GSYM=1 at create)", name);
+        return MCGRA_EINVAL;
+      }
       *ptr = e.p;
       if (rows) *rows = e.r;
       if (cols) *cols = e.c;

@@ -4,6 +4,8 @@ import os
 
 import numpy as np
 
+os.environ.setdefault("MCGRA_KEEP_GSYM", "1")     # the parity tests read each step's mirrored gradient ("G_sym")
+
 from oracle import mcgra_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("MCGRA_KEEP_GSYM", "1")     # these tests read each step's mirrored gradient ("G_sym")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
