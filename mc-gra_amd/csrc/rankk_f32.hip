@@ -30,12 +30,15 @@ __device__ __forceinline__ void rk_stage(float (*dst)[ROWS], const float* __rest
   }
 }
 
+// KMAX sizes the LDS panels: 16 -> 12 KB, 32 -> 24 KB, 64 -> 48 KB per block.  The kernel is a short latency chain
+// (stage, barrier, K FMAs, store), so what matters is how many blocks a CU can hold to overlap those chains.
+template <int KMAX>
 __global__ __launch_bounds__(RK_THREADS) void rankk_nt_kernel(
     int M, int N, int K1, float alpha1, const float* __restrict__ A1, int lda1, const float* __restrict__ B1, int ldb1,
     int K2, float alpha2, const float* __restrict__ A2, int lda2, const float* __restrict__ B2, int ldb2, float beta,
     float* __restrict__ C, int ldc, int vec1, int vec2, int vecc) {
-  __shared__ float As[RK_KMAX][RK_BM];
-  __shared__ float Bs[RK_KMAX][RK_BN];
+  __shared__ float As[KMAX][RK_BM];
+  __shared__ float Bs[KMAX][RK_BN];
   const int m0 = blockIdx.y * RK_BM, n0 = blockIdx.x * RK_BN;
   const int tn = threadIdx.x & 31, tm = threadIdx.x >> 5;     // 32 x 8 threads; each 8 rows x 4 columns
   float acc[8][4];
@@ -110,8 +113,14 @@ hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const fl
   const int v1 = rk_vec(A1, lda1, B1, ldb1, K1) ? 1 : 0;
   const int v2 = (K2 > 0 && rk_vec(A2, lda2, B2, ldb2, K2)) ? 1 : 0;
   const int vc = (ldc % 4 == 0 && (uintptr_t)C % 16 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(rankk_nt_kernel, grid, dim3(RK_THREADS), 0, st, M, N, K1, alpha1, A1, lda1, B1, ldb1, K2, alpha2, A2,
-                     lda2, B2, ldb2, beta, C, ldc, v1, v2, vc);
+  const int kmax = K1 > K2 ? K1 : K2;
+#define MCGRA_RK_LAUNCH(KM)                                                                                          \
+  hipLaunchKernelGGL(rankk_nt_kernel<KM>, grid, dim3(RK_THREADS), 0, st, M, N, K1, alpha1, A1, lda1, B1, ldb1, K2, alpha2, \
+                     A2, lda2, B2, ldb2, beta, C, ldc, v1, v2, vc)
+  if (kmax <= 16) MCGRA_RK_LAUNCH(16);
+  else if (kmax <= 32) MCGRA_RK_LAUNCH(32);
+  else MCGRA_RK_LAUNCH(64);
+#undef MCGRA_RK_LAUNCH
   return hipGetLastError();
 }
 
