@@ -145,14 +145,18 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
   auto frag = [&](const char* s, int off) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + off)); };
   auto multiply = [&](int stage, auto&& after_first_reads) {
     const char* s = smem + stage * STAGE;
+    // read order = use order of the first row tile's products (a2 b0, a1 b1, a0 b2, ...): LDS returns in order, so
+    // the first MFMA after the barrier waits for three reads instead of nine
     bf16x8 b0[2], b1[2], b2[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      b0[j] = frag(s, b_off + j * 512);
-      b1[j] = frag(s, b_off + j * 512 + PLANE);
-      b2[j] = frag(s, b_off + j * 512 + 2 * PLANE);
-    }
-    bf16x8 a0 = frag(s, a_off), a1 = frag(s, a_off + PLANE), a2 = frag(s, a_off + 2 * PLANE);
+    bf16x8 a2 = frag(s, a_off + 2 * PLANE);
+    b0[0] = frag(s, b_off);
+    b0[1] = frag(s, b_off + 512);
+    bf16x8 a1 = frag(s, a_off + PLANE);
+    b1[0] = frag(s, b_off + PLANE);
+    b1[1] = frag(s, b_off + 512 + PLANE);
+    bf16x8 a0 = frag(s, a_off);
+    b2[0] = frag(s, b_off + 2 * PLANE);
+    b2[1] = frag(s, b_off + 512 + 2 * PLANE);
     after_first_reads();     // staging of later tiles queues behind this step's first fragment reads
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
