@@ -107,7 +107,7 @@ struct mcgra_attack {
   bool lr_step = false;            // the step in flight takes it (no relu-masked pair in the decode)
   int lr_ldv = 0;
   float *lrL = 0, *lrV = 0, *lrT = 0, *lrR = 0, *lrQ = 0, *lrDelta = 0, *lrC = 0;
-  double *lrStats = 0, *lrRs = 0;
+  double *lrStats = 0, *lrRs = 0, *lrQtZ = 0;
   unsigned int* nmask = 0;
   int64_t lr_steps = 0, general_steps = 0;
   // second stream: the one N x N x N product of the low-rank path depends only on adj_norm, so it is forked
@@ -352,7 +352,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     if (h->lr_ok) {
       h->lr_ldv = (2 * he + 1 + 3) & ~3;
       A_(lrL, n * 2 * he); A_(lrR, n * 2 * he); A_(lrQ, n * 2 * he); A_(lrV, n * (size_t)h->lr_ldv);
-      A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, lr_stats_doubles(he)); A_(lrRs, ld);
+      A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, lr_stats_doubles(he)); A_(lrRs, ld); A_(lrQtZ, lr_qtz_doubles(he));
     }
     A_(nmask, 4);
     // The one N x N x N product of a low-rank step.  Default for n >= 1024: the 3-plane bf16 split on the bf16 matrix
@@ -868,16 +868,18 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // ---- backward: decode (S = Zn Zn^T, A1 = offdiag relu(S))
   if (hsic && h->lr_step && use2 && lr_decode_supported(he)) {
     // ((G + G^T) o [S > 0]) Zn for G = ie'(A1) + 2 s2 Q Z^T, without materialising G (c7 value from the same pass)
-    const int np = launch_lr_decode_bwd(st, n, ld, he, h->A1, h->Zn, h->hmax, h->lrQ, (float)(k7 / n2),
-                                        2.f * (float)(sg * k2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax);
-    launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, np, 1, h->scal + S_V7);
+    const int np = launch_lr_decode_bwd(st, n, ld, he, h->A1, h->Zn, h->hmax, h->lrQ, (float)(k7 / n2), h->ws,
+                                        h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->lrQtZ);
+    if (np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, np, 1, h->scal + S_V7);
   } else {
     launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
     CHK(eg(h, st, false, false, n, he, n, 1.f, h->G_A, ld, h->Zn, h->hmax, 0.f, h->GZn, h->hmax));
   }
   if (hsic && h->lr_step && use2) {   // the -2 s2 KX D part of d c2 / d A1, applied to Zn directly
+    const bool fused = lr_decode_supported(he);
     launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->lrRs, -2.f * (float)(sg * k2), h->GZn, h->hmax,
-                    h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld);
+                    h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld, fused ? h->lrStats + 2 * he : nullptr,
+                    fused ? h->lrQtZ : nullptr, 2.f * (float)(sg * k2));
     launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
   }
   launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);

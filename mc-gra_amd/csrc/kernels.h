@@ -93,8 +93,9 @@ void launch_argmax_eq(hipStream_t st, int m, int c, const float* logp, int ld, c
 size_t lr_stats_doubles(int h);
 int lr_decode_slabs(int n);
 bool lr_decode_supported(int h);
+size_t lr_qtz_doubles(int h);
 int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
-                         float kie7, float a2, float* slabs, double* v7part, float* GZn, int ldg);
+                         float kie7, float* slabs, double* v7part, float* GZn, int ldg, double* qtz);
 void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats);
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta);
@@ -103,6 +104,7 @@ void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const
 void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
                     const float* cvec, float a1, float a2, float* G, double* rowval);
 void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
-                     const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval);
+                     const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
+                     const double* ztz = nullptr, const double* qtz = nullptr, float a2 = 0.f);
 
 }  // namespace mcgra

@@ -131,12 +131,14 @@ __global__ __launch_bounds__(256) void k_lr_elem(int n, int ld, const float* __r
 }
 
 // per node i, after QQ = Xc [W | W2] (ld 2h) and rs_i = |xc_i|^2:
-//   G_Zn_i += kk (Q2_i + delta_i Q_i - 2 rs_i delta_i z_i)          (kk = -2 s2)
+//   G_Zn_i += kk (Q2_i + delta_i Q_i - 2 rs_i delta_i z_i)          (kk = -2 s2: the Kx D part of d c2 / d A1)
+//   G_Zn_i += a2 (q_i (Z^T Z) + z_i (Q^T Z) - 2 (q_i . z_i) z_i)    (ztz != nullptr: the Q Z^T part, see k_lr_decode_bwd)
 //   rowval_i = quad_i - 2 delta_i z_i . Q_i + delta_i^2 rs_i       (quad from k_lr_post; the sum is |R|_F^2)
 __global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const float* __restrict__ Z, int ldz,
                            const float* __restrict__ delta, const double* __restrict__ rs, float kk,
                            float* __restrict__ GZn, int ldg, const double* __restrict__ quad,
-                           double* __restrict__ rowval) {
+                           double* __restrict__ rowval, const double* __restrict__ ztz,
+                           const double* __restrict__ qtz, float a2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float d = delta[i];
@@ -144,48 +146,49 @@ __global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const flo
   const float* q = QQ + (size_t)i * 2 * h;
   const float* z = Z + (size_t)i * ldz;
   double zq = 0.0;
+  for (int k = 0; k < h; ++k) zq += (double)z[k] * (double)q[k];
   for (int k = 0; k < h; ++k) {
-    zq += (double)z[k] * (double)q[k];
-    GZn[(size_t)i * ldg + k] += kk * (q[h + k] + d * q[k] - 2.f * r * d * z[k]);
+    float add = kk * (q[h + k] + d * q[k] - 2.f * r * d * z[k]);
+    if (ztz) {
+      double t = -2.0 * zq * (double)z[k];
+      for (int b = 0; b < h; ++b) t += (double)q[b] * ztz[(size_t)b * h + k] + (double)z[b] * qtz[(size_t)b * h + k];
+      add += a2 * (float)t;
+    }
+    GZn[(size_t)i * ldg + k] += add;
   }
   rowval[i] = quad[i] - 2.0 * (double)d * zq + (double)d * (double)d * rs[i];
 }
 
 // stats needs 2h + h^2 doubles followed by (h + 2) * LR_PARTS * h doubles of scratch
 size_t lr_stats_doubles(int h) { return (size_t)2 * h + (size_t)h * h + (size_t)(h + 2) * LR_PARTS * h; }
-// Decode backward of a low-rank step without materialising d loss / d modified_adj1:
-//   G_Zn_i = sum_{j != i, A1_ij > 0} [ 2 ie'(A1_ij) + a2 (q_i.z_j + q_j.z_i) ] z_j
-// i.e. ((G + G^T) o [S > 0]) Zn for G = ie'(A1) + a2 Q Z^T (c7's entropy gradient and the Q Z^T part of c2), which
-// replaces an elementwise write, a rank-k update, the mirror/mask pass and a skinny product over N x N buffers.
+// Decode backward of a low-rank step without materialising d loss / d modified_adj1.  With every off-diagonal pair
+// active in the relu (the precondition of a low-rank step) the mask of ((G + G^T) o [S > 0]) Zn is only the diagonal, so
+// for G = ie'(A1) + a2 Q Z^T:
+//   G_Zn_i = sum_{j != i} 2 ie'(A1_ij) z_j                                      (this kernel: the only N x N pass, and only if c7 is on)
+//          + a2 [ Q (Z^T Z) + Z (Q^T Z) - 2 diag(q_i . z_i) Z ]_i                (k_lr_part2: O(n h^2))
+// which replaces an elementwise write, a rank-k update, the mirror/mask pass and a skinny product over N x N buffers.
 // A1 is symmetric (bit-exactly: both halves are the same fmaf chain), so thread i reads A1[j][i]: coalesced in i,
-// with z_j, q_j wave-uniform.  The j range is split over blockIdx.y into slabs that are summed in fixed order.
+// with z_j wave-uniform (LDS broadcast).  The j range is split over blockIdx.y into slabs summed in fixed order.
 // v7part: per-block partial of sum ie_value(A1) (c7's value).
 template <int H>
 __global__ __launch_bounds__(256) void k_lr_decode_bwd(int n, int ld, const float* __restrict__ A1,
-                                                       const float* __restrict__ Z, int ldz,
-                                                       const float* __restrict__ QQ, float kie7, float a2, int jper,
+                                                       const float* __restrict__ Z, int ldz, float kie7, int jper,
                                                        float* __restrict__ slabs, double* __restrict__ v7part) {
-  constexpr int JC = 64;                       // columns staged per chunk: z_j | q_j, read back as LDS broadcasts
-  __shared__ __attribute__((aligned(16))) float zq[JC][2 * H];
+  constexpr int JC = 128;                      // columns staged per chunk, read back as LDS broadcasts
+  __shared__ __attribute__((aligned(16))) float zs[JC][H];
   __shared__ double sh[16];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < n;
   const int j0 = blockIdx.y * jper, j1 = min(n, j0 + jper);
-  float zi[H], qi[H], acc[H];
+  float acc[H];
 #pragma unroll
-  for (int k = 0; k < H; ++k) {
-    zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f;
-    qi[k] = valid ? QQ[(size_t)i * 2 * H + k] : 0.f;
-    acc[k] = 0.f;
-  }
+  for (int k = 0; k < H; ++k) acc[k] = 0.f;
   double v7 = 0.0;
   for (int jc = j0; jc < j1; jc += JC) {
     __syncthreads();
-    for (int e = threadIdx.x; e < JC * 2 * H; e += 256) {
-      const int jj = e / (2 * H), c = e - jj * 2 * H, j = jc + jj;
-      float v = 0.f;
-      if (j < j1) v = c < H ? Z[(size_t)j * ldz + c] : QQ[(size_t)j * 2 * H + (c - H)];
-      zq[jj][c] = v;
+    for (int e = threadIdx.x; e < JC * H; e += 256) {
+      const int jj = e / H, c = e - jj * H, j = jc + jj;
+      zs[jj][c] = j < j1 ? Z[(size_t)j * ldz + c] : 0.f;
     }
     __syncthreads();
     const int jn = min(JC, j1 - jc);
@@ -194,23 +197,16 @@ __global__ __launch_bounds__(256) void k_lr_decode_bwd(int n, int ld, const floa
       const int j = jc + jj;
       const float a = a_next;
       if (jj + 1 < jn) a_next = valid ? A1[(size_t)(j + 1) * ld + i] : 0.f;
-      float zj[H], qj[H];
+      float val, g;
+      ie_term(a, kie7, val, g);
+      v7 += (double)val;
+      const float w = (i != j && a > 0.f) ? 2.f * g : 0.f;
 #pragma unroll
       for (int k = 0; k < H; k += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&zq[jj][k]);
-        zj[k] = t.x; zj[k + 1] = t.y; zj[k + 2] = t.z; zj[k + 3] = t.w;
-        const float4 u = *reinterpret_cast<const float4*>(&zq[jj][H + k]);
-        qj[k] = u.x; qj[k + 1] = u.y; qj[k + 2] = u.z; qj[k + 3] = u.w;
+        const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
+        acc[k] = fmaf(w, t.x, acc[k]); acc[k + 1] = fmaf(w, t.y, acc[k + 1]);
+        acc[k + 2] = fmaf(w, t.z, acc[k + 2]); acc[k + 3] = fmaf(w, t.w, acc[k + 3]);
       }
-      float dq = 0.f, dz = 0.f;
-#pragma unroll
-      for (int k = 0; k < H; ++k) { dq = fmaf(qi[k], zj[k], dq); dz = fmaf(qj[k], zi[k], dz); }
-      float val = 0.f, g = 0.f;
-      if (kie7 != 0.f) ie_term(a, kie7, val, g);
-      v7 += (double)val;
-      const float w = (i != j && a > 0.f) ? 2.f * g + a2 * (dq + dz) : 0.f;
-#pragma unroll
-      for (int k = 0; k < H; ++k) acc[k] = fmaf(w, zj[k], acc[k]);
     }
   }
   if (valid) {
@@ -220,6 +216,34 @@ __global__ __launch_bounds__(256) void k_lr_decode_bwd(int n, int ld, const floa
   }
   const double t = block_sum_d(valid ? v7 : 0.0, sh);
   if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+// QtZ[b][k] = sum_i X[i][b] Z[i][k] in fp64, two deterministic stages like k_lr_colstats_*
+__global__ __launch_bounds__(256) void k_lr_xtz_part(int n, int h, const float* __restrict__ X, int ldx,
+                                                     const float* __restrict__ Z, int ldz, double* __restrict__ part) {
+  __shared__ double sh[16];
+  const int b = blockIdx.x, pz = blockIdx.y;
+  const int per = (n + LR_PARTS - 1) / LR_PARTS, i0 = pz * per, i1 = min(n, i0 + per);
+  double acc[LR_HMAX];
+#pragma unroll
+  for (int k = 0; k < LR_HMAX; ++k) acc[k] = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+    const double wgt = (double)X[(size_t)i * ldx + b];
+    const float* z = Z + (size_t)i * ldz;
+#pragma unroll
+    for (int k = 0; k < LR_HMAX; ++k)
+      if (k < h) acc[k] += wgt * (double)z[k];
+  }
+  for (int k = 0; k < h; ++k) {
+    const double t = block_sum_d(acc[k], sh);
+    if (threadIdx.x == 0) part[((size_t)b * LR_PARTS + pz) * h + k] = t;
+  }
+}
+__global__ void k_lr_xtz_fin(int h, const double* __restrict__ part, double* __restrict__ out) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= h) return;
+  double t = 0.0;
+  for (int pz = 0; pz < LR_PARTS; ++pz) t += part[((size_t)b * LR_PARTS + pz) * h + k];
+  out[(size_t)b * h + k] = t;
 }
 __global__ void k_lr_sum_slabs(int n, int h, int nslab, const float* __restrict__ slabs, float* __restrict__ out,
                                int ldo) {
@@ -238,14 +262,22 @@ int lr_decode_slabs(int n) {
   if (js > n / 64) js = n / 64;        // keeps nb * js partials <= n and the j slices >= 64 long
   return js < 1 ? 1 : js;
 }
+// GZn (beta = 0) = sum_{j != i} 2 ie'(A1_ij) z_j and the v7 partials (returns their count); kie7 == 0: no N x N pass,
+// GZn = 0.  qtz (h*h + scratch doubles, see lr_qtz_doubles) receives Q^T Z for k_lr_part2.
+size_t lr_qtz_doubles(int h) { return (size_t)h * h + (size_t)h * LR_PARTS * h; }
 int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
-                         float kie7, float a2, float* slabs, double* v7part, float* GZn, int ldg) {
+                         float kie7, float* slabs, double* v7part, float* GZn, int ldg, double* qtz) {
+  double* part = qtz + (size_t)h * h;
+  LAUNCH(k_lr_xtz_part, dim3(h, LR_PARTS), dim3(256), st, n, h, QQ, 2 * h, Z, ldz, part);
+  LAUNCH(k_lr_xtz_fin, dim3(h), dim3(64), st, h, part, qtz);
+  if (kie7 == 0.f) {
+    (void)hipMemset2DAsync(GZn, (size_t)ldg * sizeof(float), 0, (size_t)h * sizeof(float), n, st);
+    return 0;
+  }
   const int nb = (n + 255) / 256, js = lr_decode_slabs(n), jper = (n + js - 1) / js;
-  // embedding widths are padded to the next supported H; Z / QQ columns beyond h must then be zero, which holds for
-  // widths that are themselves 8, 16 or 32 (others: see lr_decode_supported)
-  if (h == 8) LAUNCH(k_lr_decode_bwd<8>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, QQ, kie7, a2, jper, slabs, v7part);
-  else if (h == 16) LAUNCH(k_lr_decode_bwd<16>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, QQ, kie7, a2, jper, slabs, v7part);
-  else LAUNCH(k_lr_decode_bwd<32>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, QQ, kie7, a2, jper, slabs, v7part);
+  if (h == 8) LAUNCH(k_lr_decode_bwd<8>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, kie7, jper, slabs, v7part);
+  else if (h == 16) LAUNCH(k_lr_decode_bwd<16>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, kie7, jper, slabs, v7part);
+  else LAUNCH(k_lr_decode_bwd<32>, dim3(nb, js), dim3(256), st, n, ld, A1, Z, ldz, kie7, jper, slabs, v7part);
   LAUNCH(k_lr_sum_slabs, dim3((n * h + 255) / 256), dim3(256), st, n, h, js, slabs, GZn, ldg);
   return nb * js;
 }
@@ -268,8 +300,9 @@ void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float*
   LAUNCH(k_lr_elem, dim3(n), dim3(256), st, n, ld, Xc, P1, delta, cvec, a1, a2, G, rowval);
 }
 void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
-                     const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval) {
-  LAUNCH(k_lr_part2, dim3((n + 255) / 256), dim3(256), st, n, h, QQ, Z, ldz, delta, rs, kk, GZn, ldg, quad, rowval);
+                     const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
+                     const double* ztz, const double* qtz, float a2) {
+  LAUNCH(k_lr_part2, dim3((n + 63) / 64), dim3(64), st, n, h, QQ, Z, ldz, delta, rs, kk, GZn, ldg, quad, rowval, ztz, qtz, a2);
 }
 
 }  // namespace mcgra
