@@ -192,20 +192,27 @@ __global__ __launch_bounds__(256) void k_lr_decode_bwd(int n, int ld, const floa
     }
     __syncthreads();
     const int jn = min(JC, j1 - jc);
-    float a_next = valid ? A1[(size_t)jc * ld + i] : 0.f;
-    for (int jj = 0; jj < jn; ++jj) {
-      const int j = jc + jj;
-      const float a = a_next;
-      if (jj + 1 < jn) a_next = valid ? A1[(size_t)(j + 1) * ld + i] : 0.f;
-      float val, g;
-      ie_term(a, kie7, val, g);
-      v7 += (double)val;
-      const float w = (i != j && a > 0.f) ? 2.f * g : 0.f;
+    // eight rows of A1 in flight per thread: one dependent 4-byte load per row would make the loop latency-bound
+    constexpr int JB = 8;
+    for (int jb = 0; jb < jn; jb += JB) {
+      float av[JB];
 #pragma unroll
-      for (int k = 0; k < H; k += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
-        acc[k] = fmaf(w, t.x, acc[k]); acc[k + 1] = fmaf(w, t.y, acc[k + 1]);
-        acc[k + 2] = fmaf(w, t.z, acc[k + 2]); acc[k + 3] = fmaf(w, t.w, acc[k + 3]);
+      for (int u = 0; u < JB; ++u) av[u] = (valid && jb + u < jn) ? A1[(size_t)(jc + jb + u) * ld + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        const int jj = jb + u, j = jc + jj;
+        if (jj < jn) {
+          float val, g;
+          ie_term(av[u], kie7, val, g);
+          v7 += (double)val;
+          const float w = (i != j && av[u] > 0.f) ? 2.f * g : 0.f;
+#pragma unroll
+          for (int k = 0; k < H; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
+            acc[k] = fmaf(w, t.x, acc[k]); acc[k + 1] = fmaf(w, t.y, acc[k + 1]);
+            acc[k + 2] = fmaf(w, t.z, acc[k + 2]); acc[k + 3] = fmaf(w, t.w, acc[k + 3]);
+          }
+        }
       }
     }
   }
