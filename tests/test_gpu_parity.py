@@ -523,7 +523,8 @@ def _synthetic_case(n, nfeat, widths, nclass, seed, measure="HSIC", weight_param
 
 
 @pytest.mark.parametrize("n,widths,expect", [(97, (12, 12), "lowrank"), (130, (24, 8), "lowrank"),
-                                             (96, (40, 40), "general"), (150, (16, 16, 16), "lowrank")])
+                                             (96, (40, 40), "general"), (150, (16, 16, 16), "lowrank"),
+                                             (1100, (16, 16), "lowrank"), (1283, (16, 8), "lowrank")])
 def test_engine_matches_oracle_on_odd_shapes(pkg, n, widths, expect):
     """n not a multiple of 4 / 128, embedding widths outside {8, 16, 32} (unfused decode backward) and > 32 (Gram
     evaluation): teacher-forced per-step gradient against the oracle."""
@@ -539,6 +540,9 @@ def test_engine_matches_oracle_on_odd_shapes(pkg, n, widths, expect):
         eng.set_adj_changes(O.pack_tril(orc.M))           # teacher forcing
     ps = eng.path_stats()
     assert (ps["lowrank_steps"], ps["general_steps"]) == ((3, 0) if expect == "lowrank" else (0, 3))
+    # n >= 1024 takes the default bf16-split product (mode 2) unless the environment overrides it
+    if "MCGRA_SPLIT_BF16" not in os.environ:
+        assert eng.product_mode() == (2 if (n >= 1024 and expect == "lowrank") else 0)
 
 
 @pytest.mark.parametrize("wp", [(0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000),
