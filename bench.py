@@ -195,7 +195,8 @@ def sharded_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, mon
         dist.all_reduce(diff, op=dist.ReduceOp.MAX)
     return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "row_blocks": world,
             "rows_per_rank": plan.rows_per_rank, "max_abs_diff_across_ranks": float(diff.item()),
-            "exchange": "2 x all_gather_into_tensor of 2 row-block buffers per step (RCCL)"}
+            "exchange": "all_gather_into_tensor (RCCL) of the row blocks mcgra_attack_exchange_mask names: P1 (buffer KX) on a "
+                        "low-rank step, KX+KY and G_adjn+G_A1 on a Gram step"}
 
 
 PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
