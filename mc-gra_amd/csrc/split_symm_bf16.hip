@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __res
   if (k0 >= nkc * KC) return;
   float v[8];
   const float mu = (sub && row < n) ? sub[row] : 0.f;
+  if (!sym && row < n && k0 + 7 < n && (ld & 3) == 0) {      // interior: two 16-byte loads
+    const float4 x0 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0);
+    const float4 x1 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0 + 4);
+    v[0] = x0.x - mu; v[1] = x0.y - mu; v[2] = x0.z - mu; v[3] = x0.w - mu;
+    v[4] = x1.x - mu; v[5] = x1.y - mu; v[6] = x1.z - mu; v[7] = x1.w - mu;
+  } else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = k0 + j;
