@@ -254,7 +254,9 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode,
 
 /* Device pointer + shape of a named intermediate of the last step, for parity
  * tests ("adj_norm", "A1", "em", "G_adjn", "G_A1", "G_A", "G_sym", "M", "d",
- * "r", "logp", "sm2", "HA", "YA", "T0").  ld receives the leading dimension. */
+ * "r", "logp", "sm2", "HA", "YA", "T0", "KFC").  ld receives the leading dimension.  "G_sym" (the mirrored packed
+ * gradient of the last step) is kept only when MCGRA_KEEP_GSYM=1 was set at create; on a low-rank step "G_A1" does not
+ * hold d loss / d modified_adj1 (it is never materialised there). */
 int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr,
                         int* rows, int* cols, int* ld);
 /* copy of the same intermediate into a caller buffer dst [rows x cols], leading dimension dst_ld */
