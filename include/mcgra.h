@@ -198,7 +198,10 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
  * scalars_out (host, may be NULL) receives after a stream sync:
  *   [0] loss  [1] origin_loss  [2] c1 [3] c2 [4] c6 [5] c7 [6] c9 [7] c10
  *   [8] sum(clamp(adj_changes,0,1)) after the update  [9] nll
- * Passing NULL keeps the call asynchronous. */
+ * Passing NULL keeps the call asynchronous, except for one 4-byte device-to-host readback per step on HSIC
+ * configurations with w2 != 0 (the count of relu-masked decode pairs that selects the low-rank or the Gram
+ * evaluation).  When the preceding call on this handle was mcgra_attack_monitor (and eps == 0) the
+ * step adopts that call's forward instead of recomputing it (same bits). */
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
                       double* scalars_out);
 
