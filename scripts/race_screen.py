@@ -1,0 +1,35 @@
+"""Race screen for split3_symm_kernel (new barrier structure): many repetitions at sizes around the panel / K-step /
+split-K edges, every result compared bitwise with the first and against fp64 once.  Usage: race_screen.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import mcgra_loader
+pkg = mcgra_loader.load()
+from mc_gra_amd import engine as E
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+bad = 0
+for n in (257, 1000, 2708, 4100, 6000, 10000):
+    g = torch.Generator(device="cuda"); g.manual_seed(n)
+    F = torch.randn(n, 24, device="cuda", generator=g)
+    S = F @ F.T
+    S = (S + S.T) * 0.5
+    X = (torch.rand(n, n, device="cuda", generator=g) - 0.3) * 0.1
+    sub = torch.rand(n, device="cuda", generator=g) * 0.05
+    first = E.ssymm_split_bf16(S, X, sub).clone()
+    ref = S[:256].double() @ (X.double() - sub.double()[:, None]).T
+    scale = S[:256].abs().double() @ (X.double() - sub.double()[:, None]).abs().T
+    err = float(((first[:256].double() - ref).abs() / scale).max())
+    mism = 0
+    for r in range(reps):
+        # other work in between so that cache / clock / scheduling state differs between repetitions
+        if r % 3 == 0:
+            _ = torch.mm(X[:2048, :2048], X[:2048, :2048])
+        out = E.ssymm_split_bf16(S, X, sub)
+        if not torch.equal(out, first):
+            mism += 1
+    bad += mism + (err > 1e-6)
+    print(f"n={n}: err vs fp64 {err:.2e}, {mism} of {reps} repetitions differ", flush=True)
+print("RACE SCREEN", "FAILED" if bad else "clean")
+sys.exit(1 if bad else 0)
