@@ -273,7 +273,8 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
   hipLaunchKernelGGL(k_pack3, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (__hip_bfloat16*)out);
 }
 // C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
-// (panel_rows < 0: all panels).  Tiles are independent, so a row range gives the same bits as the full launch.
+// (panel_rows < 0: all panels).  Tiles are independent; a row range gives the same bits as the full launch except for
+// the tiles of the ragged last round, whose split along K depends on how many tiles the launch has.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes) {
   const int nkc = (n + KC - 1) / KC, tiles = (n + TB - 1) / TB;

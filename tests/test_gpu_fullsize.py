@@ -71,7 +71,7 @@ def test_lowrank_and_gram_evaluations_agree_at_10k(ctx, monkeypatch):
     assert gram.path_stats()["general_steps"] == 2
 
 
-def test_sharded_phases_bit_identical_at_10k(ctx):
+def test_sharded_phases_match_monolithic_at_10k(ctx):
     pkg, torch, bench, dev = ctx
     from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend
     n = bench.WORKLOADS[WL][0]
@@ -91,7 +91,12 @@ def test_sharded_phases_bit_identical_at_10k(ctx):
                             dst.exchanged[name][blk].copy_(src.exchanged[name][blk])
         ref = full.get_adj_changes()
         for b in bks:
-            assert torch.equal(b.eng.get_adj_changes(), ref), f"step {t}"
+            a = b.eng.get_adj_changes()
+            assert torch.equal(a, bks[0].eng.get_adj_changes()), f"ranks diverged at step {t}"     # replicas: always bitwise
+            # vs the monolithic step: the fp32 products give the same bits (same tiles, same k order); the default
+            # bf16-split product cuts the tiles of its ragged last round along K, and which tiles those are depends on
+            # the launch's row range, so there the agreement is to fp32 rounding
+            assert float((a - ref).abs().max()) <= 1e-6, f"step {t}"
     assert bks[0].exchange_names(1) == ["KX"] and bks[0].exchange_names(2) == []      # low-rank step: one buffer travels
 
 
