@@ -201,7 +201,10 @@ def sharded_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, mon
 
 PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
                  1: "3-plane bf16 split, hipBLASLt bf16 GEMM n x n x 6n on K-concatenated planes",
-                 2: "3-plane bf16 split, hand-written split3_symm_kernel on packed planes (256 x 256 tiles)"}
+                 2: "3-plane bf16 split, hand-written split3_symm_kernel on packed planes (256 x 256 tiles)",
+                 3: "2-plane fp16 split (3 plane products, exact power-of-two operand scales), hand-written "
+                    "split3_symm_kernel on packed planes (256 x 256 tiles)"}
+PLANE_PRODUCTS = {0: 1, 1: 6, 2: 6, 3: 3}
 
 
 def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode):
@@ -239,7 +242,7 @@ def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode)
         out["product_avg_launch_ms"] = ms
         out["product_fp32_equivalent_tflops"] = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
         if pm:
-            out["product_bf16_tflops_issued"] = 12.0 * n ** 3 / (ms * 1e-3) / 1e12
+            out["product_16bit_tflops_issued"] = 2.0 * PLANE_PRODUCTS[pm] * n ** 3 / (ms * 1e-3) / 1e12
     return out
 
 
@@ -359,7 +362,9 @@ def main():
             "metric": "attack-steps/sec", "value": aggregate_value(world, a.steps, dt), "unit": "attack-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not pmode else "f32 (the N x N x N product: operands as 3 bf16 planes, 6 MFMA products, fp32 accumulate)",
+            "dtype": "f32" if not pmode else ("f32 (the N x N x N product: operands as 2 fp16 planes, 3 MFMA products, fp32 accumulate)"
+                                              if pmode == 3 else
+                                              "f32 (the N x N x N product: operands as 3 bf16 planes, 6 MFMA products, fp32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": a.workload, "nodes": n, "features": f, "gcn_layers": nl, "hidden": hid,
                        "classes": c, "measure": measure, "priors": "H_A+Y_A+Y", "weight_param": list(wp),
@@ -384,21 +389,23 @@ def main():
             ps = eng_path
             lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
             tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-            role = "split" if (lowrank and pmode == 2) else "symm"
+            role = {2: "split", 3: "split_f16"}.get(pmode, "symm") if lowrank else "symm"
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
                 ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == role or not lowrank]
                 traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks)) if ks else None
             if lowrank and pmode:
-                # the bf16 matrix cores issue 6 plane products per fp32-equivalent product: 12 n^3 flop per launch
-                issued = 6.0 * ach
+                # the 16-bit matrix cores issue 6 (bf16 x 3) or 3 (fp16 x 2) plane products per fp32-equivalent product
+                npp = PLANE_PRODUCTS[pmode]
+                issued = npp * ach
+                arith = ("2-plane fp16 split: 3 plane products per product" if pmode == 3 else
+                         "3-plane bf16 split: 6 plane products per product")
                 out["roofline"] = {"bound": "mfma",
-                                   "kernel": ("split3_symm_kernel" if pmode == 2 else "hipBLASLt bf16 GEMM") +
+                                   "kernel": ("hipBLASLt bf16 GEMM" if pmode == 1 else "split3_symm_kernel") +
                                              " (P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step, as a "
-                                             "3-plane bf16 split: 6 plane products per product, fp32 accumulate, fp32-level "
-                                             "error; one launch per step)",
+                                             + arith + ", fp32 accumulate, fp32-level error; one launch per step)",
                                    "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": issued / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent_tflops": ach,
-                                   "algorithmic_flop_per_launch": 12.0 * n ** 3,
+                                   "algorithmic_flop_per_launch": 2.0 * npp * n ** 3,
                                    "traffic": traffic, "traffic_unit": "bytes/launch",
                                    "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
                                    "gemm_share_of_step": st["ms"] / (1e3 * dt)}

@@ -77,6 +77,12 @@ int mcgra_ssymm_lower(void* stream, int n, int m, float alpha, const float* S, i
  * operands itself (the engine keeps S packed across steps). */
 int mcgra_ssymm_split_bf16(void* stream, int n, const float* S, int lds, const float* X, int ldx, const float* rowsub,
                            float* C, int ldc);
+/* The same product as the 2-plane fp16 split (the engine's default for n >= 1024): each operand scaled by an exact
+ * power of two that puts its largest magnitude in [2^14, 2^15), written as x0 + x1 in fp16, the three products x0 y0 +
+ * x0 y1 + x1 y0 in the fp32 accumulator of the fp16 MFMA, scales undone exactly in the epilogue.  Half the
+ * matrix-core work of the 3-plane form; fp32-level error for elements within 2^18 of their operand's maximum. */
+int mcgra_ssymm_split_f16(void* stream, int n, const float* S, int lds, const float* X, int ldx, const float* rowsub,
+                          float* C, int ldc);
 
 /* Tuning knob for A/B measurements in one process: 2 = double-buffered LDS K loop
  * (default), 1 = single LDS stage with two barriers per K tile.  Same results bit for bit. */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
-    "mcgra_attack_step_phase", "mcgra_attack_bind_buffer", "mcgra_attack_exchange_mask", "mcgra_attack_path_stats", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16",
+    "mcgra_attack_step_phase", "mcgra_attack_bind_buffer", "mcgra_attack_exchange_mask", "mcgra_attack_path_stats", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
     "mcgra_attack_monitor", "mcgra_attack_finalize", "mcgra_attack_buffer", "mcgra_attack_copy_buffer",
     "mcgra_attack_profile",
     "mcgra_attack_gemm_stats",
@@ -92,6 +92,7 @@ def _load():
         "mcgra_attack_exchange_mask": [vp],
         "mcgra_attack_product_mode": [vp],
         "mcgra_ssymm_split_bf16": [vp, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_int],
+        "mcgra_ssymm_split_f16": [vp, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_int],
         "mcgra_attack_path_stats": [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
         "mcgra_attack_monitor": [vp, vp, fp, C.POINTER(C.c_double)],
         "mcgra_attack_finalize": [vp, vp, C.c_int, fp, fp, fp, fp],

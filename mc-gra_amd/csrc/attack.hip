@@ -120,6 +120,8 @@ struct mcgra_attack {
   bool split_on = false;
   int split_mode = 0;              // 1: planes concatenated along K through hipBLASLt; 2: hand-written kernel on packed planes
   unsigned char *Apack = 0, *Bpack = 0;
+  int split_planes = 3;            // 3: bf16 x 3 (six products); 2: fp16 x 2 (three products, operand scales from amax)
+  float *amax = 0;                 // [0] max |H Kf H| (per graph), [1] max |Xc| (per step, from the centring pass)
   unsigned short *Acat = 0, *Bcat = 0;
   int64_t split_steps = 0;
   GemmTimer timer;
@@ -355,11 +357,12 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(lrT, n * (size_t)h->lr_ldv); A_(lrDelta, ld); A_(lrC, ld); A_(lrStats, lr_stats_doubles(he)); A_(lrRs, ld); A_(lrQtZ, lr_qtz_doubles(he));
     }
     A_(nmask, 4);
-    // The one N x N x N product of a low-rank step.  Default for n >= 1024: the 3-plane bf16 split on the bf16 matrix
-    // cores (split_symm_bf16.hip: fp32-level error, 1.7x the fp32 MFMA SYMM).  MCGRA_SPLIT_BF16=0: fp32 MFMA SYMM;
-    // =1: the split through a hipBLASLt GEMM on K-concatenated planes; =2: the split kernel at any size.
+    // The one N x N x N product of a low-rank step.  Default for n >= 1024: the 2-plane fp16 split on the 16-bit matrix
+    // cores (split_symm_bf16.hip: fp32-level error, three plane products).  MCGRA_SPLIT_BF16=0: fp32 MFMA SYMM;
+    // =1: the 3-plane bf16 split through a hipBLASLt GEMM on K-concatenated planes; =2: the 3-plane bf16 split
+    // kernel (six products, fp32 exponent range) at any size; =3: the 2-plane fp16 kernel at any size.
     const char* es = getenv("MCGRA_SPLIT_BF16");
-    const char auto_mode[2] = {n >= 1024 ? '2' : '0', 0};
+    const char auto_mode[2] = {n >= 1024 ? '3' : '0', 0};
     if (!es || !es[0]) es = auto_mode;
     if (!rc && h->lr_ok && cfg->eps == 0.f && es && es[0] == '1') {
       if (!split_bf16_available()) { rc = MCGRA_ENOSUP; }
@@ -370,8 +373,10 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         h->split_mode = 1;
       }
     }
-    if (!rc && h->lr_ok && cfg->eps == 0.f && es && es[0] == '2') {
-      A_(Apack, split3_pack_bytes((int)n)); A_(Bpack, split3_pack_bytes((int)n));
+    if (!rc && h->lr_ok && cfg->eps == 0.f && es && (es[0] == '2' || es[0] == '3')) {
+      h->split_planes = es[0] == '3' ? 2 : 3;
+      A_(Apack, split3_pack_bytes((int)n, h->split_planes)); A_(Bpack, split3_pack_bytes((int)n, h->split_planes));
+      A_(amax, 2);
       h->split_on = (rc == 0);
       h->split_mode = 2;
     }
@@ -478,7 +483,13 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
     launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->cmean, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
     if (h->split_mode == 1) split3_planes_sym(st, n, ld, h->KFC, h->Acat);     // bf16 planes of the constant Gram, once
-    if (h->split_mode == 2) split3_pack(st, n, ld, h->KFC, nullptr, true, h->Apack);
+    if (h->split_mode == 2) {
+      if (h->split_planes == 2) {
+        MCGRA_HIP(hipMemsetAsync(h->amax, 0, sizeof(float), st));
+        split_absmax(st, n, ld, h->KFC, nullptr, true, h->amax);
+      }
+      split3_pack(st, n, ld, h->KFC, nullptr, true, h->Apack, h->split_planes, h->amax);
+    }
     launch_rowsumsq(st, n, ld, h->KFC, h->rowsx);
     launch_reduce_rows(st, h->rowsx, n, 1, h->cst + 0);      // hsic(feature_adj, feature_adj)
   }
@@ -674,7 +685,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (want_xc) {
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
     if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
-    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr);
+    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr,
+                       (h->split_mode == 2 && h->split_planes == 2) ? h->amax + 1 : nullptr);
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
@@ -683,7 +695,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       // (row blocks of a sharded step must start on a 256-row panel for the split kernel; otherwise fp32 SYMM)
       const bool split_now = h->split_on && !noise && (h->split_mode == 1 || (c.row_begin % split3_panel()) == 0);
       if (split_now && h->split_mode == 1) split3_planes_rows(st, n, ld, h->ADJN, h->cmean, h->Bcat);
-      if (split_now && h->split_mode == 2) split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack);
+      if (split_now && h->split_mode == 2)
+        split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr);
       if (h->overlap) {
         MCGRA_HIP(hipEventRecord(h->ev_fork, st));
         MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
@@ -698,7 +711,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         else {
           const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
           // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
-          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld));
+          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld,
+                                h->split_planes, h->amax));
         }
         CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
         ++h->split_steps;
@@ -995,7 +1009,9 @@ int mcgra_attack_exchange_mask(mcgra_attack_t* h) {
   return MCGRA_EXCHANGE_KX | (use2 ? MCGRA_EXCHANGE_KY : 0) | MCGRA_EXCHANGE_G_ADJN | (use2 ? MCGRA_EXCHANGE_G_A1 : 0);
 }
 
-int mcgra_attack_product_mode(mcgra_attack_t* h) { return h ? h->split_mode : 0; }
+int mcgra_attack_product_mode(mcgra_attack_t* h) {
+  return h ? (h->split_mode == 2 && h->split_planes == 2 ? 3 : h->split_mode) : 0;
+}
 
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps) {
   if (!h) { set_error("null handle"); return MCGRA_EINVAL; }

@@ -63,21 +63,35 @@ int mcgra_ssymm_lower(void* stream, int n, int m, float alpha, const float* S, i
   return 0;
 }
 
-int mcgra_ssymm_split_bf16(void* stream, int n, const float* S, int lds_, const float* X, int ldx, const float* rowsub,
-                           float* C, int ldc) {
+static int ssymm_split(void* stream, int planes, int n, const float* S, int lds_, const float* X, int ldx,
+                       const float* rowsub, float* C, int ldc) {
   if (n < 1 || !S || !X || !C) { set_error("bad argument"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   Scratch s;
-  const size_t pb = split3_pack_bytes(n);
+  const size_t pb = split3_pack_bytes(n, planes);
   unsigned char* Ap = s.get<unsigned char>(pb); NEED(Ap);
   unsigned char* Bp = s.get<unsigned char>(pb); NEED(Bp);
   const size_t slab_bytes = (size_t)64 << 20;
   float* slab = s.get<float>(slab_bytes / sizeof(float)); NEED(slab);
-  split3_pack(st, n, lds_, S, nullptr, true, Ap);
-  split3_pack(st, n, ldx, X, rowsub, false, Bp);
-  MCGRA_HIP(split3_symm(st, n, Ap, Bp, C, ldc, 0, -1, slab, slab_bytes));
+  float* amax = s.get<float>(2); NEED(amax);
+  if (planes == 2) {
+    MCGRA_HIP(hipMemsetAsync(amax, 0, 2 * sizeof(float), st));
+    split_absmax(st, n, lds_, S, nullptr, true, amax);
+    split_absmax(st, n, ldx, X, rowsub, false, amax + 1);
+  }
+  split3_pack(st, n, lds_, S, nullptr, true, Ap, planes, amax);
+  split3_pack(st, n, ldx, X, rowsub, false, Bp, planes, amax + 1);
+  MCGRA_HIP(split3_symm(st, n, Ap, Bp, C, ldc, 0, -1, slab, slab_bytes, planes, amax));
   MCGRA_HIP(hipStreamSynchronize(st));
   return 0;
+}
+int mcgra_ssymm_split_bf16(void* stream, int n, const float* S, int lds_, const float* X, int ldx, const float* rowsub,
+                           float* C, int ldc) {
+  return ssymm_split(stream, 3, n, S, lds_, X, ldx, rowsub, C, ldc);
+}
+int mcgra_ssymm_split_f16(void* stream, int n, const float* S, int lds_, const float* X, int ldx, const float* rowsub,
+                          float* C, int ldc) {
+  return ssymm_split(stream, 2, n, S, lds_, X, ldx, rowsub, C, ldc);
 }
 
 int mcgra_set_gemm_variant(int v) {

@@ -49,11 +49,14 @@ void split3_planes_sym(hipStream_t st, int n, int ld, const float* S_lower, void
 void split3_planes_rows(hipStream_t st, int n, int ld, const float* X, const float* mean, void* Bcat);
 int split_bf16_gemm(hipStream_t st, int n, int row0, int nrows, const void* Acat, const void* Bcat, float* C, int ldc);
 
-// split_symm_bf16.hip (opt-in, MCGRA_SPLIT_BF16=2): the same split as a hand-written kernel on packed planes
-size_t split3_pack_bytes(int n);
-void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out);
+// split_symm_bf16.hip: the split as a hand-written kernel on packed planes; planes = 3 (bf16 x 3, six products,
+// MCGRA_SPLIT_BF16=2) or 2 (fp16 x 2 with exact power-of-two operand scales from amax, three products, =3)
+size_t split3_pack_bytes(int n, int planes = 3);
+void split_absmax(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, float* amax);
+void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out, int planes = 3,
+                 const float* amax = nullptr);
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
-                       int panel_rows, float* slab, size_t slab_bytes);
+                       int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr);
 int split3_panel();
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------

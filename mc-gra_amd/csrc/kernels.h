@@ -19,7 +19,7 @@ void launch_reduce_rows(hipStream_t st, const double* rowvals, int n, int nvec, 
 void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows);
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total);
 void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* mean_scratch,
-                        float* out, double* rowsq = nullptr);
+                        float* out, double* rowsq = nullptr, float* absmax = nullptr);
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower);
 void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out);

@@ -231,17 +231,20 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center(int n, int ld, float* __
 // instead of cancelling an O(n) mean (measured on Cora's feature_adj: 3e-7 vs 2e-4 relative).
 // rowsq (optional): |row|^2 of the centred result in fp64 (diag of the centred Gram, lowrank_kernels.hip).
 // The column means arrive as fp32 (k_colmean_f32: fp64 sum / n rounded once), so the pass is pure fp32 streaming.
-__global__ void k_colmean_f32(int n, int ld, const double* __restrict__ colsum, float* __restrict__ mean) {
+__global__ void k_colmean_f32(int n, int ld, const double* __restrict__ colsum, float* __restrict__ mean,
+                              unsigned* __restrict__ absmax) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (absmax && j == 0) *absmax = 0u;      // reset for k_center_cols' atomicMax (next launch on the stream)
   if (j < ld) mean[j] = j < n ? (float)(colsum[j] / (double)n) : 0.f;
 }
 __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, const float* __restrict__ X,
                                                              const float* __restrict__ mean,
-                                                             float* __restrict__ out, double* __restrict__ rowsq) {
+                                                             float* __restrict__ out, double* __restrict__ rowsq,
+                                                             unsigned* __restrict__ absmax) {
   __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, amx = 0.f;
   double s = 0;
   for (int j = threadIdx.x * 4; j < n; j += ROW_THREADS * 4) {
     f32x4 x = *reinterpret_cast<const f32x4*>(X + base + j);
@@ -249,7 +252,13 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, cons
 #pragma unroll
     for (int t = 0; t < 4; ++t) x[t] = (j + t < n) ? x[t] - mu[t] : 0.f;
     s0 = fmaf(x[0], x[0], s0); s1 = fmaf(x[1], x[1], s1); s2 = fmaf(x[2], x[2], s2); s3 = fmaf(x[3], x[3], s3);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
     *reinterpret_cast<f32x4*>(out + base + j) = x;
+  }
+  if (absmax) {     // largest |xc| (operand scale of the 2-plane fp16 split); non-negative floats order as uints
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(absmax, __float_as_uint(amx));
   }
   if (rowsq) {      // <= ceil(n / 1024) fp32 terms per partial, then fp64
     s = (double)s0 + (double)s1 + (double)s2 + (double)s3;
@@ -876,9 +885,9 @@ void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, 
   LAUNCH(k_center, dim3(n), dim3(ROW_THREADS), st, n, ld, K, rows, total);
 }
 void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* mean_scratch,
-                        float* out, double* rowsq) {
-  LAUNCH(k_colmean_f32, dim3((ld + 255) / 256), dim3(256), st, n, ld, rows, mean_scratch);
-  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, mean_scratch, out, rowsq);
+                        float* out, double* rowsq, float* absmax) {
+  LAUNCH(k_colmean_f32, dim3((ld + 255) / 256), dim3(256), st, n, ld, rows, mean_scratch, (unsigned*)absmax);
+  LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, mean_scratch, out, rowsq, (unsigned*)absmax);
 }
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower) {

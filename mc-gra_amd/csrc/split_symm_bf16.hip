@@ -1,6 +1,13 @@
-// OPT-IN (MCGRA_SPLIT_BF16=2): hand-written kernel for the 3-plane bf16 split of P1 = (H Kf H) Xc
-// (see split_bf16.hip for the arithmetic: x = x0 + x1 + x2 in bf16, the six plane products with i + j <= 2 summed
-// in the MFMA's fp32 accumulator, fp32-level error).
+// Hand-written kernel for the split evaluation of P1 = (H Kf H) Xc on the 16-bit matrix cores, two arithmetics:
+//   planes = 3 (MCGRA_SPLIT_BF16=2): x = x0 + x1 + x2 in bf16, the six plane products with i + j <= 2 summed in the
+//     MFMA's fp32 accumulator (see split_bf16.hip); representation error 2^-24, fp32 exponent range.
+//   planes = 2 (MCGRA_SPLIT_BF16=3): x 2^s = x0 + x1 in fp16 (11 significant bits each; s puts the operand's largest
+//     magnitude in [2^14, 2^15), applied exactly and undone exactly in the epilogue), the three products x0 y0 + x0 y1
+//     + x1 y0: HALF the matrix-core work.  Representation error 2^-22 for elements within 2^18 of the operand's
+//     maximum (smaller ones keep an absolute error of 2^-40 of the maximum), dropped x1 y1 term 2^-22: measured
+//     1e-7 of |A||B| against the 3e-7 of the fp32 accumulation itself.
+// The text below describes the 3-plane kernel; the 2-plane one stages two 16-k chunks per step (32 k, 64 KB) so that
+// the barrier cadence per MFMA stays the same.
 //
 // What a library GEMM on K-concatenated planes cannot do is REUSE planes: here one K step stages the three planes
 // of both operands once (48 KB) and every fragment read from LDS feeds up to three MFMAs (a0 with b0, b1, b2; a1
@@ -19,6 +26,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -30,15 +38,26 @@ namespace mcgra {
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: arrays of it stay in scratch)
 
 constexpr int TB = 256;                       // block tile (rows of A' and of B'^T)
 constexpr int KC = 16;                        // k per step = one MFMA K
-constexpr int PLANE = TB * KC * 2;            // 8192 bytes: one plane of one operand for one step
-constexpr int OPB = 3 * PLANE;                // 24576 bytes per operand and step
-constexpr int STAGE = 2 * OPB;                // 49152
-constexpr int THREADS = 512;
-constexpr int LD_PER_T = STAGE / THREADS / 16;  // 6 x 16 B per thread and step
+constexpr int PLANE = TB * KC * 2;            // 8192 bytes: one plane of one operand for one 16-k chunk
+constexpr int THREADS = 512;                  // one 16-byte copy per thread moves exactly one PLANE
+// NP planes, KSUB chunks per step: NP * PLANE bytes per operand and chunk; a stage is [A chunks][B chunks]
+template <int NP, int KSUB> struct SplitCfg {
+  static constexpr int OPB = NP * PLANE;
+  static constexpr int AOPS = NP * KSUB;        // 16-byte copies per thread, operand and step
+  static constexpr int STAGE = 2 * KSUB * OPB;  // 48 KB (3 planes, 16 k) or 64 KB (2 planes, 32 k)
+};
+
+// exact power-of-two scale of the 2-plane arithmetic: amax = f 2^e, f in [0.5, 1)  ->  x 2^(15 - e) in [2^14, 2^15)
+__device__ __forceinline__ int amax_exp(float amax) {
+  int e = 0;
+  if (amax > 0.f && amax < 3.0e38f) frexpf(amax, &e);
+  return e;
+}
 
 __device__ __forceinline__ void split3(float x, __hip_bfloat16& p0, __hip_bfloat16& p1, __hip_bfloat16& p2) {
   p0 = __float2bfloat16(x);
@@ -50,8 +69,9 @@ __device__ __forceinline__ void split3(float x, __hip_bfloat16& p0, __hip_bfloat
 
 // pack rows of a [n x n] fp32 matrix (value(row, k) = X[row][k] - sub[row], or the symmetric S given in lower tile
 // storage when sub == nullptr and sym != 0) into [panel][kchunk][plane][k half][row][8].  One thread: 8 consecutive k of a row.
-__global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
-                                               int sym, int nkc, __hip_bfloat16* __restrict__ out) {
+template <int NP>
+__global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
+                                              int sym, int nkc, char* __restrict__ out, const float* __restrict__ amax) {
   // block: 32 rows x 8 (k chunk pairs of 8): thread (r, c): row = blockIdx.y * 32 + r, k0 = (blockIdx.x * 8 + c) * 8
   const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
   const int row = blockIdx.y * 32 + r;
@@ -79,22 +99,64 @@ __global__ __launch_bounds__(256) void k_pack3(int n, int ld, const float* __res
     }
     v[j] = x;
   }
-  __hip_bfloat16 p[3][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
   const int panel = row / TB, rin = row % TB, kc = k0 / KC, half = (k0 % KC) / 8;
-  char* base = reinterpret_cast<char*>(out) + ((size_t)panel * nkc + kc) * OPB + (size_t)half * (PLANE / 2) + (size_t)rin * 16;
+  char* base = out + ((size_t)panel * nkc + kc) * (NP * PLANE) + (size_t)half * (PLANE / 2) + (size_t)rin * 16;
+  if constexpr (NP == 3) {
+    __hip_bfloat16 p[3][8];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(base + q * PLANE) = *reinterpret_cast<const uint4*>(p[q]);
+    for (int j = 0; j < 8; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(base + q * PLANE) = *reinterpret_cast<const uint4*>(p[q]);
+  } else {
+    const float s = ldexpf(1.f, 15 - amax_exp(*amax));
+    f16x8 p0, p1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = v[j] * s;                 // exact
+      p0[j] = (_Float16)t;
+      p1[j] = (_Float16)(t - (float)p0[j]);     // the residual is exact in fp32
+    }
+    *reinterpret_cast<f16x8*>(base) = p0;
+    *reinterpret_cast<f16x8*>(base + PLANE) = p1;
+  }
+}
+
+// largest magnitude of the values k_pack would pack (same value rule), as fp32 bits: non-negative floats order as uints
+__global__ __launch_bounds__(256) void k_split_absmax(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
+                                                      int sym, unsigned* __restrict__ amax) {
+  const int row = blockIdx.x;
+  const float mu = sub ? sub[row] : 0.f;
+  const int lim = (row / SYM_TILE + 1) * SYM_TILE;
+  float m = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const float x = sym ? (k < lim ? X[(size_t)row * ld + k] : X[(size_t)k * ld + row]) : X[(size_t)row * ld + k] - mu;
+    m = fmaxf(m, fabsf(x));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
 }
 
 // One launch covers the linear tile ids [tile_base, tile_base + gridDim.x / ksplit) of the tiles_m x tiles_n tile grid.
 // ksplit > 1 (the ragged last round of a launch, split3_symm): each tile's K range is cut into ksplit parts whose
 // partial tiles go to `slab` ([part][tile - tile_base][256][256]) and are summed in fixed order by k_split3_reduce.
+// nks = K steps of KSUB chunks each (the packed operands hold nks * KSUB chunks per panel, zero padded).
+template <int NP>
+__device__ __forceinline__ f32x16 plane_mma(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (NP == 3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int NP, int KSUB>
 __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
-                                                                 float* __restrict__ C, int n, int ldc, int nkc,
+                                                                 float* __restrict__ C, int n, int ldc, int nks,
                                                                  int tiles_m, int tiles_n, int panel_off, int tile_base,
-                                                                 int ksplit, float* __restrict__ slab) {
+                                                                 int ksplit, float* __restrict__ slab,
+                                                                 const float* __restrict__ amax) {
+  using CF = SplitCfg<NP, KSUB>;
+  constexpr int OPB = CF::OPB, AOPS = CF::AOPS, STAGE = CF::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tile_m, tile_n, lin, part;
   {  // XCD-aware bijective remap of this launch's blocks, then 4-panel groups over the whole tile grid (gemm_f32.hip)
@@ -112,14 +174,14 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
     tile_m = first_m + (lin % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
     tile_n = (lin % group_sz) / gm;
   }
-  const int kper = (nkc + ksplit - 1) / ksplit;
+  const int kper = (nks + ksplit - 1) / ksplit;
   const int kc_begin = part * kper;
-  const int nk = max(0, min(nkc, kc_begin + kper) - kc_begin);          // K steps of this block
+  const int nk = max(0, min(nks, kc_begin + kper) - kc_begin);          // K steps of this block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, wave tile 128 x 64
   const int l31 = lane & 31, lh = lane >> 5;
-  const char* ga = Ap + ((size_t)tile_m * nkc + kc_begin) * OPB + (size_t)tid * 16;
-  const char* gb = Bp + ((size_t)tile_n * nkc + kc_begin) * OPB + (size_t)tid * 16;
+  const char* ga = Ap + ((size_t)tile_m * nks + kc_begin) * (KSUB * OPB) + (size_t)tid * 16;
+  const char* gb = Bp + ((size_t)tile_n * nks + kc_begin) * (KSUB * OPB) + (size_t)tid * 16;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -130,59 +192,85 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // two register sets: the tile two steps ahead is in flight while the tile one step ahead is stored to LDS
-  u32x4 rg[2][LD_PER_T];
+  u32x4 rg[2][2 * AOPS];
   auto gload = [&](auto rs_, int kc) {
     constexpr int RS = decltype(rs_)::value;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rg[RS][i] = *reinterpret_cast<const u32x4*>(ga + (size_t)kc * OPB + i * PLANE);
+    for (int i = 0; i < AOPS; ++i) rg[RS][i] = *reinterpret_cast<const u32x4*>(ga + (size_t)kc * (KSUB * OPB) + i * PLANE);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rg[RS][3 + i] = *reinterpret_cast<const u32x4*>(gb + (size_t)kc * OPB + i * PLANE);
+    for (int i = 0; i < AOPS; ++i) rg[RS][AOPS + i] = *reinterpret_cast<const u32x4*>(gb + (size_t)kc * (KSUB * OPB) + i * PLANE);
   };
   auto lstore = [&](auto rs_, int stage) {
     constexpr int RS = decltype(rs_)::value;
     char* s = smem + stage * STAGE + tid * 16;
 #pragma unroll
-    for (int i = 0; i < LD_PER_T; ++i) *reinterpret_cast<u32x4*>(s + i * PLANE) = rg[RS][i];
+    for (int i = 0; i < 2 * AOPS; ++i) *reinterpret_cast<u32x4*>(s + i * PLANE) = rg[RS][i];
   };
   using R0 = std::integral_constant<int, 0>;
   using R1 = std::integral_constant<int, 1>;
-  const int a_off = lh * (PLANE / 2) + (wm * 128 + l31) * 16;        // + i * 512 (row tile) + plane * PLANE
-  const int b_off = OPB + lh * (PLANE / 2) + (wn * 64 + l31) * 16;   // + j * 512 + plane * PLANE
-  auto frag = [&](const char* s, int off) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + off)); };
+  const int a_off = lh * (PLANE / 2) + (wm * 128 + l31) * 16;                 // + i * 512 (row tile) + plane * PLANE
+  const int b_off = KSUB * OPB + lh * (PLANE / 2) + (wn * 64 + l31) * 16;     // + j * 512 + plane * PLANE
+  auto frag = [&](const char* s, int off) { return *reinterpret_cast<const u32x4*>(s + off); };
+#define MCGRA_P(A_, B_)                                      \
+  acc[i][0] = plane_mma<NP>(A_, B_[0], acc[i][0]);           \
+  acc[i][1] = plane_mma<NP>(A_, B_[1], acc[i][1]);
   auto multiply = [&](int stage, auto&& after_first_reads) {
-    const char* s = smem + stage * STAGE;
-    // read order = use order of the first row tile's products (a2 b0, a1 b1, a0 b2, ...): LDS returns in order, so
-    // the first MFMA after the barrier waits for three reads instead of nine
-    bf16x8 b0[2], b1[2], b2[2];
-    bf16x8 a2 = frag(s, a_off + 2 * PLANE);
-    b0[0] = frag(s, b_off);
-    b0[1] = frag(s, b_off + 512);
-    bf16x8 a1 = frag(s, a_off + PLANE);
-    b1[0] = frag(s, b_off + PLANE);
-    b1[1] = frag(s, b_off + 512 + PLANE);
-    bf16x8 a0 = frag(s, a_off);
-    b2[0] = frag(s, b_off + 2 * PLANE);
-    b2[1] = frag(s, b_off + 512 + 2 * PLANE);
-    after_first_reads();     // staging of later tiles queues behind this step's first fragment reads
+    if constexpr (NP == 3) {
+      const char* s = smem + stage * STAGE;
+      // read order = use order of the first row tile's products (a2 b0, a1 b1, a0 b2, ...): LDS returns in order, so
+      // the first MFMA after the barrier waits for three reads instead of nine
+      u32x4 b0[2], b1[2], b2[2];
+      u32x4 a2 = frag(s, a_off + 2 * PLANE);
+      b0[0] = frag(s, b_off);
+      b0[1] = frag(s, b_off + 512);
+      u32x4 a1 = frag(s, a_off + PLANE);
+      b1[0] = frag(s, b_off + PLANE);
+      b1[1] = frag(s, b_off + 512 + PLANE);
+      u32x4 a0 = frag(s, a_off);
+      b2[0] = frag(s, b_off + 2 * PLANE);
+      b2[1] = frag(s, b_off + 512 + 2 * PLANE);
+      after_first_reads();     // staging of later tiles queues behind this step's first fragment reads
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16x8 n0 = a0, n1 = a1, n2 = a2;
-      if (i + 1 < 4) {      // next row tile's fragments in flight during this one's 12 MFMAs
-        n0 = frag(s, a_off + (i + 1) * 512);
-        n1 = frag(s, a_off + (i + 1) * 512 + PLANE);
-        n2 = frag(s, a_off + (i + 1) * 512 + 2 * PLANE);
+      for (int i = 0; i < 4; ++i) {
+        u32x4 n0 = a0, n1 = a1, n2 = a2;
+        if (i + 1 < 4) {      // next row tile's fragments in flight during this one's 12 MFMAs
+          n0 = frag(s, a_off + (i + 1) * 512);
+          n1 = frag(s, a_off + (i + 1) * 512 + PLANE);
+          n2 = frag(s, a_off + (i + 1) * 512 + 2 * PLANE);
+        }
+        // The six plane products of a tile, smallest terms first (they meet an accumulator that has not yet absorbed
+        // this step's leading product), alternating between the two column tiles so that consecutive MFMAs never
+        // depend on each other's accumulator.
+        MCGRA_P(a2, b0) MCGRA_P(a1, b1) MCGRA_P(a0, b2) MCGRA_P(a1, b0) MCGRA_P(a0, b1) MCGRA_P(a0, b0)
+        a0 = n0; a1 = n1; a2 = n2;
       }
-      // The six plane products of a tile, smallest terms first (they meet an accumulator that has not yet absorbed
-      // this step's leading product), alternating between the two column tiles so that consecutive MFMAs never
-      // depend on each other's accumulator.
-#define MCGRA_P(A_, B_)                                                                   \
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[0], acc[i][0], 0, 0, 0); \
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[1], acc[i][1], 0, 0, 0);
-      MCGRA_P(a2, b0) MCGRA_P(a1, b1) MCGRA_P(a0, b2) MCGRA_P(a1, b0) MCGRA_P(a0, b1) MCGRA_P(a0, b0)
-#undef MCGRA_P
-      a0 = n0; a1 = n1; a2 = n2;
+    } else {
+#pragma unroll
+      for (int u = 0; u < KSUB; ++u) {
+        const char* s = smem + stage * STAGE + u * OPB;
+        u32x4 b0[2], b1[2];
+        u32x4 a1 = frag(s, a_off + PLANE);
+        b0[0] = frag(s, b_off);
+        b0[1] = frag(s, b_off + 512);
+        u32x4 a0 = frag(s, a_off);
+        b1[0] = frag(s, b_off + PLANE);
+        b1[1] = frag(s, b_off + 512 + PLANE);
+        if (u == 0) after_first_reads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 n0 = a0, n1 = a1;
+          if (i + 1 < 4) {
+            n0 = frag(s, a_off + (i + 1) * 512);
+            n1 = frag(s, a_off + (i + 1) * 512 + PLANE);
+          }
+          // x1 y0 + x0 y1 (the 2^-11 corrections) ahead of x0 y0, alternating column tiles as above
+          MCGRA_P(a1, b0) MCGRA_P(a0, b1) MCGRA_P(a0, b0)
+          a0 = n0; a1 = n1;
+        }
+      }
     }
   };
+#undef MCGRA_P
 
   // Step t multiplies stage t & 1.  At its top (behind the first fragment reads) the tile for step t+1, in flight
   // since the top of step t-1, is written to the other stage -- free since the barrier that ended step t-1 -- and the
@@ -211,6 +299,15 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
   }
   }
 
+  if constexpr (NP == 2) {                // undo the operand scales 2^(15 - ea) 2^(15 - eb): exact
+    const float inv = ldexpf(1.f, amax_exp(amax[0]) + amax_exp(amax[1]) - 30);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+  }
   // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): 128-byte row segments per instruction
   if (ksplit > 1) {
     float* o = slab + ((size_t)part * (gridDim.x / ksplit) + (lin - tile_base)) * (TB * TB);
@@ -261,34 +358,62 @@ __global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__
     if (gc + 3 < n) o[3] = v.w;
   }
 }
+
+// 16-k chunks per panel in the packed operands: the 2-plane kernel steps two chunks at a time (zero-padded)
+int chunks_of(int n, int planes) {
+  const int nkc = (n + KC - 1) / KC;
+  return planes == 2 ? (nkc + 1) & ~1 : nkc;
+}
+
+template <int NP, int KSUB>
+hipError_t launch_split(hipStream_t st, int grid, const void* Apack, const void* Bpack, float* C, int n, int ldc, int nkc,
+                        int tm, int tiles, int panel_off, int tile_base, int ksplit, float* slab, const float* amax) {
+  static bool attr_done = false;
+  constexpr int smem = 2 * SplitCfg<NP, KSUB>::STAGE;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((split3_symm_kernel<NP, KSUB>), dim3(grid), dim3(THREADS), smem, st, (const char*)Apack, (const char*)Bpack,
+                     C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax);
+  return hipSuccess;
+}
 }  // namespace
 
-size_t split3_pack_bytes(int n) {
-  const size_t panels = (n + TB - 1) / TB, nkc = (n + KC - 1) / KC;
-  return panels * nkc * OPB;
+size_t split3_pack_bytes(int n, int planes) {
+  const size_t panels = (n + TB - 1) / TB;
+  return panels * chunks_of(n, planes) * (size_t)planes * PLANE;
 }
-void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out) {
-  const int nkc = (n + KC - 1) / KC, panels = (n + TB - 1) / TB;
+// largest magnitude of the operand (2-plane arithmetic only): amax must be zero on entry
+void split_absmax(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, float* amax) {
+  hipLaunchKernelGGL(k_split_absmax, dim3(n), dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, (unsigned*)amax);
+}
+void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out, int planes,
+                 const float* amax) {
+  const int nkc = chunks_of(n, planes), panels = (n + TB - 1) / TB;
   dim3 grid((nkc * 2 + 7) / 8, panels * (TB / 32));
-  hipLaunchKernelGGL(k_pack3, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (__hip_bfloat16*)out);
+  if (planes == 2) hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax);
+  else hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax);
 }
 // C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
 // (panel_rows < 0: all panels).  Tiles are independent; a row range gives the same bits as the full launch except for
 // the tiles of the ragged last round, whose split along K depends on how many tiles the launch has.
+// planes == 2: amax[0], amax[1] = the magnitudes the operands were packed with.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
-                       int panel_rows, float* slab, size_t slab_bytes) {
-  const int nkc = (n + KC - 1) / KC, tiles = (n + TB - 1) / TB;
+                       int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax) {
+  const int nkc = chunks_of(n, planes), tiles = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles;
   if (tm <= 0) return hipSuccess;
   static bool attr_done = false;
-  static int slots = 256;
+  static int slots = 256, ksub2 = 2;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    if (e != hipSuccess) return e;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         cus > 0)
       slots = cus;               // one block per CU
+    const char* e = getenv("MCGRA_SPLIT_KSUB");      // experiment switch: 16-k steps for the 2-plane kernel
+    if (e && e[0] == '1') ksub2 = 1;
     attr_done = true;
   }
   // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so
@@ -301,12 +426,20 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     while (ksplit > 1 && (size_t)ksplit * rem * TB * TB * sizeof(float) > slab_bytes) --ksplit;
   }
   if (ksplit <= 1) { full = total; rem = 0; }
-  if (full > 0)
-    hipLaunchKernelGGL(split3_symm_kernel, dim3(full), dim3(THREADS), 2 * STAGE, st, (const char*)Apack, (const char*)Bpack, C,
-                       n, ldc, nkc, tm, tiles, panel_off, 0, 1, nullptr);
+  auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
+    if (planes == 2 && ksub2 == 2)
+      return launch_split<2, 2>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
+    if (planes == 2)
+      return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
+    return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
+  };
+  if (full > 0) {
+    hipError_t e = launch(full, 0, 1, nullptr);
+    if (e != hipSuccess) return e;
+  }
   if (rem > 0) {
-    hipLaunchKernelGGL(split3_symm_kernel, dim3(rem * ksplit), dim3(THREADS), 2 * STAGE, st, (const char*)Apack,
-                       (const char*)Bpack, C, n, ldc, nkc, tm, tiles, panel_off, full, ksplit, slab);
+    hipError_t e = launch(rem * ksplit, full, ksplit, slab);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, full);
   }
   return hipGetLastError();

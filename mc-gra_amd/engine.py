@@ -77,6 +77,15 @@ def ssymm_split_bf16(S, X, rowsub=None, out=None):
     return out
 
 
+def ssymm_split_f16(S, X, rowsub=None, out=None):
+    """The same product through the 2-plane fp16 split kernel (mcgra_ssymm_split_f16); S symmetric."""
+    n = S.shape[0]
+    if out is None:
+        out = torch.empty(n, n, device=S.device, dtype=torch.float32)
+    check(lib.mcgra_ssymm_split_f16(_stream(), n, _p(S), S.stride(0), _p(X), X.stride(0), _p(rowsub), _p(out), out.stride(0)))
+    return out
+
+
 def normalize_adj_tensor(adj):
     """utils.normalize_adj_tensor, dense branch (utils.py:211-230)."""
     out = torch.empty_like(adj)

@@ -1,5 +1,6 @@
 """Race screen for split3_symm_kernel (new barrier structure): many repetitions at sizes around the panel / K-step /
-split-K edges, every result compared bitwise with the first and against fp64 once.  Usage: race_screen.py [reps]"""
+split-K edges, every result compared bitwise with the first and against fp64 once.
+Usage: race_screen.py [reps] [f16|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +10,7 @@ pkg = mcgra_loader.load()
 from mc_gra_amd import engine as E
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+split = E.ssymm_split_bf16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else E.ssymm_split_f16   # default: the engine's default
 bad = 0
 for n in (257, 1000, 2708, 4100, 6000, 10000):
     g = torch.Generator(device="cuda"); g.manual_seed(n)
@@ -17,7 +19,7 @@ for n in (257, 1000, 2708, 4100, 6000, 10000):
     S = (S + S.T) * 0.5
     X = (torch.rand(n, n, device="cuda", generator=g) - 0.3) * 0.1
     sub = torch.rand(n, device="cuda", generator=g) * 0.05
-    first = E.ssymm_split_bf16(S, X, sub).clone()
+    first = split(S, X, sub).clone()
     ref = S[:256].double() @ (X.double() - sub.double()[:, None]).T
     scale = S[:256].abs().double() @ (X.double() - sub.double()[:, None]).abs().T
     err = float(((first[:256].double() - ref).abs() / scale).max())
@@ -26,7 +28,7 @@ for n in (257, 1000, 2708, 4100, 6000, 10000):
         # other work in between so that cache / clock / scheduling state differs between repetitions
         if r % 3 == 0:
             _ = torch.mm(X[:2048, :2048], X[:2048, :2048])
-        out = E.ssymm_split_bf16(S, X, sub)
+        out = split(S, X, sub)
         if not torch.equal(out, first):
             mism += 1
     bad += mism + (err > 1e-6)

@@ -540,9 +540,9 @@ def test_engine_matches_oracle_on_odd_shapes(pkg, n, widths, expect):
         eng.set_adj_changes(O.pack_tril(orc.M))           # teacher forcing
     ps = eng.path_stats()
     assert (ps["lowrank_steps"], ps["general_steps"]) == ((3, 0) if expect == "lowrank" else (0, 3))
-    # n >= 1024 takes the default bf16-split product (mode 2) unless the environment overrides it
+    # n >= 1024 takes the default split product (mode 3: two fp16 planes) unless the environment overrides it
     if "MCGRA_SPLIT_BF16" not in os.environ:
-        assert eng.product_mode() == (2 if (n >= 1024 and expect == "lowrank") else 0)
+        assert eng.product_mode() == (3 if (n >= 1024 and expect == "lowrank") else 0)
 
 
 @pytest.mark.parametrize("wp", [(0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000),
@@ -563,16 +563,18 @@ def test_lowrank_with_single_terms(pkg, wp, monkeypatch):
     assert fast.path_stats()["lowrank_steps"] == 2
 
 
-# ---- opt-in 3-plane bf16 split of the P1 product (split_bf16.hip) ------------------------------------------------
-@pytest.mark.parametrize("mode", ["1", "2"])
+# ---- split evaluations of the P1 product on the 16-bit matrix cores (split_bf16.hip, split_symm_bf16.hip) -----------
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
 @pytest.mark.parametrize("case", ["s200_hsic_init", "s48_hsic"])
 def test_split_bf16_matches_fp32_path(pkg, case, mode, monkeypatch):
-    """MCGRA_SPLIT_BF16=1: same gradients as the fp32 MFMA path to fp32 rounding (the split keeps 24 mantissa bits)."""
+    """MCGRA_SPLIT_BF16=1/2/3: same gradients as the fp32 MFMA path to fp32 rounding (the splits keep 24 / 22
+    mantissa bits; 3 = two fp16 planes, the default of graphs with n >= 1024)."""
     z = H.load_case(case)
     ref = H.engine_from(pkg, z)
-    monkeypatch.setenv("MCGRA_SPLIT_BF16", mode)      # 1: hipBLASLt on concatenated planes, 2: hand-written kernel
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", mode)      # 1: hipBLASLt on concatenated planes, 2 / 3: hand-written kernel
     try:
         spl = H.engine_from(pkg, z)
+        assert spl.product_mode() == int(mode)
     except Exception as e:                       # hipBLASLt missing on the box: the option refuses loudly
         pytest.skip(f"split path unavailable: {e}")
     finally:
@@ -632,13 +634,16 @@ def test_side_stream_overlap_is_bit_identical(pkg, monkeypatch):
         assert ra == rb and torch.equal(a.get_adj_changes(), b.get_adj_changes())
 
 
+@pytest.mark.parametrize("arith", ["bf16", "f16"])
 @pytest.mark.parametrize("n", [33, 256, 257, 511, 1000, 1537, 2708, 4100])
-def test_split_bf16_product_against_fp64(pkg, torch_, n):
-    """mcgra_ssymm_split_bf16 at sizes around the 256-row panels, the 16-wide K steps and the split-K tail: error against
-    fp64 within the fp32-product class (<= 1e-6 of |S||B|), asymmetric B exposes any transposition, repeat runs are
-    bit-identical (the barrier structure of a new kernel is screened over several runs and sizes)."""
+def test_split_bf16_product_against_fp64(pkg, torch_, n, arith):
+    """mcgra_ssymm_split_bf16 / _f16 at sizes around the 256-row panels, the 16-wide K chunks (the fp16 kernel steps
+    two at a time: odd chunk counts are padded) and the split-K tail: error against fp64 within the fp32-product class
+    (<= 1e-6 of |S||B|), asymmetric B exposes any transposition, repeat runs are bit-identical (the barrier structure
+    of a new kernel is screened over several runs and sizes)."""
     import torch
     from mc_gra_amd import engine as E
+    split = E.ssymm_split_bf16 if arith == "bf16" else E.ssymm_split_f16
     rng = np.random.RandomState(n)
     F = rng.randn(n, 24).astype(np.float32)
     S = (F @ F.T).astype(np.float32)
@@ -646,7 +651,7 @@ def test_split_bf16_product_against_fp64(pkg, torch_, n):
     X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1            # NOT symmetric
     sub = rng.rand(n).astype(np.float32) * 0.05
     Sd, Xd, sd = dev(torch_, S), dev(torch_, X), dev(torch_, sub)
-    outs = [E.ssymm_split_bf16(Sd, Xd, sd).clone() for _ in range(4)]
+    outs = [split(Sd, Xd, sd).clone() for _ in range(4)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     B = (X.astype(np.float64) - sub.astype(np.float64)[:, None])
@@ -658,3 +663,30 @@ def test_split_bf16_product_against_fp64(pkg, torch_, n):
     Bt = torch.tensor(np.ascontiguousarray(B.T.astype(np.float32)), device="cuda")
     f32 = E.ssymm_lower(Sd, Bt).cpu().numpy().astype(np.float64)
     assert err.max() <= 4 * (np.abs(f32 - ref) / scale).max() + 2e-7
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.0e-12, 7.0e11])
+def test_split_f16_product_operand_scales(pkg, torch_, scale):
+    """The fp16 planes live in [2^-24, 2^16): the kernel's exact power-of-two operand scales must make the result
+    independent of the operands' magnitude (here 1e-12 ... 1e12, far outside fp16) -- scaling both operands by powers
+    of two gives bit-identical mantissas -- and elements 2^20 below their operand's maximum keep the error class."""
+    import torch
+    from mc_gra_amd import engine as E
+    n = 700
+    rng = np.random.RandomState(5)
+    S = rng.randn(n, n).astype(np.float32) * np.exp2(rng.randint(-20, 1, (n, n))).astype(np.float32)
+    S = (S + S.T) * 0.5
+    X = rng.randn(n, n).astype(np.float32) * np.exp2(rng.randint(-20, 1, (n, n))).astype(np.float32)
+    Ss = (S * np.float32(scale)).astype(np.float32)
+    Xs = (X * np.float32(4.0 / scale)).astype(np.float32)
+    got = E.ssymm_split_f16(dev(torch_, Ss), dev(torch_, Xs)).cpu().numpy()
+    ref = Ss.astype(np.float64) @ Xs.astype(np.float64).T
+    den = np.abs(Ss).astype(np.float64) @ np.abs(Xs).astype(np.float64).T
+    assert (np.abs(got - ref) / den).max() <= 1e-6
+    # power-of-two rescaling of the operands only shifts exponents
+    base = E.ssymm_split_f16(dev(torch_, S), dev(torch_, X)).cpu().numpy()
+    sc = E.ssymm_split_f16(dev(torch_, S * np.float32(2.0 ** 31)), dev(torch_, X * np.float32(2.0 ** -40))).cpu().numpy()
+    assert np.array_equal(sc, base * np.float32(2.0 ** -9))
+    # an all-zero operand is a zero product, not a NaN
+    z = E.ssymm_split_f16(dev(torch_, np.zeros((n, n), np.float32)), dev(torch_, X)).cpu().numpy()
+    assert np.array_equal(z, np.zeros_like(z))
