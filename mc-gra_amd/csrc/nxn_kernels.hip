@@ -256,9 +256,18 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, cons
     *reinterpret_cast<f32x4*>(out + base + j) = x;
   }
   if (absmax) {     // largest |xc| (operand scale of the 2-plane fp16 split); non-negative floats order as uints
+    __shared__ float shm[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(absmax, __float_as_uint(amx));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = amx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < ROW_THREADS / 64; ++w) amx = fmaxf(amx, shm[w]);
+      // one atomic per row at most, and none once the running maximum already covers this row (the atomics of
+      // 10 000 blocks on one address cost 0.28 ms otherwise)
+      const unsigned bits = __float_as_uint(amx);
+      if (bits > __hip_atomic_load(absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(absmax, bits);
+    }
   }
   if (rowsq) {      // <= ceil(n / 1024) fp32 terms per partial, then fp64
     s = (double)s0 + (double)s1 + (double)s2 + (double)s3;

@@ -21,7 +21,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
+    fs = sorted(glob.glob(os.path.join(G, pattern), recursive=True), key=os.path.getmtime)
     if not fs:
         sys.exit(f"missing {pattern}")
     return fs[-1]
@@ -57,11 +57,16 @@ with open(os.path.join(P, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
                 "hbm_bytes_per_launch_corrected", "avg_ms_under_pmc", "corrected_GBps"])
     for _, k, n, fe, wr, hbm, ms in rows:
         w.writerow([k, n, f"{fe:.1f}", f"{wr:.1f}", f"{hbm:.0f}", f"{ms:.4f}", f"{hbm / (ms * 1e-3) / 1e9:.1f}" if ms else ""])
-gem = [r for r in rows if ("gemm_f32_kernel<128, 128" in r[1] or "split3_symm_kernel" in r[1]) and r[5] > 5e9]
+gem = [r for r in rows if ("gemm_f32_kernel<128, 128" in r[1] or "split3_symm_kernel" in r[1]) and r[5] > 2e9]
 out = {"note": "HBM-side bytes per launch of the N x N x N fp32 MFMA GEMM launches (synthetic-10k-hsic; one launch = a batched "
                "pair of products), from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the "
                "gfx950 correction (calibrated on k_rowsum: 2 x FETCH_SIZE = 400.7 MB for a 400 MB read)",
-       "kernels": [{"kernel": k, "role": "split" if "split3_symm_kernel" in k else "symm" if ", 2, 2, 1>" in k else "syrk" if ", 2, 1, 1>" in k else "gemm", "launches": n, "fetch_size_kb": fe, "write_size_kb": wr, "hbm_bytes_corrected": hbm,
+       "kernels": [{"kernel": k, "role": "split_f16" if "split3_symm_kernel<2" in k else "split" if "split3_symm_kernel" in k else "symm" if ", 2, 2, 1>" in k else "syrk" if ", 2, 1, 1>" in k else "gemm", "launches": n, "fetch_size_kb": fe, "write_size_kb": wr, "hbm_bytes_corrected": hbm,
                     "avg_ms": ms} for _, k, n, fe, wr, hbm, ms in gem]}
+# entries of other evaluations of the product (earlier passes with MCGRA_SPLIT_BF16=0 / 2) stay in the file
+old_path = os.path.join(P, f"{tag}_gemm_traffic.json")
+if os.path.exists(old_path):
+    have = {k["role"] for k in out["kernels"]}
+    out["kernels"] += [k for k in json.load(open(old_path))["kernels"] if k.get("role") not in have]
 json.dump(out, open(os.path.join(P, f"{tag}_gemm_traffic.json"), "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
