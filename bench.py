@@ -207,18 +207,23 @@ PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
 PLANE_PRODUCTS = {0: 1, 1: 6, 2: 6, 3: 3}
 
 
-def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode):
+def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode, overlap=None):
     """The same workload with another evaluation of the one N x N x N product (MCGRA_SPLIT_BF16=mode): the pure fp32
-    MFMA path beside a split-bf16 headline, or the other way round.  Never the reported `value`."""
-    old = os.environ.get("MCGRA_SPLIT_BF16")
-    os.environ["MCGRA_SPLIT_BF16"] = str(mode)
+    MFMA path beside a split headline, or the other way round; overlap=0: the product alone on the chip instead of
+    beside the step's HBM-bound kernels.  Never the reported `value`."""
+    env = {"MCGRA_SPLIT_BF16": str(mode)}
+    if overlap is not None:
+        env["MCGRA_OVERLAP"] = str(overlap)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         eng, inp, adj_dev = build_engine(pkg, torch, dev, workload, seed)
     finally:
-        if old is None:
-            del os.environ["MCGRA_SPLIT_BF16"]
-        else:
-            os.environ["MCGRA_SPLIT_BF16"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
     def one_step():
         eng.step()
@@ -329,6 +334,15 @@ def main():
         except Exception as e:
             split = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # the split product by itself (no side-stream company): same engine with MCGRA_OVERLAP=0, for roofline.alone
+    alone = None
+    side_stream = (os.environ.get("MCGRA_OVERLAP") or ("1" if pmode == 3 else "0")) == "1"
+    if world == 1 and measure == "HSIC" and pmode in (2, 3) and side_stream and not a.no_split_probe:
+        try:
+            alone = product_probe(pkg, torch, dev, a.workload, a.seed + rank, min(a.steps, 10), a.warmup, monitor, pmode, overlap=0)
+        except Exception as e:
+            alone = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # BASELINE.json configs[1] (Cora-sized dense GCN + HSIC, fp32) beside the 10k headline: same engine, same timing
     extra = None
     if world == 1 and a.workload == "synthetic-10k-hsic" and not a.no_split_probe:
@@ -408,7 +422,14 @@ def main():
                                    "algorithmic_flop_per_launch": 2.0 * npp * n ** 3,
                                    "traffic": traffic, "traffic_unit": "bytes/launch",
                                    "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
-                                   "gemm_share_of_step": st["ms"] / (1e3 * dt)}
+                                   "gemm_share_of_step": st["ms"] / (1e3 * dt),
+                                   "side_stream": side_stream}
+                if alone is not None and "product_avg_launch_ms" in alone:
+                    # the same launch with nothing beside it (MCGRA_OVERLAP=0): faster product, slower step
+                    ams = alone["product_avg_launch_ms"]
+                    out["roofline"]["alone"] = {"avg_launch_ms": ams, "achieved": 2.0 * npp * n ** 3 / (ams * 1e-3) / 1e12,
+                                                "frac": 2.0 * npp * n ** 3 / (ams * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                                "steps_per_s_without_side_stream": alone["value"]}
             else:
                 what = ("P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step: SYMM on lower tile "
                         "storage, one launch per step") if lowrank else ("N x N x N products of the Gram evaluation of "

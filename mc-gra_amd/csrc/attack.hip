@@ -380,10 +380,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       h->split_on = (rc == 0);
       h->split_mode = 2;
     }
-    // Off by default: the product holds every CU's LDS and registers, so what runs beside it crawls and slows it
-    // by about as much as it hides (measured: 21.2-21.5 ms with the side stream, 21.6 without).  MCGRA_OVERLAP=1.
+    // The product on the engine's own stream, beside the HBM-bound kernels of the step that do not need it.  On by
+    // default with the 2-plane fp16 kernel (64 KB of LDS and 212 VGPRs per CU leave room for them: 9.1 vs 9.4 ms per
+    // step at N = 10 000 although the product itself slows from 4.8 to 5.6 ms); the fp32 SYMM and the 3-plane kernel
+    // hold every CU's LDS and registers, so what runs beside them crawls and slows them by about as much as it hides
+    // (measured: 21.2-21.5 ms with the side stream, 21.6 without).  MCGRA_OVERLAP=0 / 1 overrides.
     const char* eo = getenv("MCGRA_OVERLAP");
-    h->overlap = (eo && eo[0] == '1');
+    h->overlap = (eo && eo[0]) ? eo[0] == '1' : (h->split_mode == 2 && h->split_planes == 2);
     if (!rc && h->lr_ok) {
       // lowest priority: blocks of the caller's (HBM-bound) kernels take freed CU slots ahead of new tiles of
       // the forked MFMA-bound product, which otherwise fills every slot and starves them until it ends
@@ -925,8 +928,16 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
   }
   // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
-  launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, h->G_A);
-  CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 1.f, h->G_A, ld));
+  if (rankk_nt_supported(n, n, hs, 0)) {
+    // one pass: G_A = GPu Tu^T + (G_adjn_ij r_i r_j + gd_i), the apply step of the normalisation backward as the
+    // epilogue of the rank-k update
+    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, nullptr);
+    MCGRA_HIP(rankk_nt(st, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 0, 0.f, nullptr, 0, nullptr, 0, 0.f, h->G_A, ld, h->G_ADJN, ld,
+                       h->r, h->gd));
+  } else {
+    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, h->G_A);
+    CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 1.f, h->G_A, ld));
+  }
 
   // ---- packed-gradient mirror + Adam + projection + clamp (:274-283)
   h->t += 1;

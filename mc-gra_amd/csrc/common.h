@@ -31,7 +31,8 @@ void set_gemm_variant(int v);
 bool rankk_nt_supported(int M, int N, int K1, int K2);
 hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const float* A1, int lda1, const float* B1,
                     int ldb1, int K2, float alpha2, const float* A2, int lda2, const float* B2, int ldb2, float beta,
-                    float* C, int ldc);
+                    float* C, int ldc, const float* Gn = nullptr, int ldg = 0, const float* rn = nullptr,
+                    const float* gdn = nullptr);   // Gn != NULL: C = products + (Gn_ij rn_i rn_j + gdn_i), beta ignored
 
 // "Lower tile storage" of a symmetric n x n matrix: element (i, j) is valid iff
 // j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.

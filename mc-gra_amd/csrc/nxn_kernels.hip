@@ -385,7 +385,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_normbwd_apply(int n, int ld, co
     const f32x4 rj = *reinterpret_cast<const f32x4*>(r + j);
     f32x4 o;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = (j + t < n) ? g[t] * ri * rj[t] + gdi : 0.f;
+    for (int t = 0; t < 4; ++t) o[t] = (j + t < n) ? fmaf(g[t] * ri, rj[t], gdi) : 0.f;
     *reinterpret_cast<f32x4*>(GA + base + j) = o;
   }
 }
@@ -947,7 +947,7 @@ void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* 
   const int rows_per_strip = (n + nstrips - 1) / nstrips;
   LAUNCH(k_normbwd_colpart, dim3((n + 255) / 256, nstrips), dim3(256), st, n, ld, G, A, r, rows_per_strip, colpart);
   LAUNCH(k_normbwd_gd, dim3((n + 255) / 256), dim3(256), st, n, rowpart, colpart, nstrips, d, gd);
-  LAUNCH(k_normbwd_apply, dim3(n), dim3(ROW_THREADS), st, n, ld, G, r, gd, GA);
+  if (GA) LAUNCH(k_normbwd_apply, dim3(n), dim3(ROW_THREADS), st, n, ld, G, r, gd, GA);   // NULL: folded into the consumer
 }
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out) {
   const int t = (n + TP - 1) / TP;

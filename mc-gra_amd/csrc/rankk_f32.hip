@@ -36,7 +36,8 @@ template <int KMAX>
 __global__ __launch_bounds__(RK_THREADS) void rankk_nt_kernel(
     int M, int N, int K1, float alpha1, const float* __restrict__ A1, int lda1, const float* __restrict__ B1, int ldb1,
     int K2, float alpha2, const float* __restrict__ A2, int lda2, const float* __restrict__ B2, int ldb2, float beta,
-    float* __restrict__ C, int ldc, int vec1, int vec2, int vecc) {
+    float* __restrict__ C, int ldc, int vec1, int vec2, int vecc, const float* __restrict__ Gn, int ldg,
+    const float* __restrict__ rn, const float* __restrict__ gdn) {
   __shared__ float As[KMAX][RK_BM];
   __shared__ float Bs[KMAX][RK_BN];
   const int m0 = blockIdx.y * RK_BM, n0 = blockIdx.x * RK_BN;
@@ -83,6 +84,24 @@ __global__ __launch_bounds__(RK_THREADS) void rankk_nt_kernel(
     const int row = m0 + tm * 8 + r;
     if (row >= M || col >= N) continue;
     float* cp = C + (size_t)row * ldc + col;
+    if (Gn) {
+      // normalisation-backward epilogue (k_normbwd_apply folded in): C = acc + (Gn_ij r_i r_j + gd_i), beta ignored
+      const float ri = rn[row], gdi = gdn[row];
+      const float* gp = Gn + (size_t)row * ldg + col;
+      if (vecc && col + 3 < N) {
+        const float4 g = *reinterpret_cast<const float4*>(gp);
+        const float4 rj = *reinterpret_cast<const float4*>(rn + col);
+        float4 c;
+        c.x = fmaf(g.x * ri, rj.x, gdi) + acc[r][0]; c.y = fmaf(g.y * ri, rj.y, gdi) + acc[r][1];
+        c.z = fmaf(g.z * ri, rj.z, gdi) + acc[r][2]; c.w = fmaf(g.w * ri, rj.w, gdi) + acc[r][3];
+        *reinterpret_cast<float4*>(cp) = c;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (col + c < N) cp[c] = fmaf(gp[c] * ri, rn[col + c], gdi) + acc[r][c];
+      }
+      continue;
+    }
     if (vecc && col + 3 < N) {
       float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
       if (beta != 0.f) c = *reinterpret_cast<const float4*>(cp);
@@ -107,16 +126,16 @@ bool rankk_nt_supported(int M, int N, int K1, int K2) {
 
 hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const float* A1, int lda1, const float* B1,
                     int ldb1, int K2, float alpha2, const float* A2, int lda2, const float* B2, int ldb2, float beta,
-                    float* C, int ldc) {
+                    float* C, int ldc, const float* Gn, int ldg, const float* rn, const float* gdn) {
   if (M <= 0 || N <= 0) return hipSuccess;
   dim3 grid((N + RK_BN - 1) / RK_BN, (M + RK_BM - 1) / RK_BM);
   const int v1 = rk_vec(A1, lda1, B1, ldb1, K1) ? 1 : 0;
   const int v2 = (K2 > 0 && rk_vec(A2, lda2, B2, ldb2, K2)) ? 1 : 0;
-  const int vc = (ldc % 4 == 0 && (uintptr_t)C % 16 == 0) ? 1 : 0;
+  const int vc = (ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && (!Gn || (ldg % 4 == 0 && (uintptr_t)Gn % 16 == 0 && (uintptr_t)rn % 16 == 0))) ? 1 : 0;
   const int kmax = K1 > K2 ? K1 : K2;
 #define MCGRA_RK_LAUNCH(KM)                                                                                          \
   hipLaunchKernelGGL(rankk_nt_kernel<KM>, grid, dim3(RK_THREADS), 0, st, M, N, K1, alpha1, A1, lda1, B1, ldb1, K2, alpha2, \
-                     A2, lda2, B2, ldb2, beta, C, ldc, v1, v2, vc)
+                     A2, lda2, B2, ldb2, beta, C, ldc, v1, v2, vc, Gn, ldg, rn, gdn)
   if (kmax <= 16) MCGRA_RK_LAUNCH(16);
   else if (kmax <= 32) MCGRA_RK_LAUNCH(32);
   else MCGRA_RK_LAUNCH(64);

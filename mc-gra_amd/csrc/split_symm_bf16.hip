@@ -6,8 +6,8 @@
 //     + x1 y0: HALF the matrix-core work.  Representation error 2^-22 for elements within 2^18 of the operand's
 //     maximum (smaller ones keep an absolute error of 2^-40 of the maximum), dropped x1 y1 term 2^-22: measured
 //     1e-7 of |A||B| against the 3e-7 of the fp32 accumulation itself.
-// The text below describes the 3-plane kernel; the 2-plane one stages two 16-k chunks per step (32 k, 64 KB) so that
-// the barrier cadence per MFMA stays the same.
+// The text below describes the 3-plane kernel; the 2-plane one is the same with 32 KB stages (or two 16-k chunks per
+// step, 64 KB, MCGRA_SPLIT_KSUB=2: same speed).
 //
 // What a library GEMM on K-concatenated planes cannot do is REUSE planes: here one K step stages the three planes
 // of both operands once (48 KB) and every fragment read from LDS feeds up to three MFMAs (a0 with b0, b1, b2; a1
@@ -406,14 +406,16 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   const int tm = panel_rows >= 0 ? panel_rows : tiles;
   if (tm <= 0) return hipSuccess;
   static bool attr_done = false;
-  static int slots = 256, ksub2 = 2;
+  static int slots = 256, ksub2 = 1;
   if (!attr_done) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         cus > 0)
       slots = cus;               // one block per CU
-    const char* e = getenv("MCGRA_SPLIT_KSUB");      // experiment switch: 16-k steps for the 2-plane kernel
-    if (e && e[0] == '1') ksub2 = 1;
+    // 2-plane kernel: one 16-k chunk per step (32 KB stages, 212 VGPRs) leaves LDS and registers for the HBM-bound
+    // kernels the engine runs beside the product; two chunks per step (MCGRA_SPLIT_KSUB=2) is as fast alone
+    const char* e = getenv("MCGRA_SPLIT_KSUB");
+    if (e && e[0] == '2') ksub2 = 2;
     attr_done = true;
   }
   // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so

@@ -634,6 +634,22 @@ def test_side_stream_overlap_is_bit_identical(pkg, monkeypatch):
         assert ra == rb and torch.equal(a.get_adj_changes(), b.get_adj_changes())
 
 
+def test_side_stream_default_of_split_product_is_bit_identical(pkg, monkeypatch):
+    """n >= 1024: the fp16-split product runs on the engine's own stream by default; MCGRA_OVERLAP=0 gives the same bits."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 8), 4, seed=3)
+    a = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_OVERLAP", "0")
+    b = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_OVERLAP")
+    assert a.product_mode() == 3 and b.product_mode() == 3
+    for t in range(4):
+        ra, rb = a.step(want_scalars=True), b.step(want_scalars=True)
+        a.monitor(); b.monitor()
+        assert ra == rb and torch.equal(a.get_adj_changes(), b.get_adj_changes())
+    assert a.path_stats()["lowrank_steps"] == 4
+
+
 @pytest.mark.parametrize("arith", ["bf16", "f16"])
 @pytest.mark.parametrize("n", [33, 256, 257, 511, 1000, 1537, 2708, 4100])
 def test_split_bf16_product_against_fp64(pkg, torch_, n, arith):
