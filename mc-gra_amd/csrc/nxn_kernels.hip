@@ -424,15 +424,21 @@ __global__ __launch_bounds__(256) void k_sym_mask(int n, int ld, const float* __
 //   g_ij = gate_ij*G_A_ij + gate_ji*G_A_ji + cn * M_ij     (i != j)
 //   m <- m + (1-b1)(g - m); v <- b2 v + (1-b2) g^2
 //   M <- clamp(M - step_size * m / (sqrt(v)/sqrt(bc2) + eps), 0, 1)   (:279-283)
-// rowsum_new[i] accumulates sum_j M_new (for projection :339 and sparsity :291).
+// M, am, av are symmetric bit for bit (g_ij and g_ji are the same sum), so only the tile pairs on or below the
+// diagonal are computed: a block reads its tile of the state once, G_A's tile and mirrored tile, and writes the
+// results to both halves (the mirrored half through an LDS transpose): 5.5 n^2 floats instead of 8 n^2.
 __global__ __launch_bounds__(256) void k_adam_sym(int n, int ld, const float* __restrict__ GA,
                                                   const unsigned char* __restrict__ gate,
                                                   float* __restrict__ M, float* __restrict__ am,
                                                   float* __restrict__ av, const float* __restrict__ cn_ptr, float omb1, float b2,
                                                   float omb2, float step_size, float sqrt_bc2, float eps,
                                                   float* __restrict__ gsym_dbg, int do_clamp) {
+  // (fp contraction is left on: torch's vectorised CPU Adam fuses multiply-adds too, and the 100-epoch Cora run of the
+  // reference -- tests/test_gpu_parity.py::test_cora_readme_100_epochs -- is matched with it on, not with it off)
+  if (blockIdx.x > blockIdx.y) return;            // upper tile pairs: written by their mirror blocks
   __shared__ float tile[TP][TP + 1];
   const int bi = blockIdx.y * TP, bj = blockIdx.x * TP;
+  const bool offdiag = blockIdx.x != blockIdx.y;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const float cn = cn_ptr[0];   // weight_sup * 0.001 / |adj_changes|_2 (0 at the origin), device scalar
   for (int rr = ty; rr < TP; rr += 4) {
@@ -446,8 +452,12 @@ __global__ __launch_bounds__(256) void k_adam_sym(int n, int ld, const float* __
     tile[rr][tx] = v;
   }
   __syncthreads();
-  for (int rr = ty; rr < TP; rr += 4) {
+  float rp[TP / 4], rm[TP / 4], rv[TP / 4], rg[TP / 4];
+#pragma unroll
+  for (int q = 0; q < TP / 4; ++q) {
+    const int rr = ty + 4 * q;
     const int i = bi + rr, j = bj + tx;
+    rp[q] = rm[q] = rv[q] = rg[q] = 0.f;
     if (i < n && j < n && i != j) {
       const size_t o = (size_t)i * ld + j;
       float g0 = GA[o];
@@ -462,6 +472,22 @@ __global__ __launch_bounds__(256) void k_adam_sym(int n, int ld, const float* __
       if (do_clamp) pn = fminf(fmaxf(pn, 0.f), 1.f);
       am[o] = m; av[o] = v; M[o] = pn;
       if (gsym_dbg) gsym_dbg[o] = g;
+      rp[q] = pn; rm[q] = m; rv[q] = v; rg[q] = g;
+    }
+  }
+  if (!offdiag) return;                 // a diagonal tile holds both halves itself
+  // mirrored half: element (j, i) = element (i, j); one array at a time through the (now free) LDS tile
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float* dst = a == 0 ? M : a == 1 ? am : a == 2 ? av : gsym_dbg;
+    if (!dst) continue;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TP / 4; ++q) tile[ty + 4 * q][tx] = a == 0 ? rp[q] : a == 1 ? rm[q] : a == 2 ? rv[q] : rg[q];
+    __syncthreads();
+    for (int rr = ty; rr < TP; rr += 4) {
+      const int gi = bj + rr, gj = bi + tx;      // row of the mirrored tile, column = original row
+      if (gi < n && gj < n) dst[(size_t)gi * ld + gj] = tile[tx][rr];
     }
   }
 }
