@@ -916,6 +916,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                        h->Pu + h->off[Le - 1], hs, h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
   }
   CHK(chain_backward(h, st, A, ld, ltop, h->Pu, h->GPu, Le - 1, h->Gem, h->hmax));
+  bool normbwd_parts = false;
+  float* nb_colpart = h->colpart;       // column partials of the normalisation backward: [nb_strips][n]
+  int nb_strips = h->nstrips;
   if (hsic && h->lr_step && (use1 || use2)) {
     // Last contribution to G_adjn, and the only consumer of P1: everything above ran beside the forked product.
     // G_adjn += 2 s1 P1 + 2 s2 (D^2 Xc + 1 c^T);  v1 = sum P1 o Xc
@@ -923,19 +926,31 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       if (h->overlap) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
       h->p1_inflight = false;
     }
-    launch_lr_elem(st, n, ld, h->XC, use1 ? h->KX : nullptr, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
-                   2.f * (float)(sg * k1), 2.f * (float)(sg * k2), h->G_ADJN, h->rowvals + 4 * (size_t)ld);
-    launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
+    // ... fused with the two N x N reductions of the normalisation backward that follows (one pass instead of three);
+    // its partial sums live in KY, idle on a low-rank step (the product that used it as split-K slab has been joined)
+    if (lr_elem_normbwd_scratch_floats(n) <= (size_t)n * ld) {
+      double* v1part = nullptr;
+      int v1count = 0;
+      launch_lr_elem_normbwd(st, n, ld, h->XC, use1 ? h->KX : nullptr, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
+                             2.f * (float)(sg * k1), 2.f * (float)(sg * k2), h->G_ADJN, A, h->r, h->KY, h->rowpart, &nb_colpart,
+                             &nb_strips, &v1part, &v1count);
+      launch_reduce_rows(st, v1part, v1count, 1, h->scal + S_H1);
+      normbwd_parts = true;
+    } else {
+      launch_lr_elem(st, n, ld, h->XC, use1 ? h->KX : nullptr, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
+                     2.f * (float)(sg * k1), 2.f * (float)(sg * k2), h->G_ADJN, h->rowvals + 4 * (size_t)ld);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
+    }
   }
   // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
   if (rankk_nt_supported(n, n, hs, 0)) {
     // one pass: G_A = GPu Tu^T + (G_adjn_ij r_i r_j + gd_i), the apply step of the normalisation backward as the
     // epilogue of the rank-k update
-    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, nullptr);
+    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
     MCGRA_HIP(rankk_nt(st, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 0, 0.f, nullptr, 0, nullptr, 0, 0.f, h->G_A, ld, h->G_ADJN, ld,
                        h->r, h->gd));
   } else {
-    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, h->colpart, h->nstrips, h->gd, h->G_A);
+    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, h->G_A, normbwd_parts);
     CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 1.f, h->G_A, ld));
   }
 

@@ -38,7 +38,8 @@ void launch_hsic_gauss_rows(hipStream_t st, int m, int ld, const float* KX, cons
                             const double* rowsy, double* rows);
 void launch_row_sqnorm(hipStream_t st, int m, int d, const float* X, int ldx, float* sq);
 void launch_normbwd(hipStream_t st, int n, int ld, const float* G, const float* A, const float* r,
-                    const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA);
+                    const float* d, float* rowpart, float* colpart, int nstrips, float* gd, float* GA,
+                    bool have_parts = false);     // have_parts: rowpart / colpart already hold the two reductions
 void launch_sym_mask(hipStream_t st, int n, int ld, const float* G, const float* A1, const float* ori, float* out);
 void launch_adam_sym(hipStream_t st, int n, int ld, const float* GA, const unsigned char* gate, float* M,
                      float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size,
@@ -103,6 +104,10 @@ void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const
                     double* rowval);
 void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
                     const float* cvec, float a1, float a2, float* G, double* rowval);
+size_t lr_elem_normbwd_scratch_floats(int n);
+void launch_lr_elem_normbwd(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
+                            const float* cvec, float a1, float a2, float* G, const float* A, const float* r,
+                            float* scratch, float* rowpart, float** colpart, int* nstrips, double** v1part, int* v1count);
 void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
                      const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
                      const double* ztz = nullptr, const double* qtz = nullptr, float a2 = 0.f);

@@ -130,6 +130,77 @@ __global__ __launch_bounds__(256) void k_lr_elem(int n, int ld, const float* __r
   if (threadIdx.x == 0 && rowval) rowval[i] = t;
 }
 
+// The same update and, from the new G in registers, the two N x N reductions of the normalisation backward
+// (k_normbwd_row / k_normbwd_colpart, nxn_kernels.hip) in ONE pass: 5 n^2 floats of traffic instead of 8.
+// Thread = column j of a strip of rows (coalesced 1 KB row segments per block, as k_normbwd_colpart):
+//   v1part[strip][chunk]        = sum over the block's rows and columns of P1_ij Xc_ij   (fp64; linear_HSIC(Fadj, X))
+//   colpart[strip][j]           = sum_{i in strip} G_ij mx_ij r_i               (mx = A + I)
+//   rowpp[i][4 chunk + wave]    = sum_{j in the wave's 64 columns} G_ij mx_ij r_j
+__global__ __launch_bounds__(256) void k_lr_elem_normbwd(int n, int ld, const float* __restrict__ Xc,
+                                                         const float* __restrict__ P1, const float* __restrict__ delta,
+                                                         const float* __restrict__ cvec, float a1, float a2,
+                                                         float* __restrict__ G, const float* __restrict__ A,
+                                                         const float* __restrict__ r, int rows_per_strip,
+                                                         double* __restrict__ v1part, float* __restrict__ colpart,
+                                                         float* __restrict__ rowpp, int nrp) {
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;        // four columns per thread: 16-byte loads (ld % 4 == 0)
+  const int strip = blockIdx.y;
+  const int i0 = strip * rows_per_strip, i1 = min(n, i0 + rows_per_strip);
+  const bool in = j < n;
+  float4 cj = make_float4(0.f, 0.f, 0.f, 0.f), rj = cj;
+  if (in) {
+    if (cvec) cj = *reinterpret_cast<const float4*>(cvec + j);      // cvec and r are padded to ld
+    rj = *reinterpret_cast<const float4*>(r + j);
+  }
+  const float cjs[4] = {cj.x, cj.y, cj.z, cj.w}, rjs[4] = {rj.x, rj.y, rj.z, rj.w};
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  double v1 = 0.0;
+#pragma unroll 2
+  for (int i = i0; i < i1; ++i) {
+    float w = 0.f;
+    if (in) {
+      const size_t o = (size_t)i * ld + j;
+      const float4 x4 = *reinterpret_cast<const float4*>(Xc + o);
+      const float4 a4 = *reinterpret_cast<const float4*>(A + o);
+      float4 g4 = *reinterpret_cast<const float4*>(G + o);
+      float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P1) p4 = *reinterpret_cast<const float4*>(P1 + o);
+      const float di = delta ? delta[i] : 0.f, d2 = di * di, ri = r[i];
+      const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ps[4] = {p4.x, p4.y, p4.z, p4.w}, as[4] = {a4.x, a4.y, a4.z, a4.w};
+      float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j + t < n) {
+          gs[t] += a2 * (d2 * xs[t] + cjs[t]) + a1 * ps[t];
+          v1 += (double)ps[t] * (double)xs[t];
+          const float gm = gs[t] * (as[t] + (i == j + t ? 1.f : 0.f));
+          cs[t] += gm * ri;
+          w += gm * rjs[t];
+        }
+      }
+      *reinterpret_cast<float4*>(G + o) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
+    w = wave_sum(w);
+    if ((threadIdx.x & 63) == 0) rowpp[(size_t)i * nrp + slot] = w;
+  }
+  if (in) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (j + t < n) colpart[(size_t)strip * n + j + t] = cs[t];
+  }
+  __shared__ double shd[16];
+  v1 = block_sum_d(v1, shd);
+  if (threadIdx.x == 0) v1part[(size_t)strip * gridDim.x + blockIdx.x] = v1;
+}
+__global__ void k_rowpp_fin(int n, int nrp, const float* __restrict__ rowpp, float* __restrict__ rowpart) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nrp; ++c) s += rowpp[(size_t)i * nrp + c];
+  rowpart[i] = s;
+}
+
 // per node i, after QQ = Xc [W | W2] (ld 2h) and rs_i = |xc_i|^2:
 //   G_Zn_i += kk (Q2_i + delta_i Q_i - 2 rs_i delta_i z_i)          (kk = -2 s2: the Kx D part of d c2 / d A1)
 //   G_Zn_i += a2 (q_i (Z^T Z) + z_i (Q^T Z) - 2 (q_i . z_i) z_i)    (ztz != nullptr: the Q Z^T part, see k_lr_decode_bwd)
@@ -305,6 +376,36 @@ void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const
 void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
                     const float* cvec, float a1, float a2, float* G, double* rowval) {
   LAUNCH(k_lr_elem, dim3(n), dim3(256), st, n, ld, Xc, P1, delta, cvec, a1, a2, G, rowval);
+}
+// strips of the fused pass: 1024 columns per block, so many short strips are needed to fill the chip
+static int lr_fused_strips(int n) {
+  const int chunks = (n + 1023) / 1024;
+  int s = (1280 + chunks - 1) / chunks;
+  if (s > n / 16) s = n / 16;
+  return s < 1 ? 1 : s;
+}
+size_t lr_elem_normbwd_scratch_floats(int n) {
+  const size_t chunks = (n + 1023) / 1024, nrp = chunks * 4, strips = lr_fused_strips(n);
+  return 2 * strips * chunks + 2 + (size_t)n * nrp + strips * n + 64;      // v1part (fp64) + rowpp + colpart
+}
+// G update + rowpart + colpart in one pass; scratch >= lr_elem_normbwd_scratch_floats(n) floats, 8-byte aligned.
+// Returns the fp64 partials of sum P1 o Xc (for k_reduce_rows on the caller's side) and the column partials
+// [*nstrips][n] for k_normbwd_gd.
+void launch_lr_elem_normbwd(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
+                            const float* cvec, float a1, float a2, float* G, const float* A, const float* r,
+                            float* scratch, float* rowpart, float** colpart, int* nstrips, double** v1part, int* v1count) {
+  const int chunks = (n + 1023) / 1024, nrp = chunks * 4, strips = lr_fused_strips(n);
+  const int rows_per_strip = (n + strips - 1) / strips;
+  double* v1 = reinterpret_cast<double*>(scratch);
+  float* rowpp = scratch + 2 * (size_t)strips * chunks + 2;
+  float* cp = rowpp + (size_t)n * nrp;
+  LAUNCH(k_lr_elem_normbwd, dim3(chunks, strips), dim3(256), st, n, ld, Xc, P1, delta, cvec, a1, a2, G, A, r, rows_per_strip, v1,
+         cp, rowpp, nrp);
+  LAUNCH(k_rowpp_fin, dim3((n + 255) / 256), dim3(256), st, n, nrp, rowpp, rowpart);
+  *v1part = v1;
+  *v1count = strips * chunks;
+  *colpart = cp;
+  *nstrips = strips;
 }
 void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
                      const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
