@@ -67,6 +67,7 @@ struct mcgra_attack {
   // log-probs in place and the next step adopts them instead of recomputing (bit-identical, one N x N pass and two
   // skinny products less per step).  MCGRA_NO_FWD_REUSE=1 disables.
   bool fwd_cached = false, fwd_reuse = true;
+  bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
   bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
   float* ADJN_next = 0;
   bool graph_set = false, model_set = false;
@@ -345,6 +346,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
   if (cfg->eps != 0.f) { A_(Abuf, nn); A_(gate, nn); A_(colpart_d, (size_t)h->nstrips * ld); }
   { const char* e = getenv("MCGRA_NO_FWD_REUSE"); h->fwd_reuse = cfg->eps == 0.f && !(e && e[0] == '1'); }
+  { const char* e = getenv("MCGRA_NO_FUSED_TAIL"); h->fuse_tail = !(e && e[0] == '1'); }
   if (h->fwd_reuse) { A_(ADJN_next, nn); }
   A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
   {
@@ -942,8 +944,23 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 1, h->scal + S_H1);
     }
   }
+  // Adam's scalars first: the fused tail below consumes them
+  h->t += 1;
+  const double b1 = 0.9, b2 = 0.999;
+  const double bc1 = 1.0 - pow(b1, (double)h->t), bc2 = 1.0 - pow(b2, (double)h->t);
+  hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
+  // clamp(a,0,1).sum() <= n(n-1)/2, so a larger budget can never trigger the bisection (:339)
+  const bool may_project = c.num_edges < 0.5 * n2;
+  bool adam_done = false;
   // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
-  if (rankk_nt_supported(n, n, hs, 0)) {
+  if (h->fuse_tail && rankk_apply_adam_supported(n, ld, hs)) {
+    // one pass over the lower tile pairs: apply step + rank-k update + gradient mirror + Adam, no G_A in between
+    launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
+    MCGRA_HIP(rankk_apply_adam(st, n, ld, hs, h->GPu, hs, h->Tu, hs, h->G_ADJN, h->r, h->gd, gate, h->M, h->am, h->av, h->mm + 2,
+                               (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
+                               h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1));
+    adam_done = true;
+  } else if (rankk_nt_supported(n, n, hs, 0)) {
     // one pass: G_A = GPu Tu^T + (G_adjn_ij r_i r_j + gd_i), the apply step of the normalisation backward as the
     // epilogue of the rank-k update
     launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
@@ -955,15 +972,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
 
   // ---- packed-gradient mirror + Adam + projection + clamp (:274-283)
-  h->t += 1;
-  const double b1 = 0.9, b2 = 0.999;
-  const double bc1 = 1.0 - pow(b1, (double)h->t), bc2 = 1.0 - pow(b2, (double)h->t);
-  hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
-  // clamp(a,0,1).sum() <= n(n-1)/2, so a larger budget can never trigger the bisection (:339)
-  const bool may_project = c.num_edges < 0.5 * n2;
-  launch_adam_sym(st, n, ld, h->G_A, gate, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
-                  (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->keep_gsym ? h->GSYM : nullptr,
-                  may_project ? 0 : 1);
+  if (!adam_done)
+    launch_adam_sym(st, n, ld, h->G_A, gate, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
+                    (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->keep_gsym ? h->GSYM : nullptr,
+                    may_project ? 0 : 1);
   MCGRA_KERNEL_CHECK();
   h->have_step = true;
   if (may_project) CHK(project(h, st));

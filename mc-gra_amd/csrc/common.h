@@ -34,6 +34,13 @@ hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const fl
                     float* C, int ldc, const float* Gn = nullptr, int ldg = 0, const float* rn = nullptr,
                     const float* gdn = nullptr);   // Gn != NULL: C = products + (Gn_ij rn_i rn_j + gdn_i), beta ignored
 
+// the tail of a step in one pass: normalisation-backward apply + rank-k update + gradient mirror + Adam (rankk_f32.hip)
+bool rankk_apply_adam_supported(int n, int ld, int K);
+hipError_t rankk_apply_adam(hipStream_t st, int n, int ld, int K, const float* GP, int ldp, const float* TT, int ldt,
+                            const float* G, const float* rn, const float* gdn, const unsigned char* gate, float* M, float* am,
+                            float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
+                            float eps, float* gsym_dbg, int do_clamp);
+
 // "Lower tile storage" of a symmetric n x n matrix: element (i, j) is valid iff
 // j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.
 constexpr int SYM_TILE = 128;

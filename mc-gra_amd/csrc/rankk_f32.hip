@@ -116,6 +116,176 @@ __global__ __launch_bounds__(RK_THREADS) void rankk_nt_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tail of a step in one pass over the tile pairs on or below the diagonal (64 x 64 tiles):
+//   G_A_ij = G_adjn_ij r_i r_j + gd_i + sum_k GPu_ik Tu_jk        (normalisation backward apply + rank-k update)
+//   g_ij   = gate_ij G_A_ij + gate_ji G_A_ji + cn M_ij            (packed-gradient mirror, :274-283)
+//   Adam + clamp on (M, am, av), written to both halves            (k_adam_sym, nxn_kernels.hip)
+// i.e. rankk_nt's normbwd epilogue and k_adam_sym without the N x N G_A buffer between them: reads G_adjn once and
+// the lower half of the state, writes the state: 5.5 n^2 floats instead of 9.5.  Same arithmetic per element as the
+// two kernels it replaces (the fused multiply-add of the apply step, the left-to-right sum g0 + mirrored + cn p).
+constexpr int RA_T = 64;
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_rankk_apply_adam(
+    int n, int ld, int K, const float* __restrict__ GP, int ldp, const float* __restrict__ TT, int ldt, int vecp,
+    const float* __restrict__ G, const float* __restrict__ rn, const float* __restrict__ gdn,
+    const unsigned char* __restrict__ gate, float* __restrict__ M, float* __restrict__ am, float* __restrict__ av,
+    const float* __restrict__ cn_ptr, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
+    float* __restrict__ gsym_dbg, int do_clamp) {
+  if (blockIdx.x > blockIdx.y) return;            // upper tile pairs: written by their mirror blocks
+  __shared__ float As[KMAX][RA_T];
+  __shared__ float Bs[KMAX][RA_T];
+  __shared__ float T[RA_T][RA_T + 1];
+  const int bi = blockIdx.y * RA_T, bj = blockIdx.x * RA_T;
+  const bool offdiag = blockIdx.x != blockIdx.y;
+  const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;   // 4 x 4 elements per thread
+  const float cn = cn_ptr[0];
+
+  auto product = [&](float (&acc)[4][4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float4 av4 = *reinterpret_cast<const float4*>(&As[k][r0]);
+      const float4 bv4 = *reinterpret_cast<const float4*>(&Bs[k][c0]);
+      const float as_[4] = {av4.x, av4.y, av4.z, av4.w}, bs_[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(as_[a], bs_[b], acc[a][b]);
+    }
+  };
+  // G_A on the 4 x 4 patch at rows rb + r0.., columns cb + c0.. (gated; 0 outside the matrix)
+  auto apply = [&](float (&acc)[4][4], int rb, int cb) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = rb + r0 + a, col = cb + c0;
+      if (row < n && col < n) {
+        const float ri = rn[row], gdi = gdn[row];
+        const size_t o = (size_t)row * ld + col;
+        const float4 g = *reinterpret_cast<const float4*>(G + o);           // ld % 4 == 0: in bounds, padding unused
+        const float4 rj = *reinterpret_cast<const float4*>(rn + col);
+        const float gs[4] = {g.x, g.y, g.z, g.w}, rs[4] = {rj.x, rj.y, rj.z, rj.w};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          float v = fmaf(gs[b] * ri, rs[b], gdi) + acc[a][b];
+          if (col + b >= n || (gate && !gate[o + b])) v = 0.f;
+          acc[a][b] = v;
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+      }
+    }
+  };
+
+  float acc[4][4];
+  // mirrored tile (J, I): rows of GP in J, rows of TT in I
+  rk_stage<RA_T>(As, GP, ldp, bj, n, K, vecp);
+  rk_stage<RA_T>(Bs, TT, ldt, bi, n, K, vecp);
+  __syncthreads();
+  product(acc);
+  apply(acc, bj, bi);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) T[r0 + a][c0 + b] = acc[a][b];      // T[j local][i local]
+  __syncthreads();
+  // direct tile (I, J)
+  rk_stage<RA_T>(As, GP, ldp, bi, n, K, vecp);
+  rk_stage<RA_T>(Bs, TT, ldt, bj, n, K, vecp);
+  __syncthreads();
+  product(acc);
+  apply(acc, bi, bj);
+
+  float pn_[4][4], m_[4][4], v_[4][4], g_[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = bi + r0 + a, j0 = bj + c0;
+    const bool rowin = i < n && j0 < n;
+    float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = p4, v4 = p4;
+    const size_t o = (size_t)i * ld + j0;
+    if (rowin) {
+      p4 = *reinterpret_cast<const float4*>(M + o);
+      m4 = *reinterpret_cast<const float4*>(am + o);
+      v4 = *reinterpret_cast<const float4*>(av + o);
+    }
+    float ps[4] = {p4.x, p4.y, p4.z, p4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
+    float gsv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + b;
+      if (rowin && j < n && i != j) {
+        const float p = ps[b];
+        const float g = acc[a][b] + T[c0 + b][r0 + a] + cn * p;
+        float m = ms[b], v = vs[b];
+        m = m + omb1 * (g - m);            // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * b2 + omb2 * g * g;         // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(v) / sqrt_bc2 + eps;
+        float pn = p - step_size * (m / denom);
+        if (do_clamp) pn = fminf(fmaxf(pn, 0.f), 1.f);
+        ps[b] = pn; ms[b] = m; vs[b] = v; gsv[b] = g;
+      }
+      pn_[a][b] = ps[b]; m_[a][b] = ms[b]; v_[a][b] = vs[b]; g_[a][b] = gsv[b];
+    }
+    if (rowin) {
+      *reinterpret_cast<float4*>(M + o) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+      *reinterpret_cast<float4*>(am + o) = make_float4(ms[0], ms[1], ms[2], ms[3]);
+      *reinterpret_cast<float4*>(av + o) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+      if (gsym_dbg) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (j0 + b < n && i != j0 + b) gsym_dbg[o + b] = gsv[b];
+      }
+    }
+  }
+  if (!offdiag) return;                 // a diagonal tile holds both halves itself
+  // mirrored half: element (j, i) = element (i, j); one array at a time through T
+#pragma unroll
+  for (int arr = 0; arr < 4; ++arr) {
+    float* dst = arr == 0 ? M : arr == 1 ? am : arr == 2 ? av : gsym_dbg;
+    if (!dst) continue;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        T[r0 + a][c0 + b] = arr == 0 ? pn_[a][b] : arr == 1 ? m_[a][b] : arr == 2 ? v_[a][b] : g_[a][b];   // T[i local][j local]
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = bj + r0 + a, col = bi + c0;        // row j of the mirrored tile, columns i
+      if (row < n && col < n) {
+        float* q = dst + (size_t)row * ld + col;
+        if (col + 3 < n) *reinterpret_cast<float4*>(q) = make_float4(T[c0][r0 + a], T[c0 + 1][r0 + a], T[c0 + 2][r0 + a], T[c0 + 3][r0 + a]);
+        else
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (col + b < n) q[b] = T[c0 + b][r0 + a];
+      }
+    }
+  }
+}
+
+bool rankk_apply_adam_supported(int n, int ld, int K) {
+  return K > 0 && K <= RK_KMAX && (ld % 4) == 0 && n >= 256;
+}
+hipError_t rankk_apply_adam(hipStream_t st, int n, int ld, int K, const float* GP, int ldp, const float* TT, int ldt,
+                            const float* G, const float* rn, const float* gdn, const unsigned char* gate, float* M, float* am,
+                            float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
+                            float eps, float* gsym_dbg, int do_clamp) {
+  const int t = (n + RA_T - 1) / RA_T;
+  const int vp = ((K % 4) == 0 && (ldp % 4) == 0 && (ldt % 4) == 0 && (uintptr_t)GP % 16 == 0 && (uintptr_t)TT % 16 == 0) ? 1 : 0;
+#define MCGRA_RA_LAUNCH(KM)                                                                                             \
+  hipLaunchKernelGGL(k_rankk_apply_adam<KM>, dim3(t, t), dim3(256), 0, st, n, ld, K, GP, ldp, TT, ldt, vp, G, rn, gdn, gate, M, \
+                     am, av, cn, omb1, b2, omb2, step_size, sqrt_bc2, eps, gsym_dbg, do_clamp)
+  if (K <= 32) MCGRA_RA_LAUNCH(32);
+  else MCGRA_RA_LAUNCH(64);
+#undef MCGRA_RA_LAUNCH
+  return hipGetLastError();
+}
+
 static bool rk_vec(const float* A, int lda, const float* B, int ldb, int K) {
   return (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
 }
