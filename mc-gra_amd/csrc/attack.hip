@@ -68,6 +68,7 @@ struct mcgra_attack {
   // skinny products less per step).  MCGRA_NO_FWD_REUSE=1 disables.
   bool fwd_cached = false, fwd_reuse = true;
   bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
+  bool prep_valid = false;         // G_A holds the per-tile row sums of the current M (left by the fused tail kernel)
   bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
   float* ADJN_next = 0;
   bool graph_set = false, model_set = false;
@@ -422,7 +423,7 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
 
 int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W, const float* const* b,
                            const float* Wlin, const float* blin, const float* const* Ws) {
-  if (h) h->fwd_cached = false;      // whatever the last monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !W || !b || !Wlin || !blin) { set_error("null argument"); return MCGRA_EINVAL; }
   if ((h->has_self != 0) != (Ws != nullptr)) { set_error("Ws must be given exactly when has_self is set"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
@@ -440,7 +441,7 @@ int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* 
 int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* features, const float* adj,
                            const float* ori_adj, const float* feature_adj, const int32_t* labels,
                            const int32_t* idx_attack) {
-  if (h) h->fwd_cached = false;      // whatever the last monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !features || !adj || !feature_adj || !labels || !idx_attack) { set_error("null argument"); return MCGRA_EINVAL; }
   if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
   if (ori_adj) {
@@ -508,7 +509,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
 }
 
 int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed) {
-  if (h) h->fwd_cached = false;      // whatever the last monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
@@ -575,6 +576,12 @@ static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, cons
                           double* adjn_rowsum = nullptr) {
   const int n = h->n, ld = h->ld;
   const bool general = noise != nullptr;
+  if (!general && h->prep_valid) {
+    // d, r and the norm / sparsity sums from the row sums the Adam pass left behind: no pass over M
+    const size_t cnt = (size_t)n * rankk_apply_adam_tiles(n);
+    prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
+                       h->rowsum);
+  } else
   launch_prep(st, general, n, ld, h->M, nullptr, noise, h->cfg.eps, h->Abuf, h->gate, h->d, h->r, h->rowsq, h->rowsum);
   launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
   launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
@@ -956,9 +963,15 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (h->fuse_tail && rankk_apply_adam_supported(n, ld, hs)) {
     // one pass over the lower tile pairs: apply step + rank-k update + gradient mirror + Adam, no G_A in between
     launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
+    // (its row sums of the new M go to G_A, which this path leaves unused; not with a projection still to come)
+    const size_t cnt = (size_t)n * rankk_apply_adam_tiles(n);
+    static const bool no_partials = [] { const char* e = getenv("MCGRA_NO_PREP_PARTIALS"); return e && e[0] == '1'; }();
+    const bool emit = !may_project && !noise && !no_partials && 3 * cnt + 4 <= (size_t)n * ld;
     MCGRA_HIP(rankk_apply_adam(st, n, ld, hs, h->GPu, hs, h->Tu, hs, h->G_ADJN, h->r, h->gd, gate, h->M, h->am, h->av, h->mm + 2,
                                (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
-                               h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1));
+                               h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,
+                               emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr));
+    h->prep_valid = emit;
     adam_done = true;
   } else if (rankk_nt_supported(n, n, hs, 0)) {
     // one pass: G_A = GPu Tu^T + (G_adjn_ij r_i r_j + gd_i), the apply step of the normalisation backward as the
@@ -972,13 +985,14 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
 
   // ---- packed-gradient mirror + Adam + projection + clamp (:274-283)
+  if (!adam_done) h->prep_valid = false;
   if (!adam_done)
     launch_adam_sym(st, n, ld, h->G_A, gate, h->M, h->am, h->av, h->mm + 2, (float)(1.0 - b1), (float)b2,
                     (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f, h->keep_gsym ? h->GSYM : nullptr,
                     may_project ? 0 : 1);
   MCGRA_KERNEL_CHECK();
   h->have_step = true;
-  if (may_project) CHK(project(h, st));
+  if (may_project) { CHK(project(h, st)); h->prep_valid = false; }
 
   if (scalars_out) {
     launch_clamp_rowsum(st, n, ld, h->M, 0.f, h->rowsx, nullptr, nullptr);

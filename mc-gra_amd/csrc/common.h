@@ -39,7 +39,12 @@ bool rankk_apply_adam_supported(int n, int ld, int K);
 hipError_t rankk_apply_adam(hipStream_t st, int n, int ld, int K, const float* GP, int ldp, const float* TT, int ldt,
                             const float* G, const float* rn, const float* gdn, const unsigned char* gate, float* M, float* am,
                             float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
-                            float eps, float* gsym_dbg, int do_clamp);
+                            float eps, float* gsym_dbg, int do_clamp, float* ps_out = nullptr, double* pq_out = nullptr);
+// ps_out / pq_out [n][rankk_apply_adam_tiles(n)]: per-tile row sums of the new M (and of its squares, diagonal excluded);
+// prep_from_partials turns them into k_prep's outputs without another pass over M
+int rankk_apply_adam_tiles(int n);
+void prep_from_partials(hipStream_t st, int n, const float* ps, const double* pq, float* d, float* r, double* rowsq,
+                        double* rowsum);
 
 // "Lower tile storage" of a symmetric n x n matrix: element (i, j) is valid iff
 // j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.

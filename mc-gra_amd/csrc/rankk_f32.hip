@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_rankk_apply_adam(
     const float* __restrict__ G, const float* __restrict__ rn, const float* __restrict__ gdn,
     const unsigned char* __restrict__ gate, float* __restrict__ M, float* __restrict__ am, float* __restrict__ av,
     const float* __restrict__ cn_ptr, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
-    float* __restrict__ gsym_dbg, int do_clamp) {
+    float* __restrict__ gsym_dbg, int do_clamp, float* __restrict__ ps_out, double* __restrict__ pq_out) {
   if (blockIdx.x > blockIdx.y) return;            // upper tile pairs: written by their mirror blocks
   __shared__ float As[KMAX][RA_T];
   __shared__ float Bs[KMAX][RA_T];
@@ -240,7 +240,43 @@ __global__ __launch_bounds__(256) void k_rankk_apply_adam(
       }
     }
   }
+  // Row sums of the new M for the next forward (k_prep's pass over M): ps[i][tile] = sum of M_new over the tile's
+  // columns, pq likewise of M_new^2 without the diagonal; row i gets one entry per tile column -- from this block for
+  // its own rows, from the mirrored half for the rows of tile J (k_prep_fin adds them in tile order).
+  const int nt = gridDim.x;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  double cq[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ps_out) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int i = bi + r0 + a;
+      float s = 0.f;
+      double q = 0.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = bj + c0 + b;
+        if (i < n && j < n) {
+          const float v = pn_[a][b];
+          s += v; cs[b] += v;
+          if (i != j) { q += (double)v * (double)v; cq[b] += (double)v * (double)v; }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      if ((threadIdx.x & 15) == 0 && i < n) {
+        ps_out[(size_t)i * nt + blockIdx.x] = s;
+        pq_out[(size_t)i * nt + blockIdx.x] = q;
+      }
+    }
+  }
   if (!offdiag) return;                 // a diagonal tile holds both halves itself
+  float (*CS)[RA_T] = As;                                           // [16][64] floats, panels are dead by now
+  double (*CQ)[RA_T] = reinterpret_cast<double (*)[RA_T]>(&Bs[0][0]);   // [16][64] doubles = 8 KB <= sizeof(Bs)
+  __syncthreads();                      // every thread is past its panel reads
+  if (ps_out) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { CS[threadIdx.x >> 4][c0 + b] = cs[b]; CQ[threadIdx.x >> 4][c0 + b] = cq[b]; }
+  }
   // mirrored half: element (j, i) = element (i, j); one array at a time through T
 #pragma unroll
   for (int arr = 0; arr < 4; ++arr) {
@@ -266,20 +302,55 @@ __global__ __launch_bounds__(256) void k_rankk_apply_adam(
       }
     }
   }
+  if (ps_out && threadIdx.x < RA_T) {   // column sums of the tile = row sums of the mirrored half (CS visible: syncs above)
+    const int j = bj + threadIdx.x;
+    float s = 0.f;
+    double q = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { s += CS[g][threadIdx.x]; q += CQ[g][threadIdx.x]; }
+    if (j < n) {
+      ps_out[(size_t)j * nt + blockIdx.y] = s;
+      pq_out[(size_t)j * nt + blockIdx.y] = q;
+    }
+  }
 }
 
+// d, r, rowsq, rowsum of k_prep (nxn_kernels.hip) from the per-tile partial sums above: one wave per row
+__global__ __launch_bounds__(256) void k_prep_fin(int n, int nt, const float* __restrict__ ps, const double* __restrict__ pq,
+                                                  float* __restrict__ d, float* __restrict__ r, double* __restrict__ rowsq,
+                                                  double* __restrict__ rowsum) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  float s = 0.f;
+  double q = 0.0;
+  for (int t = lane; t < nt; t += 64) { s += ps[(size_t)i * nt + t]; q += pq[(size_t)i * nt + t]; }
+  s = wave_sum(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    const float di = s + 1.0f;      // rowsum(A + I)
+    float ri = 1.0f / sqrtf(di);
+    if (isinf(ri)) ri = 0.f;        // r_inv[isinf] = 0 (utils.py:225)
+    d[i] = di; r[i] = ri; rowsq[i] = q; rowsum[i] = (double)s;
+  }
+}
+
+int rankk_apply_adam_tiles(int n) { return (n + RA_T - 1) / RA_T; }
+void prep_from_partials(hipStream_t st, int n, const float* ps, const double* pq, float* d, float* r, double* rowsq,
+                        double* rowsum) {
+  hipLaunchKernelGGL(k_prep_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, rankk_apply_adam_tiles(n), ps, pq, d, r, rowsq, rowsum);
+}
 bool rankk_apply_adam_supported(int n, int ld, int K) {
   return K > 0 && K <= RK_KMAX && (ld % 4) == 0 && n >= 256;
 }
 hipError_t rankk_apply_adam(hipStream_t st, int n, int ld, int K, const float* GP, int ldp, const float* TT, int ldt,
                             const float* G, const float* rn, const float* gdn, const unsigned char* gate, float* M, float* am,
                             float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
-                            float eps, float* gsym_dbg, int do_clamp) {
+                            float eps, float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out) {
   const int t = (n + RA_T - 1) / RA_T;
   const int vp = ((K % 4) == 0 && (ldp % 4) == 0 && (ldt % 4) == 0 && (uintptr_t)GP % 16 == 0 && (uintptr_t)TT % 16 == 0) ? 1 : 0;
 #define MCGRA_RA_LAUNCH(KM)                                                                                             \
   hipLaunchKernelGGL(k_rankk_apply_adam<KM>, dim3(t, t), dim3(256), 0, st, n, ld, K, GP, ldp, TT, ldt, vp, G, rn, gdn, gate, M, \
-                     am, av, cn, omb1, b2, omb2, step_size, sqrt_bc2, eps, gsym_dbg, do_clamp)
+                     am, av, cn, omb1, b2, omb2, step_size, sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out)
   if (K <= 32) MCGRA_RA_LAUNCH(32);
   else MCGRA_RA_LAUNCH(64);
 #undef MCGRA_RA_LAUNCH
