@@ -149,14 +149,21 @@ __device__ __forceinline__ f32x16 plane_mma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int NP, int KSUB>
-__global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
+// NW = 8 waves as 2 x 4 with 128 x 64 wave tiles (the kernel described above), or NW = 4 waves as 2 x 2 with 128 x 128
+// wave tiles: 256 accumulator registers per lane, one wave per SIMD, a third less LDS read traffic per MFMA.
+template <int NP, int KSUB, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
                                                                  float* __restrict__ C, int n, int ldc, int nks,
                                                                  int tiles_m, int tiles_n, int panel_off, int tile_base,
                                                                  int ksplit, float* __restrict__ slab,
                                                                  const float* __restrict__ amax) {
   using CF = SplitCfg<NP, KSUB>;
-  constexpr int OPB = CF::OPB, AOPS = CF::AOPS, STAGE = CF::STAGE;
+  constexpr int OPB = CF::OPB, STAGE = CF::STAGE;
+  constexpr int NJ = NW == 8 ? 2 : 4;                     // 32-column MFMA tiles per wave
+  constexpr int WNC = NW == 8 ? 4 : 2;                    // waves along the columns
+  constexpr int COPY = NW * 64 * 16;                      // bytes one cooperative 16-byte copy moves
+  constexpr int AOPS = KSUB * OPB / COPY;                 // copies per operand and step
+  static_assert(NW == 8 || NP == 2, "the 4-wave layout exists for the 2-plane arithmetic only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tile_m, tile_n, lin, part;
   {  // XCD-aware bijective remap of this launch's blocks, then 4-panel groups over the whole tile grid (gemm_f32.hip)
@@ -178,16 +185,16 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
   const int kc_begin = part * kper;
   const int nk = max(0, min(nks, kc_begin + kper) - kc_begin);          // K steps of this block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, wave tile 128 x 64
+  const int wm = wave / WNC, wn = wave % WNC;               // 2 x 4 waves of 128 x 64, or 2 x 2 of 128 x 128
   const int l31 = lane & 31, lh = lane >> 5;
   const char* ga = Ap + ((size_t)tile_m * nks + kc_begin) * (KSUB * OPB) + (size_t)tid * 16;
   const char* gb = Bp + ((size_t)tile_n * nks + kc_begin) * (KSUB * OPB) + (size_t)tid * 16;
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -196,20 +203,20 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
   auto gload = [&](auto rs_, int kc) {
     constexpr int RS = decltype(rs_)::value;
 #pragma unroll
-    for (int i = 0; i < AOPS; ++i) rg[RS][i] = *reinterpret_cast<const u32x4*>(ga + (size_t)kc * (KSUB * OPB) + i * PLANE);
+    for (int i = 0; i < AOPS; ++i) rg[RS][i] = *reinterpret_cast<const u32x4*>(ga + (size_t)kc * (KSUB * OPB) + i * COPY);
 #pragma unroll
-    for (int i = 0; i < AOPS; ++i) rg[RS][AOPS + i] = *reinterpret_cast<const u32x4*>(gb + (size_t)kc * (KSUB * OPB) + i * PLANE);
+    for (int i = 0; i < AOPS; ++i) rg[RS][AOPS + i] = *reinterpret_cast<const u32x4*>(gb + (size_t)kc * (KSUB * OPB) + i * COPY);
   };
   auto lstore = [&](auto rs_, int stage) {
     constexpr int RS = decltype(rs_)::value;
     char* s = smem + stage * STAGE + tid * 16;
 #pragma unroll
-    for (int i = 0; i < 2 * AOPS; ++i) *reinterpret_cast<u32x4*>(s + i * PLANE) = rg[RS][i];
+    for (int i = 0; i < 2 * AOPS; ++i) *reinterpret_cast<u32x4*>(s + i * COPY) = rg[RS][i];
   };
   using R0 = std::integral_constant<int, 0>;
   using R1 = std::integral_constant<int, 1>;
   const int a_off = lh * (PLANE / 2) + (wm * 128 + l31) * 16;                 // + i * 512 (row tile) + plane * PLANE
-  const int b_off = KSUB * OPB + lh * (PLANE / 2) + (wn * 64 + l31) * 16;     // + j * 512 + plane * PLANE
+  const int b_off = KSUB * OPB + lh * (PLANE / 2) + (wn * (NJ * 32) + l31) * 16;     // + j * 512 + plane * PLANE
   auto frag = [&](const char* s, int off) { return *reinterpret_cast<const u32x4*>(s + off); };
 #define MCGRA_P(A_, B_)                                      \
   acc[i][0] = plane_mma<NP>(A_, B_[0], acc[i][0]);           \
@@ -248,13 +255,13 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
 #pragma unroll
       for (int u = 0; u < KSUB; ++u) {
         const char* s = smem + stage * STAGE + u * OPB;
-        u32x4 b0[2], b1[2];
+        u32x4 b0[NJ], b1[NJ];
         u32x4 a1 = frag(s, a_off + PLANE);
-        b0[0] = frag(s, b_off);
-        b0[1] = frag(s, b_off + 512);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b0[j] = frag(s, b_off + j * 512);
         u32x4 a0 = frag(s, a_off);
-        b1[0] = frag(s, b_off + PLANE);
-        b1[1] = frag(s, b_off + 512 + PLANE);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b1[j] = frag(s, b_off + j * 512 + PLANE);
         if (u == 0) after_first_reads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -263,8 +270,14 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
             n0 = frag(s, a_off + (i + 1) * 512);
             n1 = frag(s, a_off + (i + 1) * 512 + PLANE);
           }
-          // x1 y0 + x0 y1 (the 2^-11 corrections) ahead of x0 y0, alternating column tiles as above
-          MCGRA_P(a1, b0) MCGRA_P(a0, b1) MCGRA_P(a0, b0)
+          // x1 y0 + x0 y1 (the 2^-11 corrections) ahead of x0 y0, cycling through the column tiles so that
+          // consecutive MFMAs never depend on each other's accumulator
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = plane_mma<NP>(a1, b0[j], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = plane_mma<NP>(a0, b1[j], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = plane_mma<NP>(a0, b0[j], acc[i][j]);
           a0 = n0; a1 = n1;
         }
       }
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
@@ -314,17 +327,17 @@ __global__ __launch_bounds__(THREADS, 1) void split3_symm_kernel(const char* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          o[(wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TB + wn * 64 + j * 32 + l31] = acc[i][j][r];
+          o[(wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TB + wn * (NJ * 32) + j * 32 + l31] = acc[i][j][r];
     return;
   }
-  const int m0 = tile_m * TB + wm * 128, n0 = tile_n * TB + wn * 64;
+  const int m0 = tile_m * TB + wm * 128, n0 = tile_n * TB + wn * (NJ * 32);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int col = n0 + j * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -365,17 +378,17 @@ int chunks_of(int n, int planes) {
   return planes == 2 ? (nkc + 1) & ~1 : nkc;
 }
 
-template <int NP, int KSUB>
+template <int NP, int KSUB, int NW = 8>
 hipError_t launch_split(hipStream_t st, int grid, const void* Apack, const void* Bpack, float* C, int n, int ldc, int nkc,
                         int tm, int tiles, int panel_off, int tile_base, int ksplit, float* slab, const float* amax) {
   static bool attr_done = false;
   constexpr int smem = 2 * SplitCfg<NP, KSUB>::STAGE;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((split3_symm_kernel<NP, KSUB>), dim3(grid), dim3(THREADS), smem, st, (const char*)Apack, (const char*)Bpack,
+  hipLaunchKernelGGL((split3_symm_kernel<NP, KSUB, NW>), dim3(grid), dim3(NW * 64), smem, st, (const char*)Apack, (const char*)Bpack,
                      C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax);
   return hipSuccess;
 }
@@ -406,7 +419,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   const int tm = panel_rows >= 0 ? panel_rows : tiles;
   if (tm <= 0) return hipSuccess;
   static bool attr_done = false;
-  static int slots = 256, ksub2 = 1;
+  static int slots = 256, ksub2 = 1, waves2 = 8;
   if (!attr_done) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
@@ -416,6 +429,8 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     // kernels the engine runs beside the product; two chunks per step (MCGRA_SPLIT_KSUB=2) is as fast alone
     const char* e = getenv("MCGRA_SPLIT_KSUB");
     if (e && e[0] == '2') ksub2 = 2;
+    const char* ew = getenv("MCGRA_SPLIT_WAVES");      // 4: four waves with 128 x 128 wave tiles (2-plane kernel)
+    if (ew && ew[0] == '4') waves2 = 4;
     attr_done = true;
   }
   // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so
@@ -429,6 +444,8 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   }
   if (ksplit <= 1) { full = total; rem = 0; }
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
+    if (planes == 2 && waves2 == 4)
+      return launch_split<2, 1, 4>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
     if (planes == 2 && ksub2 == 2)
       return launch_split<2, 2>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
     if (planes == 2)
