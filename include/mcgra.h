@@ -84,10 +84,6 @@ int mcgra_ssymm_split_bf16(void* stream, int n, const float* S, int lds, const f
 int mcgra_ssymm_split_f16(void* stream, int n, const float* S, int lds, const float* X, int ldx, const float* rowsub,
                           float* C, int ldc);
 
-/* Tuning knob for A/B measurements in one process: 2 = double-buffered LDS K loop
- * (default), 1 = single LDS stage with two barriers per K tile.  Same results bit for bit. */
-int mcgra_set_gemm_variant(int v);
-
 /* ------------------------------------------------------- standalone ops --
  * Each mirrors one reference function on its own inputs; the attack engine
  * below runs fused forms of the same kernels. */
@@ -112,6 +108,17 @@ int mcgra_info_entropy(void* stream, int n, const float* prob, float* out);
 /* PGDAttack.dot_product_decode (topology_attack.py:414-419):
  * out[p(i,j)] = relu(<Z_i, Z_j> / (max(|Z_i|,1e-12) max(|Z_j|,1e-12))), i > j. */
 int mcgra_dot_product_decode(void* stream, int n, int d, const float* Z, float* out);
+
+/* PGDAttack.dot_product_decode2 (topology_attack.py:421-467): out [n x n] for
+ * Z [n x d].  mode selects the reference's dataset branch:
+ *   0 cora / AIDS      sigmoid(relu(Z Z^T - I))                                (:422-425)
+ *   1 citeseer         the same after F.normalize(Z, p=2, dim=1)               (:427-431)
+ *   2 brazil           relu(Z Z^T - I)                                         (:433-435)
+ *   3 polblogs / usair default: relu(F.normalize(Z Z^T, p=2, dim=1) - I)       (:438-442, :459-462)
+ *   4 / 5 / 6 usair    relu(Zn Zn^T - I), Zn = F.normalize(Z, p = 2 / 3 / 5)   (:444-458)
+ * (mc-gra_amd/topology_attack.py:_decode_mode maps args.dataset / useH_A /
+ * useY_A / useY to the mode; mcgra_attack_finalize takes the same number.) */
+int mcgra_dot_product_decode2(void* stream, int n, int d, const float* Z, int mode, float* out);
 
 /* CudaCKA.linear_HSIC (utils.py:1085-1089) for X [m x dx], Y [m x dy]:
  * *out = sum(center(X X^T) * center(Y Y^T)).  Evaluated as |Xc^T Yc|_F^2. */

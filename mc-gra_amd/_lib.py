@@ -21,10 +21,10 @@ MEASURES = {"HSIC": 0, "MSELoss": 1, "KL": 2, "CKA": 3, "DP": 4}
 
 # every symbol include/mcgra.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
-    "mcgra_version", "mcgra_last_error", "mcgra_device_count", "mcgra_sgemm", "mcgra_set_gemm_variant",
+    "mcgra_version", "mcgra_last_error", "mcgra_device_count", "mcgra_sgemm",
     "mcgra_ssyrk_lower", "mcgra_ssymm_lower",
     "mcgra_get_modified_adj", "mcgra_pack_tril", "mcgra_normalize_adj", "mcgra_info_entropy",
-    "mcgra_dot_product_decode", "mcgra_linear_hsic", "mcgra_hsic_regular", "mcgra_hsic_normalized", "mcgra_mse",
+    "mcgra_dot_product_decode", "mcgra_dot_product_decode2", "mcgra_linear_hsic", "mcgra_hsic_regular", "mcgra_hsic_normalized", "mcgra_mse",
     "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
@@ -66,7 +66,6 @@ def _load():
     sig = {
         "mcgra_sgemm": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp, C.c_int, fp, C.c_int,
                         C.c_float, fp, C.c_int],
-        "mcgra_set_gemm_variant": [C.c_int],
         "mcgra_ssyrk_lower": [vp, C.c_int, C.c_int, C.c_float, fp, C.c_int, C.c_float, fp, C.c_int],
         "mcgra_ssymm_lower": [vp, C.c_int, C.c_int, C.c_float, fp, C.c_int, fp, C.c_int, C.c_float, fp, C.c_int],
         "mcgra_get_modified_adj": [vp, C.c_int, fp, fp, fp],
@@ -74,6 +73,7 @@ def _load():
         "mcgra_normalize_adj": [vp, C.c_int, fp, fp],
         "mcgra_info_entropy": [vp, C.c_int, fp, fp],
         "mcgra_dot_product_decode": [vp, C.c_int, C.c_int, fp, fp],
+        "mcgra_dot_product_decode2": [vp, C.c_int, C.c_int, fp, C.c_int, fp],
         "mcgra_linear_hsic": [vp, C.c_int, C.c_int, C.c_int, fp, fp, fp],
         "mcgra_hsic_regular": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp],
         "mcgra_hsic_normalized": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp],

@@ -118,13 +118,12 @@ struct mcgra_attack {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool p1_inflight = false;
   bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
-  // opt-in (MCGRA_SPLIT_BF16=1): P1 through the 3-plane bf16 split of split_bf16.hip instead of the fp32 MFMA SYMM
+  // P1 through the split kernel of split_symm_bf16.hip instead of the fp32 MFMA SYMM
   bool split_on = false;
-  int split_mode = 0;              // 1: planes concatenated along K through hipBLASLt; 2: hand-written kernel on packed planes
+  int split_mode = 0;              // 0: fp32 MFMA SYMM; 2: split3_symm_kernel on packed planes
   unsigned char *Apack = 0, *Bpack = 0;
   int split_planes = 3;            // 3: bf16 x 3 (six products); 2: fp16 x 2 (three products, operand scales from amax)
   float *amax = 0;                 // [0] max |H Kf H| (per graph), [1] max |Xc| (per step, from the centring pass)
-  unsigned short *Acat = 0, *Bcat = 0;
   int64_t split_steps = 0;
   GemmTimer timer;
 };
@@ -362,20 +361,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     A_(nmask, 4);
     // The one N x N x N product of a low-rank step.  Default for n >= 1024: the 2-plane fp16 split on the 16-bit matrix
     // cores (split_symm_bf16.hip: fp32-level error, three plane products).  MCGRA_SPLIT_BF16=0: fp32 MFMA SYMM;
-    // =1: the 3-plane bf16 split through a hipBLASLt GEMM on K-concatenated planes; =2: the 3-plane bf16 split
-    // kernel (six products, fp32 exponent range) at any size; =3: the 2-plane fp16 kernel at any size.
+    // =2: the 3-plane bf16 split kernel (six products, fp32 exponent range) at any size; =3: the 2-plane fp16
+    // kernel at any size.
     const char* es = getenv("MCGRA_SPLIT_BF16");
     const char auto_mode[2] = {n >= 1024 ? '3' : '0', 0};
     if (!es || !es[0]) es = auto_mode;
-    if (!rc && h->lr_ok && cfg->eps == 0.f && es && es[0] == '1') {
-      if (!split_bf16_available()) { rc = MCGRA_ENOSUP; }
-      else {
-        const size_t cat = (size_t)n * 6 * split_bf16_kpad((int)n);
-        A_(Acat, cat); A_(Bcat, cat);
-        h->split_on = (rc == 0);
-        h->split_mode = 1;
-      }
-    }
     if (!rc && h->lr_ok && cfg->eps == 0.f && es && (es[0] == '2' || es[0] == '3')) {
       h->split_planes = es[0] == '3' ? 2 : 3;
       A_(Apack, split3_pack_bytes((int)n, h->split_planes)); A_(Bpack, split3_pack_bytes((int)n, h->split_planes));
@@ -405,6 +395,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
 #undef A_
+  // the zero fills of dalloc ran on the null stream: order them in front of whatever stream the caller uses next
+  if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed after allocation"); rc = MCGRA_EHIP; }
   if (rc) { mcgra_attack_destroy(h); return rc; }
   *out = h;
   return 0;
@@ -488,7 +480,6 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
     launch_rowsum(st, n, ld, h->FADJ, h->rowsx);
     launch_center_cols(st, n, ld, h->FADJ, h->rowsx, h->cmean, h->XC);
     CHK(eg(h, st, false, true, n, n, n, 1.f, h->XC, ld, h->XC, ld, 0.f, h->KFC, ld));
-    if (h->split_mode == 1) split3_planes_sym(st, n, ld, h->KFC, h->Acat);     // bf16 planes of the constant Gram, once
     if (h->split_mode == 2) {
       if (h->split_planes == 2) {
         MCGRA_HIP(hipMemsetAsync(h->amax, 0, sizeof(float), st));
@@ -705,27 +696,22 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       hipStream_t sp = h->overlap ? h->st2 : st;
       // bf16 planes of Xc^T (opt-in split path) on the caller's stream, ahead of the fork: cmean is reused later
       // (row blocks of a sharded step must start on a 256-row panel for the split kernel; otherwise fp32 SYMM)
-      const bool split_now = h->split_on && !noise && (h->split_mode == 1 || (c.row_begin % split3_panel()) == 0);
-      if (split_now && h->split_mode == 1) split3_planes_rows(st, n, ld, h->ADJN, h->cmean, h->Bcat);
-      if (split_now && h->split_mode == 2)
+      const bool split_now = h->split_on && !noise && (c.row_begin % split3_panel()) == 0;
+      if (split_now)
         split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr);
       if (h->overlap) {
         MCGRA_HIP(hipEventRecord(h->ev_fork, st));
         MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
       }
       if (split_now) {
-        // planes of Xc^T from the rows of the (symmetric) adj_norm, then the split product: one bf16 library GEMM
-        // (split_bf16.hip) or the hand-written plane-reusing kernel (split_symm_bf16.hip)
+        // planes of Xc^T from the rows of the (symmetric) adj_norm, then the plane-reusing kernel (split_symm_bf16.hip)
         const int row0 = t0 * SYM_TILE, row1 = t1 * SYM_TILE < n ? t1 * SYM_TILE : n;
         const bool big = h->profile;
         CHK(timer_begin(h, sp, big));
-        if (h->split_mode == 1) CHK(split_bf16_gemm(sp, n, row0, row1 - row0, h->Acat, h->Bcat, h->KX, ld));
-        else {
-          const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
-          // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
-          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld,
-                                h->split_planes, h->amax));
-        }
+        const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
+        // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
+        MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld,
+                              h->split_planes, h->amax));
         CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
         ++h->split_steps;
       } else
@@ -1119,6 +1105,9 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   hipStream_t st = (hipStream_t)stream;
   const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
   if (!h->have_step) CHK(forward_common(h, st, h->ADJN, nullptr));   // epochs == 0: adj_norm of :142
+  // M is overwritten below (:301): the forward a monitor call left for the next step and the row sums the Adam pass
+  // left for the next normalisation describe the old M
+  h->fwd_cached = h->prep_valid = false;
   // em = embedding(features, adj_norm) ; adj_changes <- dot_product_decode(em) (:300-301)
   CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu, h->Su));
   launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);

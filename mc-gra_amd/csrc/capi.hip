@@ -94,11 +94,6 @@ int mcgra_ssymm_split_f16(void* stream, int n, const float* S, int lds_, const f
   return ssymm_split(stream, 2, n, S, lds_, X, ldx, rowsub, C, ldc);
 }
 
-int mcgra_set_gemm_variant(int v) {
-  set_gemm_variant(v);
-  return 0;
-}
-
 int mcgra_get_modified_adj(void* stream, int n, const float* adj_changes, const float* ori_adj, float* out) {
   if (n < 1 || !adj_changes || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
   launch_unpack_sym((hipStream_t)stream, n, n, adj_changes, ori_adj, n, out);
@@ -160,6 +155,32 @@ int mcgra_dot_product_decode(void* stream, int n, int d, const float* Z, float* 
   launch_row_normalize(st, n, d, Z, d, Zn, dd, nullptr, 2.f);
   MCGRA_HIP(sgemm(st, false, true, n, n, d, 1.f, Zn, dd, Zn, dd, 0.f, S, ld, nullptr, 0));
   launch_pack_tril(st, n, ld, S, out, true);
+  MCGRA_KERNEL_CHECK();
+  MCGRA_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// PGDAttack.dot_product_decode2 (topology_attack.py:421-467): out[n][n] = the branch `mode` selects
+// (the mapping from args.dataset / useH_A / useY_A / useY is mc-gra_amd/topology_attack.py:_decode_mode).
+// Same kernels, in the same order, as the engine's post-loop ensemble (attack.hip: dd2).
+int mcgra_dot_product_decode2(void* stream, int n, int d, const float* Z, int mode, float* out) {
+  if (n < 1 || d < 1 || !Z || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  if (mode < 0 || mode > 6) { set_error("decode_mode %d", mode); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = (n + 3) & ~3, dd = (d + 3) & ~3;
+  Scratch s;
+  float* Zn = s.get<float>((size_t)n * dd); NEED(Zn);
+  float* S = s.get<float>((size_t)n * ld); NEED(S);
+  float* rn = s.get<float>(ld); NEED(rn);
+  const float* src = Z;
+  int lsrc = d;
+  if (mode == 1 || mode >= 4) {       // F.normalize(Z, p, dim=1) first: citeseer (p=2), usair variants (p=2,3,5)
+    launch_row_normalize(st, n, d, Z, d, Zn, dd, nullptr, mode == 5 ? 3.f : (mode == 6 ? 5.f : 2.f));
+    src = Zn; lsrc = dd;
+  }
+  MCGRA_HIP(sgemm(st, false, true, n, n, d, 1.f, src, lsrc, src, lsrc, 0.f, S, ld, nullptr, 0));
+  MCGRA_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * n, st));
+  launch_dd2_accum(st, n, ld, S, (mode == 0 || mode == 1) ? 0 : (mode == 3 ? 3 : 2), rn, out, n);
   MCGRA_KERNEL_CHECK();
   MCGRA_HIP(hipStreamSynchronize(st));
   return 0;

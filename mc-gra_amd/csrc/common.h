@@ -25,8 +25,6 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                  float* ws, size_t ws_bytes);
 
-void set_gemm_variant(int v);
-
 // rankk_f32.hip: C = beta C + alpha1 A1 B1^T (+ alpha2 A2 B2^T), K1, K2 <= 64 (HBM-bound rank-k updates)
 bool rankk_nt_supported(int M, int N, int K1, int K2);
 hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const float* A1, int lda1, const float* B1,
@@ -54,13 +52,6 @@ hipError_t ssyrk_lower(hipStream_t st, int n, int k, float alpha, const float* A
 hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S, int lds_, const float* B, int ldb,
                        float beta, float* C, int ldc, const float* S2 = nullptr, const float* B2 = nullptr,
                        float* C2 = nullptr, int tile_off = 0, int tile_rows = -1);
-
-// split_bf16.hip (opt-in): P1 = S B as a 3-plane bf16 split through one library GEMM
-bool split_bf16_available();
-int split_bf16_kpad(int n);
-void split3_planes_sym(hipStream_t st, int n, int ld, const float* S_lower, void* Acat);
-void split3_planes_rows(hipStream_t st, int n, int ld, const float* X, const float* mean, void* Bcat);
-int split_bf16_gemm(hipStream_t st, int n, int row0, int nrows, const void* Acat, const void* Bcat, float* C, int ldc);
 
 // split_symm_bf16.hip: the split as a hand-written kernel on packed planes; planes = 3 (bf16 x 3, six products,
 // MCGRA_SPLIT_BF16=2) or 2 (fp16 x 2 with exact power-of-two operand scales from amax, three products, =3)

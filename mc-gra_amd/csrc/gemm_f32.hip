@@ -79,14 +79,12 @@ __device__ __forceinline__ f32x4 load_v4(const float* __restrict__ base, int ld,
   return v;
 }
 
-static int g_gemm_sched = 0;   // block-schedule experiment knob (set_gemm_variant bits 8..15)
-
 template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool VEC, int NBUF, int SYM, int PF>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
     int k_per_split, size_t c_split_stride, int tiles_m, int tiles_n,
-    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2, int tile_off, int sched) {
+    const float* __restrict__ A2, const float* __restrict__ B2, float* __restrict__ C2, int tile_off) {
   using Cfg = GemmCfg<BM, BN, BK, WM, WN, TA, TB>;
   // blockIdx.y == 1: the second, independent product of a batched pair (same shapes and leading dimensions);
   // one launch instead of two lets the tail round of the first product overlap the head of the second
@@ -102,7 +100,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
   {
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
-    if (!(sched & 1)) {
+    {
       const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
       bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
       tile_m = tm;
       tile_n = bid - tm * (tm + 1) / 2;
     } else {
-      const int GROUP_M = ((sched >> 1) & 0x7f) ? ((sched >> 1) & 0x7f) : 8;
+      constexpr int GROUP_M = 8;
       const int group_sz = GROUP_M * tiles_n;
       const int group_id = bid / group_sz;
       const int first_m = group_id * GROUP_M;
@@ -498,7 +496,7 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
       }                                                                                                  \
     }                                                                                                    \
     hipLaunchKernelGGL(kern_, grid, block, smem_, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,      \
-                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2, tile_off, g_gemm_sched);             \
+                       k_per_split, c_split_stride, tiles_m, tiles_n, A2, B2, C2, tile_off);             \
   } while (0)
   if (SYM == SYM_RK) {  // A A^T
     if (vec) MCGRA_GEMM_LAUNCH(false, true, true); else MCGRA_GEMM_LAUNCH(false, true, false);
@@ -519,32 +517,13 @@ static hipError_t launch_cfg(hipStream_t st, bool ta, bool tb, bool vec, int M, 
   return hipGetLastError();
 }
 
-// Tuning knob (mcgra_set_gemm_variant), BK 32 unless stated:
-//   2 = two LDS stages, global loads one K tile ahead (default)    4 = two LDS stages, two tiles ahead
-//   1 = one LDS stage, one tile ahead                               3 = BK 16, two stages, one tile ahead
-static int g_gemm_nbuf = 2;
-static int g_skinny_blocks = 0;      // set_gemm_variant bits 20..27: experiment override (x 256)
-static bool g_gemm_rankk = true;   // variant 16 routes rank-k updates through the MFMA kernel again (A/B measurements)
-void set_gemm_variant(int v) {
-  g_gemm_rankk = !(v & 16);
-  g_skinny_blocks = ((v >> 20) & 0xff) * 256;
-  g_gemm_sched = (v >> 8) & 0xff;     // bit 0: no XCD remap; bits 1..7: GROUP_M (0 = 8)
-  v &= 15;
-  g_gemm_nbuf = (v == 1 || v == 3 || v == 4) ? v : 2;
-}
-
-template <int NBUF>
+// Square-ish products: 128 x 128 tiles, BK 32, two LDS stages, global loads one K tile ahead.  (Measured and not kept:
+// one stage, BK 16 at three blocks per CU, two tiles ahead: DESIGN.md section 3.)
 static hipError_t launch_big(hipStream_t st, bool ta, bool tb, bool vec, int M, int N, int K, float alpha,
                              const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                              int nsplit, int k_per_split, size_t stride) {
-  if (NBUF == 3)
-    return launch_cfg<128, 128, 16, 64, 64, 2, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                                                         ldc, nsplit, k_per_split, stride);
-  if (NBUF == 4)
-    return launch_cfg<128, 128, 32, 64, 64, 2, SYM_NONE, 2>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                                                            ldc, nsplit, k_per_split, stride);
-  return launch_cfg<128, 128, 32, 64, 64, NBUF == 1 ? 1 : 2, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb,
-                                                                       beta, C, ldc, nsplit, k_per_split, stride);
+  return launch_cfg<128, 128, 32, 64, 64, 2, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                                                       nsplit, k_per_split, stride);
 }
 
 static inline bool vec_ok(const float* A, int lda, const float* B, int ldb) {
@@ -562,7 +541,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     }
     K = 0;
   }
-  if (!ta && tb && K > 0 && g_gemm_rankk && rankk_nt_supported(M, N, K, 0))   // rank-k update: HBM-bound, not MFMA work
+  if (!ta && tb && K > 0 && rankk_nt_supported(M, N, K, 0))   // rank-k update: HBM-bound, not MFMA work
     return rankk_nt(st, M, N, K, alpha, A, lda, B, ldb, 0, 0.f, nullptr, 0, nullptr, 0, beta, C, ldc);
   const bool vec = vec_ok(A, lda, B, ldb);
   const bool skinny = N <= 64;   // up to two 32-wide column tiles: re-reading the N x N operand twice beats a 128-wide tile
@@ -575,7 +554,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     // (measured at N = 10 000: 1024 blocks 117 us vs 147 us at 512 for a 16-wide product; two column tiles want 2048;
     //  at N = 2708 more slabs only add combine work)
     const bool big = (double)M * K >= 33554432.0 || (double)N * K >= 33554432.0 * 2;
-    const int target = (skinny && big) ? (g_skinny_blocks ? g_skinny_blocks : (N > BN ? 2048 : 1024)) : 512;
+    const int target = (skinny && big) ? (N > BN ? 2048 : 1024) : 512;
     nsplit = min(min(64, (target + tiles - 1) / tiles), K / (2 * BK));
     while (nsplit > 1 && (size_t)nsplit * M * N * sizeof(float) > ws_bytes) --nsplit;
     if (nsplit < 1) nsplit = 1;
@@ -592,8 +571,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
       e = launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
                                                        nsplit, k_per_split, stride);
     else
-      e = (g_gemm_nbuf == 1 ? launch_big<1> : g_gemm_nbuf == 3 ? launch_big<3> : g_gemm_nbuf == 4 ? launch_big<4> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
-                                                             nsplit, k_per_split, stride);
+      e = launch_big(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N, nsplit, k_per_split, stride);
     if (e != hipSuccess) return e;
     const int blocks = (int)min((size_t)2048, (stride + 255) / 256);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, stride, nsplit, C, stride, N, ldc, beta);
@@ -602,8 +580,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   if (skinny)
     return launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
                                                         1, K, 0);
-  return (g_gemm_nbuf == 1 ? launch_big<1> : g_gemm_nbuf == 3 ? launch_big<3> : g_gemm_nbuf == 4 ? launch_big<4> : launch_big<2>)(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                                                            ldc, 1, K, 0);
+  return launch_big(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 1, K, 0);
 }
 
 // C = alpha A A^T + beta C on the lower tile storage (tiles of SYM_TILE = 128 with tile_n <= tile_m);

@@ -381,13 +381,11 @@ int chunks_of(int n, int planes) {
 template <int NP, int KSUB, int NW = 8>
 hipError_t launch_split(hipStream_t st, int grid, const void* Apack, const void* Bpack, float* C, int n, int ldc, int nkc,
                         int tm, int tiles, int panel_off, int tile_base, int ksplit, float* slab, const float* amax) {
-  static bool attr_done = false;
+  // the dynamic-LDS limit is a per-device function attribute: set it on every launch (a host-side table write,
+  // no device work), so that a second GPU in the same process gets it too
   constexpr int smem = 2 * SplitCfg<NP, KSUB>::STAGE;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((split3_symm_kernel<NP, KSUB, NW>), dim3(grid), dim3(NW * 64), smem, st, (const char*)Apack, (const char*)Bpack,
                      C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax);
   return hipSuccess;
@@ -418,20 +416,15 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   const int nkc = chunks_of(n, planes), tiles = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles;
   if (tm <= 0) return hipSuccess;
-  static bool attr_done = false;
-  static int slots = 256, ksub2 = 1, waves2 = 8;
-  if (!attr_done) {
+  int slots = 256;               // one block per CU of the device this launch goes to
+  {
+    static int cus_of[64] = {0};            // per device: written once with the same value by whoever gets there first
     int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        cus > 0)
-      slots = cus;               // one block per CU
-    // 2-plane kernel: one 16-k chunk per step (32 KB stages, 212 VGPRs) leaves LDS and registers for the HBM-bound
-    // kernels the engine runs beside the product; two chunks per step (MCGRA_SPLIT_KSUB=2) is as fast alone
-    const char* e = getenv("MCGRA_SPLIT_KSUB");
-    if (e && e[0] == '2') ksub2 = 2;
-    const char* ew = getenv("MCGRA_SPLIT_WAVES");      // 4: four waves with 128 x 128 wave tiles (2-plane kernel)
-    if (ew && ew[0] == '4') waves2 = 4;
-    attr_done = true;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (!cus_of[dev] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        cus_of[dev] = cus;
+      if (cus_of[dev]) slots = cus_of[dev];
+    }
   }
   // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so
   // that it fills the chip too (tiles are 256 x 256 x n: 1600 of them on 256 CUs would otherwise take 7 rounds for 6.25).
@@ -444,10 +437,6 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   }
   if (ksplit <= 1) { full = total; rem = 0; }
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
-    if (planes == 2 && waves2 == 4)
-      return launch_split<2, 1, 4>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
-    if (planes == 2 && ksub2 == 2)
-      return launch_split<2, 2>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
     if (planes == 2)
       return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
     return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);

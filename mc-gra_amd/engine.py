@@ -12,8 +12,21 @@ from . import _lib
 from ._lib import AttackConfig, check, lib
 
 
+import functools
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_operand_device(fn):
+    """Standalone ops launch on the device (and its current stream) of their first tensor argument, not on
+    whatever device happens to be current."""
+    @functools.wraps(fn)
+    def run(first, *a, **k):
+        with torch.cuda.device(first.device):
+            return fn(first, *a, **k)
+    return run
 
 
 def _p(t):
@@ -35,6 +48,7 @@ def _dev_i32(x, device):
 
 
 # ------------------------------------------------------------- standalone ops
+@_on_operand_device
 def sgemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
     """torch.mm on the fp32 MFMA kernel (mcgra_sgemm)."""
     m = A.shape[1] if ta else A.shape[0]
@@ -48,6 +62,7 @@ def sgemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
     return out
 
 
+@_on_operand_device
 def ssyrk_lower(A, out=None):
     """C = A A^T on the lower tile storage (128 x 128 tiles on or below the diagonal); the rest of
     `out` is left untouched (mcgra_ssyrk_lower)."""
@@ -58,6 +73,7 @@ def ssyrk_lower(A, out=None):
     return out
 
 
+@_on_operand_device
 def ssymm_lower(S, B, beta=0.0, out=None):
     """C = S B with symmetric S read from its lower tile storage only (mcgra_ssymm_lower)."""
     n, m = S.shape[0], B.shape[1]
@@ -68,6 +84,7 @@ def ssymm_lower(S, B, beta=0.0, out=None):
     return out
 
 
+@_on_operand_device
 def ssymm_split_bf16(S, X, rowsub=None, out=None):
     """C = S (X - rowsub 1^T)^T through the 3-plane bf16 split kernel (mcgra_ssymm_split_bf16); S symmetric."""
     n = S.shape[0]
@@ -77,6 +94,7 @@ def ssymm_split_bf16(S, X, rowsub=None, out=None):
     return out
 
 
+@_on_operand_device
 def ssymm_split_f16(S, X, rowsub=None, out=None):
     """The same product through the 2-plane fp16 split kernel (mcgra_ssymm_split_f16); S symmetric."""
     n = S.shape[0]
@@ -86,6 +104,7 @@ def ssymm_split_f16(S, X, rowsub=None, out=None):
     return out
 
 
+@_on_operand_device
 def normalize_adj_tensor(adj):
     """utils.normalize_adj_tensor, dense branch (utils.py:211-230)."""
     out = torch.empty_like(adj)
@@ -93,18 +112,21 @@ def normalize_adj_tensor(adj):
     return out
 
 
+@_on_operand_device
 def get_modified_adj(adj_changes, ori_adj, n):
     out = torch.empty(n, n, device=adj_changes.device, dtype=torch.float32)
     check(lib.mcgra_get_modified_adj(_stream(), n, _p(adj_changes), _p(ori_adj), _p(out)))
     return out
 
 
+@_on_operand_device
 def info_entropy(prob):
     out = torch.zeros(1, device=prob.device, dtype=torch.float32)
     check(lib.mcgra_info_entropy(_stream(), prob.shape[0], _p(prob), _p(out)))
     return out[0]
 
 
+@_on_operand_device
 def dot_product_decode(Z):
     n, d = Z.shape
     out = torch.empty(n * (n - 1) // 2, device=Z.device, dtype=torch.float32)
@@ -112,12 +134,23 @@ def dot_product_decode(Z):
     return out
 
 
+@_on_operand_device
+def dot_product_decode2(Z, mode):
+    """PGDAttack.dot_product_decode2 (topology_attack.py:421-467); `mode` as topology_attack._decode_mode gives it."""
+    n, d = Z.shape
+    out = torch.empty(n, n, device=Z.device, dtype=torch.float32)
+    check(lib.mcgra_dot_product_decode2(_stream(), n, d, _p(Z), int(mode), _p(out)))
+    return out
+
+
+@_on_operand_device
 def linear_hsic(X, Y):
     out = torch.zeros(1, device=X.device, dtype=torch.float32)
     check(lib.mcgra_linear_hsic(_stream(), X.shape[0], X.shape[1], Y.shape[1], _p(X), _p(Y), _p(out)))
     return out[0]
 
 
+@_on_operand_device
 def hsic_regular(x, y, sigma):
     """hsic.hsic_regular (hsic.py:117-124) with a given sigma."""
     out = torch.zeros(1, device=x.device, dtype=torch.float32)
@@ -125,6 +158,7 @@ def hsic_regular(x, y, sigma):
     return out[0]
 
 
+@_on_operand_device
 def hsic_normalized(x, y, sigma):
     """hsic.hsic_normalized (hsic.py:127-135) with a given sigma."""
     out = torch.zeros(1, device=x.device, dtype=torch.float32)
@@ -132,12 +166,14 @@ def hsic_normalized(x, y, sigma):
     return out[0]
 
 
+@_on_operand_device
 def mse(X, Y):
     out = torch.zeros(1, device=X.device, dtype=torch.float32)
     check(lib.mcgra_mse(_stream(), X.numel(), _p(X), _p(Y), _p(out)))
     return out[0]
 
 
+@_on_operand_device
 def gcn_forward(X, adj, W, b, Wlin, blin, emb_nlayer=0):
     """GCN.forward (eval) and, when emb_nlayer > 0, embedding_GCN.forward."""
     n, nfeat = X.shape

@@ -6,9 +6,8 @@ H_A / Y_A, run PGDAttack on the MI355X hot path, report the recovered-adjacency 
         --useH_A --useY_A --useY --measure MSELoss            (after mcgra_loader.load())
     python mc-gra_amd/main.py ...                             (stand-alone; bootstraps the loader itself)
 
-Not provided (each exits with a message naming the reference line): --arch gat/sage victim training
-(main.py:193-231; the attack itself accepts those victims), --mode search/baseline/gaussian/gcn_attack,
---measure KDE.
+--arch gcn | sage | gat select the victim family as main.py:175-231 does.  Not provided (each exits with a message
+naming the reference line): --mode search/baseline/gaussian/gcn_attack, --measure KDE.
 """
 import argparse
 import os
@@ -25,11 +24,15 @@ if __package__ in (None, ""):          # run as a script: load the hyphenated di
     from mc_gra_amd import utils
     from mc_gra_amd.dataset import Dataset
     from mc_gra_amd.models.gcn import GCN, embedding_GCN
+    from mc_gra_amd.models.gat import GAT, embedding_gat
+    from mc_gra_amd.models.graphsage import graphsage, embedding_graphsage
     from mc_gra_amd.topology_attack import PGDAttack
 else:
     from . import utils
     from .dataset import Dataset
     from .models.gcn import GCN, embedding_GCN
+    from .models.gat import GAT, embedding_gat
+    from .models.graphsage import graphsage, embedding_graphsage
     from .topology_attack import PGDAttack
 
 import torch
@@ -106,9 +109,6 @@ def run(args):
     np.random.seed(args.seed); random.seed(args.seed); torch.manual_seed(args.seed)       # main.py:142-146
     if args.measure == "KDE":
         sys.exit("measure=KDE needs utils.MutualInformation (utils.py:980), which is cuda:0-only and not provided")
-    if args.arch != "gcn":
-        sys.exit(f"--arch {args.arch}: victim training of main.py:193-231 is not provided (the attack accepts such "
-                 "victims: pass model objects to PGDAttack)")
     data = Dataset(root=args.dataset_root, name=args.dataset, setting='GCN')
     adj, features, labels, init_adj = data.adj, data.features, data.labels, data.init_adj
     idx_train, idx_val, idx_test = data.idx_train, data.idx_val, data.idx_test
@@ -123,11 +123,29 @@ def run(args):
         feature_adj = torch.eye(*feature_adj.size())
     init_adj = torch.FloatTensor(init_adj.todense())
 
-    victim_model = GCN(nfeat=features.shape[1], nclass=labels.max().item() + 1, nhid=16, nlayer=args.nlayers,
-                       dropout=0.5, weight_decay=5e-4, device=device).to(device)           # main.py:175-183
-    victim_model.fit(features, adj, labels, idx_train, idx_val, verbose=False)
-    embedding = embedding_GCN(nfeat=features.shape[1], nhid=16, nlayer=args.nlayers, device=device)
-    embedding.gc = deepcopy(victim_model.gc)                                               # main.py:190
+    nfeat, nclass = features.shape[1], labels.max().item() + 1
+    if args.arch == "gcn":                                                                 # main.py:175-190
+        victim_model = GCN(nfeat=nfeat, nclass=nclass, nhid=16, nlayer=args.nlayers, dropout=0.5, weight_decay=5e-4,
+                           device=device).to(device)
+        victim_model.fit(features, adj, labels, idx_train, idx_val, verbose=False)
+        embedding = embedding_GCN(nfeat=nfeat, nhid=16, nlayer=args.nlayers, device=device)
+        embedding.gc = deepcopy(victim_model.gc)
+    elif args.arch == "sage":                                                              # main.py:193-210
+        victim_model = graphsage(nfeat=nfeat, nclass=nclass, nhid=16, nlayer=args.nlayers, dropout=0.5,
+                                 weight_decay=5e-4, device=device).to(device)
+        for l in victim_model.gc:
+            l.to(device)
+        victim_model.fit(features, adj, labels, idx_train, idx_val, verbose=False)
+        embedding = embedding_graphsage(nfeat=nfeat, nhid=16, nlayer=args.nlayers, device=device)
+        embedding.gc = deepcopy(victim_model.gc)
+    else:                                                                                  # main.py:213-231
+        victim_model = GAT(nfeat=nfeat, nclass=nclass, nhid=16, nlayer=args.nlayers, dropout=0.5, alpha=0.1, nheads=5,
+                           device=device).to(device)
+        victim_model.fit(features, adj, labels, idx_train, idx_val, train_iters=getattr(args, "gat_train_iters", 200))
+        embedding = embedding_gat(nfeat=nfeat, nclass=nclass, nhid=16, nlayer=args.nlayers, dropout=0.5, alpha=0.1,
+                                  nheads=5, device=device)
+        embedding.attentions = victim_model.attentions
+    victim_model.eval(); embedding.eval()
     with torch.no_grad():
         fd, ad = features.to(device), adj.to(device)
         Y_A = victim_model(fd, ad)                                                         # main.py:236

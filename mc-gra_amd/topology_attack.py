@@ -200,10 +200,12 @@ class PGDAttack(BaseAttack):
         idx = np.asarray(idx_attack).astype(np.int64)
         W, b, Wlin, blin, Ws, act, head_act, emb_full = self._weights(victim_model, self.embedding)
         dims = [W[0].shape[0]] + [w.shape[1] for w in W]
-        emb_nlayer = len(W) if emb_full else int(getattr(self.embedding, "nlayer", 2))
-        fin_layers = (len(W), len(W)) if emb_full else (1, 2)   # embedding_gat.forward ignores set_layers
-        # inside the loop the reference ends every iteration with embedding.set_layers(2) (:179) or
-        # set_layers(nlayer) (:240); both are 2 for main.py's flow
+        # GCN / GraphSAGE embeddings: whatever embedding.nlayer holds at call time, the reference loop resets it with
+        # set_layers(2) (:179) before `em = embedding(...)` (:185), the w9 loop (:238-240) and the post-loop decode
+        # (:300) use it, so every embedding inside the loop is the 2-layer one.  embedding_gat.forward ignores
+        # set_layers (gat.py:170-174): full depth.
+        emb_nlayer = len(W) if emb_full else min(2, len(W))
+        fin_layers = (len(W), len(W)) if emb_full else (1, min(2, len(W)))
         label_adj = kwargs.get("label_adj", None)
         if label_adj is None and getattr(args, "useY", False):
             label_adj = np.load("./saved_data/" + args.dataset + ".npy")   # (:133)
@@ -242,5 +244,10 @@ class PGDAttack(BaseAttack):
             raise ValueError("args.useH_A needs H_A= at construction (main.py:298)")
         if use_YA and Y_A is None:
             raise ValueError("args.useY_A needs Y_A= at construction (main.py:298)")
+        if H_A is not None and tuple(H_A.shape) != (n, dims[emb_nlayer]):
+            raise ValueError(f"H_A has shape {tuple(H_A.shape)}; the {emb_nlayer}-layer embedding of this victim gives "
+                             f"({n}, {dims[emb_nlayer]}) (main.py:238-241)")
+        if Y_A is not None and tuple(Y_A.shape) != (n, int(Wlin.shape[0])):
+            raise ValueError(f"Y_A has shape {tuple(Y_A.shape)}, expected ({n}, {int(Wlin.shape[0])})")
         self.modified_adj = eng.finalize(_decode_mode(args), H_A, Y_A, label_adj if use_Y else None).detach()
         return 0, 0, 0, 0

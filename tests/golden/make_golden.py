@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it
 writes under tests/golden/ are data (inputs + the reference's outputs) and are
-what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cora]
+what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cora|bench10k|citeseer]
 
 Environment shims applied before importing the reference (none of them is on
 the computed path):
@@ -407,6 +407,130 @@ def gen_cora(tmp):
         print(name, "auc", res["auc"])
 
 
+def gen_citeseer_gat(tmp, train_iters=6):
+    """BASELINE.json configs[2]: Citeseer through the reference's Dataset, the dense GAT victim (models/gat.py:176-206,
+    5 heads x 16 as main.py:213-216) trained by the reference's own GAT.fit, embedding_gat sharing its attention layers
+    (main.py:226-231), priors H_A + Y, the citeseer branch of dot_product_decode2 (:427-431).  GAT.fit runs
+    `train_iters` iterations instead of main.py's 200 (each costs ~10 s on the CPU: the layer materialises an
+    N x N x 2F attention input, gat.py:36-41); the weights travel in the fixture, so the attack sees exactly this victim.
+    Two configurations: the README's `K = {X, H_A, Y}` citeseer line (measure KL) and an HSIC one (Gram evaluation:
+    ELU embeddings of width 80)."""
+    os.chdir(tmp)
+    if not os.path.exists("dataset"):
+        os.symlink(os.path.join(REF, "dataset"), "dataset")
+    os.makedirs("saved_data", exist_ok=True)
+    from dataset import Dataset
+    from models.gat import GAT
+    import time as _t
+    seed = 15
+    np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)
+    data = Dataset(root="./dataset", name="citeseer", setting="GCN")
+    adj, features, labels = data.adj, data.features, data.labels
+    idx_train, idx_val, idx_test = data.idx_train, data.idx_val, data.idx_test
+    idx_attack = np.array(random.sample(range(adj.shape[0]), int(adj.shape[0] * 1.0)))   # main.py:155
+    adj, features, labels = rutils.preprocess(adj, features, labels, preprocess_adj=False, onehot_feature=False)
+    device = torch.device("cpu")
+    victim = GAT(nfeat=features.shape[1], nclass=labels.max().item() + 1, nhid=16, nlayer=2, dropout=0.5, alpha=0.1,
+                 nheads=5, device=device)
+    t0 = _t.time()
+    victim.fit(features, adj, labels, idx_train, idx_val, train_iters=train_iters)
+    print("GAT.fit", train_iters, "iterations:", round(_t.time() - t0, 1), "s", flush=True)
+    idx_attack = np.array(random.sample(range(adj.shape[0]), int(adj.shape[0] * 1.0)))   # main.py:244
+    num_edges = int(0.5 * 1e7 * adj.sum() / adj.shape[0] ** 2 * len(idx_attack) ** 2)
+    lab = labels.numpy()
+    np.save("saved_data/citeseer.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
+    n = adj.shape[0]
+    rng = np.random.RandomState(0)
+    samp = rng.randint(0, n, size=(8192, 2))
+    npk = n * (n - 1) // 2
+    pk = np.unique(np.concatenate([np.arange(0, npk, max(1, npk // 4096)), rng.randint(0, npk, 4096)])).astype(np.int64)
+    fx = features.numpy()
+    assert set(np.unique(fx)) <= {0.0, 1.0}
+    ei = np.argwhere(np.triu(adj.numpy(), 1) > 0).astype(np.int32)
+    assert np.array_equal(adj.numpy(), adj.numpy().T) and np.trace(adj.numpy()) == 0
+    common = dict(idx_attack=idx_attack, idx_test=idx_test, num_edges=float(num_edges), sample_pos=samp, packed_pos=pk,
+                  features_bits=np.packbits(fx.astype(np.uint8), axis=1), nfeat=fx.shape[1], adj_edges=ei, labels=lab,
+                  arch="gat", nheads=5, emb_nlayer=2, fin_layers=np.array([2, 2]), dataset="citeseer",
+                  use=np.array([1, 0, 1]), train_iters=train_iters, **weights_of(victim))
+    runs = [
+        # README.md citeseer "K = {X, H_A, Y}" line: --w1=0.001 --w2=10000 --w6=0.0001 --w7=100 --w9=100 --lr=-1 KL
+        ("citeseer_gat_kl", "KL", (0.001, 10000, 0, 0, 0, 0.0001, 100, 0, 100, 0), 1.0, 10 ** -1, 3, None),
+        # HSIC on the same victim, seeded start (the origin is a fixed point of the exact HSIC dynamics)
+        ("citeseer_gat_hsic", "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0), 1.0, 10 ** -2, 3, (123, 0.05)),
+    ]
+    for name, measure, wp, wsup, lr, epochs, init in runs:
+        a0 = init_adj_changes(n, *init) if init else None
+        t0 = _t.time()
+        res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs,
+                                   "citeseer", (True, False, True), num_edges, a0=a0)
+        extra = dict(a0_seed=init[0], a0_scale=init[1]) if init else {}
+        sa = np.stack(res["steps_a"]); sg = np.stack(res["steps_g"])
+        out = dict(measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup, lr=lr, epochs=epochs,
+                   auc=res["auc"], **extra,
+                   final_sample=res["final"][samp[:, 0], samp[:, 1]], final_sum=float(res["final"].astype(np.float64).sum()),
+                   step_a=sa[:, pk], step_g=sg[:, pk], step_g_absmax=np.abs(sg).max(1),
+                   step_g_sum=sg.astype(np.float64).sum(1), step_g_sqsum=(sg.astype(np.float64) ** 2).sum(1),
+                   step_a_clip_sum=np.clip(sa, 0, 1).astype(np.float64).sum(1),
+                   H_A2=res["H_A2"], Y_A=res["Y_A"], **common)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+        print(name, "auc", res["auc"], "seconds", round(_t.time() - t0, 1), flush=True)
+
+
+def gen_bench(tmp, workload="synthetic-10k-hsic", tag="bench10k_hsic", seed=0, epochs=4, single_starts=((1, 0.2), (2, 0.6))):
+    """The bench's OWN workload (bench.WORKLOADS[workload], bench.make_inputs, bench.make_a0) through the
+    reference's PGDAttack.attack on CPU (topology_attack.py:161-324).  The inputs are regenerated from the seed by
+    the test, so the fixture holds only the reference's outputs: per-step gradient / adj_changes on a fixed sample
+    of packed positions, fp64 step sums, a sample of the final ensemble and the AUC.  Besides the `epochs`-step
+    run from bench.make_a0(n, seed), `single_starts` = ((seed offset, scale), ...) are one-step runs from other
+    seeded starts: each is a step whose starting state the test can rebuild exactly (the 50 M-entry adj_changes of
+    later steps of a run cannot be stored), i.e. teacher forcing by construction."""
+    os.chdir(tmp)
+    os.makedirs("saved_data", exist_ok=True)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import bench as B
+    n, f, c, hid, nl, measure, wp = B.WORKLOADS[workload]
+    inp = B.make_inputs(n, f, c, hid, nl, seed)
+    device = torch.device("cpu")
+    victim = GCN(nfeat=f, nclass=c, nhid=hid, nlayer=nl, dropout=0.5, weight_decay=5e-4, device=device)
+    with torch.no_grad():
+        for l in range(nl):
+            victim.gc[l].weight.copy_(torch.tensor(inp["W"][l])); victim.gc[l].bias.copy_(torch.tensor(inp["b"][l]))
+        victim.linear1.weight.copy_(torch.tensor(inp["Wlin"])); victim.linear1.bias.copy_(torch.tensor(inp["blin"]))
+    lab = inp["labels"]
+    np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
+    adj = torch.tensor(inp["adj"]); feats = torch.tensor(inp["features"]); labels = torch.LongTensor(lab)
+    npk = n * (n - 1) // 2
+    rng = np.random.RandomState(99)
+    pk = np.unique(np.concatenate([np.arange(0, npk, max(1, npk // 4096)), rng.randint(0, npk, 4096)])).astype(np.int64)
+    samp = rng.randint(0, n, size=(8192, 2))
+    out = dict(workload=workload, seed=seed, epochs=epochs, packed_pos=pk, sample_pos=samp, lr=0.01, weight_sup=1.0,
+               weight_param=np.array(wp, dtype=np.float64), measure=measure)
+    import time as _t
+    runs = [("run", seed, 0.05, epochs)] + [(f"one{k}", seed + off, sc, 1) for k, (off, sc) in enumerate(single_starts)]
+    for name, sd, sc, ep in runs:
+        a0 = B.make_a0(n, sd, sc)
+        t0 = _t.time()
+        res = run_reference_attack(adj, feats, labels, victim, inp["idx_attack"], measure, wp, 1.0, 0.01, ep,
+                                   "cora", (True, True, True), 1e30, a0=a0)
+        sa = np.stack(res["steps_a"]); sg = np.stack(res["steps_g"])
+        out.update({f"{name}_a0_seed": sd, f"{name}_a0_scale": sc,
+                    f"{name}_a": sa[:, pk], f"{name}_g": sg[:, pk],
+                    f"{name}_a_sum": sa.astype(np.float64).sum(1), f"{name}_a_sqsum": (sa.astype(np.float64) ** 2).sum(1),
+                    # the hook sees adj_changes after optimizer.step() and before projection + clamp (:281-283)
+                    f"{name}_a_clip_sum": np.clip(sa, 0, 1).astype(np.float64).sum(1),
+                    f"{name}_g_sum": sg.astype(np.float64).sum(1), f"{name}_g_sqsum": (sg.astype(np.float64) ** 2).sum(1),
+                    f"{name}_g_absmax": np.abs(sg).max(1),
+                    f"{name}_g_negfrac": (sg < 0).mean(1),
+                    f"{name}_final_sample": res["final"][samp[:, 0], samp[:, 1]],
+                    f"{name}_final_sum": float(res["final"].astype(np.float64).sum()),
+                    f"{name}_auc": res["auc"]})
+        if name == "run":
+            out.update(H_A2_sample=res["H_A2"][:64], Y_A_sample=res["Y_A"][:64])
+        print(tag, name, "auc", res["auc"], "steps", ep, "seconds", round(_t.time() - t0, 1), flush=True)
+        del res, sa, sg
+        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -419,3 +543,7 @@ if __name__ == "__main__":
             gen_small(tmp)
         if a.only in ("all", "cora"):
             gen_cora(tmp)
+        if a.only in ("citeseer",):         # ~20 min on 8 cores: not part of "all"
+            gen_citeseer_gat(tmp)
+        if a.only in ("bench10k",):         # ~25 min and ~20 GB on 8 cores: not part of "all"
+            gen_bench(tmp)

@@ -257,6 +257,58 @@ def test_free_run_final_matches_reference(pkg, torch_, name):
     eng.close()
 
 
+# dot_product_decode2 branch (topology_attack.py:421-467) -> decode_mode, with the (dataset, useH_A, useY_A, useY)
+# the reference was run with for each golden in ops.npz
+DD2_GOLDENS = [("cora", (1, 1, 1), 0), ("AIDS", (1, 0, 0), 0), ("citeseer", (1, 1, 1), 1), ("brazil", (1, 1, 1), 2),
+               ("polblogs", (1, 1, 1), 3), ("polblogs", (1, 0, 1), 3), ("usair", (0, 0, 1), 5), ("usair", (1, 1, 0), 4),
+               ("usair", (1, 0, 1), 6), ("usair", (1, 1, 1), 3)]
+
+
+@pytest.mark.parametrize("ds,use,mode", DD2_GOLDENS)
+def test_dot_product_decode2_reference_goldens(pkg, torch_, ds, use, mode):
+    """All ten dot_product_decode2 goldens of ops.npz (the reference's own outputs) through the HIP kernels the
+    post-loop ensemble uses, and through the host layer's dataset -> mode mapping."""
+    import argparse
+    from mc_gra_amd import engine as E
+    from mc_gra_amd.topology_attack import _decode_mode
+    args = argparse.Namespace(dataset=ds, useH_A=bool(use[0]), useY_A=bool(use[1]), useY=bool(use[2]))
+    assert _decode_mode(args) == mode
+    got = E.dot_product_decode2(dev(torch_, OPS["dd2_Z"]), mode).cpu().numpy()
+    ref = OPS[f"dd2_{ds}_{use[0]}{use[1]}{use[2]}"]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+
+
+FIN_MODES = {0: ("cora", (1, 1, 1)), 1: ("citeseer", (1, 1, 1)), 2: ("brazil", (1, 1, 1)), 3: ("polblogs", (1, 1, 1)),
+             4: ("usair", (1, 1, 0)), 5: ("usair", (0, 0, 1)), 6: ("usair", (1, 0, 1))}
+
+
+@pytest.mark.parametrize("mode", sorted(FIN_MODES))
+@pytest.mark.parametrize("case", ["s48_mse", "s80_hsic_l3"])
+def test_finalize_every_decode_mode_matches_oracle(pkg, torch_, case, mode):
+    """mcgra_attack_finalize (post-loop ensemble, topology_attack.py:300-324) with every dot_product_decode2 branch:
+    HIP against the oracle (itself pinned to the ten reference goldens by tests/test_oracle_golden.py), priors
+    switched as the branch's own flags say."""
+    ds, use = FIN_MODES[mode]
+    z = H.load_case(case)
+    eng = H.engine_from(pkg, z)
+    orc = H.oracle_from(z)
+    for t in range(2):
+        eng.step(); orc.step()
+        orc.set_adj_changes(eng.get_adj_changes().cpu().numpy())      # same state going into the ensemble
+    lab = z["labels"]
+    label_adj = (lab[:, None] == lab[None, :]).astype(np.float32)
+    got = eng.finalize(mode, z["H_A2"] if use[0] else None, z["Y_A"] if use[1] else None,
+                       label_adj if use[2] else None).cpu().numpy()
+    ref = orc.finalize(ds, bool(use[0]), bool(use[1]), bool(use[2]), label_adj, z["H_A2"], z["Y_A"])
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (mode, np.abs(got - ref).max())
+    # finalize replaced the learnable adjacency by the decoded one: whatever the last step left behind for the next
+    # forward is stale, a following step must recompute it (and must not silently use it)
+    sc = eng.step(want_scalars=True)
+    assert np.isfinite(sc["loss"])
+    eng.close()
+
+
 def test_projection_bisection_matches_oracle(pkg, torch_):
     z = H.load_case("s80_mse_proj")
     eng = H.engine_from(pkg, z)
@@ -564,14 +616,14 @@ def test_lowrank_with_single_terms(pkg, wp, monkeypatch):
 
 
 # ---- split evaluations of the P1 product on the 16-bit matrix cores (split_bf16.hip, split_symm_bf16.hip) -----------
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("mode", ["2", "3"])
 @pytest.mark.parametrize("case", ["s200_hsic_init", "s48_hsic"])
 def test_split_bf16_matches_fp32_path(pkg, case, mode, monkeypatch):
-    """MCGRA_SPLIT_BF16=1/2/3: same gradients as the fp32 MFMA path to fp32 rounding (the splits keep 24 / 22
+    """MCGRA_SPLIT_BF16=2/3: same gradients as the fp32 MFMA path to fp32 rounding (the splits keep 24 / 22
     mantissa bits; 3 = two fp16 planes, the default of graphs with n >= 1024)."""
     z = H.load_case(case)
     ref = H.engine_from(pkg, z)
-    monkeypatch.setenv("MCGRA_SPLIT_BF16", mode)      # 1: hipBLASLt on concatenated planes, 2 / 3: hand-written kernel
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", mode)      # 2: three bf16 planes, 3: two fp16 planes
     try:
         spl = H.engine_from(pkg, z)
         assert spl.product_mode() == int(mode)
