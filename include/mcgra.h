@@ -244,6 +244,11 @@ int mcgra_attack_exchange_mask(mcgra_attack_t* h);
 int mcgra_attack_product_mode(mcgra_attack_t* h);
 /* Steps that took the low-rank / the Gram (general) evaluation of the N x N linear_HSIC terms since creation. */
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps);
+/* How many of the low-rank steps ran as the fused step that evaluates every N x N quantity from the learnable
+ * adjacency and n-vectors (attack_fused.hip: adj_norm, its centred copy, modified_adj1 and d loss / d adj_norm are
+ * never stored).  Conditions: measure HSIC, ReLU GCN victim, eps == 0, the split product (n >= 1024 or
+ * MCGRA_SPLIT_BF16=2/3), n >= 256, widths <= 32; MCGRA_NO_FUSED_LR=1 disables it. */
+long long mcgra_attack_fused_steps(mcgra_attack_t* h);
 
 /* Use caller-owned device memory ([>= n rows][ld] fp32, ld from mcgra_attack_buffer) for one of the exchanged
  * buffers "KX", "KY", "G_adjn", "G_A1", so that the host layer can hand it to its collective library. */

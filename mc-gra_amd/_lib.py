@@ -28,7 +28,7 @@ SYMBOLS = [
     "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
-    "mcgra_attack_step_phase", "mcgra_attack_bind_buffer", "mcgra_attack_exchange_mask", "mcgra_attack_path_stats", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
+    "mcgra_attack_step_phase", "mcgra_attack_bind_buffer", "mcgra_attack_exchange_mask", "mcgra_attack_path_stats", "mcgra_attack_fused_steps", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
     "mcgra_attack_monitor", "mcgra_attack_finalize", "mcgra_attack_buffer", "mcgra_attack_copy_buffer",
     "mcgra_attack_profile",
     "mcgra_attack_gemm_stats",
@@ -106,6 +106,8 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.mcgra_attack_fused_steps.argtypes = [vp]
+    lib.mcgra_attack_fused_steps.restype = C.c_longlong
     return lib
 
 

@@ -38,101 +38,9 @@ const char* last_error() { return g_err; }
 
 }  // namespace mcgra
 
+#include "engine.h"
+
 using namespace mcgra;
-
-// utils.Align_Parameter_Cora (utils.py:1100-1111)
-static const double AP_C1 = 100, AP_C2 = 1000, AP_C6 = 10, AP_C7 = 10, AP_C9 = 1, AP_C10 = 1;
-
-enum Scal {  // device scalar slots (double)
-  S_SQ = 0, S_SUM, S_NLL, S_V1, S_V2, S_V6, S_V7, S_H1, S_H2, S_C9, S_C10, S_TOTX, S_TOTY, S_CLAMPSUM,
-  S_TMP, S_TMP2, S_CK0, S_CK1, S_CK2, S_CK3, S_COUNT = 32
-};
-
-struct GemmTimer {
-  std::vector<hipEvent_t> ev;  // pairs
-  size_t used = 0;
-  int64_t launches = 0;
-  double flops = 0;
-};
-
-struct mcgra_attack {
-  mcgra_attack_config_t cfg;
-  int n = 0, ld = 0, L = 0, Le = 0, C = 0, na = 0, hsum = 0, hmax = 0;
-  int off[MCGRA_MAX_LAYERS + 1];   // column offset of layer l inside the concatenated node buffers
-  int wdt[MCGRA_MAX_LAYERS + 1];   // width of layer l output (dims[l+1])
-  int64_t t = 0;                   // Adam step count
-  bool have_step = false;
-  // The monitoring forward of :290-296 (victim on the updated adjacency) is exactly the first forward of the next
-  // iteration (:164-167) when eps == 0: mcgra_attack_monitor leaves its adj_norm, degree vectors, chain and
-  // log-probs in place and the next step adopts them instead of recomputing (bit-identical, one N x N pass and two
-  // skinny products less per step).  MCGRA_NO_FWD_REUSE=1 disables.
-  bool fwd_cached = false, fwd_reuse = true;
-  bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
-  bool prep_valid = false;         // G_A holds the per-tile row sums of the current M (left by the fused tail kernel)
-  bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
-  float* ADJN_next = 0;
-  bool graph_set = false, model_set = false;
-  std::vector<void*> allocs;
-  // N x N
-  float *M = 0, *am = 0, *av = 0, *ADJN = 0, *A1 = 0, *G_ADJN = 0, *G_A1 = 0, *G_A = 0;
-  float *KX = 0, *KY = 0, *KFC = 0, *FADJ = 0, *GSYM = 0, *XC = 0, *YC = 0;
-  // vectors
-  float *cmean = 0;                // fp32 column means for the centring passes
-  float *d = 0, *r = 0, *rowpart = 0, *colpart = 0, *gd = 0, *nrm = 0, *cnt = 0, *rowmin = 0, *rowmax = 0, *mm = 0;
-  double *rowsq = 0, *rowsum = 0, *rowvals = 0, *rowsx = 0, *rowsy = 0, *scal = 0;
-  int *labels = 0, *idx = 0, *correct = 0;
-  // weights
-  float* W[MCGRA_MAX_LAYERS] = {0};
-  float* b[MCGRA_MAX_LAYERS] = {0};
-  float *Wlin = 0, *blin = 0;
-  float* Ws[MCGRA_MAX_LAYERS] = {0};   // GraphSAGE self weights (has_self), [dims[l] x dims[l+1]]
-  float *S0 = 0, *Sv = 0, *Su = 0;    // self terms X Ws_0 (constant) and H_{l-1} Ws_l of both chains
-  int act = 0, head_act = 0, has_self = 0, fin0 = 1, fin1 = 2;
-  // node-level
-  float *Tv = 0, *Pv = 0, *Hv = 0, *GPv = 0;   // victim(adj_norm) chain, [n x hsum]
-  float *Tu = 0, *Pu = 0, *Hu = 0, *GPu = 0;   // victim/embedding(modified_adj) chain
-  float *Y = 0, *GT = 0, *Z = 0, *logp = 0, *sm = 0, *Z2 = 0, *sm2 = 0, *GZ = 0, *GZ2 = 0, *Gsm = 0;
-  float *Zn = 0, *GZn = 0, *Gem = 0;
-  float *HA = 0, *YA = 0, *HAg = 0, *HAc = 0, *YAg = 0, *YAc = 0, *Yg = 0, *Gg = 0, *Q = 0;
-  float *Q2 = 0, *Gg2 = 0, *coef = 0;
-  float* Abuf = 0;                 // modified_adj after adding_noise (only when eps != 0; otherwise it is M itself)
-  unsigned char* gate = 0;         // clamp pass-through mask of adding_noise's torch.clamp
-  double* colpart_d = 0;
-  double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)
-  float* ws = 0;
-  size_t ws_bytes = 0;
-  int nstrips = 32;
-  bool profile = false;
-  bool use_sym = true;             // SYRK / SYMM on lower tile storage for the linear_HSIC Grams (MCGRA_NO_SYM=1 disables)
-  // low-rank linear_HSIC(adj_norm, modified_adj1) (lowrank_kernels.hip); MCGRA_NO_LOWRANK=1 disables
-  bool lr_ok = false;              // configuration allows it (HSIC, ReLU embedding, width <= 32)
-  bool lr_step = false;            // the step in flight takes it (no relu-masked pair in the decode)
-  int lr_ldv = 0;
-  float *lrL = 0, *lrV = 0, *lrT = 0, *lrR = 0, *lrQ = 0, *lrDelta = 0, *lrC = 0;
-  double *lrStats = 0, *lrRs = 0, *lrQtZ = 0;
-  unsigned int* nmask = 0;
-  int64_t lr_steps = 0, general_steps = 0;
-  // second stream: the one N x N x N product of the low-rank path depends only on adj_norm, so it is forked
-  // right after the normalisation and runs (MFMA-bound) under the HBM-bound rest of the step
-  hipStream_t st2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool p1_inflight = false;
-  bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
-  // P1 through the split kernel of split_symm_bf16.hip instead of the fp32 MFMA SYMM
-  bool split_on = false;
-  int split_mode = 0;              // 0: fp32 MFMA SYMM; 2: split3_symm_kernel on packed planes
-  unsigned char *Apack = 0, *Bpack = 0;
-  int split_planes = 3;            // 3: bf16 x 3 (six products); 2: fp16 x 2 (three products, operand scales from amax)
-  float *amax = 0;                 // [0] max |H Kf H| (per graph), [1] max |Xc| (per step, from the centring pass)
-  int64_t split_steps = 0;
-  GemmTimer timer;
-};
-
-#define CHK(expr)            \
-  do {                       \
-    int rc__ = (expr);       \
-    if (rc__ != 0) return rc__; \
-  } while (0)
 
 template <typename T>
 static int dalloc(mcgra_attack* h, T** p, size_t count) {
@@ -151,7 +59,7 @@ static int dalloc(mcgra_attack* h, T** p, size_t count) {
 }
 
 // HIP-event bracket around the N x N x N launches of the MFMA GEMM (roofline numbers of bench.py)
-static int timer_begin(mcgra_attack* h, hipStream_t st, bool big) {
+int timer_begin(mcgra_attack* h, hipStream_t st, bool big) {
   if (!big) return 0;
   GemmTimer& T = h->timer;
   if (T.used + 2 > T.ev.size()) {
@@ -160,7 +68,7 @@ static int timer_begin(mcgra_attack* h, hipStream_t st, bool big) {
   MCGRA_HIP(hipEventRecord(T.ev[T.used], st));
   return 0;
 }
-static int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops) {
+int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops) {
   if (!big) return 0;
   GemmTimer& T = h->timer;
   MCGRA_HIP(hipEventRecord(T.ev[T.used + 1], st));
@@ -171,7 +79,7 @@ static int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops) {
 }
 
 // every GEMM of the engine goes through here (timed when profiling)
-static int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A,
+int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A,
               int lda, const float* B, int ldb, float beta, float* C, int ldc) {
   const bool big = h->profile && (double)M * N * K >= 0.25 * (double)h->n * h->n * h->n;
   CHK(timer_begin(h, st, big));
@@ -179,7 +87,7 @@ static int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, i
   return timer_end(h, st, big, 2.0 * M * N * K);
 }
 // C = A A^T (A is [n x k]); sym: lower tile storage only.  (A2, C2): second Gram in the same launch.
-static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, const float* A, int lda, float* C, int ldc,
+int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, const float* A, int lda, float* C, int ldc,
                    const float* A2 = nullptr, float* C2 = nullptr, int t0 = 0, int trows = -1) {
   if (!sym) {
     CHK(eg(h, st, false, true, n, n, k, 1.f, A, lda, A, lda, 0.f, C, ldc));
@@ -193,7 +101,7 @@ static int eg_syrk(mcgra_attack* h, hipStream_t st, bool sym, int n, int k, cons
   return timer_end(h, st, big, (C2 ? 2.0 : 1.0) * 2.0 * (tb * (tb + 1) / 2 - ta * (ta + 1) / 2) * SYM_TILE * SYM_TILE * k);
 }
 // C = S B + beta C (S symmetric [n x n], B [n x m]); sym: S is in lower tile storage
-static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, const float* S, int lds_, const float* B,
+int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, const float* S, int lds_, const float* B,
                    int ldb, float beta, float* C, int ldc, const float* S2 = nullptr, const float* B2 = nullptr,
                    float* C2 = nullptr, int t0 = 0, int trows = -1) {
   if (!sym) {
@@ -210,7 +118,7 @@ static int eg_symm(mcgra_attack* h, hipStream_t st, bool sym, int n, int m, cons
 
 // x = relu(adj @ (x W_l) + b_l) for `depth` layers (models/gcn.py:71-76,164-172).
 // T[:, off[0]..] must already hold T_0 = X W_0.
-static int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int depth, float* T, float* P,
+int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int depth, float* T, float* P,
                          float* H, float* S) {
   const int n = h->n, hs = h->hsum;
   for (int l = 0; l < depth; ++l) {
@@ -231,7 +139,7 @@ static int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int 
 }
 
 // linear1 + log_softmax (models/gcn.py:173-174)
-static int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, float* logp, float* sm) {
+int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, float* logp, float* sm) {
   const int l = h->L - 1;
   launch_rowmat(st, h->n, h->wdt[l], h->C, H + h->off[l], h->hsum, h->Wlin, 1, h->wdt[l], h->blin, Z, h->C);
   launch_log_softmax(st, h->n, h->C, Z, h->C, logp, sm, h->C, h->head_act);   // Z keeps the linear output
@@ -241,7 +149,7 @@ static int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* 
 
 // Backward through layers ltop..0 of a chain.  GP[:, off[ltop]] holds G_P_ltop on
 // entry.  add_at/Add: extra gradient w.r.t. H_{add_at} (e.g. d loss / d em).
-static int chain_backward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int ltop, const float* P,
+int chain_backward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld, int ltop, const float* P,
                           float* GP, int add_at, const float* Add, int add_ld) {
   const int n = h->n, hs = h->hsum;
   for (int l = ltop; l >= 1; --l) {
@@ -257,7 +165,7 @@ static int chain_backward(mcgra_attack* h, hipStream_t st, const float* adj, int
   return 0;
 }
 
-static double sign_of(const mcgra_attack* h) { return h->cfg.measure == MCGRA_MEASURE_HSIC ? -1.0 : 1.0; }
+double sign_of(const mcgra_attack* h) { return h->cfg.measure == MCGRA_MEASURE_HSIC ? -1.0 : 1.0; }
 
 extern "C" {
 
@@ -392,6 +300,25 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       }
     }
   }
+  {
+    // The fused low-rank step (attack_fused.hip): HSIC with a ReLU GCN embedding, eps == 0, the split product, widths
+    // that fit the 64-column skinny products and the rank-k panels of the tail.  MCGRA_NO_FUSED_LR=1: general path only.
+    const char* e = getenv("MCGRA_NO_FUSED_LR");
+    const int he = h->wdt[h->Le - 1];
+    int fc = 2 * he + 1 + h->wdt[h->L - 1];
+    for (int l = 0; l < h->L; ++l) fc = (2 * h->wdt[l] + 1) > fc ? 2 * h->wdt[l] + 1 : fc;
+    fc = (fc + 3) & ~3;
+    const int kmax = h->hsum > 2 * he ? h->hsum : 2 * he;
+    h->fused_ok = !rc && !(e && e[0] == '1') && cfg->measure == MCGRA_MEASURE_HSIC && h->lr_ok && cfg->eps == 0.f &&
+                  !h->has_self && h->act == 0 && h->head_act == 0 && h->split_on && h->split_mode == 2 &&
+                  lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
+                  (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
+    if (h->fused_ok) {
+      h->fcols = fc;
+      A_(FV, n * (size_t)fc); A_(FY, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256);
+      h->fused_ok = (rc == 0);
+    }
+  }
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
 #undef A_
@@ -415,7 +342,7 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
 
 int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W, const float* const* b,
                            const float* Wlin, const float* blin, const float* const* Ws) {
-  if (h) h->fwd_cached = h->prep_valid = false;      // whatever the last step / monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !W || !b || !Wlin || !blin) { set_error("null argument"); return MCGRA_EINVAL; }
   if ((h->has_self != 0) != (Ws != nullptr)) { set_error("Ws must be given exactly when has_self is set"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
@@ -433,7 +360,7 @@ int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* 
 int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* features, const float* adj,
                            const float* ori_adj, const float* feature_adj, const int32_t* labels,
                            const int32_t* idx_attack) {
-  if (h) h->fwd_cached = h->prep_valid = false;      // whatever the last step / monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !features || !adj || !feature_adj || !labels || !idx_attack) { set_error("null argument"); return MCGRA_EINVAL; }
   if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
   if (ori_adj) {
@@ -500,7 +427,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
 }
 
 int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed) {
-  if (h) h->fwd_cached = h->prep_valid = false;      // whatever the last step / monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
@@ -515,7 +442,7 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
 
 // calc(X[idx], Y[idx]) on small operands: gradient w.r.t. Y scattered into G (zero-filled by caller).
 // Xg raw gathered constant, Xc its column-centred copy.  Value lands in scal[slot].
-static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg,
+int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg,
                       const float* Xc, double k_signed, float* G, int ldg, int slot) {
   const int na = h->na, hm = h->hmax;
   launch_gather_rows(st, na, width, Ysrc, ldy, h->idx, h->Yg, hm);
@@ -563,7 +490,7 @@ static int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Y
 }
 
 // noise == NULL: modified_adj == M (monitoring forward :290-293 and eps == 0); otherwise adding_noise (:165)
-static int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, const float* noise,
+int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, const float* noise,
                           double* adjn_rowsum = nullptr) {
   const int n = h->n, ld = h->ld;
   const bool general = noise != nullptr;
@@ -605,7 +532,7 @@ static int clamp_sum(mcgra_attack* h, hipStream_t st, float x, bool minmax, doub
 
 // PGDAttack.projection + bisection (topology_attack.py:338-347, 397-412).  Host-driven:
 // only reachable when num_edges < n(n-1)/2, never with main.py's default density.
-static int project(mcgra_attack* h, hipStream_t st) {
+int project(mcgra_attack* h, hipStream_t st) {
   const double ne = h->cfg.num_edges;
   double s0; float mn, mx;
   CHK(clamp_sum(h, st, 0.f, true, &s0, &mn, &mx));
@@ -631,6 +558,52 @@ static int project(mcgra_attack* h, hipStream_t st) {
   return 0;
 }
 
+// loss terms of the step just taken, from the device scalar slots (one readback + sync): layout of mcgra_attack_step's
+// scalars_out
+int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out) {
+  const mcgra_attack_config_t& c = h->cfg;
+  const int n = h->n, ld = h->ld, C = h->C;
+  const int he = h->wdt[h->Le - 1];
+  const double sg = sign_of(h);
+  const double w1 = c.w[0], w2 = c.w[1], w6 = c.w[5], w7 = c.w[6], w9 = c.w[8], w10 = c.w[9];
+  const double k1 = w1 * 1000 * AP_C1, k2 = w2 * 100 * AP_C2, k6 = w6 * 100 * AP_C6, k7 = w7 * AP_C7;
+  const double k9 = w9 * AP_C9, k10 = w10 * AP_C10;
+  const double n2 = (double)n * n;
+  const bool cka = c.measure == MCGRA_MEASURE_CKA;
+  const bool hsic = c.measure == MCGRA_MEASURE_HSIC || cka;
+  const bool use1 = (w1 != 0), use2 = (w2 != 0);
+    launch_clamp_rowsum(st, n, ld, h->M, 0.f, h->rowsx, nullptr, nullptr);
+    launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_CLAMPSUM);
+    double s[S_COUNT];
+    MCGRA_HIP(hipMemcpyAsync(s, h->scal, sizeof(s), hipMemcpyDeviceToHost, st));
+    MCGRA_HIP(hipStreamSynchronize(st));
+    const double nll = s[S_NLL] / h->na;
+    const double norm_a = sqrt(0.5 * s[S_SQ]);
+    const double origin = nll + norm_a * 0.001;
+    double c1v = 0, c2v = 0;
+    const bool kl = c.measure == MCGRA_MEASURE_KL, dp = c.measure == MCGRA_MEASURE_DP;
+    if (cka) {
+      double cst[8];
+      MCGRA_HIP(hipMemcpy(cst, h->cst, sizeof(cst), hipMemcpyDeviceToHost));
+      const double d1 = sqrt(cst[0]) * sqrt(s[S_CK1]), d2 = sqrt(s[S_CK1]) * sqrt(s[S_CK3]);
+      c1v = d1 > 0 ? k1 * s[S_CK0] / d1 : 0;
+      c2v = d2 > 0 ? k2 * s[S_CK2] / d2 : 0;
+    }
+    else if (dp) { c1v = k1 * sqrt(s[S_H1]); c2v = k2 * sqrt(s[S_H2]); }
+    else if (hsic || kl) { c1v = k1 * s[S_H1]; c2v = k2 * s[S_H2]; }
+    else { c1v = k1 * s[S_V1] / n2; c2v = k2 * s[S_V2] / n2; }
+    if (!use1) c1v = 0;
+    if (!use2) c2v = 0;
+    const double c6v = k6 * (-s[S_V6] / n2), c7v = k7 * (-s[S_V7] / n2);
+    double c9v = 0, c10v = 0;
+    if (w9 != 0) c9v = dp ? k9 * sqrt(s[S_C9]) : (hsic || kl) ? k9 * s[S_C9] : k9 * s[S_C9] / ((double)h->na * he);
+    if (w10 != 0) c10v = dp ? k10 * sqrt(s[S_C10]) : (hsic || kl) ? k10 * s[S_C10] : k10 * s[S_C10] / ((double)h->na * C);
+    scalars_out[0] = c.weight_sup * origin + sg * (c1v + c2v + c9v + c10v) + c6v + c7v;
+    scalars_out[1] = origin; scalars_out[2] = c1v; scalars_out[3] = c2v; scalars_out[4] = c6v; scalars_out[5] = c7v;
+    scalars_out[6] = c9v; scalars_out[7] = c10v; scalars_out[8] = 0.5 * s[S_CLAMPSUM]; scalars_out[9] = nll;
+  return 0;
+}
+
 // Phases of one step (bit k of `phases`), for row-block sharding over ranks:
 //   0  replicated: forward, losses, centred operands Xc / Yc (every measure other than HSIC / CKA finishes its
 //      N x N terms here)
@@ -647,6 +620,12 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     return MCGRA_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (phases == 0xF && !noise && fused_step_possible(h)) {
+    const int rc = fused_step(h, st, scalars_out);      // 1: a relu-masked pair in the decode, the general path redoes the step
+    if (rc <= 0) return rc;
+  }
+  h->fused_last = false;
+  h->fused_fwd_valid = false;
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C;
   const double sg = sign_of(h);
@@ -980,37 +959,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   h->have_step = true;
   if (may_project) { CHK(project(h, st)); h->prep_valid = false; }
 
-  if (scalars_out) {
-    launch_clamp_rowsum(st, n, ld, h->M, 0.f, h->rowsx, nullptr, nullptr);
-    launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_CLAMPSUM);
-    double s[S_COUNT];
-    MCGRA_HIP(hipMemcpyAsync(s, h->scal, sizeof(s), hipMemcpyDeviceToHost, st));
-    MCGRA_HIP(hipStreamSynchronize(st));
-    const double nll = s[S_NLL] / h->na;
-    const double norm_a = sqrt(0.5 * s[S_SQ]);
-    const double origin = nll + norm_a * 0.001;
-    double c1v = 0, c2v = 0;
-    const bool kl = c.measure == MCGRA_MEASURE_KL, dp = c.measure == MCGRA_MEASURE_DP;
-    if (cka) {
-      double cst[8];
-      MCGRA_HIP(hipMemcpy(cst, h->cst, sizeof(cst), hipMemcpyDeviceToHost));
-      const double d1 = sqrt(cst[0]) * sqrt(s[S_CK1]), d2 = sqrt(s[S_CK1]) * sqrt(s[S_CK3]);
-      c1v = d1 > 0 ? k1 * s[S_CK0] / d1 : 0;
-      c2v = d2 > 0 ? k2 * s[S_CK2] / d2 : 0;
-    }
-    else if (dp) { c1v = k1 * sqrt(s[S_H1]); c2v = k2 * sqrt(s[S_H2]); }
-    else if (hsic || kl) { c1v = k1 * s[S_H1]; c2v = k2 * s[S_H2]; }
-    else { c1v = k1 * s[S_V1] / n2; c2v = k2 * s[S_V2] / n2; }
-    if (!use1) c1v = 0;
-    if (!use2) c2v = 0;
-    const double c6v = k6 * (-s[S_V6] / n2), c7v = k7 * (-s[S_V7] / n2);
-    double c9v = 0, c10v = 0;
-    if (w9 != 0) c9v = dp ? k9 * sqrt(s[S_C9]) : (hsic || kl) ? k9 * s[S_C9] : k9 * s[S_C9] / ((double)h->na * he);
-    if (w10 != 0) c10v = dp ? k10 * sqrt(s[S_C10]) : (hsic || kl) ? k10 * s[S_C10] : k10 * s[S_C10] / ((double)h->na * C);
-    scalars_out[0] = c.weight_sup * origin + sg * (c1v + c2v + c9v + c10v) + c6v + c7v;
-    scalars_out[1] = origin; scalars_out[2] = c1v; scalars_out[3] = c2v; scalars_out[4] = c6v; scalars_out[5] = c7v;
-    scalars_out[6] = c9v; scalars_out[7] = c10v; scalars_out[8] = 0.5 * s[S_CLAMPSUM]; scalars_out[9] = nll;
-  }
+  if (scalars_out) CHK(collect_scalars(h, st, scalars_out));
   }  // phase 3
   return 0;
 #undef PH
@@ -1058,9 +1007,27 @@ int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long lo
   return 0;
 }
 
+long long mcgra_attack_fused_steps(mcgra_attack_t* h) { return h ? (long long)h->fused_steps : 0; }
+
 int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, double* sparsity) {
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
+  if (fused_step_possible(h) && h->fused_last && h->cfg.eps == 0.f) {
+    // the monitoring forward IS the next iteration's forward (eps == 0): both chains from M, adopted by fused_step
+    CHK(fused_forward(h, st));
+    h->fused_fwd_valid = true;
+    h->fwd_cached = false;
+    if (out_logp)
+      MCGRA_HIP(hipMemcpyAsync(out_logp, h->logp, sizeof(float) * (size_t)h->n * h->C, hipMemcpyDeviceToDevice, st));
+    if (sparsity) {
+      double s;
+      MCGRA_HIP(hipMemcpyAsync(&s, h->scal + S_SUM, sizeof(double), hipMemcpyDeviceToHost, st));
+      MCGRA_HIP(hipStreamSynchronize(st));
+      *sparsity = s / ((double)h->n * h->n);
+    }
+    return 0;
+  }
+  h->fused_fwd_valid = false;
   // adj_norm2 must not overwrite ADJN, which has to survive for the post-loop decode (:300): it goes to ADJN_next
   // (adopted by the next step, see fwd_cached) or, without reuse, to the A1 buffer.
   const bool want_xc = (h->cfg.measure == MCGRA_MEASURE_HSIC || h->cfg.measure == MCGRA_MEASURE_CKA) &&
@@ -1107,10 +1074,16 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   if (!h->have_step) CHK(forward_common(h, st, h->ADJN, nullptr));   // epochs == 0: adj_norm of :142
   // M is overwritten below (:301): the forward a monitor call left for the next step and the row sums the Adam pass
   // left for the next normalisation describe the old M
-  h->fwd_cached = h->prep_valid = false;
+  h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;
   // em = embedding(features, adj_norm) ; adj_changes <- dot_product_decode(em) (:300-301)
-  CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu, h->Su));
-  launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);
+  if (h->fused_last && h->have_step) {
+    // the fused step never stores adj_norm; embedding(features, adj_norm) of the last iteration is its victim-chain
+    // activation of layer emb_nlayer (shared weights), saved by fused_step
+    launch_row_normalize(st, n, h->wdt[Le - 1], h->em_last, h->hmax, h->Zn, h->hmax, h->nrm, 2.f);
+  } else {
+    CHK(chain_forward(h, st, h->ADJN, ld, Le, h->Tu, h->Pu, h->Hu, h->Su));
+    launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);
+  }
   CHK(eg(h, st, false, true, n, n, h->wdt[Le - 1], 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->M, ld));
   launch_decode_post(st, n, ld, h->M, nullptr);            // modified_adj = get_modified_adj (:302)
   // out = modified_adj + feature_adj (:314)

@@ -59,6 +59,9 @@ size_t split3_pack_bytes(int n, int planes = 3);
 void split_absmax(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, float* amax);
 void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out, int planes = 3,
                  const float* amax = nullptr);
+int split3_pack_rsq_parts(int n, int planes);
+void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
+                        const float* amax, int panel_off, int panel_rows, float* rsq_part);
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr);
 int split3_panel();

@@ -1,0 +1,137 @@
+// The attack engine's state (one mcgra_attack_t) and the helpers its step implementations share.
+// attack.hip: create / set_* / the general step (every measure, eps != 0, Gram evaluation of linear_HSIC);
+// attack_fused.hip: the low-rank HSIC step evaluated from the learnable adjacency M directly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/mcgra.h"
+#include "common.h"
+#include "kernels.h"
+
+// utils.Align_Parameter_Cora (utils.py:1100-1111)
+static const double AP_C1 = 100, AP_C2 = 1000, AP_C6 = 10, AP_C7 = 10, AP_C9 = 1, AP_C10 = 1;
+
+enum Scal {  // device scalar slots (double)
+  S_SQ = 0, S_SUM, S_NLL, S_V1, S_V2, S_V6, S_V7, S_H1, S_H2, S_C9, S_C10, S_TOTX, S_TOTY, S_CLAMPSUM,
+  S_TMP, S_TMP2, S_CK0, S_CK1, S_CK2, S_CK3, S_COUNT = 32
+};
+
+struct GemmTimer {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  int64_t launches = 0;
+  double flops = 0;
+};
+
+struct mcgra_attack {
+  mcgra_attack_config_t cfg;
+  int n = 0, ld = 0, L = 0, Le = 0, C = 0, na = 0, hsum = 0, hmax = 0;
+  int off[MCGRA_MAX_LAYERS + 1];   // column offset of layer l inside the concatenated node buffers
+  int wdt[MCGRA_MAX_LAYERS + 1];   // width of layer l output (dims[l+1])
+  int64_t t = 0;                   // Adam step count
+  bool have_step = false;
+  // The monitoring forward of :290-296 (victim on the updated adjacency) is exactly the first forward of the next
+  // iteration (:164-167) when eps == 0: mcgra_attack_monitor leaves its adj_norm, degree vectors, chain and
+  // log-probs in place and the next step adopts them instead of recomputing (bit-identical, one N x N pass and two
+  // skinny products less per step).  MCGRA_NO_FWD_REUSE=1 disables.
+  bool fwd_cached = false, fwd_reuse = true;
+  bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
+  bool prep_valid = false;         // G_A holds the per-tile row sums of the current M (left by the fused tail kernel)
+  bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
+  float* ADJN_next = 0;
+  bool graph_set = false, model_set = false;
+  std::vector<void*> allocs;
+  // N x N
+  float *M = 0, *am = 0, *av = 0, *ADJN = 0, *A1 = 0, *G_ADJN = 0, *G_A1 = 0, *G_A = 0;
+  float *KX = 0, *KY = 0, *KFC = 0, *FADJ = 0, *GSYM = 0, *XC = 0, *YC = 0;
+  // vectors
+  float *cmean = 0;                // fp32 column means for the centring passes
+  float *d = 0, *r = 0, *rowpart = 0, *colpart = 0, *gd = 0, *nrm = 0, *cnt = 0, *rowmin = 0, *rowmax = 0, *mm = 0;
+  double *rowsq = 0, *rowsum = 0, *rowvals = 0, *rowsx = 0, *rowsy = 0, *scal = 0;
+  int *labels = 0, *idx = 0, *correct = 0;
+  // weights
+  float* W[MCGRA_MAX_LAYERS] = {0};
+  float* b[MCGRA_MAX_LAYERS] = {0};
+  float *Wlin = 0, *blin = 0;
+  float* Ws[MCGRA_MAX_LAYERS] = {0};   // GraphSAGE self weights (has_self), [dims[l] x dims[l+1]]
+  float *S0 = 0, *Sv = 0, *Su = 0;    // self terms X Ws_0 (constant) and H_{l-1} Ws_l of both chains
+  int act = 0, head_act = 0, has_self = 0, fin0 = 1, fin1 = 2;
+  // node-level
+  float *Tv = 0, *Pv = 0, *Hv = 0, *GPv = 0;   // victim(adj_norm) chain, [n x hsum]
+  float *Tu = 0, *Pu = 0, *Hu = 0, *GPu = 0;   // victim/embedding(modified_adj) chain
+  float *Y = 0, *GT = 0, *Z = 0, *logp = 0, *sm = 0, *Z2 = 0, *sm2 = 0, *GZ = 0, *GZ2 = 0, *Gsm = 0;
+  float *Zn = 0, *GZn = 0, *Gem = 0;
+  float *HA = 0, *YA = 0, *HAg = 0, *HAc = 0, *YAg = 0, *YAc = 0, *Yg = 0, *Gg = 0, *Q = 0;
+  float *Q2 = 0, *Gg2 = 0, *coef = 0;
+  float* Abuf = 0;                 // modified_adj after adding_noise (only when eps != 0; otherwise it is M itself)
+  unsigned char* gate = 0;         // clamp pass-through mask of adding_noise's torch.clamp
+  double* colpart_d = 0;
+  double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)
+  float* ws = 0;
+  size_t ws_bytes = 0;
+  int nstrips = 32;
+  bool profile = false;
+  bool use_sym = true;             // SYRK / SYMM on lower tile storage for the linear_HSIC Grams (MCGRA_NO_SYM=1 disables)
+  // low-rank linear_HSIC(adj_norm, modified_adj1) (lowrank_kernels.hip); MCGRA_NO_LOWRANK=1 disables
+  bool lr_ok = false;              // configuration allows it (HSIC, ReLU embedding, width <= 32)
+  bool lr_step = false;            // the step in flight takes it (no relu-masked pair in the decode)
+  int lr_ldv = 0;
+  float *lrL = 0, *lrV = 0, *lrT = 0, *lrR = 0, *lrQ = 0, *lrDelta = 0, *lrC = 0;
+  double *lrStats = 0, *lrRs = 0, *lrQtZ = 0;
+  unsigned int* nmask = 0;
+  int64_t lr_steps = 0, general_steps = 0;
+  // second stream: the one N x N x N product of the low-rank path depends only on adj_norm, so it is forked
+  // right after the normalisation and runs (MFMA-bound) under the HBM-bound rest of the step
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool p1_inflight = false;
+  bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
+  // P1 through the split kernel of split_symm_bf16.hip instead of the fp32 MFMA SYMM
+  bool split_on = false;
+  int split_mode = 0;              // 0: fp32 MFMA SYMM; 2: split3_symm_kernel on packed planes
+  unsigned char *Apack = 0, *Bpack = 0;
+  int split_planes = 3;            // 3: bf16 x 3 (six products); 2: fp16 x 2 (three products, operand scales from amax)
+  float *amax = 0;                 // [0] max |H Kf H| (per graph), [1] max |Xc| (per step, from the centring pass)
+  int64_t split_steps = 0;
+  GemmTimer timer;
+  // fused low-rank step (attack_fused.hip): everything N x N from M and n-vectors; MCGRA_NO_FUSED_LR=1 disables
+  bool fused_ok = false;           // configuration allows it
+  bool fused_fwd_valid = false;    // both chains, heads, d / r / mean of the CURRENT M are in place (left by the monitor call)
+  bool fused_last = false;         // the last step ran fused: adj_norm of that iteration was never stored (see em_last)
+  int fcols = 0;                   // leading dimension of FV / FY
+  float *FV = 0, *FY = 0;          // right-hand sides / results of the skinny products on M  [n x fcols]
+  float *em_last = 0;              // embedding(features, adj_norm) of the last iteration (:300), = its victim-chain activations
+  double *fstat = 0;               // small fp64 vectors: colsum(V) [64] | colsum(W) [64] | mean^T W [64] | sum(mean) [2]
+  int64_t fused_steps = 0;
+};
+
+// attack_fused.hip
+bool fused_step_possible(const mcgra_attack* h);
+int fused_forward(mcgra_attack* h, hipStream_t st);
+// returns 1 when the step must be redone by the general path (a relu-masked pair in the decode), 0 when done
+int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out);
+
+#define CHK(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+
+// ---- shared helpers (attack.hip)
+int timer_begin(mcgra_attack* h, hipStream_t st, bool big);
+int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops);
+int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
+       const float* B, int ldb, float beta, float* C, int ldc);
+int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, float* logp, float* sm);
+double sign_of(const mcgra_attack* h);
+extern "C" {      // (defined inside attack.hip's extern "C" block)
+int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg, const float* Xc,
+               double k_signed, float* G, int ldg, int slot);
+int project(mcgra_attack* h, hipStream_t st);
+int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out);
+__global__ void k_cn(const double* __restrict__ scal, float coef, float* __restrict__ out);
+}

@@ -1,0 +1,665 @@
+// Kernels of the fused low-rank HSIC step (attack_fused.hip): every N x N quantity of the step
+// is evaluated from the learnable adjacency M and n-vectors, so adj_norm, its centred copy Xc, modified_adj1 and the
+// gradient w.r.t. adj_norm are never stored:
+//
+//   adj_norm_ij = (r_i (M_ij + [i == j])) r_j        Xc_ij = adj_norm_ij - mean_j        (mean_j = rowsum_j(adj_norm) / n)
+//   adj_norm V  = r o (M (r o V) + r o V)            skinny products read M only (sgemm on M, node kernels below)
+//   A1_ij       = [i != j] relu(zn_i . zn_j)         recomputed per pair from Zn [n x h] (k_decode_fly)
+//   G_adjn_ij   = ie'(adj_norm_ij) + sum_k GPv_ik Tv_jk + a2 sum_k L_ik R_jk + a1 P1_ij + a2 (delta_i^2 Xc_ij + c_j)
+//
+// Only G_adjn + G_adjn^T reaches the optimiser (the packed gradient is mirrored and adj_norm is symmetric), so the tail
+// is two passes over 64 x 64 tile pairs: k_tail_reduce forms Gs = G + G^T per pair (rank-k terms as VALU FMAs on LDS
+// panels, P1 tile and its mirror), stores it and reduces the row sums of the normalisation backward;
+// k_tail_adam turns Gs into the packed gradient, adds the rank-k term of the modified_adj chain and runs Adam on the
+// pair, writing both halves of the state.  A row-block rank (row range [row0, row1), all columns: `pair == 0`) runs
+// the same code without mirrored writes.
+#include "common.h"
+#include "kernels.h"
+
+namespace mcgra {
+
+#define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
+
+// ------------------------------------------------------------------------------------------------ node kernels
+// V[i][col0 + k] = (r ? r_i : 1) X[i][k], k < w; columns [col0 + w, col0 + wpad) zero-filled
+__global__ void k_cat_scaled(int n, int w, int wpad, const float* __restrict__ X, int ldx, const float* __restrict__ r,
+                             float* __restrict__ V, int ldv, int col0) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * wpad) return;
+  const int i = e / wpad, k = e - i * wpad;
+  V[(size_t)i * ldv + col0 + k] = k < w ? (r ? r[i] : 1.f) * X[(size_t)i * ldx + k] : 0.f;
+}
+// out[i][k] = r_i (Y[i][c0 + k] + Vs[i][c0 + k])          (adj_norm V from Y = M Vs, Vs = r o V)
+__global__ void k_an_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy, int c0,
+                          const float* __restrict__ r, float* __restrict__ out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e - i * w;
+  const size_t o = (size_t)i * ldy + c0 + k;
+  out[(size_t)i * ldo + k] = r[i] * (Y[o] + Vs[o]);
+}
+// out[i][k] = Y[i][c0 + k]
+__global__ void k_copy_cols(int n, int w, const float* __restrict__ Y, int ldy, int c0, float* __restrict__ out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e - i * w;
+  out[(size_t)i * ldo + k] = Y[(size_t)i * ldy + c0 + k];
+}
+
+// Forward layer l of both chains from ONE product Y = M [r o Tv | Tu | r]:
+//   victim(adj_norm):   Pv = r o (Y_a + r o Tv) + b          embedding / victim(M):   Pu = Y_b + b
+//   with_r (layer 0):   rowsum(adj_norm)_i = r_i (Y_c + r_i)  ->  mean_i = rowsum_i / n
+__global__ void k_fl_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ V, int ldy,
+                          const float* __restrict__ r, const float* __restrict__ b, float* __restrict__ Pv,
+                          float* __restrict__ Hv, float* __restrict__ Pu, float* __restrict__ Hu, int ldo, int with_r,
+                          float* __restrict__ mean, double* __restrict__ rowsum) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e - i * w;
+  const size_t o = (size_t)i * ldy;
+  const float ri = r[i];
+  const float pv = ri * (Y[o + k] + V[o + k]) + b[k];
+  const float pu = Y[o + w + k] + b[k];
+  Pv[(size_t)i * ldo + k] = pv; Hv[(size_t)i * ldo + k] = fmaxf(pv, 0.f);
+  Pu[(size_t)i * ldo + k] = pu; Hu[(size_t)i * ldo + k] = fmaxf(pu, 0.f);
+  if (with_r && k == 0) {
+    const double rs = (double)ri * ((double)Y[o + 2 * w] + (double)ri);
+    rowsum[i] = rs;
+    mean[i] = (float)(rs / (double)n);
+  }
+}
+
+// out[k] = sum_i wgt_i X[i][k] in fp64 (wgt == nullptr: plain column sums); one block per column, fixed tree
+__global__ __launch_bounds__(256) void k_wcolsum(int n, const float* __restrict__ X, int ldx, const float* __restrict__ wgt,
+                                                 double* __restrict__ out) {
+  __shared__ double sh[16];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)(wgt ? wgt[i] : 1.f) * (double)X[(size_t)i * ldx + k];
+  s = block_sum_d(s, sh);
+  if (threadIdx.x == 0) out[k] = s;
+}
+// out[0] = sum_i x_i (fp64), out[1] = max_i r_i^2 + max_i |mean_i| as a float in out2 (operand-scale bound of the split)
+__global__ __launch_bounds__(256) void k_mean_stats(int n, const float* __restrict__ mean, const float* __restrict__ r,
+                                                    double* __restrict__ msum, float* __restrict__ amax_bound) {
+  __shared__ double sh[16];
+  __shared__ float shm[8];
+  double s = 0.0;
+  float mr = 0.f, mm = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    s += (double)mean[i];
+    mr = fmaxf(mr, r[i] * r[i]);
+    mm = fmaxf(mm, fabsf(mean[i]));
+  }
+  s = block_sum_d(s, sh);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mr = fmaxf(mr, __shfl_xor(mr, o)); mm = fmaxf(mm, __shfl_xor(mm, o)); }
+  if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mr; shm[4 + (threadIdx.x >> 6)] = mm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    msum[0] = s;
+    const float a = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+    const float b = fmaxf(fmaxf(shm[4], shm[5]), fmaxf(shm[6], shm[7]));
+    amax_bound[0] = a + b;       // |adj_norm_ij - mean| <= r_i r_j (M_ij + [i == j]) + |mean| <= max r^2 + max |mean|
+  }
+}
+
+// T = Xc^T Vc from Y = M (r o Vc):  T_i = r_i (Y_i + r_i Vc_i) - mean_i (1^T Vc)      (Xc^T = adj_norm - mean 1^T)
+__global__ void k_lrt_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy,
+                           const float* __restrict__ r, const float* __restrict__ mean, const double* __restrict__ colsum,
+                           float* __restrict__ T, int ldt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e - i * w;
+  const size_t o = (size_t)i * ldy + k;
+  T[(size_t)i * ldt + k] = r[i] * (Y[o] + Vs[o]) - (float)((double)mean[i] * colsum[k]);
+}
+// Vs = r o (W - wbar), wbar_k = colsum_k / n        (right-hand side of Q = Xc [W | W2], column-centred)
+__global__ void k_lrq_pre(int n, int w, const float* __restrict__ W, int ldw, const float* __restrict__ r,
+                          const double* __restrict__ colsum, float* __restrict__ Vs, int ldv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e - i * w;
+  Vs[(size_t)i * ldv + k] = r[i] * (W[(size_t)i * ldw + k] - (float)(colsum[k] / (double)n));
+}
+// Q = Xc W = adj_norm Wc - 1 (mean^T Wc) + n (mean - mbar 1) wbar^T   with Wc = W - 1 wbar^T:
+//   Q_ik = r_i (Y_ik + Vs_ik) - kappa_k + n (mean_i - mbar) wbar_k,   kappa_k = mean^T W_k - (sum mean) wbar_k
+__global__ void k_lrq_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy,
+                           const float* __restrict__ r, const float* __restrict__ mean, const double* __restrict__ colsum,
+                           const double* __restrict__ mw, const double* __restrict__ msum, float* __restrict__ Q, int ldq) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e - i * w;
+  const double wbar = colsum[k] / (double)n, ms = msum[0];
+  const double kappa = mw[k] - ms * wbar;
+  const size_t o = (size_t)i * ldy + k;
+  Q[(size_t)i * ldq + k] = r[i] * (Y[o] + Vs[o]) - (float)kappa + (float)((double)n * ((double)mean[i] - ms / (double)n) * wbar);
+}
+
+// ---------------------------------------------------------------------------------- decode, recomputed per pair
+// For rows i in [row0, row1), all j:  S_ij = zn_i . zn_j (the fmaf chain of rankk_nt: same bits as the stored form),
+// A1_ij = [i != j] relu(S_ij);  nmask += #{i != j : S_ij <= 0};  v7 partials of sum ie_value(A1) (diagonal included, as
+// Info_entropy runs over the whole matrix, :44-52);  slabs: G_Zn_i = sum_{j != i, S_ij > 0} 2 ie'(A1_ij) zn_j.
+template <int H>
+__global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
+                                                    float kie7, int jper, float* __restrict__ slabs,
+                                                    double* __restrict__ v7part, unsigned int* __restrict__ nmask) {
+  constexpr int JC = 128;
+  __shared__ __attribute__((aligned(16))) float zs[JC][H];
+  __shared__ double sh[16];
+  const int i = row0 + blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < row1;
+  const int j0 = blockIdx.y * jper, j1 = min(n, j0 + jper);
+  float zi[H], acc[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) { zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f; acc[k] = 0.f; }
+  double v7 = 0.0;
+  int masked = 0;
+  for (int jc = j0; jc < j1; jc += JC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < JC * H; e += 256) {
+      const int jj = e / H, c = e - jj * H, j = jc + jj;
+      zs[jj][c] = j < j1 ? Z[(size_t)j * ldz + c] : 0.f;
+    }
+    __syncthreads();
+    const int jn = min(JC, j1 - jc);
+    for (int jj = 0; jj < jn; ++jj) {
+      const int j = jc + jj;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < H; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
+        s = fmaf(zi[k], t.x, s); s = fmaf(zi[k + 1], t.y, s); s = fmaf(zi[k + 2], t.z, s); s = fmaf(zi[k + 3], t.w, s);
+      }
+      const bool off = valid && i != j;
+      if (off && !(s > 0.f)) ++masked;
+      const float a1 = off ? fmaxf(s, 0.f) : 0.f;
+      float val, g;
+      ie_term(a1, kie7, val, g);
+      if (valid) v7 += (double)val;
+      const float w = (off && a1 > 0.f) ? 2.f * g : 0.f;
+#pragma unroll
+      for (int k = 0; k < H; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
+        acc[k] = fmaf(w, t.x, acc[k]); acc[k + 1] = fmaf(w, t.y, acc[k + 1]);
+        acc[k + 2] = fmaf(w, t.z, acc[k + 2]); acc[k + 3] = fmaf(w, t.w, acc[k + 3]);
+      }
+    }
+  }
+  if (valid) {
+    float* o = slabs + ((size_t)blockIdx.y * n + i) * H;
+#pragma unroll
+    for (int k = 0; k < H; ++k) o[k] = acc[k];
+  }
+  const double t = block_sum_d(v7, sh);
+  if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o, 64);
+  if ((threadIdx.x & 63) == 0 && masked) atomicAdd(nmask, (unsigned int)masked);
+}
+__global__ void k_sum_slabs_rows(int n, int row0, int row1, int h, int nslab, const float* __restrict__ slabs,
+                                 float* __restrict__ out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (row1 - row0) * h) return;
+  const int i = row0 + e / h, k = e % h;
+  float t = 0.f;
+  for (int s = 0; s < nslab; ++s) t += slabs[((size_t)s * n + i) * h + k];
+  out[(size_t)i * ldo + k] = t;
+}
+
+// -------------------------------------------------------------------------------------------------- the tail
+constexpr int FT = 64;           // tile edge
+// Symmetrised rank-k terms sum_f alpha_f (L_f,i . R_f,j + R_f,i . L_f,j).  The terms are concatenated along k into
+// rounds of at most KMAX columns (host side: make_factors), so that e.g. the victim-chain term (K = 32) and the
+// low-rank term (K = 32) of a 2-layer GCN cost one pair of staged products instead of two.
+struct TailFactors {
+  const float* L[4];
+  const float* R[4];
+  int ldl[4], ldr[4], K[4], koff[4], round[4];
+  float alpha[4];
+  int count, nrounds, kround[4];
+};
+
+// stage rows [r0, r0 + 64) x [0, K) of a row-major panel, scaled, into LDS as dst[koff + k][64]
+__device__ __forceinline__ void ft_stage(float (*dst)[FT], int koff, const float* __restrict__ src, int ld, int r0, int nrows,
+                                         int K, float scale) {
+  const int kq = (K + 3) >> 2;
+  for (int e = threadIdx.x; e < FT * kq; e += 256) {
+    const int m = e / kq, k4 = (e - m * kq) << 2;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + m < nrows) {
+      const float* p = src + (size_t)(r0 + m) * ld + k4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (k4 + t < K) v[t] = scale * p[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (k4 + t < K) dst[koff + k4 + t][m] = v[t];
+  }
+}
+
+// acc[a][b] += sum_f alpha_f (L_i . R_j + R_i . L_j) for the thread's 4 x 4 patch of tile (bi, bj).  Bitwise symmetric
+// under i <-> j: the two dot products of a round are the same fmaf chains with the roles swapped (alpha is folded into
+// the staged L values) and are added to each other first, so a diagonal tile, whose two triangles are computed by
+// different threads, stays symmetric.
+template <int KMAX>
+__device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int bj, int n, float (*As)[FT], float (*Bs)[FT],
+                                             int r0, int c0, float (&acc)[4][4]) {
+  for (int rd = 0; rd < F.nrounds; ++rd) {
+    const int K = F.kround[rd];
+    float part[2][4][4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();                       // previous users of the panels are done
+      for (int f = 0; f < F.count; ++f) {
+        if (F.round[f] != rd) continue;
+        ft_stage(As, F.koff[f], half ? F.R[f] : F.L[f], half ? F.ldr[f] : F.ldl[f], bi, n, F.K[f], half ? 1.f : F.alpha[f]);
+        ft_stage(Bs, F.koff[f], half ? F.L[f] : F.R[f], half ? F.ldl[f] : F.ldr[f], bj, n, F.K[f], half ? F.alpha[f] : 1.f);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) part[half][a][b] = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float4 av4 = *reinterpret_cast<const float4*>(&As[k][r0]);
+        const float4 bv4 = *reinterpret_cast<const float4*>(&Bs[k][c0]);
+        const float as_[4] = {av4.x, av4.y, av4.z, av4.w}, bs_[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) part[half][a][b] = fmaf(as_[a], bs_[b], part[half][a][b]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] += part[0][a][b] + part[1][a][b];
+  }
+}
+
+// Pass 1 of the tail.  pair != 0: grid (nt, nt), blocks with bj > bi return (their pair block covers them); a block
+// handles tile (I, J) and its mirror.  pair == 0: grid (nt, tile rows of [row0, row1)), every block its own tile only.
+//   GS[i][j] = G_adjn_ij + G_adjn_ji                      (pair: tiles on or below the diagonal only)
+//   ps[i][J] = sum_{j in tile J} GS_ij mx_ij r_j          (S_i = sum_J ps[i][J] = rowpart_i + colpart_i of the
+//                                                          normalisation backward, mx = M + I)
+//   vpart[block] = { sum P1 o Xc over the block's elements (both orientations when pair), sum ie_value(adj_norm) }
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, int tile_row0, TailFactors F,
+                                                     const float* __restrict__ M, const float* __restrict__ P1,
+                                                     const float* __restrict__ r, const float* __restrict__ mean,
+                                                     const float* __restrict__ delta, const float* __restrict__ cvec,
+                                                     float a1, float a2, float kie6, float* __restrict__ GS,
+                                                     float* __restrict__ ps, double* __restrict__ vpart) {
+  __shared__ float As[KMAX][FT];
+  __shared__ float Bs[KMAX][FT];
+  __shared__ float T[FT][FT + 1];
+  __shared__ double shd[16];
+  const int nt = gridDim.x;
+  const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
+  const size_t vslot = (size_t)blockIdx.y * nt + blockIdx.x, vtot = (size_t)gridDim.y * nt;   // v1 partials, then v6 partials
+  if (pair && tj > ti) {
+    if (threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; }
+    return;
+  }
+  const int bi = ti * FT, bj = tj * FT;
+  const bool offdiag = ti != tj;
+  const bool mirror = pair && offdiag;
+  const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  ft_sym_rankk<KMAX>(F, bi, bj, n, As, Bs, r0, c0, acc);
+  // mirrored P1 tile (J, I) through LDS: T[j local][i local]
+  if (P1) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = bj + r0 + a, col = bi + c0;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n && col < n) v = *reinterpret_cast<const float4*>(P1 + (size_t)row * ld + col);   // ld % 4 == 0: in bounds
+      T[r0 + a][c0] = v.x; T[r0 + a][c0 + 1] = v.y; T[r0 + a][c0 + 2] = v.z; T[r0 + a][c0 + 3] = v.w;
+    }
+  }
+  __syncthreads();
+  double v1 = 0.0, v6 = 0.0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  const float4 rj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(r + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 mj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(mean + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float rjs[4] = {rj4.x, rj4.y, rj4.z, rj4.w}, mjs[4] = {mj4.x, mj4.y, mj4.z, mj4.w};
+  float djs[4] = {0.f, 0.f, 0.f, 0.f}, cjs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (delta && bj + c0 < n) {
+    const float4 d4 = *reinterpret_cast<const float4*>(delta + bj + c0), c4 = *reinterpret_cast<const float4*>(cvec + bj + c0);
+    djs[0] = d4.x; djs[1] = d4.y; djs[2] = d4.z; djs[3] = d4.w; cjs[0] = c4.x; cjs[1] = c4.y; cjs[2] = c4.z; cjs[3] = c4.w;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = bi + r0 + a, j0 = bj + c0;
+    const bool rowin = i < n && j0 < n;
+    float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), p4 = m4;
+    const size_t o = (size_t)i * ld + j0;
+    if (rowin) {
+      m4 = *reinterpret_cast<const float4*>(M + o);
+      if (P1) p4 = *reinterpret_cast<const float4*>(P1 + o);
+    }
+    const float ms[4] = {m4.x, m4.y, m4.z, m4.w}, pd[4] = {p4.x, p4.y, p4.z, p4.w};
+    const float ri = rowin ? r[i] : 0.f, mi = rowin ? mean[i] : 0.f;
+    const float di = (delta && rowin) ? delta[i] : 0.f, ci = (delta && rowin) ? cvec[i] : 0.f;
+    float gs[4], rowacc = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + b;
+      float g = 0.f;
+      if (rowin && j < n) {
+        const float mx = ms[b] + (i == j ? 1.f : 0.f);
+        // every term below is bitwise symmetric under i <-> j (see ft_sym_rankk): adj_norm_ij as mx (r_i r_j)
+        const float an = mx * (ri * rjs[b]);
+        const float xij = an - mjs[b], xji = an - mi;        // Xc_ij, Xc_ji
+        const float pt = P1 ? T[c0 + b][r0 + a] : 0.f;       // P1_ji
+        float val, g6;
+        ie_term(an, kie6, val, g6);
+        g = acc[a][b] + 2.f * g6 + a1 * (pd[b] + pt) + a2 * (fmaf(di * di, xij, cjs[b]) + fmaf(djs[b] * djs[b], xji, ci));
+        const float w = g * mx;
+        rowacc += w * rjs[b];
+        cs[b] += w * ri;
+        v1 += (double)pd[b] * (double)xij;
+        if (mirror) v1 += (double)pt * (double)xji;
+        v6 += mirror ? 2.0 * (double)val : (double)val;
+      }
+      gs[b] = g;
+    }
+    if (rowin) *reinterpret_cast<float4*>(GS + o) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+#pragma unroll
+    for (int o2 = 1; o2 < 16; o2 <<= 1) rowacc += __shfl_xor(rowacc, o2);
+    if ((threadIdx.x & 15) == 0 && i < n) ps[(size_t)i * nt + tj] = rowacc;
+  }
+  if (mirror) {      // column sums of the tile = the mirrored tile's contribution to the rows of tile J
+    float (*CS)[FT] = As;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) CS[threadIdx.x >> 4][c0 + b] = cs[b];
+    __syncthreads();
+    if (threadIdx.x < FT) {
+      const int j = bj + threadIdx.x;
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += CS[g][threadIdx.x];
+      if (j < n) ps[(size_t)j * nt + ti] = s;
+    }
+  }
+  v1 = block_sum_d(v1, shd);
+  v6 = block_sum_d(v6, shd);
+  if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; }
+}
+
+// gd_i = -1/2 d_i^-3/2 sum_J ps[i][J]      (k_normbwd_gd with rowpart + colpart already merged per tile)
+__global__ __launch_bounds__(256) void k_tail_gd(int n, int row0, int row1, int nt, const float* __restrict__ ps,
+                                                 const float* __restrict__ d, float* __restrict__ gd) {
+  const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= row1) return;
+  float s = 0.f;
+  for (int t = lane; t < nt; t += 64) s += ps[(size_t)i * nt + t];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float di = d[i];
+    gd[i] = di > 0.f ? -0.5f * s * (1.0f / (di * sqrtf(di))) : 0.f;
+  }
+}
+
+// Pass 2 of the tail: g_ij = GS_ij r_i r_j + gd_i + gd_j + sum_k (GPu_ik Tu_jk + Tu_ik GPu_jk) + cn M_ij, Adam, clamp
+// (:274-283).  pair: both halves of the state are written from the lower pair; otherwise only rows of the row block.
+// ps_out / pq_out: per-tile row sums of the new M (and of its squares) for the next normalisation (k_prep_fin).
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int tile_row0, TailFactors F,
+                                                   const float* __restrict__ GS, const float* __restrict__ r,
+                                                   const float* __restrict__ gd, float* __restrict__ M,
+                                                   float* __restrict__ am, float* __restrict__ av,
+                                                   const float* __restrict__ cn_ptr, float omb1, float b2, float omb2,
+                                                   float step_size, float sqrt_bc2, float eps, float* __restrict__ gsym_dbg,
+                                                   int do_clamp, float* __restrict__ ps_out, double* __restrict__ pq_out) {
+  __shared__ float As[KMAX][FT];
+  __shared__ float Bs[KMAX][FT];
+  __shared__ float T[FT][FT + 1];
+  const int nt = gridDim.x;
+  const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
+  if (pair && tj > ti) return;
+  const int bi = ti * FT, bj = tj * FT;
+  const bool mirror = pair && ti != tj;
+  const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;
+  const float cn = cn_ptr[0];
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  ft_sym_rankk<KMAX>(F, bi, bj, n, As, Bs, r0, c0, acc);
+  const float4 rj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(r + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 gj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(gd + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float rjs[4] = {rj4.x, rj4.y, rj4.z, rj4.w}, gdj[4] = {gj4.x, gj4.y, gj4.z, gj4.w};
+  float pn_[4][4], m_[4][4], v_[4][4], g_[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = bi + r0 + a, j0 = bj + c0;
+    const bool rowin = i < n && j0 < n;
+    float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = p4, v4 = p4, s4 = p4;
+    const size_t o = (size_t)i * ld + j0;
+    if (rowin) {
+      p4 = *reinterpret_cast<const float4*>(M + o);
+      m4 = *reinterpret_cast<const float4*>(am + o);
+      v4 = *reinterpret_cast<const float4*>(av + o);
+      s4 = *reinterpret_cast<const float4*>(GS + o);
+    }
+    const float ri = rowin ? r[i] : 0.f, gdi = rowin ? gd[i] : 0.f;
+    float ps[4] = {p4.x, p4.y, p4.z, p4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
+    const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+    float gsv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + b;
+      if (rowin && j < n && i != j) {
+        const float p = ps[b];
+        const float g = (fmaf(ss[b], ri * rjs[b], gdi + gdj[b]) + acc[a][b]) + cn * p;     // symmetric under i <-> j
+        float m = ms[b], v = vs[b];
+        m = m + omb1 * (g - m);            // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * b2 + omb2 * g * g;         // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(v) / sqrt_bc2 + eps;
+        float pn = p - step_size * (m / denom);
+        if (do_clamp) pn = fminf(fmaxf(pn, 0.f), 1.f);
+        ps[b] = pn; ms[b] = m; vs[b] = v; gsv[b] = g;
+      }
+      pn_[a][b] = ps[b]; m_[a][b] = ms[b]; v_[a][b] = vs[b]; g_[a][b] = gsv[b];
+    }
+    if (rowin) {
+      *reinterpret_cast<float4*>(M + o) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+      *reinterpret_cast<float4*>(am + o) = make_float4(ms[0], ms[1], ms[2], ms[3]);
+      *reinterpret_cast<float4*>(av + o) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+      if (gsym_dbg) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (j0 + b < n && i != j0 + b) gsym_dbg[o + b] = gsv[b];
+      }
+    }
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  double cq[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ps_out) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int i = bi + r0 + a;
+      float s = 0.f;
+      double q = 0.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = bj + c0 + b;
+        if (i < n && j < n) {
+          const float v = pn_[a][b];
+          s += v; cs[b] += v;
+          if (i != j) { q += (double)v * (double)v; cq[b] += (double)v * (double)v; }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      if ((threadIdx.x & 15) == 0 && i < n) {
+        ps_out[(size_t)i * nt + tj] = s;
+        pq_out[(size_t)i * nt + tj] = q;
+      }
+    }
+  }
+  if (!mirror) return;
+  float (*CS)[FT] = As;                                             // [16][64] floats, panels are dead by now
+  double (*CQ)[FT] = reinterpret_cast<double (*)[FT]>(&Bs[0][0]);   // [16][64] doubles = 8 KB <= sizeof(Bs)
+  __syncthreads();
+  if (ps_out) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { CS[threadIdx.x >> 4][c0 + b] = cs[b]; CQ[threadIdx.x >> 4][c0 + b] = cq[b]; }
+  }
+#pragma unroll
+  for (int arr = 0; arr < 4; ++arr) {      // mirrored half: element (j, i) = element (i, j); one array at a time through T
+    float* dst = arr == 0 ? M : arr == 1 ? am : arr == 2 ? av : gsym_dbg;
+    if (!dst) continue;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        T[r0 + a][c0 + b] = arr == 0 ? pn_[a][b] : arr == 1 ? m_[a][b] : arr == 2 ? v_[a][b] : g_[a][b];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = bj + r0 + a, col = bi + c0;
+      if (row < n && col < n) {
+        float* q = dst + (size_t)row * ld + col;
+        if (col + 3 < n) *reinterpret_cast<float4*>(q) = make_float4(T[c0][r0 + a], T[c0 + 1][r0 + a], T[c0 + 2][r0 + a], T[c0 + 3][r0 + a]);
+        else
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (col + b < n) q[b] = T[c0 + b][r0 + a];
+      }
+    }
+  }
+  if (ps_out && threadIdx.x < FT) {
+    const int j = bj + threadIdx.x;
+    float s = 0.f;
+    double q = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { s += CS[g][threadIdx.x]; q += CQ[g][threadIdx.x]; }
+    if (j < n) {
+      ps_out[(size_t)j * nt + ti] = s;
+      pq_out[(size_t)j * nt + ti] = q;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- launchers
+static inline dim3 g1(size_t count) { return dim3((unsigned)((count + 255) / 256)); }
+
+void fl_cat_scaled(hipStream_t st, int n, int w, int wpad, const float* X, int ldx, const float* r, float* V, int ldv, int col0) {
+  LAUNCH(k_cat_scaled, g1((size_t)n * wpad), dim3(256), st, n, w, wpad, X, ldx, r, V, ldv, col0);
+}
+void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, int c0, const float* r, float* out, int ldo) {
+  LAUNCH(k_an_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, c0, r, out, ldo);
+}
+void fl_copy_cols(hipStream_t st, int n, int w, const float* Y, int ldy, int c0, float* out, int ldo) {
+  LAUNCH(k_copy_cols, g1((size_t)n * w), dim3(256), st, n, w, Y, ldy, c0, out, ldo);
+}
+void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V, int ldy, const float* r, const float* b,
+                   float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum) {
+  LAUNCH(k_fl_post, g1((size_t)n * w), dim3(256), st, n, w, Y, V, ldy, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0, mean, rowsum);
+}
+void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out) {
+  LAUNCH(k_wcolsum, dim3(w), dim3(256), st, n, X, ldx, wgt, out);
+}
+void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound) {
+  LAUNCH(k_mean_stats, dim3(1), dim3(256), st, n, mean, r, msum, amax_bound);
+}
+void fl_lrt_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+                 const double* colsum, float* T, int ldt) {
+  LAUNCH(k_lrt_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, r, mean, colsum, T, ldt);
+}
+void fl_lrq_pre(hipStream_t st, int n, int w, const float* W, int ldw, const float* r, const double* colsum, float* Vs, int ldv) {
+  LAUNCH(k_lrq_pre, g1((size_t)n * w), dim3(256), st, n, w, W, ldw, r, colsum, Vs, ldv);
+}
+void fl_lrq_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+                 const double* colsum, const double* mw, const double* msum, float* Q, int ldq) {
+  LAUNCH(k_lrq_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, r, mean, colsum, mw, msum, Q, ldq);
+}
+
+// decode recomputed per pair for rows [row0, row1); returns the number of v7 partials (0 and GZn = 0 when kie7 == 0:
+// then only the mask count is produced, by the same kernel with kie7 = 0).  slabs: lr_decode_slabs(n) * n * h floats.
+int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
+                  double* v7part, float* GZn, int ldg, unsigned int* nmask) {
+  const int rows = row1 - row0;
+  if (rows <= 0) return 0;
+  const int nb = (rows + 255) / 256, js = lr_decode_slabs(n), jper = (n + js - 1) / js;
+  if (h == 8) LAUNCH(k_decode_fly<8>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
+  else if (h == 16) LAUNCH(k_decode_fly<16>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
+  else LAUNCH(k_decode_fly<32>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
+  LAUNCH(k_sum_slabs_rows, g1((size_t)rows * h), dim3(256), st, n, row0, row1, h, js, slabs, GZn, ldg);
+  return nb * js;
+}
+
+// terms packed greedily, in order, into rounds of at most kmax concatenated columns
+static TailFactors make_factors(int count, const float* const* L, const int* ldl, const float* const* R, const int* ldr,
+                                const int* K, const float* alpha, int kmax) {
+  TailFactors F;
+  F.count = count; F.nrounds = 0;
+  for (int f = 0; f < 4; ++f) {
+    F.L[f] = F.R[f] = nullptr; F.ldl[f] = F.ldr[f] = F.K[f] = F.koff[f] = F.round[f] = 0; F.alpha[f] = 0.f; F.kround[f] = 0;
+  }
+  int used = 0;
+  for (int f = 0; f < count; ++f) {
+    if (f == 0 || used + K[f] > kmax) { ++F.nrounds; used = 0; }
+    F.L[f] = L[f]; F.R[f] = R[f]; F.ldl[f] = ldl[f]; F.ldr[f] = ldr[f]; F.K[f] = K[f]; F.alpha[f] = alpha[f];
+    F.koff[f] = used; F.round[f] = F.nrounds - 1;
+    used += K[f];
+    F.kround[F.nrounds - 1] = used;
+  }
+  return F;
+}
+int fl_tail_tiles(int n) { return (n + FT - 1) / FT; }
+bool fl_tail_supported(int n, int ld, int kmax) { return kmax > 0 && kmax <= 64 && (ld % 4) == 0 && n >= 256; }
+
+// vpart: nblk v1 partials followed by nblk v6 partials, nblk = nt * (tile rows) = the return value
+int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
+                   const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha, const float* M,
+                   const float* P1, const float* r, const float* mean, const float* delta, const float* cvec, float a1,
+                   float a2, float kie6, float* GS, float* ps, double* vpart) {
+  const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
+  if (t1 <= t0) return 0;
+  int ktot = 0, kbig = 1;
+  for (int f = 0; f < nfac; ++f) { ktot += K[f]; kbig = K[f] > kbig ? K[f] : kbig; }
+  const int kmax = (ktot <= 32 && kbig <= 32) ? 32 : 64;       // LDS panel depth of the kernel instance
+  const TailFactors F = make_factors(nfac, L, ldl, R, ldr, K, alpha, kmax);
+  dim3 grid(nt, t1 - t0);
+  if (kmax <= 32)
+    LAUNCH(k_tail_reduce<32>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, M, P1, r, mean, delta, cvec, a1, a2, kie6, GS, ps, vpart);
+  else
+    LAUNCH(k_tail_reduce<64>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, M, P1, r, mean, delta, cvec, a1, a2, kie6, GS, ps, vpart);
+  return nt * (t1 - t0);
+}
+void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd) {
+  if (row1 <= row0) return;
+  LAUNCH(k_tail_gd, dim3((row1 - row0 + 3) / 4), dim3(256), st, n, row0, row1, fl_tail_tiles(n), ps, d, gd);
+}
+void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* GPu, int ldp, const float* Tu,
+                  int ldt, int K, const float* GS, const float* r, const float* gd, float* M, float* am, float* av,
+                  const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
+                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out) {
+  const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
+  if (t1 <= t0) return;
+  const float* Ls[1] = {GPu}; const float* Rs[1] = {Tu};
+  const int ll[1] = {ldp}, lr_[1] = {ldt}, Ks[1] = {K};
+  const float al[1] = {1.f};
+  const TailFactors F = make_factors(1, Ls, ll, Rs, lr_, Ks, al, K <= 32 ? 32 : 64);
+  dim3 grid(nt, t1 - t0);
+  if (K <= 32)
+    LAUNCH(k_tail_adam<32>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, GS, r, gd, M, am, av, cn, omb1, b2, omb2, step_size,
+           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out);
+  else
+    LAUNCH(k_tail_adam<64>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, GS, r, gd, M, am, av, cn, omb1, b2, omb2, step_size,
+           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out);
+}
+
+}  // namespace mcgra

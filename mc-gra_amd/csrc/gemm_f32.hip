@@ -544,8 +544,10 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   if (!ta && tb && K > 0 && rankk_nt_supported(M, N, K, 0))   // rank-k update: HBM-bound, not MFMA work
     return rankk_nt(st, M, N, K, alpha, A, lda, B, ldb, 0, 0.f, nullptr, 0, nullptr, 0, beta, C, ldc);
   const bool vec = vec_ok(A, lda, B, ldb);
-  const bool skinny = N <= 64;   // up to two 32-wide column tiles: re-reading the N x N operand twice beats a 128-wide tile
-  const int BM = 128, BN = skinny ? 32 : 128, BK = 32;
+  // skinny products stream the big operand once: one 32- or 64-wide column tile (a 33..64-column product on two
+  // 32-wide tiles took 2.4x the time of a 32-column one: 202 vs 85 us at N = 10 000)
+  const bool skinny = N <= 64, wide = skinny && N > 32;
+  const int BM = 128, BN = skinny ? (wide ? 64 : 32) : 128, BK = 32;
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nsplit = 1;
   if (ws && tiles < 256 && K >= 4 * BK) {
@@ -554,7 +556,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     // (measured at N = 10 000: 1024 blocks 117 us vs 147 us at 512 for a 16-wide product; two column tiles want 2048;
     //  at N = 2708 more slabs only add combine work)
     const bool big = (double)M * K >= 33554432.0 || (double)N * K >= 33554432.0 * 2;
-    const int target = (skinny && big) ? (N > BN ? 2048 : 1024) : 512;
+    const int target = (skinny && big) ? 1024 : 512;
     nsplit = min(min(64, (target + tiles - 1) / tiles), K / (2 * BK));
     while (nsplit > 1 && (size_t)nsplit * M * N * sizeof(float) > ws_bytes) --nsplit;
     if (nsplit < 1) nsplit = 1;
@@ -567,7 +569,10 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
   hipError_t e;
   if (nsplit > 1) {
     const size_t stride = (size_t)M * N;
-    if (skinny)
+    if (wide)
+      e = launch_cfg<128, 64, 32, 32, 64, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
+                                                       nsplit, k_per_split, stride);
+    else if (skinny)
       e = launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N,
                                                        nsplit, k_per_split, stride);
     else
@@ -577,6 +582,9 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, stride, nsplit, C, stride, N, ldc, beta);
     return hipGetLastError();
   }
+  if (wide)
+    return launch_cfg<128, 64, 32, 32, 64, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                                                        1, K, 0);
   if (skinny)
     return launch_cfg<128, 32, 32, 32, 32, 1, SYM_NONE>(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
                                                         1, K, 0);

@@ -112,4 +112,33 @@ void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float*
                      const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
                      const double* ztz = nullptr, const double* qtz = nullptr, float a2 = 0.f);
 
+void launch_lr_xtz(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, double* qtz);   // Q^T Z (fp64)
+
+// ---- fused_lowrank.hip (the low-rank HSIC step evaluated from M directly)
+void fl_cat_scaled(hipStream_t st, int n, int w, int wpad, const float* X, int ldx, const float* r, float* V, int ldv, int col0);
+void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, int c0, const float* r, float* out, int ldo);
+void fl_copy_cols(hipStream_t st, int n, int w, const float* Y, int ldy, int c0, float* out, int ldo);
+void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V, int ldy, const float* r, const float* b,
+                   float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum);
+void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out);
+void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound);
+void fl_lrt_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+                 const double* colsum, float* T, int ldt);
+void fl_lrq_pre(hipStream_t st, int n, int w, const float* W, int ldw, const float* r, const double* colsum, float* Vs, int ldv);
+void fl_lrq_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+                 const double* colsum, const double* mw, const double* msum, float* Q, int ldq);
+int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
+                  double* v7part, float* GZn, int ldg, unsigned int* nmask);
+int fl_tail_tiles(int n);
+bool fl_tail_supported(int n, int ld, int kmax);
+int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
+                   const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha, const float* M,
+                   const float* P1, const float* r, const float* mean, const float* delta, const float* cvec, float a1,
+                   float a2, float kie6, float* GS, float* ps, double* vpart);
+void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd);
+void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* GPu, int ldp, const float* Tu,
+                  int ldt, int K, const float* GS, const float* r, const float* gd, float* M, float* am, float* av,
+                  const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
+                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out);
+
 }  // namespace mcgra

@@ -17,9 +17,9 @@ namespace mcgra {
 #define LAUNCH(k, g, b, st, ...) hipLaunchKernelGGL(k, g, b, 0, st, __VA_ARGS__)
 constexpr int LR_HMAX = 32;
 
-// stats (double): zbar[h] | zeta[h] | ZtZ[h*h].  Two deterministic stages: grid (h + 2, LR_PARTS) partial sums
-// over row slices (block x = k < h : column k of Z^T Z;  x = h : column sums;  x = h+1 : zeta = sum_i delta_i z_i),
-// then a fixed-order combine.
+// stats (double): zbar[h] | zeta[h] | ZtZ[h*h] | d2bar | pad.  Two deterministic stages: grid (h + 3, LR_PARTS)
+// partial sums over row slices (block x = k < h : column k of Z^T Z;  x = h : column sums;  x = h+1 : zeta = sum_i
+// delta_i z_i;  x = h+2 : sum_i delta_i^2 in slot 0), then a fixed-order combine.
 constexpr int LR_PARTS = 16;
 __global__ __launch_bounds__(256) void k_lr_colstats_part(int n, int h, const float* __restrict__ Z, int ldz,
                                                           double* __restrict__ part) {
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_lr_colstats_part(int n, int h, const fl
       for (int k = 0; k < h; ++k) d += z[k] * z[k];
       wgt = (double)d;
     }
+    if (b == h + 2) { acc[0] += wgt * wgt; continue; }
 #pragma unroll
     for (int k = 0; k < LR_HMAX; ++k)
       if (k < h) acc[k] += wgt * (double)z[k];
@@ -55,10 +56,15 @@ __global__ void k_lr_colstats_fin(int n, int h, const double* __restrict__ part,
   for (int pz = 0; pz < LR_PARTS; ++pz) t += part[((size_t)b * LR_PARTS + pz) * h + k];
   if (b < h) stats[2 * h + (size_t)b * h + k] = t;
   else if (b == h) stats[k] = t / (double)n;
-  else stats[h + k] = t;
+  else if (b == h + 1) stats[h + k] = t;
+  else if (k == 0) stats[2 * h + (size_t)h * h] = t / (double)n;
 }
 
-// per node i: delta_i = |z_i|^2;  Lf = [U | -delta z] (ld 2h);  V = [U | delta z | delta^2 | 0...] (ld ldv)
+// per node i: delta_i = |z_i|^2;  Lf = [U | -delta z] (ld 2h);  V = [U | delta z - mean | delta^2 - mean | 0...] (ld ldv).
+// V only ever multiplies Xc^T, whose rows sum to zero (Xc is column-centred), so removing the column means of V
+// changes nothing in exact arithmetic; in fp32 it removes a cancellation: the rows of Zn are nearly equal (the
+// embedding aggregates over a dense adjacency), so Xc^T (delta z) is the small difference of large partial sums
+// otherwise (scripts/fused_lowrank_proto.py: error of W2 against float64 1.5e-3 -> 5.7e-5 at n = 2048).
 __global__ void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, const double* __restrict__ stats,
                           float* __restrict__ Lf, float* __restrict__ V, int ldv, float* __restrict__ delta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,9 +78,9 @@ __global__ void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, co
     Lf[(size_t)i * 2 * h + k] = u;
     Lf[(size_t)i * 2 * h + h + k] = -d * z[k];
     V[(size_t)i * ldv + k] = u;
-    V[(size_t)i * ldv + h + k] = d * z[k];
+    V[(size_t)i * ldv + h + k] = d * z[k] - (float)(stats[h + k] / (double)n);
   }
-  V[(size_t)i * ldv + 2 * h] = d * d;
+  V[(size_t)i * ldv + 2 * h] = d * d - (float)stats[2 * h + (size_t)h * h];
   for (int k = 2 * h + 1; k < ldv; ++k) V[(size_t)i * ldv + k] = 0.f;
 }
 
@@ -230,8 +236,8 @@ __global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const flo
   rowval[i] = quad[i] - 2.0 * (double)d * zq + (double)d * (double)d * rs[i];
 }
 
-// stats needs 2h + h^2 doubles followed by (h + 2) * LR_PARTS * h doubles of scratch
-size_t lr_stats_doubles(int h) { return (size_t)2 * h + (size_t)h * h + (size_t)(h + 2) * LR_PARTS * h; }
+// stats needs 2h + h^2 + 2 doubles followed by (h + 3) * LR_PARTS * h doubles of scratch
+size_t lr_stats_doubles(int h) { return (size_t)2 * h + (size_t)h * h + 2 + (size_t)(h + 3) * LR_PARTS * h; }
 // Decode backward of a low-rank step without materialising d loss / d modified_adj1.  With every off-diagonal pair
 // active in the relu (the precondition of a low-rank step) the mask of ((G + G^T) o [S > 0]) Zn is only the diagonal, so
 // for G = ie'(A1) + a2 Q Z^T:
@@ -343,11 +349,14 @@ int lr_decode_slabs(int n) {
 // GZn (beta = 0) = sum_{j != i} 2 ie'(A1_ij) z_j and the v7 partials (returns their count); kie7 == 0: no N x N pass,
 // GZn = 0.  qtz (h*h + scratch doubles, see lr_qtz_doubles) receives Q^T Z for k_lr_part2.
 size_t lr_qtz_doubles(int h) { return (size_t)h * h + (size_t)h * LR_PARTS * h; }
-int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
-                         float kie7, float* slabs, double* v7part, float* GZn, int ldg, double* qtz) {
+void launch_lr_xtz(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, double* qtz) {
   double* part = qtz + (size_t)h * h;
   LAUNCH(k_lr_xtz_part, dim3(h, LR_PARTS), dim3(256), st, n, h, QQ, 2 * h, Z, ldz, part);
   LAUNCH(k_lr_xtz_fin, dim3(h), dim3(64), st, h, part, qtz);
+}
+int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
+                         float kie7, float* slabs, double* v7part, float* GZn, int ldg, double* qtz) {
+  launch_lr_xtz(st, n, h, QQ, Z, ldz, qtz);
   if (kie7 == 0.f) {
     (void)hipMemset2DAsync(GZn, (size_t)ldg * sizeof(float), 0, (size_t)h * sizeof(float), n, st);
     return 0;
@@ -361,9 +370,9 @@ int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, 
 }
 
 void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats) {
-  double* part = stats + (size_t)2 * h + (size_t)h * h;
-  LAUNCH(k_lr_colstats_part, dim3(h + 2, LR_PARTS), dim3(256), st, n, h, Z, ldz, part);
-  LAUNCH(k_lr_colstats_fin, dim3(h + 2), dim3(64), st, n, h, part, stats);
+  double* part = stats + (size_t)2 * h + (size_t)h * h + 2;
+  LAUNCH(k_lr_colstats_part, dim3(h + 3, LR_PARTS), dim3(256), st, n, h, Z, ldz, part);
+  LAUNCH(k_lr_colstats_fin, dim3(h + 3), dim3(64), st, n, h, part, stats);
 }
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta) {

@@ -69,16 +69,46 @@ __device__ __forceinline__ void split3(float x, __hip_bfloat16& p0, __hip_bfloat
 
 // pack rows of a [n x n] fp32 matrix (value(row, k) = X[row][k] - sub[row], or the symmetric S given in lower tile
 // storage when sub == nullptr and sym != 0) into [panel][kchunk][plane][k half][row][8].  One thread: 8 consecutive k of a row.
+// rvec != nullptr: X is the learnable adjacency M and the packed value is the centred normalised adjacency formed on
+// the fly, (r_row (M[row][k] + [row == k])) r_k - sub[row] (adj_norm is never stored: fused low-rank step); rows of the
+// grid start at row_base.  rsq_part != nullptr: rsq_part[row][blockIdx.x] = sum of the squares of the block's 64 values
+// of that row (|xc_row|^2 = diag(Xc Xc^T) once summed over the blocks of the row).
 template <int NP>
 __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
-                                              int sym, int nkc, char* __restrict__ out, const float* __restrict__ amax) {
+                                              int sym, int nkc, char* __restrict__ out, const float* __restrict__ amax,
+                                              const float* __restrict__ rvec, int row_base, float* __restrict__ rsq_part) {
   // block: 32 rows x 8 (k chunk pairs of 8): thread (r, c): row = blockIdx.y * 32 + r, k0 = (blockIdx.x * 8 + c) * 8
   const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
-  const int row = blockIdx.y * 32 + r;
+  const int row = row_base + blockIdx.y * 32 + r;
   const int k0 = (blockIdx.x * 8 + c) * 8;
   if (k0 >= nkc * KC) return;
   float v[8];
   const float mu = (sub && row < n) ? sub[row] : 0.f;
+  if (rvec) {
+    const float rr = row < n ? rvec[row] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (row < n && k0 + 7 < n) {
+      const float4 x0 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0);
+      const float4 x1 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0 + 4);
+      const float4 q0 = *reinterpret_cast<const float4*>(rvec + k0);
+      const float4 q1 = *reinterpret_cast<const float4*>(rvec + k0 + 4);
+      const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, qs[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (rr * (xs[j] + (k0 + j == row ? 1.f : 0.f))) * qs[j] - mu;
+    } else if (row < n) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < n) v[j] = (rr * (X[(size_t)row * ld + k0 + j] + (k0 + j == row ? 1.f : 0.f))) * rvec[k0 + j] - mu;
+    }
+    if (rsq_part) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(v[j], v[j], s);
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      if (c == 0 && row < n) rsq_part[(size_t)row * gridDim.x + blockIdx.x] = s;
+    }
+  } else
   if (!sym && row < n && k0 + 7 < n && (ld & 3) == 0) {      // interior: two 16-byte loads
     const float4 x0 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0);
     const float4 x1 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0 + 4);
@@ -404,8 +434,24 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
                  const float* amax) {
   const int nkc = chunks_of(n, planes), panels = (n + TB - 1) / TB;
   dim3 grid((nkc * 2 + 7) / 8, panels * (TB / 32));
-  if (planes == 2) hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax);
-  else hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax);
+  if (planes == 2)
+    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr);
+  else
+    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr);
+}
+// Panels [panel_off, panel_off + panel_rows) of the centred normalised adjacency formed from M on the fly (see k_pack);
+// rsq_part [n][split3_pack_rsq_parts(n, planes)] receives the per-block sums of squares of each packed row.
+int split3_pack_rsq_parts(int n, int planes) { return (chunks_of(n, planes) * 2 + 7) / 8; }
+void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
+                        const float* amax, int panel_off, int panel_rows, float* rsq_part) {
+  const int nkc = chunks_of(n, planes), panels = (n + TB - 1) / TB;
+  const int pr = panel_rows >= 0 ? panel_rows : panels;
+  if (pr <= 0) return;
+  dim3 grid((nkc * 2 + 7) / 8, pr * (TB / 32));
+  if (planes == 2)
+    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part);
+  else
+    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part);
 }
 // C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
 // (panel_rows < 0: all panels).  Tiles are independent; a row range gives the same bits as the full launch except for

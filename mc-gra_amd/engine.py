@@ -312,6 +312,10 @@ class AttackEngine:
         check(lib.mcgra_attack_path_stats(self._h, C.byref(a), C.byref(b)))
         return {"lowrank_steps": a.value, "general_steps": b.value}
 
+    def fused_steps(self):
+        """Low-rank steps that ran as the fused step (mcgra_attack_fused_steps)."""
+        return int(lib.mcgra_attack_fused_steps(self._h))
+
     def leading_dim(self):
         ptr, r, c, ld = C.c_void_p(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib.mcgra_attack_buffer(self._h, b"M", C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))

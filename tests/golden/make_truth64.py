@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""float64 evaluation of the reference ALGORITHM (the numpy oracle with F32 := float64) on the bench's own workload:
+the step-0 gradient at the packed positions tests/golden/bench10k_hsic.npz samples.  It says how far the reference's
+own float32 run is from the exact gradient at N = 10 000 (its Gram evaluation of linear_HSIC sums 10^8 products of
+O(1) Gram entries in fp32), which bounds what "equal to the reference" can mean per entry at that size.
+
+    python tests/golden/make_truth64.py          (~10 min and ~30 GB per start on 8 cores)
+
+Writes tests/golden/bench10k_hsic_fp64.npz: for each start of the fixture (`run`, `one0`, ...) `<name>_g64` = the
+mirrored packed gradient of its first step at `packed_pos`, plus its largest magnitude over the whole vector."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench as B                     # noqa: E402
+from oracle import mcgra_oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main(workload="synthetic-10k-hsic", tag="bench10k_hsic"):
+    z = np.load(os.path.join(OUT, f"{tag}.npz"))
+    seed = int(z["seed"])
+    n, f, c, hid, nl, measure, wp = B.WORKLOADS[workload]
+    O.F32 = np.float64
+    inp = B.make_inputs(n, f, c, hid, nl, seed)
+    X = inp["features"].astype(np.float64)
+    fadj = 1.0 / (1.0 + np.exp(-np.maximum(X @ X.T - np.eye(n), 0)))
+    w = O.GCNWeights([x.astype(np.float64) for x in inp["W"]], [x.astype(np.float64) for x in inp["b"]],
+                     inp["Wlin"].astype(np.float64), inp["blin"].astype(np.float64))
+    cfg = O.AttackConfig(measure=measure, weight_sup=1.0, weight_param=wp, lr=0.01, num_edges=float("inf"))
+    pk = z["packed_pos"]
+    i = ((1.0 + np.sqrt(1.0 + 8.0 * pk.astype(np.float64))) / 2.0).astype(np.int64)
+    i = np.where(i * (i - 1) // 2 > pk, i - 1, i)
+    i = np.where((i + 1) * i // 2 <= pk, i + 1, i)
+    j = pk - i * (i - 1) // 2
+    out = dict(workload=workload, packed_pos=pk)
+    for name in ["run"] + sorted({k[:4] for k in z.files if k.startswith("one")}):
+        sd, sc = int(z[f"{name}_a0_seed"]), float(z[f"{name}_a0_scale"])
+        t0 = time.time()
+        orc = O.PGDAttackOracle(w, X, inp["adj"].astype(np.float64), np.zeros((n, n)), fadj, inp["labels"],
+                                inp["idx_attack"], cfg)
+        orc.w = w                                    # keep the float64 weights (f32() would be a no-op cast anyway)
+        orc.set_adj_changes(B.make_a0(n, sd, sc).astype(np.float64))
+        orc.step()
+        G = orc.last["G_sym"]
+        out[f"{name}_g64"] = G[i, j].astype(np.float64)
+        out[f"{name}_g64_absmax"] = float(np.abs(G).max())
+        ref = z[f"{name}_g"][0].astype(np.float64)
+        e = np.abs(ref - out[f"{name}_g64"]).max() / out[f"{name}_g64_absmax"]
+        print(name, "reference fp32 vs float64 oracle: max err / gmax =", e, "seconds", round(time.time() - t0, 1), flush=True)
+        del orc, G
+        np.savez_compressed(os.path.join(OUT, f"{tag}_fp64.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

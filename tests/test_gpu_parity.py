@@ -779,3 +779,101 @@ def test_fused_tail_matches_separate_kernels(pkg, n, measure, monkeypatch):
         assert torch.equal(ma[:n, :n], ma[:n, :n].T)
         assert float((a.get_adj_changes() - b.get_adj_changes()).abs().max()) <= 1e-6
         b.set_adj_changes(a.get_adj_changes())
+
+
+# ---- the fused low-rank step (attack_fused.hip): N x N quantities from M and n-vectors only -------------------------
+NXN_ONLY = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 0, 0)        # c1, c2, c6, c7: the terms the fused step restructures
+
+
+@pytest.mark.parametrize("n,widths,wp,split", [
+    (1100, (16, 16), None, None), (1283, (16, 8), NXN_ONLY, None), (700, (16, 16), NXN_ONLY, "3"),
+    (1100, (16, 16, 16), None, None), (515, (8, 8), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), "2"),
+    (1030, (16, 16), (0.01, 0, 0, 0, 0, 10, 0, 0, 10, 0), None)])
+def test_fused_lowrank_step_matches_general_path_and_oracle(pkg, n, widths, wp, split, monkeypatch):
+    """Same step through attack_fused.hip and through the general path (MCGRA_NO_FUSED_LR=1), teacher-forced, with the
+    monitor forward adopted in between: mirrored gradient, every loss term and the updated adjacency agree to fp32
+    rounding; and the fused gradient matches the ORACLE (with the small-operand terms off the N x N terms carry the
+    whole gradient, so this pins the restructured algebra to the reference's algorithm)."""
+    kw = {} if wp is None else {"weight_param": wp}
+    z = _synthetic_case(n, 11, widths, 4, seed=n, **kw)
+    if split:
+        monkeypatch.setenv("MCGRA_SPLIT_BF16", split)
+    fused = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
+    gen = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_FUSED_LR")
+    orc = H.oracle_from(z)
+    for t in range(3):
+        a, b = fused.step(want_scalars=True), gen.step(want_scalars=True)
+        orc.step()
+        gf, gg = fused.buffer("G_sym").cpu().numpy(), gen.buffer("G_sym").cpu().numpy()
+        gr = orc.last["G_sym"]
+        scale = np.abs(gr).max()
+        assert np.abs(gf - gg).max() <= 3e-5 * scale, (t, np.abs(gf - gg).max() / scale)
+        assert np.abs(gf - gr).max() <= 3e-4 * scale, (t, np.abs(gf - gr).max() / scale)
+        for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "origin_loss"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-6 * max(1.0, abs(b["loss"]))), (t, k, a[k], b[k])
+        if wp is NXN_ONLY:      # (with c9 / c10 on, the oracle's Gram-form fp32 VALUE of the small-operand HSIC is the noisy one)
+            assert abs(a["loss"] - orc.last["loss"]) <= 2e-4 * abs(orc.last["loss"]) + 1e-5
+        Mf = fused.buffer("M")
+        assert bool((Mf == Mf.T).all()), "the learnable adjacency must stay symmetric bit for bit"
+        assert bool((fused.buffer("adam_m") == fused.buffer("adam_m").T).all()) and bool((fused.buffer("adam_v") == fused.buffer("adam_v").T).all())
+        gsf = fused.buffer("G_sym")
+        assert bool((gsf == gsf.T).all())
+        ma, mb = fused.get_adj_changes(), gen.get_adj_changes()
+        lr = float(z["lr"])
+        assert float(((ma - mb).abs() > 0.05 * lr).float().mean()) < 2e-3       # Adam: +-lr on noise-level gradients
+        la, _ = fused.monitor(); lb, _ = gen.monitor()
+        assert float((la - lb).abs().max()) < 1e-4
+        nxt = O.pack_tril(orc.M)
+        fused.set_adj_changes(nxt); gen.set_adj_changes(nxt)                   # teacher forcing (drops the adopted forward)
+    assert fused.fused_steps() == 3 and gen.fused_steps() == 0
+    assert fused.path_stats() == gen.path_stats() == {"lowrank_steps": 3, "general_steps": 0}
+
+
+def test_fused_lowrank_adopts_the_monitor_forward_bit_identically(pkg, monkeypatch):
+    """Free-running fused steps with and without monitor calls in between give the same bits (the monitor's forward
+    on the updated adjacency IS the next step's forward), and finalize after a fused loop equals finalize after the
+    same loop on the general path to fp32 rounding (em_last stands in for embedding(features, adj_norm))."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5)
+    e1, e2 = H.engine_from(pkg, z), H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
+    e3 = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_FUSED_LR")
+    for t in range(3):
+        e1.step(); e1.monitor()
+        e2.step()
+        e3.step(); e3.monitor()
+    assert torch.equal(e1.get_adj_changes(), e2.get_adj_changes())
+    assert e1.fused_steps() == 3
+    lab = z["labels"]
+    label_adj = (lab[:, None] == lab[None, :]).astype(np.float32)
+    o = H.oracle_from(z)
+    HA, YA = o.HA, o.YA
+    f1 = e1.finalize(0, HA, YA, label_adj).cpu().numpy()
+    f3 = e3.finalize(0, HA, YA, label_adj).cpu().numpy()
+    assert np.mean(np.abs(f1 - f3) > 1e-3) < 0.01
+    assert abs(O.metric_pool(z["adj"], f1, z["idx_attack"]) - O.metric_pool(z["adj"], f3, z["idx_attack"])) < 1e-4
+
+
+def test_fused_lowrank_hands_masked_steps_to_the_general_path(pkg, monkeypatch):
+    """A decode that masks a pair (S_ij <= 0) cannot take the low-rank algebra: the fused step detects it from Zn and
+    the general (Gram) path redoes the step -- same result as an engine that never tries the fused step."""
+    import torch
+    z = _synthetic_case(300, 11, (16, 16), 4, seed=9, weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0))
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", "3")
+    w = H.weights_from(z)
+    probe = H.oracle_from(z); probe.step()
+    w.b = [b.copy() for b in w.b]
+    w.b[1] = (w.b[1] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)      # about half of em dies
+    engs = []
+    for no_fused in ("0", "1"):
+        monkeypatch.setenv("MCGRA_NO_FUSED_LR", no_fused)
+        e = H.engine_from(pkg, z)
+        e.set_model(w.W, w.b, w.Wlin, w.b and w.blin, w.Ws)
+        e.step(); e.monitor(); e.step()
+        engs.append(e)
+    assert engs[0].path_stats() == engs[1].path_stats() == {"lowrank_steps": 0, "general_steps": 2}
+    assert engs[0].fused_steps() == 0
+    assert torch.equal(engs[0].get_adj_changes(), engs[1].get_adj_changes())
