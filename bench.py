@@ -208,9 +208,10 @@ def aggregate_value(world, steps, dt):
     return world * steps / dt
 
 
-def build_engine(pkg, torch, dev, workload, seed, **kw):
+def build_engine(pkg, torch, dev, workload, seed, weight_param=None, **kw):
     """Engine + inputs of one workload, seeded: the same seed gives bit-identical state on every rank."""
     n, f, c, hid, nl, measure, wp = WORKLOADS[workload]
+    wp = wp if weight_param is None else weight_param
     inp = make_inputs(n, f, c, hid, nl, seed)
     X = torch.as_tensor(inp["features"], device=dev)
     fadj = feature_adj_cora(X, torch)

@@ -74,6 +74,15 @@ def load_cora(name):
     return z
 
 
+def tril_pos(p):
+    """packed position (torch.tril_indices(n, n, -1) order, topology_attack.py:369) -> (row, col)"""
+    p = np.asarray(p, dtype=np.int64)
+    i = ((1.0 + np.sqrt(1.0 + 8.0 * p.astype(np.float64))) / 2.0).astype(np.int64)
+    i = np.where(i * (i - 1) // 2 > p, i - 1, i)
+    i = np.where((i + 1) * i // 2 <= p, i + 1, i)
+    return i, p - i * (i - 1) // 2
+
+
 def cora_feature_adj(feats):
     """main.dot_product_decode for cora (main.py:44-48)."""
     Z = feats @ feats.T

@@ -38,13 +38,7 @@ def _engine(ctx, seed=0, **kw):
     return bench.build_engine(pkg, torch, dev, WL, seed, **kw)
 
 
-def _tril_pos(p):
-    """packed position (torch.tril_indices(n, n, -1) order, topology_attack.py:369) -> (row, col)"""
-    p = np.asarray(p, dtype=np.int64)
-    i = ((1.0 + np.sqrt(1.0 + 8.0 * p.astype(np.float64))) / 2.0).astype(np.int64)
-    i = np.where(i * (i - 1) // 2 > p, i - 1, i)
-    i = np.where((i + 1) * i // 2 <= p, i + 1, i)
-    return i, p - i * (i - 1) // 2
+from tests.helpers import tril_pos as _tril_pos  # noqa: E402
 
 
 def test_tril_pos_helper():
@@ -214,3 +208,48 @@ def test_gradient_is_linear_in_the_loss_weights_at_10k(ctx):
     g_sum = grad(0.0, wa) + grad(1.0, wb)
     err = float((g_all - g_sum).abs().max()) / float(g_all.abs().max())
     assert err < 2e-5, err
+
+
+# ---- BASELINE.json configs[4]: N = 30 000, d = 256, 3-layer GCN, on ONE MI355X (58 GB of N x N buffers + 7 GB of planes)
+WL30 = "synthetic-30k-hsic-3layer"
+
+
+def test_config4_shape_30k_3layer_properties(ctx, monkeypatch):
+    """The largest BASELINE shape through the default path (fused low-rank step, fp16-split product, 3-layer chains:
+    rank-k panels of 48 + 32 columns in two rounds): state invariants, bit-determinism of two runs, and agreement of
+    the low-rank evaluation with the Gram evaluation (the reference's formulation: four fp32 MFMA products) on the
+    N x N terms.  The oracle cannot run at this size; the same code paths are pinned to the reference at N <= 10 000."""
+    pkg, torch, bench, dev = ctx
+    outs = []
+    for rep in range(2):
+        eng, inp, _ = bench.build_engine(pkg, torch, dev, WL30, 0)
+        assert eng.product_mode() == 3
+        sc = []
+        for t in range(2):
+            sc.append(eng.step(want_scalars=True)); eng.monitor()
+        M = eng.buffer("M")
+        assert torch.equal(M, M.t()) and float(M.diagonal().abs().max()) == 0.0
+        assert float(M.min()) >= 0.0 and float(M.max()) <= 1.0
+        assert eng.path_stats() == {"lowrank_steps": 2, "general_steps": 0} and eng.fused_steps() == 2
+        assert all(np.isfinite(s["loss"]) for s in sc)
+        outs.append((eng.get_adj_changes().clone(), [s["loss"] for s in sc]))
+        del eng, M
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], "two runs must give identical bits"
+    del outs
+    nxn = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 0, 0)       # without the small-operand terms the N x N terms carry the gradient
+    fast, _, _ = bench.build_engine(pkg, torch, dev, WL30, 0, weight_param=nxn)
+    a = fast.step(want_scalars=True)
+    gf = fast.buffer("G_sym")
+    del fast
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    gram, _, _ = bench.build_engine(pkg, torch, dev, WL30, 0, weight_param=nxn)
+    monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    b = gram.step(want_scalars=True)
+    gg = gram.buffer("G_sym")
+    assert gram.path_stats()["general_steps"] == 1
+    err = float((gf - gg).abs().max()) / float(gg.abs().max())
+    assert err < 1e-4, err
+    for k in ("loss", "c1", "c2", "c6", "c7"):
+        assert a[k] == pytest.approx(b[k], rel=1e-3, abs=1e-6), k
