@@ -225,32 +225,21 @@ def build_engine(pkg, torch, dev, workload, seed, weight_param=None, **kw):
     return eng, inp, adj_dev
 
 
-def sharded_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, monitor):
-    """ONE attack row-block sharded over all ranks, timed like the main region.  Reported
-    beside the replica throughput at N > 1; never the headline value."""
-    from mc_gra_amd.sharded import RowBlockPlan, ShardedStepper, HipShardBackend
-    n = WORKLOADS[workload][0]
-    plan = RowBlockPlan(n, world, rank)
-    eng, _, _ = build_engine(pkg, torch, dev, workload, seed, row_begin=plan.row_begin, row_end=plan.row_end)
-    st = ShardedStepper(HipShardBackend(eng, plan), plan, dist=dist)
+def replica_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, warmup, monitor):
+    """N independent attacks, one per rank, each on its own graph and with no data-path collective (e.g. the trials of
+    main.py's search loop): aggregate throughput of the job used that way.  A side figure at N > 1, never `value`."""
+    eng, _, _ = build_engine(pkg, torch, dev, workload, seed + 1 + rank)
 
     def one_step():
-        st.step()
+        eng.step()
         if monitor:
             eng.monitor()
 
-    dt = timed_region(one_step, steps, 2, torch.cuda.synchronize, world, dist, dev, torch)
-    a = eng.get_adj_changes()
-    diff = torch.zeros(1, device=dev)
-    if world > 1:
-        ref = a.clone()
-        dist.broadcast(ref, src=0)
-        diff = (a - ref).abs().max().reshape(1)
-        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
-    return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "row_blocks": world,
-            "rows_per_rank": plan.rows_per_rank, "max_abs_diff_across_ranks": float(diff.item()),
-            "exchange": "all_gather_into_tensor (RCCL) of the row blocks mcgra_attack_exchange_mask names: P1 (buffer KX) on a "
-                        "low-rank step, KX+KY and G_adjn+G_A1 on a Gram step"}
+    dt = timed_region(one_step, steps, warmup, torch.cuda.synchronize, world, dist, dev, torch)
+    del eng
+    torch.cuda.empty_cache()
+    return {"steps_per_s_all_replicas": aggregate_value(world, steps, dt), "ms_per_step_per_replica": 1e3 * dt / steps,
+            "replicas": world, "steps": steps, "what": "independent attacks, one per GPU, no collective (weak scaling)"}
 
 
 PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
@@ -314,8 +303,7 @@ def main():
     ap.add_argument("--no-monitor", action="store_true", help="skip the per-step monitoring forward (:290-296)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-shard-probe", action="store_true",
-                    help="N > 1: skip the extra (untimed-for-value) run of one attack row-block sharded over the ranks")
-    ap.add_argument("--force-shard-probe", action="store_true", help="run the probe at N = 1 too (phase API, one row block)")
+                    help="N > 1: skip the extra (untimed-for-value) run of independent replicas, one attack per rank")
     ap.add_argument("--no-split-probe", action="store_true",
                     help="skip the extra runs at N = 1 (other evaluation of the N x N x N product, Cora-shape workload)")
     a = ap.parse_args()
@@ -336,13 +324,27 @@ def main():
     pkg = mcgra_loader.load()
 
     n, f, c, hid, nl, measure, wp = WORKLOADS[a.workload]
-    eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed + rank)     # replicas: every rank its own graph
     monitor = not a.no_monitor
+    stepper = plan = None
+    if world > 1:
+        # ONE attack, row-block sharded over the ranks: every rank builds the same graph and owns
+        # the rows of the learnable adjacency its plan names; collectives over RCCL inside the timed region
+        from mc_gra_amd.sharded import RowBlockPlan, ShardedStepper, HipShardBackend
+        plan = RowBlockPlan(n, world, rank)
+        eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed, plan=plan)
+        stepper = ShardedStepper(HipShardBackend(eng, plan), plan, dist=dist)
 
-    def one_step():
-        eng.step()
-        if monitor:
-            eng.monitor()
+        def one_step():
+            stepper.step()
+            if monitor:
+                stepper.monitor()
+    else:
+        eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed)
+
+        def one_step():
+            eng.step()
+            if monitor:
+                eng.monitor()
 
     for _ in range(a.warmup):
         one_step()
@@ -351,10 +353,11 @@ def main():
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
     eng_path = eng.path_stats()
+    stepper_exchanges = (stepper.exchanges / (a.warmup + a.steps)) if stepper is not None else None
 
     # the same N x N x N product alone on the chip (no side-stream company), for the roofline's "alone" figure
     alone_ms = None
-    if st["launches"] and eng_path["lowrank_steps"] > 0 and measure == "HSIC" and eng.product_mode() == 0:
+    if world == 1 and st["launches"] and eng_path["lowrank_steps"] > 0 and measure == "HSIC" and eng.product_mode() == 0:
         from mc_gra_amd import engine as E
         KFC, Bop = eng.buffer("KFC"), eng.buffer("adj_norm")
         out_s = torch.empty_like(Bop)
@@ -415,21 +418,21 @@ def main():
         except Exception as e:
             extra = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    shard = None
-    if (world > 1 or a.force_shard_probe) and not a.no_shard_probe and os.environ.get("MCGRA_BENCH_NO_SHARD_PROBE") != "1":
-        del eng, final, H_A, Y_A, label_adj
+    replicas = None
+    if world > 1 and not a.no_shard_probe:
+        del eng, final, H_A, Y_A, label_adj, stepper
         torch.cuda.empty_cache()
         try:
-            shard = sharded_probe(pkg, torch, dist, dev, rank, world, a.workload, a.seed, min(a.steps, 10), monitor)
-            shard["speedup_vs_one_gpu_step"] = (dt / a.steps) / (shard["ms_per_step"] * 1e-3)
+            replicas = replica_probe(pkg, torch, dist, dev, rank, world, a.workload, a.seed, min(a.steps, 10), 2, monitor)
         except Exception as e:                       # never lose the headline line to the probe
-            shard = {"error": f"{type(e).__name__}: {e}"[:300]}
+            replicas = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         out = {
-            "metric": "attack-steps/sec", "value": aggregate_value(world, a.steps, dt), "unit": "attack-steps/s",
+            # N > 1: ONE attack sharded over the ranks -- steps of that attack per second, not a sum over replicas
+            "metric": "attack-steps/sec", "value": a.steps / dt, "unit": "attack-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32" if not pmode else ("f32 (the N x N x N product: operands as 2 fp16 planes, 3 MFMA products, fp32 accumulate)"
                                               if pmode == 3 else
                                               "f32 (the N x N x N product: operands as 3 bf16 planes, 6 MFMA products, fp32 accumulate)"),
@@ -438,11 +441,16 @@ def main():
                        "classes": c, "measure": measure, "priors": "H_A+Y_A+Y", "weight_param": list(wp),
                        "monitor_forward": monitor,
                        "forward_reuse": bool(monitor and os.environ.get("MCGRA_NO_FWD_REUSE") != "1"),
-                       "parallelism": "replicas" if world > 1 else "single"},
+                       "parallelism": (f"row-block x{world}: one attack, rows of the learnable adjacency and of every N x N pass "
+                                       f"split over the ranks ({plan.rows_per_rank} rows each); per step one all-to-all of "
+                                       "P1 tile blocks, all-gathers of n x c node arrays, all-reduces of scalars (RCCL)"
+                                       if world > 1 else "single")},
             "auc": auc,
         }
-        if shard is not None:
-            out["sharded_probe"] = shard
+        if replicas is not None:
+            out["replica_probe"] = replicas
+        if stepper_exchanges is not None:
+            out["collectives_per_step"] = stepper_exchanges
         if split is not None:
             out["fp32_mfma_probe" if pmode else "split_bf16_probe"] = split
         if extra is not None:
@@ -475,8 +483,8 @@ def main():
                                              "launch per step)",
                                    "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                                   "algorithmic_flop_per_launch": 2.0 * n ** 3,
-                                   "issued_flop_per_launch": 2.0 * npp * n ** 3, "issued_achieved": issued,
+                                   "algorithmic_flop_per_launch": st["flops"] / st["launches"],      # 2 n^2 x the rank's rows
+                                   "issued_flop_per_launch": npp * st["flops"] / st["launches"], "issued_achieved": issued,
                                    "issued_frac": issued / PEAK_BF16_MFMA_TFLOPS,
                                    "fp32_mfma_peak_multiple": ach / PEAK_F32_MFMA_TFLOPS,
                                    "traffic": traffic, "traffic_unit": "bytes/launch",

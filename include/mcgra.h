@@ -167,10 +167,8 @@ typedef struct mcgra_attack_config {
   float lr;            /* Adam lr (lr_ori) */
   float eps;           /* args.eps; != 0 needs noise passed to mcgra_attack_step */
   double num_edges;    /* projection budget (topology_attack.py:338) */
-  /* row-block sharding over ranks (one process per GPU).  row_begin/row_end
-     is the block of adjacency rows this object computes; a single-GPU object
-     uses [0, n).  The caller runs the collectives named in DESIGN.md between
-     the phases of mcgra_attack_step_phase(). */
+  /* row-block sharding over ranks (one process per GPU, see "row-block sharded step" below).  row_begin/row_end is
+     the block of adjacency rows this object owns; a single-GPU object uses [0, n) (row_end 0 = n). */
   int32_t row_begin, row_end;
   /* victim family, unified layer form  P_l = adj @ (H W_l) + H Ws_l + b_l,  H_l = act(P_l):
    *   GCN (models/gcn.py:35-46,164-174)        act 0 (relu), head_act 0, has_self 0
@@ -181,6 +179,9 @@ typedef struct mcgra_attack_config {
   /* depths of the H_A1 / H_A2 embedding forwards of the post-loop ensemble (topology_attack.py:304-307):
      {1, 2}; embedding_gat.forward ignores set_layers (gat.py:170-174), so a GAT uses {nlayer, nlayer}. 0 = default */
   int32_t fin_layers[2];
+  /* shard_world > 0: this object is rank row_begin / shard_rows of shard_world row-block ranks with shard_rows rows
+     each (a multiple of 256; the last ranks may own fewer or no rows: n <= shard_rows * shard_world).  0: unsharded. */
+  int32_t shard_world, shard_rows;
 } mcgra_attack_config_t;
 
 int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg);
@@ -218,29 +219,46 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
                       double* scalars_out);
 
-/* Row-block sharding over ranks (one process per GPU).  A step is four phases; the host layer runs the
- * collectives between them (mc-gra_amd/sharded.py):
- *   phase 0  replicated   forward, losses, centred operands
- *   phase 1  sharded      centred Grams KX, KY: tile rows of [cfg.row_begin, cfg.row_end) only
- *            -> all-gather the row blocks of "KX", "KY"
- *   phase 2  sharded      gradient products into rows [row_begin, row_end) of "G_adjn", "G_A1"
- *            -> all-gather the row blocks of "G_adjn", "G_A1"
- *   phase 3  replicated   small-operand terms, backward chains, Adam, projection (scalars_out as in mcgra_attack_step)
- * mcgra_attack_step == phases 0..3 with the full row range.  Measures without N x N x N products (MSELoss, KL) do
- * all their work in phases 0 and 3. */
-int mcgra_attack_step_phase(mcgra_attack_t* h, void* stream, int phase, const float* noise,
-                            double* scalars_out);
-/* Which of the exchanged buffers the step in flight needs gathered (valid after phase 0; the choice between the
- * low-rank and the Gram evaluation of linear_HSIC(adj_norm, modified_adj1) is data dependent).
- * After phase 1: the KX / KY bits; after phase 2: the G_ADJN / G_A1 bits. */
-#define MCGRA_EXCHANGE_KX 1
-#define MCGRA_EXCHANGE_KY 2
-#define MCGRA_EXCHANGE_G_ADJN 4
-#define MCGRA_EXCHANGE_G_A1 8
-int mcgra_attack_exchange_mask(mcgra_attack_t* h);
-/* How the one N x N x N product of a low-rank step is evaluated by this engine: 0 = fp32 MFMA SYMM, 1 = 3-plane bf16
- * split through a hipBLASLt GEMM, 2 = 3-plane bf16 split, hand-written kernel (the default for n >= 1024; fp32-level
- * error).  Chosen at create from MCGRA_SPLIT_BF16. */
+/* ------------------------------------------------ row-block sharded step --
+ * One process per GPU; rank r owns rows [row_begin, row_end) of the learnable adjacency and of the Adam moments and
+ * does 1/world of every N x N pass of the fused low-rank step:
+ *   - skinny products M[rows, :] V, then an all-gather of the n x c result rows (node-level work is replicated);
+ *   - the N x N x N product as a COLUMN block P1[:, rows] = (H Kf H) Xc[:, rows] from planes packed from the rank's
+ *     own rows (Xc^T rows = adj_norm rows by symmetry), then one all-to-all of tile blocks that hands every rank its
+ *     ROW block P1[rows, :] as well (the mirrored gradient needs P1_ij and P1_ji);
+ *   - decode, tail reductions and Adam on the rank's rows; n-vectors (r, d, gd, ...) are all-gathered, the few
+ *     scalars all-reduced.
+ * The engine runs until the next exchange point and describes the collective; the host layer (mc-gra_amd/sharded.py)
+ * executes it with torch.distributed (backend "nccl" = RCCL) on views of ONE caller-owned device arena:
+ *     mcgra_attack_bind_exchange(h, arena, mcgra_attack_exchange_bytes(h));
+ *     mcgra_attack_shard_begin(h, stream, MCGRA_SHARD_STEP, want_scalars);
+ *     while (mcgra_attack_shard_next(h, stream, &ex) == 0 && ex.kind != MCGRA_XCHG_DONE)  run_collective(ex);
+ * All offsets are bytes from the arena base.  The collectives must run on `stream` (or be ordered after it).
+ * A step whose decode masks a pair all-gathers M and the Adam moments and is redone, replicated, by the general
+ * path on every rank (rare: DESIGN.md 1b).  Supported for the configurations the fused step supports
+ * (mcgra_attack_fused_steps); anything else returns MCGRA_ENOSUP from mcgra_attack_create with shard_world > 0. */
+#define MCGRA_XCHG_DONE 0
+#define MCGRA_XCHG_ALLGATHER 1      /* `world` chunks of chunk_bytes at offset; this rank's chunk (index rank) is filled */
+#define MCGRA_XCHG_ALLREDUCE_F64 2  /* sum over ranks of `count` doubles at offset */
+#define MCGRA_XCHG_ALLTOALL 3       /* `world` chunks of chunk_bytes: send from offset, receive into offset2 */
+typedef struct mcgra_exchange {
+  int32_t kind, count;
+  int64_t offset, offset2, chunk_bytes;
+} mcgra_exchange_t;
+#define MCGRA_SHARD_STEP 0          /* one iteration of the loop (:161-283) */
+#define MCGRA_SHARD_MONITOR 1       /* the monitoring forward (:290-296); the next step adopts it */
+int64_t mcgra_attack_exchange_bytes(mcgra_attack_t* h);
+int mcgra_attack_bind_exchange(mcgra_attack_t* h, void* arena, int64_t bytes);
+int mcgra_attack_shard_begin(mcgra_attack_t* h, void* stream, int what, int want_scalars);
+int mcgra_attack_shard_next(mcgra_attack_t* h, void* stream, mcgra_exchange_t* ex);
+/* after a MCGRA_SHARD_STEP begun with want_scalars: the ten values of mcgra_attack_step's scalars_out (identical on
+ * every rank); after MCGRA_SHARD_MONITOR: out[0] = mean(modified_adj).  Synchronises. */
+int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out);
+/* rows [row_begin, row_end) of adj_changes' dense form: out [row_end - row_begin][n] fp32 (tests, checkpoints) */
+int mcgra_attack_get_rows(mcgra_attack_t* h, void* stream, float* out);
+/* How the one N x N x N product of a low-rank step is evaluated by this engine: 0 = fp32 MFMA SYMM, 2 = 3-plane bf16
+ * split, 3 = 2-plane fp16 split (the default for n >= 1024), both by the hand-written kernel of split_symm_bf16.hip at
+ * fp32-level error.  Chosen at create from MCGRA_SPLIT_BF16. */
 int mcgra_attack_product_mode(mcgra_attack_t* h);
 /* Steps that took the low-rank / the Gram (general) evaluation of the N x N linear_HSIC terms since creation. */
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps);
@@ -249,10 +267,6 @@ int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long lo
  * never stored).  Conditions: measure HSIC, ReLU GCN victim, eps == 0, the split product (n >= 1024 or
  * MCGRA_SPLIT_BF16=2/3), n >= 256, widths <= 32; MCGRA_NO_FUSED_LR=1 disables it. */
 long long mcgra_attack_fused_steps(mcgra_attack_t* h);
-
-/* Use caller-owned device memory ([>= n rows][ld] fp32, ld from mcgra_attack_buffer) for one of the exchanged
- * buffers "KX", "KY", "G_adjn", "G_A1", so that the host layer can hand it to its collective library. */
-int mcgra_attack_bind_buffer(mcgra_attack_t* h, const char* name, float* ptr);
 
 /* Monitoring forward of topology_attack.py:290-296 on the current adjacency:
  * out_logp [n x nclass] = victim(features, normalize(get_modified_adj)),

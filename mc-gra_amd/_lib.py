@@ -28,7 +28,8 @@ SYMBOLS = [
     "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
-    "mcgra_attack_step_phase", "mcgra_attack_bind_buffer", "mcgra_attack_exchange_mask", "mcgra_attack_path_stats", "mcgra_attack_fused_steps", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
+    "mcgra_attack_exchange_bytes", "mcgra_attack_bind_exchange", "mcgra_attack_shard_begin", "mcgra_attack_shard_next",
+    "mcgra_attack_shard_scalars", "mcgra_attack_get_rows", "mcgra_attack_path_stats", "mcgra_attack_fused_steps", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
     "mcgra_attack_monitor", "mcgra_attack_finalize", "mcgra_attack_buffer", "mcgra_attack_copy_buffer",
     "mcgra_attack_profile",
     "mcgra_attack_gemm_stats",
@@ -42,7 +43,14 @@ class AttackConfig(C.Structure):
         ("n_attack", C.c_int32), ("weight_sup", C.c_float), ("w", C.c_float * 10), ("lr", C.c_float),
         ("eps", C.c_float), ("num_edges", C.c_double), ("row_begin", C.c_int32), ("row_end", C.c_int32),
         ("act", C.c_int32), ("head_act", C.c_int32), ("has_self", C.c_int32), ("fin_layers", C.c_int32 * 2),
+        ("shard_world", C.c_int32), ("shard_rows", C.c_int32),
     ]
+
+
+class Exchange(C.Structure):
+    """mcgra_exchange_t"""
+    _fields_ = [("kind", C.c_int32), ("count", C.c_int32), ("offset", C.c_int64), ("offset2", C.c_int64),
+                ("chunk_bytes", C.c_int64)]
 
 
 class McgraError(RuntimeError):
@@ -87,9 +95,11 @@ def _load():
         "mcgra_attack_set_adj_changes": [vp, vp, fp],
         "mcgra_attack_get_adj_changes": [vp, vp, fp],
         "mcgra_attack_step": [vp, vp, fp, C.POINTER(C.c_double)],
-        "mcgra_attack_step_phase": [vp, vp, C.c_int, fp, C.POINTER(C.c_double)],
-        "mcgra_attack_bind_buffer": [vp, C.c_char_p, fp],
-        "mcgra_attack_exchange_mask": [vp],
+        "mcgra_attack_bind_exchange": [vp, vp, C.c_int64],
+        "mcgra_attack_shard_begin": [vp, vp, C.c_int, C.c_int],
+        "mcgra_attack_shard_next": [vp, vp, C.POINTER(Exchange)],
+        "mcgra_attack_shard_scalars": [vp, vp, C.POINTER(C.c_double)],
+        "mcgra_attack_get_rows": [vp, vp, fp],
         "mcgra_attack_product_mode": [vp],
         "mcgra_ssymm_split_bf16": [vp, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_int],
         "mcgra_ssymm_split_f16": [vp, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_int],
@@ -108,6 +118,8 @@ def _load():
         fn.restype = C.c_int
     lib.mcgra_attack_fused_steps.argtypes = [vp]
     lib.mcgra_attack_fused_steps.restype = C.c_longlong
+    lib.mcgra_attack_exchange_bytes.argtypes = [vp]
+    lib.mcgra_attack_exchange_bytes.restype = C.c_int64
     return lib
 
 

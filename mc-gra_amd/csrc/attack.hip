@@ -191,9 +191,19 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
               cfg->measure);
     return MCGRA_ENOSUP;
   }
-  if (cfg->row_begin < 0 || cfg->row_begin % 128 != 0 || (cfg->row_end != 0 && cfg->row_end <= cfg->row_begin)) {
-    set_error("row block [%d, %d): row_begin must be a multiple of 128 and row_end > row_begin", cfg->row_begin, cfg->row_end);
+  if (cfg->shard_world < 0 || (cfg->shard_world == 0 && (cfg->row_begin != 0 || (cfg->row_end != 0 && cfg->row_end < cfg->n)))) {
+    set_error("row block [%d, %d) without shard_world", cfg->row_begin, cfg->row_end);
     return MCGRA_EINVAL;
+  }
+  if (cfg->shard_world > 0) {
+    const int rpr = cfg->shard_rows;
+    if (rpr < 256 || rpr % 256 != 0 || (long long)rpr * cfg->shard_world < cfg->n || cfg->row_begin % rpr != 0 ||
+        cfg->row_begin / rpr >= cfg->shard_world ||
+        cfg->row_end != (cfg->row_begin + rpr < cfg->n ? cfg->row_begin + rpr : (cfg->row_begin < cfg->n ? cfg->n : cfg->row_begin))) {
+      set_error("row block [%d, %d) is not rank %d's block of %d x %d rows (shard_rows: a multiple of 256 with shard_rows * "
+                "shard_world >= n)", cfg->row_begin, cfg->row_end, rpr > 0 ? cfg->row_begin / rpr : -1, cfg->shard_world, rpr);
+      return MCGRA_EINVAL;
+    }
   }
   mcgra_attack* h = new mcgra_attack();
   h->cfg = *cfg;
@@ -313,9 +323,27 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                   !h->has_self && h->act == 0 && h->head_act == 0 && h->split_on && h->split_mode == 2 &&
                   lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
                   (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
-    if (h->fused_ok) {
+    h->row0 = 0; h->row1 = (int)n;
+    if (cfg->shard_world > 0) {
+      // row-block rank: only the fused step is sharded, and the host-driven bisection of the projection is not
+      if (!h->fused_ok || cfg->num_edges < 0.5 * (double)n * (double)n) {
+        if (!rc) {
+          set_error("shard_world > 0 needs a configuration the fused low-rank step covers (HSIC, ReLU GCN victim, eps == 0, "
+                    "n >= 1024 or MCGRA_SPLIT_BF16=2/3, widths <= 32) and a projection budget that cannot bind");
+          rc = MCGRA_ENOSUP;
+        }
+      } else {
+        h->sharded = true;
+        h->world = cfg->shard_world; h->rpr = cfg->shard_rows; h->rank = cfg->row_begin / cfg->shard_rows;
+        h->npad = h->rpr * h->world;
+        h->row0 = cfg->row_begin; h->row1 = cfg->row_end;
+        h->sgw = (he + 2 + 3) & ~3;
+      }
+    }
+    if (h->fused_ok && !rc) {
       h->fcols = fc;
-      A_(FV, n * (size_t)fc); A_(FY, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256);
+      A_(FV, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256);
+      if (!h->sharded) { A_(FY, n * (size_t)fc); }      // a row-block rank keeps FY in the exchange arena
       h->fused_ok = (rc == 0);
     }
   }
@@ -435,6 +463,7 @@ int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* p
 }
 int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed) {
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
+  if (h->sharded && h->have_step) { set_error("row-block rank: only rows [row_begin, row_end) are kept (mcgra_attack_get_rows)"); return MCGRA_EINVAL; }
   launch_pack_tril((hipStream_t)stream, h->n, h->ld, h->M, packed, false);
   MCGRA_KERNEL_CHECK();
   return 0;
@@ -560,7 +589,7 @@ int project(mcgra_attack* h, hipStream_t st) {
 
 // loss terms of the step just taken, from the device scalar slots (one readback + sync): layout of mcgra_attack_step's
 // scalars_out
-int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out) {
+int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out, bool have_clampsum) {
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, C = h->C;
   const int he = h->wdt[h->Le - 1];
@@ -572,8 +601,10 @@ int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out) {
   const bool cka = c.measure == MCGRA_MEASURE_CKA;
   const bool hsic = c.measure == MCGRA_MEASURE_HSIC || cka;
   const bool use1 = (w1 != 0), use2 = (w2 != 0);
-    launch_clamp_rowsum(st, n, ld, h->M, 0.f, h->rowsx, nullptr, nullptr);
-    launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_CLAMPSUM);
+    if (!have_clampsum) {
+      launch_clamp_rowsum(st, n, ld, h->M, 0.f, h->rowsx, nullptr, nullptr);
+      launch_reduce_rows(st, h->rowsx, n, 1, h->scal + S_CLAMPSUM);
+    }
     double s[S_COUNT];
     MCGRA_HIP(hipMemcpyAsync(s, h->scal, sizeof(s), hipMemcpyDeviceToHost, st));
     MCGRA_HIP(hipStreamSynchronize(st));
@@ -601,6 +632,7 @@ int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out) {
     scalars_out[0] = c.weight_sup * origin + sg * (c1v + c2v + c9v + c10v) + c6v + c7v;
     scalars_out[1] = origin; scalars_out[2] = c1v; scalars_out[3] = c2v; scalars_out[4] = c6v; scalars_out[5] = c7v;
     scalars_out[6] = c9v; scalars_out[7] = c10v; scalars_out[8] = 0.5 * s[S_CLAMPSUM]; scalars_out[9] = nll;
+    (void)ld;
   return 0;
 }
 
@@ -620,7 +652,11 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     return MCGRA_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (phases == 0xF && !noise && fused_step_possible(h)) {
+  if (h->sharded && !h->fs_active) {
+    set_error("this engine is a row-block rank: drive it with mcgra_attack_shard_begin / mcgra_attack_shard_next");
+    return MCGRA_EINVAL;
+  }
+  if (phases == 0xF && !noise && !h->sharded && fused_step_possible(h)) {
     const int rc = fused_step(h, st, scalars_out);      // 1: a relu-masked pair in the decode, the general path redoes the step
     if (rc <= 0) return rc;
   }
@@ -644,9 +680,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // tile rows of this rank (single GPU: all of them)
   const int t_all = (n + SYM_TILE - 1) / SYM_TILE;
   // (a trailing rank of a padded plan may own no tile rows at all: t0 == t1 == t_all)
-  const int t0 = c.row_begin / SYM_TILE < t_all ? c.row_begin / SYM_TILE : t_all;
-  const int t1 = (c.row_end >= n || c.row_end <= 0) ? t_all : (c.row_end + SYM_TILE - 1) / SYM_TILE;
-  const bool sharded = (t0 != 0 || t1 != t_all);
+  const int t0 = 0, t1 = t_all;          // (row-block ranks run the fused step: attack_fused.hip)
+  const bool sharded = false;
 
   if (PH(0)) {
   const bool adopt = h->fwd_cached && !noise;       // forward of this iteration already done by the last monitor call
@@ -675,7 +710,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       hipStream_t sp = h->overlap ? h->st2 : st;
       // bf16 planes of Xc^T (opt-in split path) on the caller's stream, ahead of the fork: cmean is reused later
       // (row blocks of a sharded step must start on a 256-row panel for the split kernel; otherwise fp32 SYMM)
-      const bool split_now = h->split_on && !noise && (c.row_begin % split3_panel()) == 0;
+      const bool split_now = h->split_on && !noise;
       if (split_now)
         split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr);
       if (h->overlap) {
@@ -968,32 +1003,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out) {
   return step_impl(h, stream, noise, scalars_out, 0xF);
 }
-
-int mcgra_attack_step_phase(mcgra_attack_t* h, void* stream, int phase, const float* noise, double* scalars_out) {
-  if (phase < 0 || phase > 3) { set_error("phase %d", phase); return MCGRA_EINVAL; }
-  return step_impl(h, stream, noise, phase == 3 ? scalars_out : nullptr, 1 << phase);
-}
-
-int mcgra_attack_bind_buffer(mcgra_attack_t* h, const char* name, float* ptr) {
-  if (!h || !name || !ptr) { set_error("null argument"); return MCGRA_EINVAL; }
-  float** slot = nullptr;
-  if (!strcmp(name, "KX")) slot = &h->KX;
-  else if (!strcmp(name, "KY")) slot = &h->KY;
-  else if (!strcmp(name, "G_adjn")) slot = &h->G_ADJN;
-  else if (!strcmp(name, "G_A1")) slot = &h->G_A1;
-  if (!slot) { set_error("buffer '%s' cannot be bound", name); return MCGRA_EINVAL; }
-  *slot = ptr;     // [>= n rows][ld] fp32, caller-owned (exchanged between ranks by the host layer)
-  return 0;
-}
-
-int mcgra_attack_exchange_mask(mcgra_attack_t* h) {
-  if (!h) return 0;
-  const int m = h->cfg.measure;
-  if (m != MCGRA_MEASURE_HSIC && m != MCGRA_MEASURE_CKA) return 0;
-  const bool use1 = h->cfg.w[0] != 0, use2 = h->cfg.w[1] != 0;
-  if (!use1 && !use2) return 0;
-  if (h->lr_step) return use1 ? MCGRA_EXCHANGE_KX : 0;
-  return MCGRA_EXCHANGE_KX | (use2 ? MCGRA_EXCHANGE_KY : 0) | MCGRA_EXCHANGE_G_ADJN | (use2 ? MCGRA_EXCHANGE_G_A1 : 0);
+int step_general(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out) {
+  return step_impl(h, stream, noise, scalars_out, 0xF);
 }
 
 int mcgra_attack_product_mode(mcgra_attack_t* h) {
@@ -1012,6 +1023,7 @@ long long mcgra_attack_fused_steps(mcgra_attack_t* h) { return h ? (long long)h-
 int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, double* sparsity) {
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
+  if (h->sharded) { set_error("row-block rank: use mcgra_attack_shard_begin(MCGRA_SHARD_MONITOR)"); return MCGRA_EINVAL; }
   if (fused_step_possible(h) && h->fused_last && h->cfg.eps == 0.f) {
     // the monitoring forward IS the next iteration's forward (eps == 0): both chains from M, adopted by fused_step
     CHK(fused_forward(h, st));

@@ -1,17 +1,21 @@
 // The low-rank HSIC step of the attack loop (topology_attack.py:161-298) evaluated from the learnable adjacency M and
-// n-vectors only.  Same mathematics as the general step of attack.hip on a low-rank step
-// (section 1b), different data flow: adj_norm = R (M + I) R, its centred copy Xc, modified_adj1 = offdiag relu(Zn Zn^T)
-// and d loss / d adj_norm are never written to HBM.
+// n-vectors only, monolithic or as one of `world` row-block ranks (section 6).  Same
+// mathematics as the general step of attack.hip on a low-rank step (section 1b), different data flow: adj_norm =
+// R (M + I) R, its centred copy Xc, modified_adj1 = offdiag relu(Zn Zn^T) and d loss / d adj_norm are never in HBM.
 //
 //   forward     one product Y = M [r o Tv_l | Tu_l (| r)] per GCN layer serves the victim chain on adj_norm, the
 //               embedding / victim chain on M and (layer 0) the row sums of adj_norm, i.e. the centring means
 //   product     P1 = (H Kf H) Xc from planes packed straight from M (split_symm_bf16.hip), forked onto the side stream
 //   decode      mask count, entropy term of modified_adj1 and its backward from Zn (k_decode_fly)
-//   low rank    T = Xc^T Vc and Q = Xc [W | W2] as products on M with column-centred right-hand sides (section 1c:
-//               the centring removes a cancellation the stored-Xc form has)
+//   low rank    T = Xc^T Vc and Q = Xc [W | W2] as products on M with column-centred right-hand sides
 //   tail        k_tail_reduce (Gs = G + G^T per tile pair, reductions of the normalisation backward) and k_tail_adam
 //
-// A step whose decode masks a pair (S_ij <= 0 off the diagonal) is handed back to the general path (return 1).
+// The step is written as a resumable routine (fs_state / fw_state hold the resume point, every variable that lives
+// across an exchange point lives in the handle): a row-block rank runs it up to the next collective, describes the
+// collective to the host layer (mcgra_attack_shard_next) and continues behind it; the monolithic engine runs the same
+// code straight through with the full row range.  Every N x N pass touches rows [row0, row1) only; node-level
+// (n x h) work is replicated on all ranks.
+// A step whose decode masks a pair (S_ij <= 0 off the diagonal) is handed back to the general path.
 #include <math.h>
 #include <stdlib.h>
 
@@ -20,56 +24,147 @@
 using namespace mcgra;
 
 namespace mcgra {
-// rowsum of per-block partial sums (float) in fp64: out[i] = sum_p part[i][p]
-__global__ __launch_bounds__(256) void k_rsq_fin(int n, int np, const float* __restrict__ part, double* __restrict__ out) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n) return;
+// rowsum of per-block partial sums (float) in fp64: out[i] = sum_p part[i][p], rows [row0, row1)
+__global__ __launch_bounds__(256) void k_rsq_fin(int row0, int row1, int np, const float* __restrict__ part, double* __restrict__ out) {
+  const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= row1) return;
   double s = 0.0;
   for (int p = lane; p < np; p += 64) s += (double)part[(size_t)i * np + p];
   s = wave_sum_d(s);
   if (lane == 0) out[i] = s;
 }
+// stage[i][c0 + k] = src[i][k] for rows [row0, row1), k < w      (own rows of an n-vector block into the exchange stage)
+__global__ void k_rows_to_stage(int row0, int row1, int w, const float* __restrict__ src, int lds_, float* __restrict__ stage,
+                                int sgw, int c0) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (row1 - row0) * w) return;
+  const int i = row0 + e / w, k = e % w;
+  stage[(size_t)i * sgw + c0 + k] = src[(size_t)i * lds_ + k];
+}
+__global__ void k_stage_to_rows(int n, int w, const float* __restrict__ stage, int sgw, int c0, float* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w) return;
+  const int i = e / w, k = e % w;
+  dst[(size_t)i * ldd + k] = stage[(size_t)i * sgw + c0 + k];
+}
+__global__ void k_u32_to_f64(const unsigned int* __restrict__ a, double* __restrict__ out) { out[0] = (double)a[0]; }
 }  // namespace mcgra
 
-bool fused_step_possible(const mcgra_attack* h) {
-  return h->fused_ok && h->cfg.row_begin == 0 && (h->cfg.row_end <= 0 || h->cfg.row_end >= h->n);
+static inline dim3 g1(size_t count) { return dim3((unsigned)((count + 255) / 256)); }
+static void rows_to_stage(mcgra_attack* h, hipStream_t st, int w, const float* src, int lds_, int c0) {
+  if (h->row1 > h->row0)
+    hipLaunchKernelGGL(k_rows_to_stage, g1((size_t)(h->row1 - h->row0) * w), dim3(256), 0, st, h->row0, h->row1, w, src, lds_, h->SG, h->sgw, c0);
+}
+static void stage_to_rows(mcgra_attack* h, hipStream_t st, int w, int c0, float* dst, int ldd) {
+  hipLaunchKernelGGL(k_stage_to_rows, g1((size_t)h->n * w), dim3(256), 0, st, h->n, w, h->SG, h->sgw, c0, dst, ldd);
 }
 
-// d, r, both chains, heads, the means of adj_norm's columns and the operand-scale bound of the current M
-int fused_forward(mcgra_attack* h, hipStream_t st) {
-  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, fc = h->fcols;
-  if (h->prep_valid) {
-    const size_t cnt = (size_t)n * fl_tail_tiles(n);
-    prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
-                       h->rowsum);
-  } else {
-    launch_prep(st, false, n, ld, h->M, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum);
+bool fused_step_possible(const mcgra_attack* h) { return h->fused_ok; }
+
+// ---- exchange descriptors (all offsets are bytes from the arena base) ---------------------------------------------------
+static void x_allgather(mcgra_exchange_t* ex, int64_t off, int64_t chunk_bytes) {
+  ex->kind = MCGRA_XCHG_ALLGATHER; ex->count = 0; ex->offset = off; ex->offset2 = 0; ex->chunk_bytes = chunk_bytes;
+}
+static void x_allreduce(mcgra_exchange_t* ex, int64_t off, int count) {
+  ex->kind = MCGRA_XCHG_ALLREDUCE_F64; ex->count = count; ex->offset = off; ex->offset2 = 0; ex->chunk_bytes = 0;
+}
+static void x_alltoall(mcgra_exchange_t* ex, int64_t off_send, int64_t off_recv, int64_t chunk_bytes) {
+  ex->kind = MCGRA_XCHG_ALLTOALL; ex->count = 0; ex->offset = off_send; ex->offset2 = off_recv; ex->chunk_bytes = chunk_bytes;
+}
+#define X_FY(h) x_allgather(ex, (h)->off_fy, (int64_t)(h)->rpr * (h)->fcols * 4)
+#define X_SG(h) x_allgather(ex, (h)->off_sg, (int64_t)(h)->rpr * (h)->sgw * 4)
+
+int64_t fused_exchange_bytes(const mcgra_attack* h) {
+  if (!h->sharded) return 0;
+  const int64_t a = 256;
+  auto up = [&](int64_t x) { return (x + a - 1) / a * a; };
+  return up((int64_t)h->npad * h->fcols * 4) + up((int64_t)h->npad * h->sgw * 4) + up(16 * 8) +
+         2 * up((int64_t)h->world * h->rpr * h->rpr * 4) + up((int64_t)h->npad * h->ld * 4);
+}
+
+// Y rows [row0, row1) = M[rows, :] V      (V = FV [n x ncol], result in FY)
+static int mm_rows(mcgra_attack* h, hipStream_t st, int ncol) {
+  const int rows = h->row1 - h->row0;
+  if (rows <= 0) return 0;
+  return eg(h, st, false, false, rows, ncol, h->n, 1.f, h->M + (size_t)h->row0 * h->ld, h->ld, h->FV, h->fcols, 0.f,
+            h->FY + (size_t)h->row0 * h->fcols, h->fcols);
+}
+
+// Resume points: the code between two FS_XCHG runs without interruption.  `var` is h->fs_state or h->fw_state.
+#define FS_XCHG(var, label, setup)                              \
+  if (h->sharded) { (var) = (label); setup; return 1; }         \
+  case label:;
+
+// d, r, both chains, heads, the means of adj_norm's columns and the operand-scale bound of the current M.
+// Returns 1 at an exchange point (ex filled), 0 when done, < 0 on error.
+static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
+  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, fc = h->fcols, R0 = h->row0, R1 = h->row1;
+  switch (h->fw_state) {
+    case 0:
+      if (h->prep_valid) {
+        const size_t cnt = (size_t)n * fl_tail_tiles(n);
+        prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
+                           h->rowsum, R0, R1);
+      } else {
+        launch_prep(st, false, n, ld, h->M, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum, R0, R1);
+      }
+      if (!h->sharded) {
+        launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
+        launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
+      } else {
+        MCGRA_HIP(hipMemsetAsync(h->SC, 0, 2 * sizeof(double), st));
+        if (R1 > R0) {
+          launch_reduce_rows(st, h->rowsq + R0, R1 - R0, 1, h->SC + 0);
+          launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, h->SC + 1);
+        }
+        rows_to_stage(h, st, 1, h->r, 1, 0);
+        rows_to_stage(h, st, 1, h->d, 1, 1);
+      }
+      FS_XCHG(h->fw_state, 1, X_SG(h))
+      if (h->sharded) {
+        stage_to_rows(h, st, 1, 0, h->r, 1);
+        stage_to_rows(h, st, 1, 1, h->d, 1);
+      }
+      FS_XCHG(h->fw_state, 2, x_allreduce(ex, h->off_sc, 2))
+      if (h->sharded) MCGRA_HIP(hipMemcpyAsync(h->scal + S_SQ, h->SC, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+      for (h->fs_l = 0; h->fs_l < L; ++h->fs_l) {
+        {
+          const int l = h->fs_l, w = h->wdt[l];
+          fl_cat_scaled(st, n, w, w, h->Tv + h->off[l], hs, h->r, h->FV, fc, 0);
+          fl_cat_scaled(st, n, w, w, h->Tu + h->off[l], hs, nullptr, h->FV, fc, w);
+          if (l == 0) fl_cat_scaled(st, n, 1, 1, h->r, 1, nullptr, h->FV, fc, 2 * w);
+          CHK(mm_rows(h, st, 2 * w + (l == 0 ? 1 : 0)));
+        }
+        FS_XCHG(h->fw_state, 3, X_FY(h))
+        {
+          const int l = h->fs_l, w = h->wdt[l];
+          fl_layer_post(st, n, w, h->FY, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
+                        h->Hu + h->off[l], hs, l == 0, h->cmean, h->rowsx);
+          if (l + 1 < L) {
+            launch_rowmat(st, n, w, h->wdt[l + 1], h->Hv + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tv + h->off[l + 1], hs);
+            launch_rowmat(st, n, w, h->wdt[l + 1], h->Hu + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tu + h->off[l + 1], hs);
+          }
+        }
+      }
+      CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
+      CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
+      fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
+      MCGRA_KERNEL_CHECK();
   }
-  launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
-  launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
-  for (int l = 0; l < L; ++l) {
-    const int w = h->wdt[l], ncol = 2 * w + (l == 0 ? 1 : 0);
-    fl_cat_scaled(st, n, w, w, h->Tv + h->off[l], hs, h->r, h->FV, fc, 0);
-    fl_cat_scaled(st, n, w, w, h->Tu + h->off[l], hs, nullptr, h->FV, fc, w);
-    if (l == 0) fl_cat_scaled(st, n, 1, 1, h->r, 1, nullptr, h->FV, fc, 2 * w);
-    CHK(eg(h, st, false, false, n, ncol, n, 1.f, h->M, ld, h->FV, fc, 0.f, h->FY, fc));
-    fl_layer_post(st, n, w, h->FY, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
-                  h->Hu + h->off[l], hs, l == 0, h->cmean, h->rowsx);
-    if (l + 1 < L) {
-      launch_rowmat(st, n, w, h->wdt[l + 1], h->Hv + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tv + h->off[l + 1], hs);
-      launch_rowmat(st, n, w, h->wdt[l + 1], h->Hu + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tu + h->off[l + 1], hs);
-    }
-  }
-  CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
-  CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
-  fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
-  MCGRA_KERNEL_CHECK();
+  h->fw_state = 0;
   return 0;
 }
 
-int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out) {
+int fused_forward(mcgra_attack* h, hipStream_t st) {      // monolithic engines only
+  h->fw_state = 0;
+  return fused_forward_pt(h, st, nullptr);
+}
+
+// Returns 1 at an exchange point, 0 when the step is done, 2 when the step must be redone by the general path (a
+// relu-masked pair in the decode; every rank then holds the full M / am / av), < 0 on error.
+static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
   const mcgra_attack_config_t& c = h->cfg;
-  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C, fc = h->fcols;
+  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C, fc = h->fcols, R0 = h->row0, R1 = h->row1;
   const double sg = -1.0;      // measure == HSIC
   const double w1 = c.w[0], w2 = c.w[1], w6 = c.w[5], w7 = c.w[6], w9 = c.w[8], w10 = c.w[9];
   const double k1 = w1 * 1000 * AP_C1, k2 = w2 * 100 * AP_C2, k6 = w6 * 100 * AP_C6, k7 = w7 * AP_C7;
@@ -78,38 +173,10 @@ int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out) {
   const float* em = h->Hu + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
   const float a1 = use1 ? 2.f * (float)(sg * k1) : 0.f, a2 = use2 ? 2.f * (float)(sg * k2) : 0.f;
-
-  const bool adopted = h->fused_fwd_valid;
-  h->fused_fwd_valid = false;
-  h->fwd_cached = false;
-  MCGRA_HIP(hipMemsetAsync(h->scal + (adopted ? 2 : 0), 0, sizeof(double) * (S_COUNT - (adopted ? 2 : 0)), st));
-  if (!adopted) CHK(fused_forward(h, st));
-  // embedding(features, adj_norm) of this iteration (= the victim chain's activations: shared weights, main.py:190),
-  // kept for the post-loop decode (:300): adj_norm itself is never stored
-  MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
-                             hipMemcpyDeviceToDevice, st));
-
-  // ---- planes of Xc^T rows straight from M, |xc_i|^2 from the same pass; P1 forked onto the side stream
-  h->p1_inflight = false;
-  {
-    float* rsq = use2 ? h->A1 : nullptr;
-    split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1, rsq);
-    if (use2) hipLaunchKernelGGL(k_rsq_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, split3_pack_rsq_parts(n, h->split_planes), h->A1, h->lrRs);
-    if (use1) {
-      hipStream_t sp = h->overlap ? h->st2 : st;
-      if (h->overlap) {
-        MCGRA_HIP(hipEventRecord(h->ev_fork, st));
-        MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-      }
-      CHK(timer_begin(h, sp, h->profile));
-      MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
-                            h->amax));
-      CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * n));
-      ++h->split_steps;
-      if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
-      h->p1_inflight = true;
-    }
-  }
+  const int wtop = h->wdt[L - 1], cv = 2 * he + 1, c_gt = use2 ? cv : 0;
+  const int P = split3_panel(), p_off = R0 / P, p_cnt = R1 > R0 ? (R1 - R0 + P - 1) / P : 0;
+  const int nt = fl_tail_tiles(n);
+  const bool pair = !h->sharded;
   auto join = [&]() -> int {
     if (h->p1_inflight) {
       if (h->overlap) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -117,143 +184,371 @@ int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out) {
     }
     return 0;
   };
+  int rc;
 
-  // ---- CE loss (:172) and its gradient into the victim chain
-  launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
-  launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
-  launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
-                     h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
+  switch (h->fs_state) {
+    case 0:
+      h->fs_adopted = h->fused_fwd_valid;
+      h->fused_fwd_valid = false;
+      h->fwd_cached = false;
+      h->fw_state = 0;
+    case 1:
+      if (!h->fs_adopted) {
+        rc = fused_forward_pt(h, st, ex);
+        if (rc == 1) { h->fs_state = 1; return 1; }
+        if (rc < 0) return rc;
+      }
+      MCGRA_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(double) * (S_COUNT - 2), st));
+      // embedding(features, adj_norm) of this iteration (= the victim chain's activations: shared weights, main.py:190),
+      // kept for the post-loop decode (:300): adj_norm itself is never stored
+      MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
+                                 hipMemcpyDeviceToDevice, st));
 
-  // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn
-  launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
-  MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
-  {
-    const int np = fl_decode_fly(st, n, 0, n, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
-                                 h->hmax, h->nmask);
-    launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, np, 1, h->scal + S_V7);
-  }
-  MCGRA_KERNEL_CHECK();
-  unsigned int masked = 0;
-  if (use2) {
-    MCGRA_HIP(hipMemcpyAsync(&masked, h->nmask, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    MCGRA_HIP(hipStreamSynchronize(st));
-  }
-  if (masked != 0) {       // relu'(0) = 0 masks a pair in the reference's backward: the low-rank algebra does not apply
-    CHK(join());
-    return 1;
-  }
-  h->lr_step = true;
-  ++h->lr_steps;
-  ++h->fused_steps;
+      // ---- planes of Xc^T rows straight from M, |xc_i|^2 from the same pass; P1 (column block of the own rows: Xc^T
+      //      rows = adj_norm rows by symmetry) forked onto the side stream
+      h->p1_inflight = false;
+      if (p_cnt > 0) {
+        float* rsq = use2 ? h->A1 : nullptr;
+        split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt, rsq);
+        if (use2)
+          hipLaunchKernelGGL(k_rsq_fin, dim3((R1 - R0 + 3) / 4), dim3(256), 0, st, R0, R1, split3_pack_rsq_parts(n, h->split_planes), h->A1, h->lrRs);
+        if (use1) {
+          hipStream_t sp = h->overlap ? h->st2 : st;
+          if (h->overlap) {
+            MCGRA_HIP(hipEventRecord(h->ev_fork, st));
+            MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+          }
+          CHK(timer_begin(h, sp, h->profile));
+          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
+                                h->amax, p_off, p_cnt));
+          CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
+          ++h->split_steps;
+          if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
+          h->p1_inflight = true;
+        }
+      }
 
-  // ---- low-rank factors (section 1b) with the products on M (section 1c); victim-chain backward rides along
-  const int wtop = h->wdt[L - 1], cv = 2 * he + 1;
-  int c_gt = 0;     // column of FY / FV where r o GPv_top sits
-  if (use2) {
-    launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
-    launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
-    fl_wcolsum(st, n, cv, h->lrV, h->lr_ldv, nullptr, h->fstat);
-    fl_cat_scaled(st, n, cv, cv, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
-    c_gt = cv;
-  }
-  if (L >= 2) fl_cat_scaled(st, n, wtop, wtop, h->GPv + h->off[L - 1], hs, h->r, h->FV, fc, c_gt);
-  if (use2 || L >= 2)
-    CHK(eg(h, st, false, false, n, c_gt + (L >= 2 ? wtop : 0), n, 1.f, h->M, ld, h->FV, fc, 0.f, h->FY, fc));
-  if (L >= 2) fl_an_post(st, n, wtop, h->FY, h->FV, fc, c_gt, h->r, h->GT, h->hmax);       // adj_norm^T G_P_top
-  if (use2) {
-    fl_lrt_post(st, n, cv, h->FY, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // T = Xc^T Vc
-    launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
-  }
-  // rest of the victim(adj_norm) chain backward: G_P_{l-1} = (G_T_l W_l^T) o relu'(P_{l-1}), G_T_l = adj_norm G_P_l
-  for (int l = L - 1; l >= 1; --l) {
-    launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], nullptr, 0, 0, nullptr, 0, 0,
-                       h->Pv + h->off[l - 1], hs, h->act, nullptr, 0, h->GPv + h->off[l - 1], hs);
-    if (l - 1 >= 1) {
-      const int w = h->wdt[l - 1];
-      fl_cat_scaled(st, n, w, w, h->GPv + h->off[l - 1], hs, h->r, h->FV, fc, 0);
-      CHK(eg(h, st, false, false, n, w, n, 1.f, h->M, ld, h->FV, fc, 0.f, h->FY, fc));
-      fl_an_post(st, n, w, h->FY, h->FV, fc, 0, h->r, h->GT, h->hmax);
-    }
-  }
-  if (use2) {     // [Q | Q2] = Xc [W | W2]
-    fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, nullptr, h->fstat + 64);
-    fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 128);
-    fl_lrq_pre(st, n, 2 * he, h->lrT, h->lr_ldv, h->r, h->fstat + 64, h->FV, fc);
-    CHK(eg(h, st, false, false, n, 2 * he, n, 1.f, h->M, ld, h->FV, fc, 0.f, h->FY, fc));
-    fl_lrq_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 192, h->lrQ, 2 * he);
-  }
-  MCGRA_KERNEL_CHECK();
+      // ---- CE loss (:172) and its gradient into the victim chain
+      launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
+      launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
+      launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
+                         h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
 
-  // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
-  MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
-  if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
-  if (w10 != 0) {
-    MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
-    CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
-    launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
-  }
+      // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
+      launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
+      MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+      h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
+                               h->hmax, h->nmask);
+      if (!h->sharded) {
+        launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->scal + S_V7);
+      } else {
+        MCGRA_HIP(hipMemsetAsync(h->SC + 2, 0, 2 * sizeof(double), st));
+        hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, h->SC + 2);
+        if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->SC + 3);
+        rows_to_stage(h, st, he, h->GZn, h->hmax, 0);
+        if (use2) rows_to_stage(h, st, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
+      }
+      MCGRA_KERNEL_CHECK();
+      FS_XCHG(h->fs_state, 2, X_SG(h))
+      if (h->sharded) {
+        stage_to_rows(h, st, he, 0, h->GZn, h->hmax);
+        if (use2) stage_to_rows(h, st, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
+      }
+      FS_XCHG(h->fs_state, 3, x_allreduce(ex, h->off_sc + 16, 2))
+      if (h->sharded) MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 3, sizeof(double), hipMemcpyDeviceToDevice, st));
+      {
+        unsigned int masked = 0;
+        if (use2) {
+          if (h->sharded) {
+            double m = 0;
+            MCGRA_HIP(hipMemcpyAsync(&m, h->SC + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+            MCGRA_HIP(hipStreamSynchronize(st));
+            masked = m != 0.0 ? 1u : 0u;
+          } else {
+            MCGRA_HIP(hipMemcpyAsync(&masked, h->nmask, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            MCGRA_HIP(hipStreamSynchronize(st));
+          }
+        }
+        if (masked == 0) goto lowrank_ok;
+      }
+      // relu'(0) = 0 masks a pair in the reference's backward: the low-rank algebra does not apply.  A row-block rank
+      // first collects the full M / am / av (own rows through the N x N stage), then every rank redoes the step.
+      CHK(join());
+      for (h->fs_l = 0; h->fs_l < 3; ++h->fs_l) {
+        if (h->sharded && R1 > R0) {
+          float* src = h->fs_l == 0 ? h->M : (h->fs_l == 1 ? h->am : h->av);
+          MCGRA_HIP(hipMemcpyAsync(h->NXS + (size_t)R0 * ld, src + (size_t)R0 * ld, sizeof(float) * (size_t)(R1 - R0) * ld,
+                                   hipMemcpyDeviceToDevice, st));
+        }
+        FS_XCHG(h->fs_state, 4, x_allgather(ex, h->off_nxn, (int64_t)h->rpr * ld * 4))
+        if (h->sharded) {
+          float* dst = h->fs_l == 0 ? h->M : (h->fs_l == 1 ? h->am : h->av);
+          MCGRA_HIP(hipMemcpyAsync(dst, h->NXS, sizeof(float) * (size_t)n * ld, hipMemcpyDeviceToDevice, st));
+        }
+      }
+      h->fs_state = 0;
+      return 2;
 
-  // ---- decode backward (the entropy part is already in GZn), normalisation of em
-  if (use2) {
-    launch_lr_xtz(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrQtZ);
-    launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->lrRs, -2.f * (float)(sg * k2), h->GZn, h->hmax,
-                    h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld, h->lrStats + 2 * he, h->lrQtZ, 2.f * (float)(sg * k2));
-    launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
-  }
-  launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
+    lowrank_ok:
+      h->lr_step = true;
+      ++h->lr_steps;
+      ++h->fused_steps;
 
-  // ---- backward: modified_adj chain (embedding + output2), products on M
-  int ltop;
-  if (w10 != 0) {
-    ltop = L - 1;
-    launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
-                       h->Pu + h->off[L - 1], hs, h->act, (L - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[L - 1], hs);
-  } else {
-    ltop = Le - 1;
-    if (L > Le) MCGRA_HIP(hipMemsetAsync(h->GPu, 0, sizeof(float) * (size_t)n * hs, st));
-    launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, nullptr, 0, 0, nullptr, 0, 0, h->Pu + h->off[Le - 1], hs,
-                       h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
-  }
-  for (int l = ltop; l >= 1; --l) {
-    CHK(eg(h, st, false, false, n, h->wdt[l], n, 1.f, h->M, ld, h->GPu + h->off[l], hs, 0.f, h->GT, h->hmax));   // M symmetric
-    launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], nullptr, 0, 0, nullptr, 0, 0,
-                       h->Pu + h->off[l - 1], hs, h->act, (l - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[l - 1], hs);
-  }
-  MCGRA_KERNEL_CHECK();
+      // ---- low-rank factors (section 1b) with the products on M (section 1c); victim-chain backward rides along
+      if (use2) {
+        launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
+        launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
+        fl_wcolsum(st, n, cv, h->lrV, h->lr_ldv, nullptr, h->fstat);
+        fl_cat_scaled(st, n, cv, cv, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
+      }
+      if (L >= 2) fl_cat_scaled(st, n, wtop, wtop, h->GPv + h->off[L - 1], hs, h->r, h->FV, fc, c_gt);
+      if (use2 || L >= 2) CHK(mm_rows(h, st, c_gt + (L >= 2 ? wtop : 0)));
+      if (use2 || L >= 2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
+      if (L >= 2) fl_an_post(st, n, wtop, h->FY, h->FV, fc, c_gt, h->r, h->GT, h->hmax);       // adj_norm^T G_P_top
+      if (use2) {
+        fl_lrt_post(st, n, cv, h->FY, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // T = Xc^T Vc
+        launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
+      }
+      // rest of the victim(adj_norm) chain backward: G_P_{l-1} = (G_T_l W_l^T) o relu'(P_{l-1}), G_T_l = adj_norm G_P_l
+      for (h->fs_l = L - 1; h->fs_l >= 1; --h->fs_l) {
+        {
+          const int l = h->fs_l;
+          launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], nullptr, 0, 0, nullptr, 0, 0,
+                             h->Pv + h->off[l - 1], hs, h->act, nullptr, 0, h->GPv + h->off[l - 1], hs);
+        }
+        if (h->fs_l - 1 >= 1) {
+          {
+            const int w = h->wdt[h->fs_l - 1];
+            fl_cat_scaled(st, n, w, w, h->GPv + h->off[h->fs_l - 1], hs, h->r, h->FV, fc, 0);
+            CHK(mm_rows(h, st, w));
+          }
+          FS_XCHG(h->fs_state, 6, X_FY(h))
+          fl_an_post(st, n, h->wdt[h->fs_l - 1], h->FY, h->FV, fc, 0, h->r, h->GT, h->hmax);
+        }
+      }
+      if (use2) {     // [Q | Q2] = Xc [W | W2]
+        fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, nullptr, h->fstat + 64);
+        fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 128);
+        fl_lrq_pre(st, n, 2 * he, h->lrT, h->lr_ldv, h->r, h->fstat + 64, h->FV, fc);
+        CHK(mm_rows(h, st, 2 * he));
+      }
+      if (use2) { FS_XCHG(h->fs_state, 7, X_FY(h)) }
+      if (use2)
+        fl_lrq_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 192, h->lrQ, 2 * he);
+      MCGRA_KERNEL_CHECK();
 
-  // ---- tail: everything above ran beside the forked product
-  CHK(join());
-  const int nt = fl_tail_tiles(n);
-  float* ps1 = h->KY;                                            // [n][nt]: idle (the product's split-K slabs are done)
-  double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
-  {
-    const float* Ls[2] = {h->GPv, h->lrL};
-    const float* Rs[2] = {h->Tv, h->lrR};
-    const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
-    const float al[2] = {1.f, a2};
-    const int nblk = fl_tail_reduce(st, n, ld, true, 0, n, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->M, use1 ? h->KX : nullptr, h->r,
+      // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
+      MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
+      if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
+      if (w10 != 0) {
+        MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
+        CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
+        launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
+      }
+
+      // ---- decode backward (the entropy part is already in GZn), normalisation of em
+      if (use2) {
+        launch_lr_xtz(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrQtZ);
+        launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->lrRs, -2.f * (float)(sg * k2), h->GZn, h->hmax,
+                        h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld, h->lrStats + 2 * he, h->lrQtZ, 2.f * (float)(sg * k2));
+        launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
+      }
+      launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
+
+      // ---- backward: modified_adj chain (embedding + output2), products on M
+      if (w10 != 0) {
+        launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
+                           h->Pu + h->off[L - 1], hs, h->act, (L - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[L - 1], hs);
+      } else {
+        if (L > Le) MCGRA_HIP(hipMemsetAsync(h->GPu, 0, sizeof(float) * (size_t)n * hs, st));
+        launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, nullptr, 0, 0, nullptr, 0, 0, h->Pu + h->off[Le - 1], hs,
+                           h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
+      }
+      for (h->fs_l = (w10 != 0 ? L - 1 : Le - 1); h->fs_l >= 1; --h->fs_l) {
+        {
+          const int l = h->fs_l, w = h->wdt[l];
+          fl_cat_scaled(st, n, w, w, h->GPu + h->off[l], hs, nullptr, h->FV, fc, 0);
+          CHK(mm_rows(h, st, w));                                                                // M symmetric: M^T G_P_l = M G_P_l
+        }
+        FS_XCHG(h->fs_state, 8, X_FY(h))
+        {
+          const int l = h->fs_l;
+          fl_copy_cols(st, n, h->wdt[l], h->FY, fc, 0, h->GT, h->hmax);
+          launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], nullptr, 0, 0, nullptr, 0, 0,
+                             h->Pu + h->off[l - 1], hs, h->act, (l - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[l - 1], hs);
+        }
+      }
+      MCGRA_KERNEL_CHECK();
+
+      // ---- tail: everything above ran beside the forked product.  A row-block rank holds the column block
+      //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
+      CHK(join());
+      if (h->sharded && use1) {
+        for (int s = 0; s < h->world; ++s) {
+          const int sr0 = s * h->rpr, sr1 = sr0 + h->rpr < n ? sr0 + h->rpr : n;
+          if (sr1 > sr0 && R1 > R0)
+            MCGRA_HIP(hipMemcpy2DAsync(h->A2S + (size_t)s * h->rpr * h->rpr, (size_t)h->rpr * 4, h->KX + (size_t)sr0 * ld + R0,
+                                       (size_t)ld * 4, (size_t)(R1 - R0) * 4, sr1 - sr0, hipMemcpyDeviceToDevice, st));
+        }
+      }
+      if (use1) { FS_XCHG(h->fs_state, 9, x_alltoall(ex, h->off_a2s, h->off_a2r, (int64_t)h->rpr * h->rpr * 4)) }
+      if (h->sharded && use1) {
+        for (int s = 0; s < h->world; ++s) {
+          const int sr0 = s * h->rpr, sr1 = sr0 + h->rpr < n ? sr0 + h->rpr : n;
+          if (s != h->rank && sr1 > sr0 && R1 > R0)       // peer s packed its KX[my rows, its columns]
+            MCGRA_HIP(hipMemcpy2DAsync(h->KX + (size_t)R0 * ld + sr0, (size_t)ld * 4, h->A2R + (size_t)s * h->rpr * h->rpr,
+                                       (size_t)h->rpr * 4, (size_t)(sr1 - sr0) * 4, R1 - R0, hipMemcpyDeviceToDevice, st));
+        }
+      }
+      {
+        float* ps1 = h->KY;                                            // [n][nt]: idle (the product's split-K slabs are done)
+        double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
+        const float* Ls[2] = {h->GPv, h->lrL};
+        const float* Rs[2] = {h->Tv, h->lrR};
+        const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
+        const float al[2] = {1.f, a2};
+        h->fs_nblk = fl_tail_reduce(st, n, ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->M, use1 ? h->KX : nullptr, h->r,
                                     h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr, a1, a2, (float)(k6 / n2),
                                     h->G_ADJN, ps1, vpart);
-    launch_reduce_rows(st, vpart, nblk, 1, h->scal + S_H1);
-    launch_reduce_rows(st, vpart + nblk, nblk, 1, h->scal + S_V6);
+        if (h->sharded) MCGRA_HIP(hipMemsetAsync(h->SC + 4, 0, 3 * sizeof(double), st));
+        if (h->fs_nblk > 0) {
+          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? h->SC + 4 : h->scal + S_H1);
+          launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? h->SC + 5 : h->scal + S_V6);
+        }
+        fl_tail_gd(st, n, R0, R1, ps1, h->d, h->gd);
+        if (h->sharded) rows_to_stage(h, st, 1, h->gd, 1, 0);
+      }
+      FS_XCHG(h->fs_state, 10, X_SG(h))
+      if (h->sharded) stage_to_rows(h, st, 1, 0, h->gd, 1);
+      {
+        h->t += 1;
+        const double b1 = 0.9, b2 = 0.999;
+        const double bc1 = 1.0 - pow(b1, (double)h->t), bc2 = 1.0 - pow(b2, (double)h->t);
+        hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
+        const bool may_project = c.num_edges < 0.5 * n2;
+        const size_t cnt = (size_t)n * nt;
+        const bool emit = !may_project && 3 * cnt + 4 <= (size_t)n * ld;
+        fl_tail_adam(st, n, ld, pair, R0, R1, h->GPu, hs, h->Tu, hs, hs, h->G_ADJN, h->r, h->gd, h->M, h->am, h->av, h->mm + 2,
+                     (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
+                     h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,
+                     emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr);
+        MCGRA_KERNEL_CHECK();
+        h->prep_valid = emit;
+        h->have_step = true;
+        h->fused_last = true;
+        if (may_project) { CHK(project(h, st)); h->prep_valid = false; }      // (monolithic only: refused at create otherwise)
+      }
+      if (h->sharded && h->fs_want) {
+        // sum(clamp(adj_changes, 0, 1)) after the update = the row sums the Adam pass just left behind, own rows
+        const size_t cnt = (size_t)n * nt;
+        prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
+                           h->rowsum, R0, R1);
+        if (R1 > R0) launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, h->SC + 6);
+      }
+      if (h->fs_want) { FS_XCHG(h->fs_state, 11, x_allreduce(ex, h->off_sc + 32, 3)) }
+      if (h->sharded && h->fs_want) {
+        MCGRA_HIP(hipMemcpyAsync(h->scal + S_H1, h->SC + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
+        MCGRA_HIP(hipMemcpyAsync(h->scal + S_V6, h->SC + 5, sizeof(double), hipMemcpyDeviceToDevice, st));
+        MCGRA_HIP(hipMemcpyAsync(h->scal + S_CLAMPSUM, h->SC + 6, sizeof(double), hipMemcpyDeviceToDevice, st));
+      }
   }
-  fl_tail_gd(st, n, 0, n, ps1, h->d, h->gd);
-  h->t += 1;
-  const double b1 = 0.9, b2 = 0.999;
-  const double bc1 = 1.0 - pow(b1, (double)h->t), bc2 = 1.0 - pow(b2, (double)h->t);
-  hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
-  const bool may_project = c.num_edges < 0.5 * n2;
-  const size_t cnt = (size_t)n * nt;
-  const bool emit = !may_project && 3 * cnt + 4 <= (size_t)n * ld;
-  fl_tail_adam(st, n, ld, true, 0, n, h->GPu, hs, h->Tu, hs, hs, h->G_ADJN, h->r, h->gd, h->M, h->am, h->av, h->mm + 2,
-               (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
-               h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,
-               emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr);
-  MCGRA_KERNEL_CHECK();
-  h->prep_valid = emit;
-  h->have_step = true;
-  h->fused_last = true;
-  if (may_project) { CHK(project(h, st)); h->prep_valid = false; }
+  h->fs_state = 0;
+  return 0;
+}
+
+int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out) {      // monolithic engines only
+  h->fs_state = 0;
+  h->fs_want = scalars_out ? 1 : 0;
+  const int rc = fused_step_pt(h, st, nullptr);
+  if (rc == 2) return 1;
+  if (rc != 0) return rc;
   if (scalars_out) CHK(collect_scalars(h, st, scalars_out));
   return 0;
 }
+
+extern "C" {
+
+int64_t mcgra_attack_exchange_bytes(mcgra_attack_t* h) { return h ? fused_exchange_bytes(h) : 0; }
+
+int mcgra_attack_bind_exchange(mcgra_attack_t* h, void* arena, int64_t bytes) {
+  if (!h || !arena) { set_error("null argument"); return MCGRA_EINVAL; }
+  if (!h->sharded) { set_error("not a row-block rank (shard_world == 0)"); return MCGRA_EINVAL; }
+  if (bytes < fused_exchange_bytes(h) || ((uintptr_t)arena & 255)) { set_error("exchange arena too small or not 256-byte aligned"); return MCGRA_EINVAL; }
+  const int64_t a = 256;
+  auto up = [&](int64_t x) { return (x + a - 1) / a * a; };
+  h->arena = (char*)arena; h->arena_bytes = bytes;
+  int64_t o = 0;
+  h->off_fy = o; o += up((int64_t)h->npad * h->fcols * 4);
+  h->off_sg = o; o += up((int64_t)h->npad * h->sgw * 4);
+  h->off_sc = o; o += up(16 * 8);
+  h->off_a2s = o; o += up((int64_t)h->world * h->rpr * h->rpr * 4);
+  h->off_a2r = o; o += up((int64_t)h->world * h->rpr * h->rpr * 4);
+  h->off_nxn = o;
+  h->FY = (float*)(h->arena + h->off_fy); h->SG = (float*)(h->arena + h->off_sg); h->SC = (double*)(h->arena + h->off_sc);
+  h->A2S = (float*)(h->arena + h->off_a2s); h->A2R = (float*)(h->arena + h->off_a2r); h->NXS = (float*)(h->arena + h->off_nxn);
+  MCGRA_HIP(hipMemset(arena, 0, (size_t)fused_exchange_bytes(h)));
+  return 0;
+}
+
+int mcgra_attack_shard_begin(mcgra_attack_t* h, void* stream, int what, int want_scalars) {
+  (void)stream;
+  if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
+  if (!h->sharded || !h->arena) { set_error("not a row-block rank, or no exchange arena bound"); return MCGRA_EINVAL; }
+  if (what != MCGRA_SHARD_STEP && what != MCGRA_SHARD_MONITOR) { set_error("what = %d", what); return MCGRA_EINVAL; }
+  h->fs_what = what; h->fs_want = want_scalars ? 1 : 0;
+  h->fs_state = 0; h->fw_state = 0;
+  h->fs_active = true;
+  return 0;
+}
+
+int mcgra_attack_shard_next(mcgra_attack_t* h, void* stream, mcgra_exchange_t* ex) {
+  if (!h || !ex) { set_error("null argument"); return MCGRA_EINVAL; }
+  if (!h->fs_active) { set_error("mcgra_attack_shard_begin first"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  ex->kind = MCGRA_XCHG_DONE; ex->count = 0; ex->offset = ex->offset2 = ex->chunk_bytes = 0;
+  int rc;
+  if (h->fs_what == MCGRA_SHARD_MONITOR) {
+    rc = fused_forward_pt(h, st, ex);
+    if (rc == 1) return 0;
+    h->fs_active = false;
+    if (rc < 0) return rc;
+    h->fused_fwd_valid = true;
+    return 0;
+  }
+  rc = fused_step_pt(h, st, ex);
+  if (rc == 1) return 0;
+  if (rc == 2) {      // every rank holds the full state now: the general path redoes the step, replicated
+    rc = step_general(h, stream, nullptr, h->fs_want ? h->fs_scalars : nullptr);
+    h->fs_active = false;
+    h->fs_want = h->fs_want ? 2 : 0;       // scalars already collected
+    return rc;
+  }
+  h->fs_active = false;
+  return rc;
+}
+
+int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out) {
+  if (!h || !out) { set_error("null argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  if (h->fs_what == MCGRA_SHARD_MONITOR) {
+    double s;
+    MCGRA_HIP(hipMemcpyAsync(&s, h->scal + S_SUM, sizeof(double), hipMemcpyDeviceToHost, st));
+    MCGRA_HIP(hipStreamSynchronize(st));
+    out[0] = s / ((double)h->n * h->n);
+    return 0;
+  }
+  if (h->fs_want == 2) { for (int i = 0; i < 10; ++i) out[i] = h->fs_scalars[i]; return 0; }
+  if (h->fs_want != 1) { set_error("the step was begun without want_scalars"); return MCGRA_EINVAL; }
+  return collect_scalars(h, st, out, true);
+}
+
+int mcgra_attack_get_rows(mcgra_attack_t* h, void* stream, float* out) {
+  if (!h || !out) { set_error("null argument"); return MCGRA_EINVAL; }
+  const int r0 = h->sharded ? h->row0 : 0, r1 = h->sharded ? h->row1 : h->n;
+  if (r1 > r0)
+    MCGRA_HIP(hipMemcpy2DAsync(out, (size_t)h->n * 4, h->M + (size_t)r0 * h->ld, (size_t)h->ld * 4, (size_t)h->n * 4, r1 - r0,
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

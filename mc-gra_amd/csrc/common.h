@@ -42,7 +42,7 @@ hipError_t rankk_apply_adam(hipStream_t st, int n, int ld, int K, const float* G
 // prep_from_partials turns them into k_prep's outputs without another pass over M
 int rankk_apply_adam_tiles(int n);
 void prep_from_partials(hipStream_t st, int n, const float* ps, const double* pq, float* d, float* r, double* rowsq,
-                        double* rowsum);
+                        double* rowsum, int row0 = 0, int row1 = -1);
 
 // "Lower tile storage" of a symmetric n x n matrix: element (i, j) is valid iff
 // j < (i / SYM_TILE + 1) * SYM_TILE, i.e. the 128 x 128 tiles on or below the diagonal.
@@ -63,7 +63,8 @@ int split3_pack_rsq_parts(int n, int planes);
 void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
                         const float* amax, int panel_off, int panel_rows, float* rsq_part);
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
-                       int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr);
+                       int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr,
+                       int npanel_off = 0, int npanel_cols = -1);
 int split3_panel();
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------

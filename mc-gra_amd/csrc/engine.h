@@ -106,6 +106,19 @@ struct mcgra_attack {
   float *em_last = 0;              // embedding(features, adj_norm) of the last iteration (:300), = its victim-chain activations
   double *fstat = 0;               // small fp64 vectors: colsum(V) [64] | colsum(W) [64] | mean^T W [64] | sum(mean) [2]
   int64_t fused_steps = 0;
+  // row-block sharding (mcgra_attack_shard_*): this rank owns rows [row0, row1) of M / am / av
+  bool sharded = false;
+  int world = 1, rank = 0, rpr = 0, npad = 0, row0 = 0, row1 = 0;
+  char* arena = nullptr;           // caller-owned exchange arena (mcgra_attack_bind_exchange)
+  int64_t arena_bytes = 0;
+  int64_t off_fy = 0, off_sg = 0, off_sc = 0, off_a2s = 0, off_a2r = 0, off_nxn = 0;
+  float *SG = 0, *A2S = 0, *A2R = 0, *NXS = 0;   // views into the arena: n-vector stage [npad][sgw], all-to-all send / recv, N x N stage
+  double* SC = 0;                  // 16 exchanged scalars
+  int sgw = 0;
+  // resumable step (protothread state: the step runs to the next exchange point and returns)
+  int fs_state = 0, fw_state = 0, fs_l = 0, fs_what = 0, fs_want = 0, fs_np = 0, fs_nblk = 0;
+  bool fs_active = false, fs_adopted = false;
+  double fs_scalars[10] = {0};
 };
 
 // attack_fused.hip
@@ -113,6 +126,8 @@ bool fused_step_possible(const mcgra_attack* h);
 int fused_forward(mcgra_attack* h, hipStream_t st);
 // returns 1 when the step must be redone by the general path (a relu-masked pair in the decode), 0 when done
 int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out);
+int64_t fused_exchange_bytes(const mcgra_attack* h);
+extern "C" int step_general(mcgra_attack_t* h, void* stream, const float* noise, double* scalars_out);     // attack.hip: every row, replicated
 
 #define CHK(expr)            \
   do {                       \
@@ -132,6 +147,6 @@ extern "C" {      // (defined inside attack.hip's extern "C" block)
 int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg, const float* Xc,
                double k_signed, float* G, int ldg, int slot);
 int project(mcgra_attack* h, hipStream_t st);
-int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out);
+int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out, bool have_clampsum = false);
 __global__ void k_cn(const double* __restrict__ scal, float coef, float* __restrict__ out);
 }

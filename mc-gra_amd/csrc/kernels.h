@@ -9,7 +9,7 @@ namespace mcgra {
 // ---- nxn_kernels.hip
 void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, const float* ori,
                  const float* noise, float eps, float* A, unsigned char* gate, float* d, float* r,
-                 double* rowsq, double* rowsum);
+                 double* rowsq, double* rowsum, int row0 = 0, int row1 = -1);
 void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out, double* rowsum = nullptr);
 void launch_decode_post(hipStream_t st, int n, int ld, float* S, const float* ori, unsigned int* nmask = nullptr);
 void launch_loss_elem(hipStream_t st, int n, int ld, const float* X, const float* Y, const float* F,

@@ -28,10 +28,10 @@ __global__ __launch_bounds__(ROW_THREADS) void k_prep(int n, int ld, const float
                                                       const float* __restrict__ noise, float eps,
                                                       float* __restrict__ A, unsigned char* __restrict__ gate,
                                                       float* __restrict__ d, float* __restrict__ r,
-                                                      double* __restrict__ rowsq, double* __restrict__ rowsum) {
+                                                      double* __restrict__ rowsq, double* __restrict__ rowsum, int row0) {
   __shared__ float shf[16];
   __shared__ double shd[16];
-  const int i = blockIdx.x;
+  const int i = row0 + blockIdx.x;
   const size_t base = (size_t)i * ld;
   float s = 0.f;
   double sq = 0.0;
@@ -902,9 +902,11 @@ __global__ void k_row_sqnorm(int m, int d, const float* __restrict__ X, int ldx,
 
 void launch_prep(hipStream_t st, bool general, int n, int ld, const float* M, const float* ori,
                  const float* noise, float eps, float* A, unsigned char* gate, float* d, float* r,
-                 double* rowsq, double* rowsum) {
-  if (general) LAUNCH(k_prep<true>, dim3(n), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum);
-  else LAUNCH(k_prep<false>, dim3(n), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum);
+                 double* rowsq, double* rowsum, int row0, int row1) {
+  if (row1 < 0) row1 = n;            // rows [row0, row1) only (row-block ranks); default: all
+  if (row1 <= row0) return;
+  if (general) LAUNCH(k_prep<true>, dim3(row1 - row0), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum, row0);
+  else LAUNCH(k_prep<false>, dim3(row1 - row0), dim3(ROW_THREADS), st, n, ld, M, ori, noise, eps, A, gate, d, r, rowsq, rowsum, row0);
 }
 void launch_adjn(hipStream_t st, int n, int ld, const float* A, const float* r, float* out, double* rowsum) {
   LAUNCH(k_adjn, dim3(n), dim3(ROW_THREADS), st, n, ld, A, r, out, rowsum);

@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void k_rankk_apply_adam(
 // d, r, rowsq, rowsum of k_prep (nxn_kernels.hip) from the per-tile partial sums above: one wave per row
 __global__ __launch_bounds__(256) void k_prep_fin(int n, int nt, const float* __restrict__ ps, const double* __restrict__ pq,
                                                   float* __restrict__ d, float* __restrict__ r, double* __restrict__ rowsq,
-                                                  double* __restrict__ rowsum) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n) return;
+                                                  double* __restrict__ rowsum, int row0, int row1) {
+  const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= row1) return;
   float s = 0.f;
   double q = 0.0;
   for (int t = lane; t < nt; t += 64) { s += ps[(size_t)i * nt + t]; q += pq[(size_t)i * nt + t]; }
@@ -336,8 +336,11 @@ __global__ __launch_bounds__(256) void k_prep_fin(int n, int nt, const float* __
 
 int rankk_apply_adam_tiles(int n) { return (n + RA_T - 1) / RA_T; }
 void prep_from_partials(hipStream_t st, int n, const float* ps, const double* pq, float* d, float* r, double* rowsq,
-                        double* rowsum) {
-  hipLaunchKernelGGL(k_prep_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, rankk_apply_adam_tiles(n), ps, pq, d, r, rowsq, rowsum);
+                        double* rowsum, int row0, int row1) {
+  if (row1 < 0) row1 = n;
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(k_prep_fin, dim3((row1 - row0 + 3) / 4), dim3(256), 0, st, n, rankk_apply_adam_tiles(n), ps, pq, d, r, rowsq,
+                     rowsum, row0, row1);
 }
 bool rankk_apply_adam_supported(int n, int ld, int K) {
   return K > 0 && K <= RK_KMAX && (ld % 4) == 0 && n >= 256;

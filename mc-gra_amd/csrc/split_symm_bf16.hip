@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
                                                                  float* __restrict__ C, int n, int ldc, int nks,
                                                                  int tiles_m, int tiles_n, int panel_off, int tile_base,
                                                                  int ksplit, float* __restrict__ slab,
-                                                                 const float* __restrict__ amax) {
+                                                                 const float* __restrict__ amax, int npanel_off) {
   using CF = SplitCfg<NP, KSUB>;
   constexpr int OPB = CF::OPB, STAGE = CF::STAGE;
   constexpr int NJ = NW == 8 ? 2 : 4;                     // 32-column MFMA tiles per wave
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
     const int first_m = group_id * GROUP_M;
     const int gm = min(tiles_m - first_m, GROUP_M);
     tile_m = first_m + (lin % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
-    tile_n = (lin % group_sz) / gm;
+    tile_n = (lin % group_sz) / gm + npanel_off;                // column-block ranks: this launch starts at column panel npanel_off
   }
   const int kper = (nks + ksplit - 1) / ksplit;
   const int kc_begin = part * kper;
@@ -379,12 +379,13 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
 
 // C tile = sum over parts of the partial tiles of the split-K tail (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__ slab, int ntile, int ksplit, float* __restrict__ C,
-                                                       int n, int ldc, int tiles_m, int tiles_n, int panel_off, int tile_base) {
+                                                       int n, int ldc, int tiles_m, int tiles_n, int panel_off, int tile_base,
+                                                       int npanel_off) {
   const int t = blockIdx.x, lin = tile_base + t;
   constexpr int GROUP_M = 4;
   const int group_sz = GROUP_M * tiles_n, group_id = lin / group_sz, first_m = group_id * GROUP_M;
   const int gm = min(tiles_m - first_m, GROUP_M);
-  const int tile_m = first_m + (lin % group_sz) % gm + panel_off, tile_n = (lin % group_sz) / gm;
+  const int tile_m = first_m + (lin % group_sz) % gm + panel_off, tile_n = (lin % group_sz) / gm + npanel_off;
   for (int e = blockIdx.y * 256 + threadIdx.x; e < TB * TB / 4; e += gridDim.y * 256) {
     const int row = e / (TB / 4), c4 = (e % (TB / 4)) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -410,14 +411,15 @@ int chunks_of(int n, int planes) {
 
 template <int NP, int KSUB, int NW = 8>
 hipError_t launch_split(hipStream_t st, int grid, const void* Apack, const void* Bpack, float* C, int n, int ldc, int nkc,
-                        int tm, int tiles, int panel_off, int tile_base, int ksplit, float* slab, const float* amax) {
+                        int tm, int tiles, int panel_off, int tile_base, int ksplit, float* slab, const float* amax,
+                        int npanel_off) {
   // the dynamic-LDS limit is a per-device function attribute: set it on every launch (a host-side table write,
   // no device work), so that a second GPU in the same process gets it too
   constexpr int smem = 2 * SplitCfg<NP, KSUB>::STAGE;
   hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((split3_symm_kernel<NP, KSUB, NW>), dim3(grid), dim3(NW * 64), smem, st, (const char*)Apack, (const char*)Bpack,
-                     C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax);
+                     C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax, npanel_off);
   return hipSuccess;
 }
 }  // namespace
@@ -458,10 +460,12 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
 // the tiles of the ragged last round, whose split along K depends on how many tiles the launch has.
 // planes == 2: amax[0], amax[1] = the magnitudes the operands were packed with.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
-                       int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax) {
-  const int nkc = chunks_of(n, planes), tiles = (n + TB - 1) / TB;
-  const int tm = panel_rows >= 0 ? panel_rows : tiles;
-  if (tm <= 0) return hipSuccess;
+                       int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax, int npanel_off,
+                       int npanel_cols) {
+  const int nkc = chunks_of(n, planes), tiles_all = (n + TB - 1) / TB;
+  const int tm = panel_rows >= 0 ? panel_rows : tiles_all;
+  const int tiles = npanel_cols >= 0 ? npanel_cols : tiles_all;      // column panels of this launch
+  if (tm <= 0 || tiles <= 0) return hipSuccess;
   int slots = 256;               // one block per CU of the device this launch goes to
   {
     static int cus_of[64] = {0};            // per device: written once with the same value by whoever gets there first
@@ -484,8 +488,8 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   if (ksplit <= 1) { full = total; rem = 0; }
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2)
-      return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
-    return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax);
+      return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
+    return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
   };
   if (full > 0) {
     hipError_t e = launch(full, 0, 1, nullptr);
@@ -494,7 +498,8 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   if (rem > 0) {
     hipError_t e = launch(rem * ksplit, full, ksplit, slab);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, full);
+    hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, full,
+                       npanel_off);
   }
   return hipGetLastError();
 }

@@ -196,7 +196,7 @@ class AttackEngine:
 
     def __init__(self, n, dims, nclass, emb_nlayer, measure, weight_sup, weight_param, lr, num_edges,
                  n_attack, eps=0.0, device="cuda:0", act="relu", head_act="none", has_self=False, fin_layers=(1, 2),
-                 row_begin=0, row_end=None):
+                 plan=None):
         _lib.require_device()
         self.device = torch.device(device)
         self.n, self.nclass, self.dims = int(n), int(nclass), list(int(d) for d in dims)
@@ -214,7 +214,9 @@ class AttackEngine:
             cfg.w[i] = float(weight_param[i])
         cfg.lr, cfg.eps = float(lr), float(eps)
         cfg.num_edges = float(min(num_edges, 1e300))
-        cfg.row_begin, cfg.row_end = int(row_begin), int(self.n if row_end is None else row_end)
+        # plan: a sharded.RowBlockPlan makes this engine one of plan.world row-block ranks (include/mcgra.h)
+        cfg.row_begin, cfg.row_end = (0, self.n) if plan is None else (int(plan.row_begin), int(plan.row_end))
+        cfg.shard_world, cfg.shard_rows = (0, 0) if plan is None else (int(plan.world), int(plan.rows_per_rank))
         cfg.act = {"relu": 0, "elu": 1}[act]
         cfg.head_act = {"none": 0, "elu": 1}[head_act]
         cfg.has_self = int(bool(has_self))
@@ -288,20 +290,40 @@ class AttackEngine:
             check(lib.mcgra_attack_step(self._h, _stream(), _p(noise), None))
         return None
 
-    def step_phase(self, phase, noise=None, want_scalars=False):
-        """One phase of a row-block sharded step (mcgra_attack_step_phase)."""
-        with torch.cuda.device(self.device):
-            if want_scalars and phase == 3:
-                buf = (C.c_double * 10)()
-                check(lib.mcgra_attack_step_phase(self._h, _stream(), int(phase), _p(noise), buf))
-                keys = ("loss", "origin_loss", "c1", "c2", "c6", "c7", "c9", "c10", "clamp_sum", "nll")
-                return dict(zip(keys, list(buf)))
-            check(lib.mcgra_attack_step_phase(self._h, _stream(), int(phase), _p(noise), None))
-        return None
+    # ---- row-block sharded step (mcgra_attack_shard_*, driven by mc-gra_amd/sharded.py) ----------------------------
+    def exchange_bytes(self):
+        return int(lib.mcgra_attack_exchange_bytes(self._h))
 
-    def exchange_mask(self):
-        """Bit mask (KX=1, KY=2, G_adjn=4, G_A1=8) of the buffers the step in flight needs gathered."""
-        return int(lib.mcgra_attack_exchange_mask(self._h))
+    def bind_exchange(self, arena):
+        assert arena.dtype == torch.uint8 and arena.is_contiguous() and arena.device == self.device
+        self._keep.append(arena)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_bind_exchange(self._h, _p(arena), arena.numel()))
+
+    def shard_begin(self, what, want_scalars=False):
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_shard_begin(self._h, _stream(), int(what), int(bool(want_scalars))))
+
+    def shard_next(self):
+        ex = _lib.Exchange()
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_shard_next(self._h, _stream(), C.byref(ex)))
+        return (ex.kind, ex.count, ex.offset, ex.offset2, ex.chunk_bytes)
+
+    def shard_scalars(self):
+        buf = (C.c_double * 10)()
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_shard_scalars(self._h, _stream(), buf))
+        keys = ("loss", "origin_loss", "c1", "c2", "c6", "c7", "c9", "c10", "clamp_sum", "nll")
+        return dict(zip(keys, list(buf)))
+
+    def get_rows(self):
+        """Rows [row_begin, row_end) of the learnable adjacency (dense form of adj_changes)."""
+        r0, r1 = self.cfg.row_begin, (self.cfg.row_end or self.n)
+        out = torch.empty(max(r1 - r0, 0), self.n, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_get_rows(self._h, _stream(), _p(out)))
+        return out
 
     def product_mode(self):
         """0: fp32 MFMA SYMM, 1: bf16 split through hipBLASLt, 2: bf16 split, hand-written kernel (mcgra_attack_product_mode)."""
@@ -320,13 +342,6 @@ class AttackEngine:
         ptr, r, c, ld = C.c_void_p(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib.mcgra_attack_buffer(self._h, b"M", C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))
         return ld.value
-
-    def bind_buffer(self, name, tensor):
-        """Hand one of the exchanged buffers (KX, KY, G_adjn, G_A1) to the engine as caller-owned memory."""
-        assert tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous()
-        assert tensor.shape[0] >= self.n and tensor.shape[1] == self.leading_dim()
-        self._keep.append(tensor)
-        check(lib.mcgra_attack_bind_buffer(self._h, name.encode(), _p(tensor)))
 
     def monitor(self, want_sparsity=False):
         out = torch.empty(self.n, self.nclass, device=self.device, dtype=torch.float32)

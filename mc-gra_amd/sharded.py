@@ -1,81 +1,143 @@
 """Row-block sharded attack step over ranks (one process per GPU, torch.distributed; backend "nccl" is RCCL).
 
-Only the N x N x N products of linear_HSIC / linear_CKA are sharded (they are ~90 % of a step at N = 10 000):
-rank r computes the tile rows [row_begin, row_end) of the two centred Grams and of the two gradient products;
-one all-gather of row blocks follows each.  Everything else is O(n^2) and stays replicated, so every rank holds
-the full learnable adjacency and no parameter exchange is needed.  The backend is duck-typed (``phase(k, noise)``
-plus the four exchanged tensors) so that the same orchestration runs on the HIP engine and, in the gloo CPU
-tests, on a numpy stand-in supplied by the test.
+Rank r owns rows [row_begin, row_end) of the learnable adjacency and of the Adam moments and does 1/world of every
+N x N pass of the fused low-rank step (csrc/attack_fused.hip).  The engine runs to the next
+exchange point and describes the collective (include/mcgra.h: mcgra_exchange_t); this module executes it on views of
+ONE device arena the engine was bound to:
+
+  ALLGATHER      rows of an n x c node array (skinny products M[rows, :] V; r, d, gd, decode backward) -- `world`
+                 equal chunks, this rank's chunk filled
+  ALLREDUCE_F64  a handful of scalars (|adj_changes|^2, mask count, loss terms)
+  ALLTOALL       tile blocks of the N x N x N product: every rank computed the COLUMN block P1[:, rows] and receives
+                 its ROW block P1[rows, :] (the mirrored gradient needs P1_ij and P1_ji) -- n^2 / world floats per rank
+                 and step, the only N x N-sized traffic
+
+The backend is duck-typed (arena / begin / next / scalars / plan) so that the same orchestration drives the HIP engine
+(HipShardBackend) and, in the gloo CPU tests, a numpy stand-in.
 """
 import torch
 
-TILE = 256          # row blocks are whole 256-row panels (2 x SYM_TILE of csrc/common.h; panel of split_symm_bf16.hip)
-EXCHANGED_AFTER_PHASE = {1: ("KX", "KY"), 2: ("G_adjn", "G_A1")}
-EXCHANGE_BIT = {"KX": 1, "KY": 2, "G_adjn": 4, "G_A1": 8}          # MCGRA_EXCHANGE_* of include/mcgra.h
+PANEL = 256          # row blocks are whole 256-row panels (split_symm_bf16.hip), i.e. whole 64-row tiles of the tail
+XCHG_DONE, XCHG_ALLGATHER, XCHG_ALLREDUCE_F64, XCHG_ALLTOALL = 0, 1, 2, 3
+SHARD_STEP, SHARD_MONITOR = 0, 1
 
 
 class RowBlockPlan:
-    """Equal row blocks of whole tiles: rows_per_rank = ceil(n / (TILE * world)) * TILE; the exchanged buffers
-    have n_pad = rows_per_rank * world rows so that all_gather chunks are equal."""
+    """Equal row blocks of whole panels: rows_per_rank = ceil(panels / world) * 256; exchanged node arrays have
+    n_pad = rows_per_rank * world rows so that all-gather chunks are equal.  Trailing ranks may own fewer rows or none
+    (they still take part in every collective)."""
 
     def __init__(self, n, world, rank):
         self.n, self.world, self.rank = int(n), int(world), int(rank)
-        tiles = (self.n + TILE - 1) // TILE
-        self.rows_per_rank = ((tiles + self.world - 1) // self.world) * TILE
+        panels = (self.n + PANEL - 1) // PANEL
+        self.rows_per_rank = ((panels + self.world - 1) // self.world) * PANEL
         self.n_pad = self.rows_per_rank * self.world
-        self.row_begin = min(self.rank * self.rows_per_rank, self.n_pad)
-        self.row_end = self.row_begin + self.rows_per_rank
-        # a trailing rank may own no real rows (n small against world * TILE): it still takes part in collectives
+        self.row_begin = self.rank * self.rows_per_rank
+        self.row_end = min(self.row_begin + self.rows_per_rank, self.n) if self.row_begin < self.n else self.row_begin
         self.has_rows = self.row_begin < self.n
 
 
+def run_exchange(ex, arena, plan, dist=None, group=None, clone_input=False, always=False):
+    """One collective of the protocol on the rank's arena (uint8 tensor).  dist None / world 1: nothing to move
+    (always=True issues the world-1 collectives anyway: a hardware smoke test of the RCCL calls)."""
+    kind, count, off, off2, chunk = ex
+    if kind == XCHG_DONE or dist is None or (plan.world == 1 and not always):
+        return
+    w, r = plan.world, plan.rank
+    if kind == XCHG_ALLGATHER:
+        full = arena[off:off + w * chunk]
+        mine = full[r * chunk:(r + 1) * chunk]
+        dist.all_gather_into_tensor(full, mine.clone() if clone_input else mine, group=group)
+    elif kind == XCHG_ALLREDUCE_F64:
+        dist.all_reduce(arena[off:off + 8 * count].view(torch.float64), group=group)
+    elif kind == XCHG_ALLTOALL:
+        send, recv = arena[off:off + w * chunk], arena[off2:off2 + w * chunk]
+        dist.all_to_all_single(recv, send, group=group)
+    else:
+        raise ValueError(f"exchange kind {kind}")
+
+
 class ShardedStepper:
-    def __init__(self, backend, plan, dist=None, clone_input=False):
-        """backend: .phase(k, noise) and .exchanged[name] -> tensor [n_pad, ld]; dist: torch.distributed or None
-        (world 1); clone_input: gloo needs a non-aliased all_gather input."""
-        self.b, self.plan, self.dist, self.clone_input = backend, plan, dist, clone_input
+    def __init__(self, backend, plan=None, dist=None, group=None, clone_input=False, always=False):
+        """backend: .arena, .begin(what, want_scalars), .next() -> (kind, count, offset, offset2, chunk_bytes),
+        .scalars(); dist: torch.distributed or None (world 1); clone_input: gloo needs a non-aliased all_gather
+        input."""
+        self.b, self.plan = backend, plan or backend.plan
+        self.dist, self.group, self.clone_input, self.always = dist, group, clone_input, always
+        self.exchanges = 0
 
-    def _all_gather_rows(self, t):
-        if self.dist is None or self.plan.world == 1:
-            return
-        p = self.plan
-        mine = t[p.rank * p.rows_per_rank:(p.rank + 1) * p.rows_per_rank]
-        if self.clone_input:
-            mine = mine.clone()
-        self.dist.all_gather_into_tensor(t.view(-1), mine.reshape(-1))
+    def _run(self, what, want_scalars):
+        self.b.begin(what, want_scalars)
+        while True:
+            ex = self.b.next()
+            if ex[0] == XCHG_DONE:
+                break
+            run_exchange(ex, self.b.arena, self.plan, self.dist, self.group, self.clone_input, self.always)
+            self.exchanges += 1
+        return self.b.scalars() if want_scalars else None
 
-    def step(self, noise=None, want_scalars=False):
-        out = None
-        for k in range(4):
-            r = self.b.phase(k, noise) if k < 3 else self.b.phase(k, noise, want_scalars)
-            if k == 3:
-                out = r
-            if self.b.needs_exchange:
-                for name in self.b.exchange_names(k):
-                    self._all_gather_rows(self.b.exchanged[name])
-        return out
+    def step(self, want_scalars=False):
+        """One iteration of the loop (topology_attack.py:161-283) on this rank's row block."""
+        return self._run(SHARD_STEP, want_scalars)
+
+    def monitor(self, want_sparsity=False):
+        """The monitoring forward (:290-296); the next step adopts it.  Returns mean(modified_adj) if asked."""
+        out = self._run(SHARD_MONITOR, want_sparsity)
+        return out[0] if want_sparsity else None
+
+
+def run_lockstep(backends, what=SHARD_STEP, want_scalars=False):
+    """All ranks of one attack inside ONE process (one GPU, or numpy stand-ins): the backends advance in lockstep and
+    the collectives are plain copies between their arenas.  For tests and for per-rank timing on a single device."""
+    w = len(backends)
+    for b in backends:
+        b.begin(what, want_scalars)
+    n_ex = 0
+    while True:
+        exs = [b.next() for b in backends]
+        kinds = {e[0] for e in exs}
+        assert len(kinds) == 1, f"ranks disagree on the next exchange: {exs}"
+        kind, count, off, off2, chunk = exs[0]
+        assert all(e == exs[0] for e in exs), f"ranks disagree on the exchange geometry: {exs}"
+        if kind == XCHG_DONE:
+            break
+        n_ex += 1
+        arenas = [b.arena for b in backends]
+        if kind == XCHG_ALLGATHER:
+            for src in range(w):
+                piece = arenas[src][off + src * chunk: off + (src + 1) * chunk]
+                for dst in range(w):
+                    if dst != src:
+                        arenas[dst][off + src * chunk: off + (src + 1) * chunk].copy_(piece)
+        elif kind == XCHG_ALLREDUCE_F64:
+            vs = [a[off:off + 8 * count].view(torch.float64) for a in arenas]
+            tot = vs[0].clone()
+            for v in vs[1:]:
+                tot += v
+            for v in vs:
+                v.copy_(tot)
+        elif kind == XCHG_ALLTOALL:
+            for src in range(w):
+                for dst in range(w):
+                    arenas[dst][off2 + src * chunk: off2 + (src + 1) * chunk].copy_(
+                        arenas[src][off + dst * chunk: off + (dst + 1) * chunk])
+    return [b.scalars() for b in backends] if want_scalars else n_ex
 
 
 class HipShardBackend:
-    """AttackEngine restricted to this rank's row block, with the exchanged buffers owned by torch."""
+    """An AttackEngine created as a row-block rank, with its exchange arena owned by torch."""
 
     def __init__(self, engine, plan):
         self.eng, self.plan = engine, plan
-        ld = engine.leading_dim()
-        dev = engine.device
-        self.needs_exchange = engine.cfg.measure in (0, 3)          # HSIC, CKA: the N x N x N products
-        self.exchanged = {}
-        if self.needs_exchange:
-            for name in ("KX", "KY", "G_adjn", "G_A1"):
-                t = torch.zeros(plan.n_pad, ld, device=dev, dtype=torch.float32)
-                engine.bind_buffer(name, t)
-                self.exchanged[name] = t
+        nbytes = engine.exchange_bytes()
+        self.arena = torch.zeros(nbytes, device=engine.device, dtype=torch.uint8)
+        engine.bind_exchange(self.arena)
 
-    def phase(self, k, noise=None, want_scalars=False):
-        return self.eng.step_phase(k, noise=noise, want_scalars=want_scalars)
+    def begin(self, what, want_scalars):
+        self.eng.shard_begin(what, want_scalars)
 
-    def exchange_names(self, k):
-        """Buffers to gather after phase k of the step in flight: the engine picks, per step, between the
-        low-rank evaluation (one product: only KX rows travel) and the Gram evaluation (all four)."""
-        mask = self.eng.exchange_mask()
-        return [nm for nm in EXCHANGED_AFTER_PHASE.get(k, ()) if mask & EXCHANGE_BIT[nm]]
+    def next(self):
+        return self.eng.shard_next()
+
+    def scalars(self):
+        return self.eng.shard_scalars()

@@ -45,7 +45,7 @@ def test_config_struct_layout_matches_header(pkg):
     C = pkg._lib.AttackConfig
     assert C.dims.offset == 20 and C.measure.offset == 56 and C.weight_sup.offset == 64
     assert C.w.offset == 68 and C.lr.offset == 108 and C.num_edges.offset == 120 and C.row_begin.offset == 128
-    assert C.act.offset == 136 and C.fin_layers.offset == 148 and ctypes.sizeof(C) == 160
+    assert C.act.offset == 136 and C.fin_layers.offset == 148 and C.shard_world.offset == 156 and ctypes.sizeof(C) == 168
 
 
 def test_no_cpu_fallback(pkg):

@@ -50,16 +50,21 @@ def test_tril_pos_helper():
 
 def test_bench_workload_matches_reference_at_10k(ctx):
     """The configuration the headline number is quoted on, against the reference itself (fixture generated from
-    /root/reference by make_golden.py; nothing here reads the reference).  Bars: per-step gradient within 3e-4 of the
-    gradient's largest magnitude on 8k sampled entries (the bar of the small teacher-forced goldens), recovered-adjacency
-    AUC within north_star's 1e-4.  `run`: the 4-step loop from bench.make_a0; `one*`: single steps from other seeded
-    starts, i.e. steps whose starting state is the reference's own by construction (a 50 M-entry adj_changes per step
-    cannot be stored, so the later steps of `run` free-run: Adam moves an entry whose gradient sits at the fp32 noise
-    level by +-lr on its sign alone, and such entries are counted, not compared)."""
+    /root/reference by make_golden.py; nothing here reads the reference).  `run`: the 4-step loop from bench.make_a0;
+    `one*`: single steps from other seeded starts, i.e. steps whose starting state is the reference's own by
+    construction (a 50 M-entry adj_changes per step cannot be stored, so the later steps of `run` free-run: Adam moves
+    an entry whose gradient sits at the fp32 noise level by +-lr on its sign alone; such entries are counted).
+
+    Bars.  AUC: north_star's 1e-4.  Gradient: at this size the reference's OWN fp32 gradient is 0.8e-3 ... 1.5e-3 of
+    the gradient's largest magnitude away from a float64 evaluation of the same algorithm
+    (tests/golden/bench10k_hsic_fp64.npz, make_truth64.py: w9 / w10 put HSIC terms of 10^4-row operands with nearly
+    identical rows in charge of the gradient, and centring them costs three digits).  So the engine is held to 3e-4 of
+    the EXACT gradient -- the bar the small goldens hold against the reference -- and to the reference within the
+    reference's own distance from the exact gradient plus 3e-4; free-running steps, which have no float64 truth, to 2e-3."""
     pkg, torch, bench, dev = ctx
-    path = os.path.join(ROOT, "tests", "golden", "bench10k_hsic.npz")
-    z = np.load(path)
-    assert str(z["workload"]) == WL
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bench10k_hsic.npz"))
+    z64 = np.load(os.path.join(ROOT, "tests", "golden", "bench10k_hsic_fp64.npz"))
+    assert str(z["workload"]) == WL and np.array_equal(z["packed_pos"], z64["packed_pos"])
     seed, lr = int(z["seed"]), float(z["lr"])
     n = bench.WORKLOADS[WL][0]
     pi, pj = _tril_pos(z["packed_pos"])
@@ -78,13 +83,21 @@ def test_bench_workload_matches_reference_at_10k(ctx):
             Gs = eng.buffer("G_sym")
             g = Gs[ti, tj].cpu().numpy()
             gmax = float(z[f"{name}_g_absmax"][t])
-            err = np.abs(g - G[t]).max() / gmax
-            assert err <= 3e-4, (name, t, err)
+            err_ref = np.abs(g - G[t]).max() / gmax
+            if t == 0 and f"{name}_g64" in z64.files:
+                g64 = z64[f"{name}_g64"]
+                assert abs(float(z64[f"{name}_g64_absmax"]) - gmax) <= 2e-3 * gmax
+                err_true = np.abs(g - g64).max() / gmax
+                ref_true = np.abs(G[t] - g64).max() / gmax
+                assert err_true <= 3e-4, (name, t, err_true)
+                assert err_ref <= ref_true + 3e-4, (name, t, err_ref, ref_true)
+            else:
+                assert err_ref <= 2e-3, (name, t, err_ref)
             # whole-matrix sums (fp64): the packed gradient is half of the mirrored matrix
             gsum = float(Gs.double().sum()) * 0.5
             ref_l1 = float(np.sqrt(z[f"{name}_g_sqsum"][t]) * np.sqrt(n * (n - 1) / 2))     # >= sum |g|
-            assert abs(gsum - float(z[f"{name}_g_sum"][t])) <= 3e-4 * ref_l1, (name, t, gsum, float(z[f"{name}_g_sum"][t]))
-            assert abs(float(Gs.abs().max()) - gmax) <= 3e-4 * gmax
+            assert abs(gsum - float(z[f"{name}_g_sum"][t])) <= 2e-3 * ref_l1, (name, t, gsum, float(z[f"{name}_g_sum"][t]))
+            assert abs(float(Gs.abs().max()) - gmax) <= 2e-3 * gmax
             M = eng.buffer("M")
             a = M[ti, tj].cpu().numpy()
             # (the reference's hook sees adj_changes after optimizer.step(), before the clamp of :283)
@@ -94,7 +107,7 @@ def test_bench_workload_matches_reference_at_10k(ctx):
                 asum = float(M.double().sum()) * 0.5
                 ref_sum = float(z[f"{name}_a_clip_sum"][t])
                 assert abs(asum - ref_sum) <= 1e-4 * ref_sum, (name, t, asum, ref_sum)
-        assert eng.path_stats()["general_steps"] == 0
+        assert eng.path_stats()["general_steps"] == 0 and eng.fused_steps() == G.shape[0]
         lab = torch.as_tensor(inp["labels"], device=dev)
         final = eng.finalize(0, eng.buffer("HA"), eng.buffer("YA"), (lab[:, None] == lab[None, :]).float())
         auc = bench.gpu_auc(adj_dev, final, torch)
@@ -149,35 +162,27 @@ def test_lowrank_and_gram_evaluations_agree_at_10k(ctx, monkeypatch):
     assert gram.path_stats()["general_steps"] == 2
 
 
-def test_sharded_phases_match_monolithic_at_10k(ctx):
+def test_sharded_ranks_match_monolithic_at_10k(ctx):
+    """Two row-block ranks of the headline workload on one GPU (lockstep emulation, collectives as copies): every
+    N x N pass of a rank touches its 5120 rows only; the union of the rows equals the monolithic step's adjacency up to
+    the entries Adam moves on rounding noise, and the ranks agree bit for bit on mirrored entries."""
     pkg, torch, bench, dev = ctx
-    from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend
+    from mc_gra_amd import sharded as S
     n = bench.WORKLOADS[WL][0]
     full, _, _ = _engine(ctx)
-    plans = [RowBlockPlan(n, 2, r) for r in range(2)]
-    bks = [HipShardBackend(_engine(ctx, row_begin=p.row_begin, row_end=p.row_end)[0], p) for p in plans]
+    plans = [S.RowBlockPlan(n, 2, r) for r in range(2)]
+    bks = [S.HipShardBackend(_engine(ctx, plan=p)[0], p) for p in plans]
     for t in range(2):
-        full.step()
-        for k in range(4):
-            for b in bks:
-                b.phase(k)
-            for name in bks[0].exchange_names(k):
-                for src, p in zip(bks, plans):
-                    blk = slice(p.rank * p.rows_per_rank, (p.rank + 1) * p.rows_per_rank)
-                    for dst in bks:
-                        if dst is not src:
-                            dst.exchanged[name][blk].copy_(src.exchanged[name][blk])
-        ref = full.get_adj_changes()
-        for b in bks:
-            a = b.eng.get_adj_changes()
-            assert torch.equal(a, bks[0].eng.get_adj_changes()), f"ranks diverged at step {t}"     # replicas: always bitwise
-            # vs the monolithic step: the fp32 products give the same bits (same tiles, same k order); the default
-            # bf16-split product cuts the tiles of its ragged last round along K, and which tiles those are depends on
-            # the launch's row range, so there the agreement is to fp32 rounding
-            # (the monolithic step runs the fused low-rank path, the phases the general one: Adam moves an entry whose
-            #  gradient sits at the fp32 noise level by +-lr on its sign alone, so entries are counted, not compared)
-            assert float(((a - ref).abs() > 5e-4).float().mean()) < 2e-3, f"step {t}"
-    assert bks[0].exchange_names(1) == ["KX"] and bks[0].exchange_names(2) == []      # low-rank step: one buffer travels
+        a = full.step(want_scalars=True); full.monitor()
+        sc = S.run_lockstep(bks, S.SHARD_STEP, want_scalars=True)
+        S.run_lockstep(bks, S.SHARD_MONITOR)
+        rows = torch.cat([b.eng.get_rows() for b in bks], 0)
+        ref = full.buffer("M")
+        assert float(((rows - ref).abs() > 5e-4).float().mean()) < 2e-3, f"step {t}"
+        assert float((rows - rows.T).abs().max()) == 0.0
+        for k in ("loss", "c1", "c2", "c9", "c10"):
+            assert sc[0][k] == sc[1][k] and sc[0][k] == pytest.approx(a[k], rel=1e-4), (t, k)
+    assert all(b.eng.fused_steps() == 2 for b in bks)
 
 
 def test_gradient_is_linear_in_the_loss_weights_at_10k(ctx):

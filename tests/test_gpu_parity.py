@@ -461,45 +461,110 @@ def test_main_entry_end_to_end(pkg, torch_, tmp_path, monkeypatch):
     assert os.path.exists(tmp_path / "results" / "result.txt")
 
 
-# ---- row-block sharded step (scope row (e)) -------------------------------------------------------------------
-@pytest.mark.parametrize("case,world", [("s200_hsic_init", 1), ("s200_hsic_init", 2), ("s200_hsic_init", 3),
-                                        ("s200_hsic", 2), ("s48_cka_init", 1), ("s200_mse", 2), ("synthetic600", 2),
-                                        ("synthetic600", 3)])
-def test_sharded_phases_match_monolithic_step(pkg, case, world):
-    """`world` engines on one GPU, each restricted to its row block, driven by the product's ShardedStepper
-    phase protocol with the all-gather emulated by device copies: same adjacency as mcgra_attack_step."""
-    import torch
-    from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend, EXCHANGED_AFTER_PHASE
-    z = _synthetic_case(600, 11, (16, 16), 4, seed=5) if case == "synthetic600" else H.load_case(case)
+NXN_ONLY = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 0, 0)        # c1, c2, c6, c7 only: the N x N terms carry the whole gradient
+
+
+# ---- row-block sharded step (scope row (e)) -----------------------------------------------------------------
+def _shard_engines(pkg, z, world, **kw):
+    from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend
     n = z["adj"].shape[0]
-    full = H.engine_from(pkg, z)
     plans = [RowBlockPlan(n, world, r) for r in range(world)]
-    bks = [HipShardBackend(H.engine_from(pkg, z, row_begin=p.row_begin, row_end=p.row_end), p) for p in plans]
+    return plans, [HipShardBackend(H.engine_from(pkg, z, plan=p, **kw), p) for p in plans]
+
+
+def _gather_rows(bks):
+    import torch
+    return torch.cat([b.eng.get_rows() for b in bks if b.plan.has_rows], 0)
+
+
+@pytest.mark.parametrize("n,widths,world,wp", [(1100, (16, 16), 2, None), (1100, (16, 16), 3, None), (1283, (16, 8), 2, NXN_ONLY),
+                                               (1030, (16, 16, 16), 4, None), (1100, (16, 16), 1, None),
+                                               (600, (16, 16), 5, None)])
+def test_sharded_ranks_match_monolithic_step(pkg, n, widths, world, wp, monkeypatch):
+    """`world` row-block ranks on one GPU (each an engine that owns its rows of M and of the Adam moments and touches
+    only those rows in every N x N pass), advanced in lockstep with the collectives of the protocol executed as copies
+    between their arenas (sharded.run_lockstep): the union of their rows equals the monolithic fused step's adjacency
+    to fp32 rounding, the loss terms agree on every rank, monitor + adopted forward included.  world 4 on n = 1030
+    leaves the last ranks with 6 rows / none; world 1 is the degenerate protocol; n = 600 needs MCGRA_SPLIT_BF16."""
+    import torch
+    from mc_gra_amd import sharded as S
+    kw = {} if wp is None else {"weight_param": wp}
+    z = _synthetic_case(n, 11, widths, 4, seed=n, **kw)
+    if n < 1024:
+        monkeypatch.setenv("MCGRA_SPLIT_BF16", "3")
+    mono = H.engine_from(pkg, z)
+    plans, bks = _shard_engines(pkg, z, world)
+    lr = float(z["lr"])
     for t in range(3):
-        noise = H.noise_of(z, t)
-        noise = None if noise is None else torch.tensor(noise, device="cuda")
-        ref = full.step(want_scalars=True, noise=noise)
-        outs = [None] * world
-        for k in range(4):
-            for r, b in enumerate(bks):
-                outs[r] = b.phase(k, noise, want_scalars=True) if k == 3 else b.phase(k, noise)
-            if bks[0].needs_exchange:
-                for name in bks[0].exchange_names(k):
-                    for src, p in zip(bks, plans):                       # emulated all_gather of equal row blocks
-                        blk = slice(p.rank * p.rows_per_rank, (p.rank + 1) * p.rows_per_rank)
-                        for dst in bks:
-                            if dst is not src:
-                                dst.exchanged[name][blk].copy_(src.exchanged[name][blk])
-        a_ref = full.get_adj_changes()
-        for r, b in enumerate(bks):
-            a = b.eng.get_adj_changes()
-            assert torch.equal(a, bks[0].eng.get_adj_changes()), f"rank {r} diverged from rank 0 at step {t}"
-            # row-range launches run the same tiles with the same k order as the full launch: bit-identical
-            assert torch.equal(a, a_ref), f"sharded != monolithic at step {t}: {(a - a_ref).abs().max().item():.3e}"
-            assert outs[r]["loss"] == pytest.approx(ref["loss"], rel=1e-6)
+        a = mono.step(want_scalars=True); mono.monitor()
+        sc = S.run_lockstep(bks, S.SHARD_STEP, want_scalars=True)
+        S.run_lockstep(bks, S.SHARD_MONITOR)
+        rows = _gather_rows(bks)
+        M = mono.buffer("M")
+        assert rows.shape == M.shape
+        assert float(((rows - M).abs() > 0.05 * lr).float().mean()) < 2e-3, t      # Adam: +-lr on noise-level gradients
+        assert float((rows - rows.T).abs().max()) == 0.0, "ranks must agree on mirrored entries bit for bit"
+        for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "clamp_sum"):
+            for b in sc:
+                assert b[k] == pytest.approx(a[k], rel=3e-5, abs=1e-6 * max(1.0, abs(a["loss"]))), (t, k, b[k], a[k])
+            assert all(b[k] == sc[0][k] for b in sc), "scalars are identical on every rank"
+    assert all(b.eng.fused_steps() == 3 for b in bks) and mono.fused_steps() == 3
 
 
-# ---- low-rank evaluation of linear_HSIC(adj_norm, modified_adj1) (DESIGN.md section 1b) -------------------------
+def test_sharded_ranks_hand_masked_steps_to_the_general_path(pkg, monkeypatch):
+    """A decode-masked step on row-block ranks: M and the Adam moments are all-gathered and every rank redoes the step
+    with the general (Gram) path, replicated; the ranks' rows then equal the monolithic engine's bit for bit."""
+    import torch
+    from mc_gra_amd import sharded as S
+    z = _synthetic_case(600, 11, (16, 16), 4, seed=9, weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0))
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", "3")
+    w = H.weights_from(z)
+    probe = H.oracle_from(z); probe.step()
+    w.b = [b.copy() for b in w.b]
+    w.b[1] = (w.b[1] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)      # about half of em dies
+    mono = H.engine_from(pkg, z)
+    mono.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
+    plans, bks = _shard_engines(pkg, z, 2)
+    for b in bks:
+        b.eng.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
+    for t in range(2):
+        mono.step(); mono.monitor()
+        S.run_lockstep(bks, S.SHARD_STEP)
+        S.run_lockstep(bks, S.SHARD_MONITOR)
+    assert mono.path_stats()["general_steps"] == 2 and all(b.eng.path_stats()["general_steps"] == 2 for b in bks)
+    assert torch.equal(_gather_rows(bks), mono.buffer("M"))
+
+
+def test_sharded_stepper_on_a_one_rank_rccl_group(pkg):
+    """RCCL on hardware: torch.distributed with backend "nccl" (= RCCL), world size 1, drives the product's
+    ShardedStepper -- all_gather_into_tensor, all_reduce and all_to_all_single on views of the engine's arena are
+    executed by the collective library, and the rank's rows equal the monolithic step's."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mc_gra_amd import sharded as S
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=3)
+    mono = H.engine_from(pkg, z)
+    plans, bks = _shard_engines(pkg, z, 1)
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0)); port = sck.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        st = S.ShardedStepper(bks[0], plans[0], dist=dist, clone_input=True, always=True)
+        for t in range(2):
+            mono.step(); mono.monitor()
+            st.step(want_scalars=(t == 1)); st.monitor()
+        assert st.exchanges >= 2 * 10
+        rows, M = bks[0].eng.get_rows(), mono.buffer("M")
+        assert float(((rows - M).abs() > 0.05 * float(z["lr"])).float().mean()) < 2e-3
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("case", ["s200_hsic_init", "s48_hsic_eps", "s80_hsic_l3", "s48_sage_hsic_init", "s200_hsic"])
 def test_lowrank_hsic_matches_gram_path(pkg, case, monkeypatch):
     """Same steps through the low-rank path (default for a ReLU embedding) and through the Gram path
@@ -782,9 +847,6 @@ def test_fused_tail_matches_separate_kernels(pkg, n, measure, monkeypatch):
 
 
 # ---- the fused low-rank step (attack_fused.hip): N x N quantities from M and n-vectors only -------------------------
-NXN_ONLY = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 0, 0)        # c1, c2, c6, c7: the terms the fused step restructures
-
-
 @pytest.mark.parametrize("n,widths,wp,split", [
     (1100, (16, 16), None, None), (1283, (16, 8), NXN_ONLY, None), (700, (16, 16), NXN_ONLY, "3"),
     (1100, (16, 16, 16), None, None), (515, (8, 8), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), "2"),
