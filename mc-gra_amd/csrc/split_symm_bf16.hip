@@ -377,6 +377,137 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
     }
 }
 
+// The 2-plane fp16 product on v_mfma_f32_16x16x32_f16: same packed operands, same 256 x 256 block tile and 2 x 4 wave
+// grid, a K step of 32 (two packed 16-k chunks: the k octet of lane group g = lane >> 4 is chunk g >> 1, half g & 1, so a
+// 16-row fragment is still one conflict-free ds_read_b128: 16 lanes x 16 B per (chunk, half) cover all 64 banks once).
+// Wave tile 128 x 64 = 8 x 4 tiles of 16 x 16 = 128 accumulator registers; 96 MFMAs and 24 fragment reads per wave and
+// step, one barrier per 32 k.  On a power-limited chip the 16 x 16 shape holds a higher clock than 32 x 32
+// (MI355X_MICROARCH.md: 1.12-1.15 x the FLOP/s at equal cycles on random operands).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
+                                                            float* __restrict__ C, int n, int ldc, int nks,
+                                                            int tiles_m, int tiles_n, int panel_off, int tile_base,
+                                                            int ksplit, float* __restrict__ slab,
+                                                            const float* __restrict__ amax, int npanel_off) {
+  using CF = SplitCfg<2, 2>;
+  constexpr int OPB = CF::OPB, STAGE = CF::STAGE;     // 16 KB per operand and chunk, 64 KB per stage
+  constexpr int COPY = 512 * 16, AOPS = 2 * OPB / COPY;   // 4 copies per operand and step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, tile_n, lin, part;
+  {
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    part = bid % ksplit;
+    lin = tile_base + bid / ksplit;
+    constexpr int GROUP_M = 4;
+    const int group_sz = GROUP_M * tiles_n;
+    const int group_id = lin / group_sz;
+    const int first_m = group_id * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    tile_m = first_m + (lin % group_sz) % gm + panel_off;
+    tile_n = (lin % group_sz) / gm + npanel_off;
+  }
+  const int kper = (nks + ksplit - 1) / ksplit;
+  const int kc_begin = part * kper;
+  const int nk = max(0, min(nks, kc_begin + kper) - kc_begin);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const char* ga = Ap + ((size_t)tile_m * nks + kc_begin) * (2 * OPB) + (size_t)tid * 16;
+  const char* gb = Bp + ((size_t)tile_n * nks + kc_begin) * (2 * OPB) + (size_t)tid * 16;
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // Staging without registers: global_load_lds_dwordx4 copies 16 B per lane straight into the LDS image (a wave's 64
+  // lanes write 1 KB at a wave-uniform base, which is exactly the linear copy this image needs).  The tile of step t+1
+  // is issued at the top of step t, behind the first fragment reads, into the stage that step t-1 released; it has the
+  // whole step (96 MFMAs per wave) to land before the barrier that ends the step.
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage_tile = [&](int kc, int stage) {
+    char* sbase = smem + stage * STAGE + (tid & ~63) * 16;          // wave-uniform; the hardware adds lane * 16
+#pragma unroll
+    for (int i = 0; i < AOPS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga + (size_t)kc * (2 * OPB) + i * COPY), (lptr_t)(sbase + i * COPY), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < AOPS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gb + (size_t)kc * (2 * OPB) + i * COPY), (lptr_t)(sbase + (AOPS + i) * COPY), 16, 0, 0);
+  };
+  // lane group g: chunk g >> 1, k half g & 1
+  const int k_off = (lg >> 1) * OPB + (lg & 1) * (PLANE / 2);
+  const int a_off = k_off + (wm * 128 + l15) * 16;                 // + i * 256 (row tile of 16) + plane * PLANE
+  const int b_off = 2 * OPB + k_off + (wn * 64 + l15) * 16;        // + j * 256 + plane * PLANE
+  auto frag = [&](const char* s, int off) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(s + off)); };
+  auto multiply = [&](int stage, auto&& after_first_reads) {
+    const char* s = smem + stage * STAGE;
+    f16x8 b0[4], b1[4];
+    f16x8 a1 = frag(s, a_off + PLANE);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = frag(s, b_off + j * 256);
+    f16x8 a0 = frag(s, a_off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = frag(s, b_off + j * 256 + PLANE);
+    after_first_reads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f16x8 n0 = a0, n1 = a1;
+      if (i + 1 < 8) {
+        n0 = frag(s, a_off + (i + 1) * 256);
+        n1 = frag(s, a_off + (i + 1) * 256 + PLANE);
+      }
+      // x1 y0 + x0 y1 (the 2^-11 corrections) ahead of x0 y0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc[i][j], 0, 0, 0);
+      a0 = n0; a1 = n1;
+    }
+  };
+
+  if (nk > 0) {
+    stage_tile(0, 0);
+    __syncthreads();                      // (waits for the copies of this wave, then for everybody's)
+    for (int kc = 0; kc < nk; ++kc) {
+      multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
+      __syncthreads();
+    }
+  }
+  const float inv = ldexpf(1.f, amax_exp(amax[0]) + amax_exp(amax[1]) - 30);      // undo the operand scales: exact
+  // C/D layout of 16 x 16: col = lane & 15, row = 4 (lane >> 4) + r
+  if (ksplit > 1) {
+    float* o = slab + ((size_t)part * (gridDim.x / ksplit) + (lin - tile_base)) * (TB * TB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(wm * 128 + i * 16 + 4 * lg + r) * TB + wn * 64 + j * 16 + l15] = acc[i][j][r] * inv;
+    return;
+  }
+  const int m0 = tile_m * TB + wm * 128, n0 = tile_n * TB + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + i * 16 + 4 * lg + r;
+        if (row < n && col < n) C[(size_t)row * ldc + col] = acc[i][j][r] * inv;
+      }
+    }
+}
+
 // C tile = sum over parts of the partial tiles of the split-K tail (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__ slab, int ntile, int ksplit, float* __restrict__ C,
                                                        int n, int ldc, int tiles_m, int tiles_n, int panel_off, int tile_base,
@@ -486,7 +617,17 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     while (ksplit > 1 && (size_t)ksplit * rem * TB * TB * sizeof(float) > slab_bytes) --ksplit;
   }
   if (ksplit <= 1) { full = total; rem = 0; }
+  // MCGRA_SPLIT_MFMA=32 keeps the 32 x 32 x 16 form of the 2-plane kernel (A/B measurements); default 16 x 16 x 32
+  static const bool m16 = [] { const char* e = getenv("MCGRA_SPLIT_MFMA"); return !(e && e[0] == '3'); }();
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
+    if (planes == 2 && m16) {
+      constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;
+      hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(split2_m16_kernel, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc,
+                         nkc / 2, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
+      return hipSuccess;
+    }
     if (planes == 2)
       return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
     return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);

@@ -1,41 +1,46 @@
-"""Per-phase time of ONE rank of a row-block sharded step, measured on a single GPU (no exchange; rows owned
-by other ranks hold stale data, which does not change the work done).  Usage: shard_emulate.py [world] [rank ...]"""
-import os, sys, json
+"""Per-rank compute time of the row-block sharded step, measured on ONE GPU: `world` row-block engines of the bench
+workload advance in lockstep (sharded.run_lockstep: the collectives are device copies between their arenas), so the
+wall time of a step is the SUM over ranks of their compute (+ the copies); divided by `world` it is what one rank of
+a real job spends computing per step -- the part of a multi-GPU step that is not RCCL time.  Also splits the time of
+rank 0 into sharded N x N passes and replicated node-level work by running the same step with world = 1.
+
+    python scripts/shard_emulate.py [--workload synthetic-10k-hsic] [--worlds 1,2,4,8] [--steps 6]
+"""
+import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import mcgra_loader
 pkg = mcgra_loader.load()
 import bench
-from mc_gra_amd.sharded import RowBlockPlan, HipShardBackend
+from mc_gra_amd import sharded as S
 
-world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-ranks = [int(x) for x in sys.argv[2:]] or [0, world - 1]
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="synthetic-10k-hsic")
+ap.add_argument("--worlds", default="1,2,4,8")
+ap.add_argument("--steps", type=int, default=6)
+a = ap.parse_args()
 dev = torch.device("cuda:0")
-wl = "synthetic-10k-hsic"
-n = bench.WORKLOADS[wl][0]
-res = {}
-for r in ranks:
-    plan = RowBlockPlan(n, world, r)
-    eng, _, _ = bench.build_engine(pkg, torch, dev, wl, 0, row_begin=plan.row_begin, row_end=plan.row_end)
-    b = HipShardBackend(eng, plan)
-    for name in ("KX", "KY", "G_adjn", "G_A1"):
-        b.exchanged[name].zero_()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    acc = [0.0] * 4
-    for it in range(6):
-        for k in range(4):
-            ev[k].record()
-            b.phase(k)
-        ev[4].record()
-        torch.cuda.synchronize()
-        if it >= 2:
-            for k in range(4):
-                acc[k] += ev[k].elapsed_time(ev[k + 1]) / 4
-    res[f"rank{r}"] = {"rows": [plan.row_begin, min(plan.row_end, n)], "phase_ms": [round(x, 3) for x in acc],
-                       "total_ms": round(sum(acc), 3)}
-    del eng, b
+n = bench.WORKLOADS[a.workload][0]
+out = {"workload": a.workload, "what": __doc__.split("\n\n")[0], "rows": []}
+for world in [int(x) for x in a.worlds.split(",")]:
+    plans = [S.RowBlockPlan(n, world, r) for r in range(world)]
+    bks = [S.HipShardBackend(bench.build_engine(pkg, torch, dev, a.workload, 0, plan=p)[0], p) for p in plans]
+    for _ in range(2):
+        S.run_lockstep(bks, S.SHARD_STEP); S.run_lockstep(bks, S.SHARD_MONITOR)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nex = 0
+    for _ in range(a.steps):
+        nex += S.run_lockstep(bks, S.SHARD_STEP); nex += S.run_lockstep(bks, S.SHARD_MONITOR)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    row = {"world": world, "rows_per_rank": plans[0].rows_per_rank, "sum_over_ranks_ms": 1e3 * dt,
+           "per_rank_compute_ms": 1e3 * dt / world, "collectives_per_step": nex / a.steps,
+           "alltoall_bytes_per_rank": 4 * world * plans[0].rows_per_rank ** 2 if world > 1 else 0,
+           "allgather_node_bytes_per_rank": plans[0].n_pad * 64 * 4}
+    out["rows"].append(row)
+    print(json.dumps(row), flush=True)
+    del bks
     torch.cuda.empty_cache()
-blk = plan.rows_per_rank * eng_ld if (eng_ld := ((n + 3) // 4) * 4) else 0
-res["exchange_bytes_per_rank_per_step"] = 4 * 4 * plan.rows_per_rank * eng_ld * (world - 1)
-print(json.dumps({"world": world, **res}))
+print(json.dumps(out))
