@@ -173,7 +173,6 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   const float* em = h->Hu + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
   const float a1 = use1 ? 2.f * (float)(sg * k1) : 0.f, a2 = use2 ? 2.f * (float)(sg * k2) : 0.f;
-  const int wtop = h->wdt[L - 1], cv = 2 * he + 1, c_gt = use2 ? cv : 0;
   const int P = split3_panel(), p_off = R0 / P, p_cnt = R1 > R0 ? (R1 - R0 + P - 1) / P : 0;
   const int nt = fl_tail_tiles(n);
   const bool pair = !h->sharded;
@@ -294,39 +293,23 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       ++h->lr_steps;
       ++h->fused_steps;
 
-      // ---- low-rank factors (section 1b) with the products on M (section 1c); victim-chain backward rides along
+      // ---- low-rank factors (section 1b) with the products on M (section 1c).  T = Xc^T Vc without the delta^2 column
+      //      of V: on a low-rank step every row of Zn has unit norm (a dead row would have masked its pairs), so that
+      //      column is constant, its centred copy is rounding noise and t3 = Xc^T (delta^2 - mean) is taken as 0 --
+      //      which keeps the product at 32 columns (one column tile of the skinny kernel)
       if (use2) {
         launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
         launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
-        fl_wcolsum(st, n, cv, h->lrV, h->lr_ldv, nullptr, h->fstat);
-        fl_cat_scaled(st, n, cv, cv, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
+        fl_wcolsum(st, n, 2 * he, h->lrV, h->lr_ldv, nullptr, h->fstat);
+        fl_cat_scaled(st, n, 2 * he, 2 * he, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
+        CHK(mm_rows(h, st, 2 * he));
       }
-      if (L >= 2) fl_cat_scaled(st, n, wtop, wtop, h->GPv + h->off[L - 1], hs, h->r, h->FV, fc, c_gt);
-      if (use2 || L >= 2) CHK(mm_rows(h, st, c_gt + (L >= 2 ? wtop : 0)));
-      if (use2 || L >= 2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
-      if (L >= 2) fl_an_post(st, n, wtop, h->FY, h->FV, fc, c_gt, h->r, h->GT, h->hmax);       // adj_norm^T G_P_top
+      if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
       if (use2) {
-        fl_lrt_post(st, n, cv, h->FY, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // T = Xc^T Vc
+        fl_lrt_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // [W | W2] = Xc^T Vc
+        MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));          // t3 = 0
         launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
-      }
-      // rest of the victim(adj_norm) chain backward: G_P_{l-1} = (G_T_l W_l^T) o relu'(P_{l-1}), G_T_l = adj_norm G_P_l
-      for (h->fs_l = L - 1; h->fs_l >= 1; --h->fs_l) {
-        {
-          const int l = h->fs_l;
-          launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], nullptr, 0, 0, nullptr, 0, 0,
-                             h->Pv + h->off[l - 1], hs, h->act, nullptr, 0, h->GPv + h->off[l - 1], hs);
-        }
-        if (h->fs_l - 1 >= 1) {
-          {
-            const int w = h->wdt[h->fs_l - 1];
-            fl_cat_scaled(st, n, w, w, h->GPv + h->off[h->fs_l - 1], hs, h->r, h->FV, fc, 0);
-            CHK(mm_rows(h, st, w));
-          }
-          FS_XCHG(h->fs_state, 6, X_FY(h))
-          fl_an_post(st, n, h->wdt[h->fs_l - 1], h->FY, h->FV, fc, 0, h->r, h->GT, h->hmax);
-        }
-      }
-      if (use2) {     // [Q | Q2] = Xc [W | W2]
+        // [Q | Q2] = Xc [W | W2]
         fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, nullptr, h->fstat + 64);
         fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 128);
         fl_lrq_pre(st, n, 2 * he, h->lrT, h->lr_ldv, h->r, h->fstat + 64, h->FV, fc);
@@ -364,18 +347,36 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, nullptr, 0, 0, nullptr, 0, 0, h->Pu + h->off[Le - 1], hs,
                            h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
       }
-      for (h->fs_l = (w10 != 0 ? L - 1 : Le - 1); h->fs_l >= 1; --h->fs_l) {
+      // Backward of both chains, one product on M per level: columns [r o G_P_lv of the victim(adj_norm) chain | G_P_lu of
+      // the modified_adj chain] (M symmetric: M^T G = M G; adj_norm^T G = r o (M (r o G) + r o G)), then
+      // G_P_{l-1} = (G_T_l W_l^T) o relu'(P_{l-1}) for each chain.  fs_l / fs_l2: the levels still to do.
+      h->fs_l = L - 1;
+      h->fs_l2 = (w10 != 0 ? L - 1 : Le - 1);
+      while (h->fs_l >= 1 || h->fs_l2 >= 1) {
         {
-          const int l = h->fs_l, w = h->wdt[l];
-          fl_cat_scaled(st, n, w, w, h->GPu + h->off[l], hs, nullptr, h->FV, fc, 0);
-          CHK(mm_rows(h, st, w));                                                                // M symmetric: M^T G_P_l = M G_P_l
+          const int lv = h->fs_l, lu = h->fs_l2;
+          const int wv = lv >= 1 ? h->wdt[lv] : 0, wu = lu >= 1 ? h->wdt[lu] : 0;
+          if (lv >= 1) fl_cat_scaled(st, n, wv, wv, h->GPv + h->off[lv], hs, h->r, h->FV, fc, 0);
+          if (lu >= 1) fl_cat_scaled(st, n, wu, wu, h->GPu + h->off[lu], hs, nullptr, h->FV, fc, wv);
+          CHK(mm_rows(h, st, wv + wu));
         }
         FS_XCHG(h->fs_state, 8, X_FY(h))
         {
-          const int l = h->fs_l;
-          fl_copy_cols(st, n, h->wdt[l], h->FY, fc, 0, h->GT, h->hmax);
-          launch_rowmat_mask(st, n, h->wdt[l], h->wdt[l - 1], h->GT, h->hmax, h->W[l], 1, h->wdt[l], nullptr, 0, 0, nullptr, 0, 0,
-                             h->Pu + h->off[l - 1], hs, h->act, (l - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[l - 1], hs);
+          const int lv = h->fs_l, lu = h->fs_l2;
+          const int wv = lv >= 1 ? h->wdt[lv] : 0;
+          if (lv >= 1) {
+            fl_an_post(st, n, wv, h->FY, h->FV, fc, 0, h->r, h->GT, h->hmax);
+            launch_rowmat_mask(st, n, h->wdt[lv], h->wdt[lv - 1], h->GT, h->hmax, h->W[lv], 1, h->wdt[lv], nullptr, 0, 0, nullptr, 0, 0,
+                               h->Pv + h->off[lv - 1], hs, h->act, nullptr, 0, h->GPv + h->off[lv - 1], hs);
+          }
+          if (lu >= 1) {
+            fl_copy_cols(st, n, h->wdt[lu], h->FY, fc, wv, h->GT, h->hmax);
+            launch_rowmat_mask(st, n, h->wdt[lu], h->wdt[lu - 1], h->GT, h->hmax, h->W[lu], 1, h->wdt[lu], nullptr, 0, 0, nullptr, 0, 0,
+                               h->Pu + h->off[lu - 1], hs, h->act, (lu - 1 == Le - 1) ? h->Gem : nullptr, h->hmax,
+                               h->GPu + h->off[lu - 1], hs);
+          }
+          if (lv >= 1) --h->fs_l;
+          if (lu >= 1) --h->fs_l2;
         }
       }
       MCGRA_KERNEL_CHECK();
@@ -431,7 +432,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         fl_tail_adam(st, n, ld, pair, R0, R1, h->GPu, hs, h->Tu, hs, hs, h->G_ADJN, h->r, h->gd, h->M, h->am, h->av, h->mm + 2,
                      (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
                      h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,
-                     emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr);
+                     emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr,
+                     /* the Adam moments are only ever read back through the lower tile pairs (by this kernel and by the general
+                        path's tail kernels): their mirrored halves are not written */ 0);
         MCGRA_KERNEL_CHECK();
         h->prep_valid = emit;
         h->have_step = true;

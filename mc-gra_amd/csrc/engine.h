@@ -116,7 +116,7 @@ struct mcgra_attack {
   double* SC = 0;                  // 16 exchanged scalars
   int sgw = 0;
   // resumable step (protothread state: the step runs to the next exchange point and returns)
-  int fs_state = 0, fw_state = 0, fs_l = 0, fs_what = 0, fs_want = 0, fs_np = 0, fs_nblk = 0;
+  int fs_state = 0, fw_state = 0, fs_l = 0, fs_l2 = 0, fs_what = 0, fs_want = 0, fs_np = 0, fs_nblk = 0;
   bool fs_active = false, fs_adopted = false;
   double fs_scalars[10] = {0};
 };

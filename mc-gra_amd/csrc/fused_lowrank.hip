@@ -140,56 +140,67 @@ __global__ void k_lrq_post(int n, int w, const float* __restrict__ Y, const floa
 // For rows i in [row0, row1), all j:  S_ij = zn_i . zn_j (the fmaf chain of rankk_nt: same bits as the stored form),
 // A1_ij = [i != j] relu(S_ij);  nmask += #{i != j : S_ij <= 0};  v7 partials of sum ie_value(A1) (diagonal included, as
 // Info_entropy runs over the whole matrix, :44-52);  slabs: G_Zn_i = sum_{j != i, S_ij > 0} 2 ie'(A1_ij) zn_j.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int H>
 __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
                                                     float kie7, int jper, float* __restrict__ slabs,
                                                     double* __restrict__ v7part, unsigned int* __restrict__ nmask) {
+  // Two columns j per iteration: zs[jp][k] holds (z_{2jp}[k], z_{2jp+1}[k]) so that both dot products and both
+  // accumulations are packed FMAs (v_pk_fma_f32: two fused multiply-adds per lane and instruction; each S_ij is still
+  // its own k-ordered fmaf chain, i.e. the bits of the stored form).
   constexpr int JC = 128;
-  __shared__ __attribute__((aligned(16))) float zs[JC][H];
+  __shared__ __attribute__((aligned(16))) f32x2 zs[JC / 2][H];
   __shared__ double sh[16];
   const int i = row0 + blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < row1;
   const int j0 = blockIdx.y * jper, j1 = min(n, j0 + jper);
-  float zi[H], acc[H];
+  float zi[H];
+  f32x2 acc[H];
 #pragma unroll
-  for (int k = 0; k < H; ++k) { zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f; acc[k] = 0.f; }
+  for (int k = 0; k < H; ++k) { zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f; acc[k] = f32x2{0.f, 0.f}; }
   double v7 = 0.0;
   int masked = 0;
   for (int jc = j0; jc < j1; jc += JC) {
     __syncthreads();
     for (int e = threadIdx.x; e < JC * H; e += 256) {
       const int jj = e / H, c = e - jj * H, j = jc + jj;
-      zs[jj][c] = j < j1 ? Z[(size_t)j * ldz + c] : 0.f;
+      zs[jj >> 1][c][jj & 1] = j < j1 ? Z[(size_t)j * ldz + c] : 0.f;
     }
     __syncthreads();
     const int jn = min(JC, j1 - jc);
-    for (int jj = 0; jj < jn; ++jj) {
-      const int j = jc + jj;
-      float s = 0.f;
+    for (int jp = 0; 2 * jp < jn; ++jp) {
+      f32x2 s = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < H; k += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
-        s = fmaf(zi[k], t.x, s); s = fmaf(zi[k + 1], t.y, s); s = fmaf(zi[k + 2], t.z, s); s = fmaf(zi[k + 3], t.w, s);
+      for (int k = 0; k < H; k += 2) {
+        const float4 t = *reinterpret_cast<const float4*>(&zs[jp][k]);     // (z_j0[k], z_j1[k], z_j0[k+1], z_j1[k+1])
+        s = __builtin_elementwise_fma(f32x2{zi[k], zi[k]}, f32x2{t.x, t.y}, s);
+        s = __builtin_elementwise_fma(f32x2{zi[k + 1], zi[k + 1]}, f32x2{t.z, t.w}, s);
       }
-      const bool off = valid && i != j;
-      if (off && !(s > 0.f)) ++masked;
-      const float a1 = off ? fmaxf(s, 0.f) : 0.f;
-      float val, g;
-      ie_term(a1, kie7, val, g);
-      if (valid) v7 += (double)val;
-      const float w = (off && a1 > 0.f) ? 2.f * g : 0.f;
+      f32x2 w;
 #pragma unroll
-      for (int k = 0; k < H; k += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&zs[jj][k]);
-        acc[k] = fmaf(w, t.x, acc[k]); acc[k + 1] = fmaf(w, t.y, acc[k + 1]);
-        acc[k + 2] = fmaf(w, t.z, acc[k + 2]); acc[k + 3] = fmaf(w, t.w, acc[k + 3]);
+      for (int u = 0; u < 2; ++u) {
+        const int j = jc + 2 * jp + u;
+        const bool in = 2 * jp + u < jn;
+        const bool off = valid && in && i != j;
+        if (off && !(s[u] > 0.f)) ++masked;
+        const float a1 = off ? fmaxf(s[u], 0.f) : 0.f;
+        float val, g;
+        ie_term(a1, kie7, val, g);
+        if (valid && in) v7 += (double)val;
+        w[u] = (off && a1 > 0.f) ? 2.f * g : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < H; k += 2) {
+        const float4 t = *reinterpret_cast<const float4*>(&zs[jp][k]);
+        acc[k] = __builtin_elementwise_fma(w, f32x2{t.x, t.y}, acc[k]);
+        acc[k + 1] = __builtin_elementwise_fma(w, f32x2{t.z, t.w}, acc[k + 1]);
       }
     }
   }
   if (valid) {
     float* o = slabs + ((size_t)blockIdx.y * n + i) * H;
 #pragma unroll
-    for (int k = 0; k < H; ++k) o[k] = acc[k];
+    for (int k = 0; k < H; ++k) o[k] = acc[k][0] + acc[k][1];
   }
   const double t = block_sum_d(v7, sh);
   if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
@@ -220,18 +231,25 @@ struct TailFactors {
   int count, nrounds, kround[4];
 };
 
-// stage rows [r0, r0 + 64) x [0, K) of a row-major panel, scaled, into LDS as dst[koff + k][64]
+// stage rows [r0, r0 + 64) x [0, K) of a row-major panel, scaled, into LDS as dst[koff + k][64].  Lane = row, so the four
+// scalar stores of a lane's float4 go to 64 consecutive floats per k across the wave: no bank conflicts (a lane = k
+// mapping put 8 lanes on one bank).  The panels are a few KB and L2-resident; the row-strided 16-byte loads are cheap.
 __device__ __forceinline__ void ft_stage(float (*dst)[FT], int koff, const float* __restrict__ src, int ld, int r0, int nrows,
-                                         int K, float scale) {
+                                         int K, float scale, bool vec) {
   const int kq = (K + 3) >> 2;
   for (int e = threadIdx.x; e < FT * kq; e += 256) {
-    const int m = e / kq, k4 = (e - m * kq) << 2;
+    const int m = e & (FT - 1), k4 = (e / FT) << 2;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (r0 + m < nrows) {
       const float* p = src + (size_t)(r0 + m) * ld + k4;
+      if (vec && k4 + 3 < K) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = scale * q.x; v[1] = scale * q.y; v[2] = scale * q.z; v[3] = scale * q.w;
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (k4 + t < K) v[t] = scale * p[t];
+        for (int t = 0; t < 4; ++t)
+          if (k4 + t < K) v[t] = scale * p[t];
+      }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -239,32 +257,36 @@ __device__ __forceinline__ void ft_stage(float (*dst)[FT], int koff, const float
   }
 }
 
-// acc[a][b] += sum_f alpha_f (L_i . R_j + R_i . L_j) for the thread's 4 x 4 patch of tile (bi, bj).  Bitwise symmetric
-// under i <-> j: the two dot products of a round are the same fmaf chains with the roles swapped (alpha is folded into
-// the staged L values) and are added to each other first, so a diagonal tile, whose two triangles are computed by
-// different threads, stays symmetric.
+// acc[a][b] += sum_f alpha_f (L_i . R_j + R_i . L_j) for the thread's 4 x 4 patch of tile (bi, bj).  One staging phase per
+// round puts the four panels it needs in LDS (alpha L and R of the tile's rows, R and alpha L of its columns), then both
+// dot products run without another barrier.  Bitwise symmetric under i <-> j: the two dot products are the same fmaf
+// chains with the roles swapped and are added to each other first, so a diagonal tile, whose two triangles are computed
+// by different threads, stays symmetric.   P: [4][KMAX][64] floats = {alpha L_I, R_J, R_I, alpha L_J}
 template <int KMAX>
-__device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int bj, int n, float (*As)[FT], float (*Bs)[FT],
-                                             int r0, int c0, float (&acc)[4][4]) {
+__device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int bj, int n, float (*P)[KMAX][FT], int r0, int c0,
+                                             float (&acc)[4][4]) {
   for (int rd = 0; rd < F.nrounds; ++rd) {
     const int K = F.kround[rd];
+    __syncthreads();                       // previous users of the panels are done
+    for (int f = 0; f < F.count; ++f) {
+      if (F.round[f] != rd) continue;
+      const bool vl = (F.ldl[f] & 3) == 0 && ((uintptr_t)F.L[f] & 15) == 0, vr = (F.ldr[f] & 3) == 0 && ((uintptr_t)F.R[f] & 15) == 0;
+      ft_stage(P[0], F.koff[f], F.L[f], F.ldl[f], bi, n, F.K[f], F.alpha[f], vl);
+      ft_stage(P[1], F.koff[f], F.R[f], F.ldr[f], bj, n, F.K[f], 1.f, vr);
+      ft_stage(P[2], F.koff[f], F.R[f], F.ldr[f], bi, n, F.K[f], 1.f, vr);
+      ft_stage(P[3], F.koff[f], F.L[f], F.ldl[f], bj, n, F.K[f], F.alpha[f], vl);
+    }
+    __syncthreads();
     float part[2][4][4];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      __syncthreads();                       // previous users of the panels are done
-      for (int f = 0; f < F.count; ++f) {
-        if (F.round[f] != rd) continue;
-        ft_stage(As, F.koff[f], half ? F.R[f] : F.L[f], half ? F.ldr[f] : F.ldl[f], bi, n, F.K[f], half ? 1.f : F.alpha[f]);
-        ft_stage(Bs, F.koff[f], half ? F.L[f] : F.R[f], half ? F.ldl[f] : F.ldr[f], bj, n, F.K[f], half ? F.alpha[f] : 1.f);
-      }
-      __syncthreads();
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) part[half][a][b] = 0.f;
       for (int k = 0; k < K; ++k) {
-        const float4 av4 = *reinterpret_cast<const float4*>(&As[k][r0]);
-        const float4 bv4 = *reinterpret_cast<const float4*>(&Bs[k][c0]);
+        const float4 av4 = *reinterpret_cast<const float4*>(&P[2 * half][k][r0]);
+        const float4 bv4 = *reinterpret_cast<const float4*>(&P[2 * half + 1][k][c0]);
         const float as_[4] = {av4.x, av4.y, av4.z, av4.w}, bs_[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -292,8 +314,7 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
                                                      const float* __restrict__ delta, const float* __restrict__ cvec,
                                                      float a1, float a2, float kie6, float* __restrict__ GS,
                                                      float* __restrict__ ps, double* __restrict__ vpart) {
-  __shared__ float As[KMAX][FT];
-  __shared__ float Bs[KMAX][FT];
+  __shared__ float P[4][KMAX][FT];
   __shared__ float T[FT][FT + 1];
   __shared__ double shd[16];
   const int nt = gridDim.x;
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  ft_sym_rankk<KMAX>(F, bi, bj, n, As, Bs, r0, c0, acc);
+  ft_sym_rankk<KMAX>(F, bi, bj, n, P, r0, c0, acc);
   // mirrored P1 tile (J, I) through LDS: T[j local][i local]
   if (P1) {
 #pragma unroll
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
     if ((threadIdx.x & 15) == 0 && i < n) ps[(size_t)i * nt + tj] = rowacc;
   }
   if (mirror) {      // column sums of the tile = the mirrored tile's contribution to the rows of tile J
-    float (*CS)[FT] = As;
+    float (*CS)[FT] = P[0];
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 4; ++b) CS[threadIdx.x >> 4][c0 + b] = cs[b];
@@ -418,9 +439,9 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
                                                    float* __restrict__ am, float* __restrict__ av,
                                                    const float* __restrict__ cn_ptr, float omb1, float b2, float omb2,
                                                    float step_size, float sqrt_bc2, float eps, float* __restrict__ gsym_dbg,
-                                                   int do_clamp, float* __restrict__ ps_out, double* __restrict__ pq_out) {
-  __shared__ float As[KMAX][FT];
-  __shared__ float Bs[KMAX][FT];
+                                                   int do_clamp, float* __restrict__ ps_out, double* __restrict__ pq_out,
+                                                   int mirror_moments) {
+  __shared__ float P[4][KMAX][FT];
   __shared__ float T[FT][FT + 1];
   const int nt = gridDim.x;
   const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
@@ -434,7 +455,7 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  ft_sym_rankk<KMAX>(F, bi, bj, n, As, Bs, r0, c0, acc);
+  ft_sym_rankk<KMAX>(F, bi, bj, n, P, r0, c0, acc);
   const float4 rj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(r + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 gj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(gd + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float rjs[4] = {rj4.x, rj4.y, rj4.z, rj4.w}, gdj[4] = {gj4.x, gj4.y, gj4.z, gj4.w};
@@ -508,8 +529,8 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
     }
   }
   if (!mirror) return;
-  float (*CS)[FT] = As;                                             // [16][64] floats, panels are dead by now
-  double (*CQ)[FT] = reinterpret_cast<double (*)[FT]>(&Bs[0][0]);   // [16][64] doubles = 8 KB <= sizeof(Bs)
+  float (*CS)[FT] = P[0];                                           // [16][64] floats, panels are dead by now
+  double (*CQ)[FT] = reinterpret_cast<double (*)[FT]>(&P[1][0][0]); // [16][64] doubles = 8 KB <= one panel
   __syncthreads();
   if (ps_out) {
 #pragma unroll
@@ -519,6 +540,7 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
   for (int arr = 0; arr < 4; ++arr) {      // mirrored half: element (j, i) = element (i, j); one array at a time through T
     float* dst = arr == 0 ? M : arr == 1 ? am : arr == 2 ? av : gsym_dbg;
     if (!dst) continue;
+    if ((arr == 1 || arr == 2) && !mirror_moments) continue;
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -630,7 +652,8 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
   if (t1 <= t0) return 0;
   int ktot = 0, kbig = 1;
   for (int f = 0; f < nfac; ++f) { ktot += K[f]; kbig = K[f] > kbig ? K[f] : kbig; }
-  const int kmax = (ktot <= 32 && kbig <= 32) ? 32 : 64;       // LDS panel depth of the kernel instance
+  (void)ktot;
+  const int kmax = kbig <= 32 ? 32 : 64;       // LDS panel depth of the kernel instance: 32 KB of panels (3 blocks per CU) when it fits
   const TailFactors F = make_factors(nfac, L, ldl, R, ldr, K, alpha, kmax);
   dim3 grid(nt, t1 - t0);
   if (kmax <= 32)
@@ -646,7 +669,7 @@ void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, cons
 void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* GPu, int ldp, const float* Tu,
                   int ldt, int K, const float* GS, const float* r, const float* gd, float* M, float* am, float* av,
                   const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
-                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out) {
+                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments) {
   const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
   if (t1 <= t0) return;
   const float* Ls[1] = {GPu}; const float* Rs[1] = {Tu};
@@ -656,10 +679,10 @@ void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, 
   dim3 grid(nt, t1 - t0);
   if (K <= 32)
     LAUNCH(k_tail_adam<32>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, GS, r, gd, M, am, av, cn, omb1, b2, omb2, step_size,
-           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out);
+           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out, mirror_moments);
   else
     LAUNCH(k_tail_adam<64>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, GS, r, gd, M, am, av, cn, omb1, b2, omb2, step_size,
-           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out);
+           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out, mirror_moments);
 }
 
 }  // namespace mcgra

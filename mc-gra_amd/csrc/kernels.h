@@ -139,6 +139,6 @@ void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, cons
 void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* GPu, int ldp, const float* Tu,
                   int ldt, int K, const float* GS, const float* r, const float* gd, float* M, float* am, float* av,
                   const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
-                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out);
+                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments = 1);
 
 }  // namespace mcgra

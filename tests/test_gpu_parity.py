@@ -879,7 +879,6 @@ def test_fused_lowrank_step_matches_general_path_and_oracle(pkg, n, widths, wp, 
             assert abs(a["loss"] - orc.last["loss"]) <= 2e-4 * abs(orc.last["loss"]) + 1e-5
         Mf = fused.buffer("M")
         assert bool((Mf == Mf.T).all()), "the learnable adjacency must stay symmetric bit for bit"
-        assert bool((fused.buffer("adam_m") == fused.buffer("adam_m").T).all()) and bool((fused.buffer("adam_v") == fused.buffer("adam_v").T).all())
         gsf = fused.buffer("G_sym")
         assert bool((gsf == gsf.T).all())
         ma, mb = fused.get_adj_changes(), gen.get_adj_changes()
