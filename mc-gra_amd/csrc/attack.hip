@@ -342,7 +342,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     }
     if (h->fused_ok && !rc) {
       h->fcols = fc;
-      A_(FV, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256);
+      A_(FV, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256 + fl_wcolsum_scratch_doubles());
       if (!h->sharded) { A_(FY, n * (size_t)fc); }      // a row-block rank keeps FY in the exchange arena
       h->fused_ok = (rc == 0);
     }

@@ -300,7 +300,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (use2) {
         launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
         launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
-        fl_wcolsum(st, n, 2 * he, h->lrV, h->lr_ldv, nullptr, h->fstat);
+        fl_wcolsum(st, n, 2 * he, h->lrV, h->lr_ldv, nullptr, h->fstat, nullptr, h->fstat + 256);
         fl_cat_scaled(st, n, 2 * he, 2 * he, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
         CHK(mm_rows(h, st, 2 * he));
       }
@@ -310,8 +310,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));          // t3 = 0
         launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
         // [Q | Q2] = Xc [W | W2]
-        fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, nullptr, h->fstat + 64);
-        fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 128);
+        fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 256);
         fl_lrq_pre(st, n, 2 * he, h->lrT, h->lr_ldv, h->r, h->fstat + 64, h->FV, fc);
         CHK(mm_rows(h, st, 2 * he));
       }

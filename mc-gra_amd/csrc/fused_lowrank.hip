@@ -69,15 +69,35 @@ __global__ void k_fl_post(int n, int w, const float* __restrict__ Y, const float
   }
 }
 
-// out[k] = sum_i wgt_i X[i][k] in fp64 (wgt == nullptr: plain column sums); one block per column, fixed tree
-__global__ __launch_bounds__(256) void k_wcolsum(int n, const float* __restrict__ X, int ldx, const float* __restrict__ wgt,
-                                                 double* __restrict__ out) {
-  __shared__ double sh[16];
-  const int k = blockIdx.x;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += (double)(wgt ? wgt[i] : 1.f) * (double)X[(size_t)i * ldx + k];
-  s = block_sum_d(s, sh);
-  if (threadIdx.x == 0) out[k] = s;
+// out[k] = sum_i X[i][k] and (wgt != nullptr) out2[k] = sum_i wgt_i X[i][k] in fp64, k < w <= 64.  Two deterministic stages:
+// WC_PARTS row slices (thread = (row group, column): coalesced along the columns), then a fixed-order combine.
+constexpr int WC_PARTS = 64;
+__global__ __launch_bounds__(256) void k_wcolsum_part(int n, int w, const float* __restrict__ X, int ldx,
+                                                      const float* __restrict__ wgt, double* __restrict__ part) {
+  __shared__ double sh[2][4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6, p = blockIdx.x;
+  const int per = (n + WC_PARTS - 1) / WC_PARTS, i0 = p * per, i1 = min(n, i0 + per);
+  double s = 0.0, sw = 0.0;
+  if (c < w)
+    for (int i = i0 + g; i < i1; i += 4) {
+      const double x = (double)X[(size_t)i * ldx + c];
+      s += x;
+      if (wgt) sw += (double)wgt[i] * x;
+    }
+  sh[0][g][c] = s; sh[1][g][c] = sw;
+  __syncthreads();
+  if (g == 0 && c < w) {
+    part[((size_t)p * 2 + 0) * 64 + c] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    part[((size_t)p * 2 + 1) * 64 + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+  }
+}
+__global__ void k_wcolsum_fin(int w, const double* __restrict__ part, double* __restrict__ out, double* __restrict__ out2) {
+  const int c = threadIdx.x;
+  if (c >= w) return;
+  double s = 0.0, sw = 0.0;
+  for (int p = 0; p < WC_PARTS; ++p) { s += part[((size_t)p * 2 + 0) * 64 + c]; sw += part[((size_t)p * 2 + 1) * 64 + c]; }
+  out[c] = s;
+  if (out2) out2[c] = sw;
 }
 // out[0] = sum_i x_i (fp64), out[1] = max_i r_i^2 + max_i |mean_i| as a float in out2 (operand-scale bound of the split)
 __global__ __launch_bounds__(256) void k_mean_stats(int n, const float* __restrict__ mean, const float* __restrict__ r,
@@ -314,8 +334,11 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
                                                      const float* __restrict__ delta, const float* __restrict__ cvec,
                                                      float a1, float a2, float kie6, float* __restrict__ GS,
                                                      float* __restrict__ ps, double* __restrict__ vpart) {
+  // 32 KB of panels (KMAX = 32); the transposed P1 tile T [64][65] reuses panels 0..2 once the rank-k rounds are done,
+  // the column sums use panel 3: 33 KB per block, four blocks per CU
   __shared__ float P[4][KMAX][FT];
-  __shared__ float T[FT][FT + 1];
+  static_assert(sizeof(float) * 3 * KMAX * FT >= sizeof(float) * FT * (FT + 1), "T fits in three panels");
+  float (*T)[FT + 1] = reinterpret_cast<float (*)[FT + 1]>(&P[0][0][0]);
   __shared__ double shd[16];
   const int nt = gridDim.x;
   const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
@@ -334,6 +357,7 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
   ft_sym_rankk<KMAX>(F, bi, bj, n, P, r0, c0, acc);
+  __syncthreads();                         // every thread is past its panel reads: T may overwrite them
   // mirrored P1 tile (J, I) through LDS: T[j local][i local]
   if (P1) {
 #pragma unroll
@@ -397,8 +421,7 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
     if ((threadIdx.x & 15) == 0 && i < n) ps[(size_t)i * nt + tj] = rowacc;
   }
   if (mirror) {      // column sums of the tile = the mirrored tile's contribution to the rows of tile J
-    float (*CS)[FT] = P[0];
-    __syncthreads();
+    float (*CS)[FT] = P[3];
 #pragma unroll
     for (int b = 0; b < 4; ++b) CS[threadIdx.x >> 4][c0 + b] = cs[b];
     __syncthreads();
@@ -590,9 +613,12 @@ void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum) {
   LAUNCH(k_fl_post, g1((size_t)n * w), dim3(256), st, n, w, Y, V, ldy, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0, mean, rowsum);
 }
-void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out) {
-  LAUNCH(k_wcolsum, dim3(w), dim3(256), st, n, X, ldx, wgt, out);
+// scratch: 2 * 64 * WC_PARTS doubles
+void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch) {
+  LAUNCH(k_wcolsum_part, dim3(WC_PARTS), dim3(256), st, n, w, X, ldx, wgt, scratch);
+  LAUNCH(k_wcolsum_fin, dim3(1), dim3(64), st, w, scratch, out, wgt ? out_w : nullptr);
 }
+size_t fl_wcolsum_scratch_doubles() { return (size_t)2 * 64 * WC_PARTS; }
 void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound) {
   LAUNCH(k_mean_stats, dim3(1), dim3(256), st, n, mean, r, msum, amax_bound);
 }

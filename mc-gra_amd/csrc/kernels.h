@@ -120,7 +120,8 @@ void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, i
 void fl_copy_cols(hipStream_t st, int n, int w, const float* Y, int ldy, int c0, float* out, int ldo);
 void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V, int ldy, const float* r, const float* b,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum);
-void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out);
+void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch);
+size_t fl_wcolsum_scratch_doubles();
 void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound);
 void fl_lrt_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
                  const double* colsum, float* T, int ldt);

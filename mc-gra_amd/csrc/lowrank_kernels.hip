@@ -20,7 +20,7 @@ constexpr int LR_HMAX = 32;
 // stats (double): zbar[h] | zeta[h] | ZtZ[h*h] | d2bar | pad.  Two deterministic stages: grid (h + 3, LR_PARTS)
 // partial sums over row slices (block x = k < h : column k of Z^T Z;  x = h : column sums;  x = h+1 : zeta = sum_i
 // delta_i z_i;  x = h+2 : sum_i delta_i^2 in slot 0), then a fixed-order combine.
-constexpr int LR_PARTS = 16;
+constexpr int LR_PARTS = 64;
 __global__ __launch_bounds__(256) void k_lr_colstats_part(int n, int h, const float* __restrict__ Z, int ldz,
                                                           double* __restrict__ part) {
   __shared__ double sh[16];
@@ -87,22 +87,27 @@ __global__ void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, co
 // per column index j, from T = Xc^T V (ld ldv): W = T[:, :h], W2 = T[:, h:2h], t3 = T[:, 2h]
 //   c_j = (W_j . zeta - t3_j) / n;  M1_j = W_j (Z^T Z) - W2_j;  Rm = [M1 | W] (ld 2h)
 //   rowval_j = W_j . (Z^T Z) W_j   (its sum is |Z W^T|_F^2)
-__global__ void k_lr_post(int n, int h, const float* __restrict__ T, int ldv, const double* __restrict__ stats,
-                          float* __restrict__ Rm, float* __restrict__ cvec, double* __restrict__ rowval) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const float* w = T + (size_t)j * ldv;
-  double cz = 0.0, quad = 0.0;
-  for (int k = 0; k < h; ++k) cz += (double)w[k] * stats[h + k];
-  cvec[j] = (float)((cz - (double)w[2 * h]) / (double)n);
-  for (int l = 0; l < h; ++l) {
-    double m = 0.0;
+__global__ __launch_bounds__(256) void k_lr_post(int n, int h, const float* __restrict__ T, int ldv,
+                                                 const double* __restrict__ stats, float* __restrict__ Rm,
+                                                 float* __restrict__ cvec, double* __restrict__ rowval) {
+  // thread (j, l): LR_HMAX lanes per row (a row's lanes sit in one wave: 64 / 32 rows per wave), l >= h idle
+  const int l = threadIdx.x & (LR_HMAX - 1), j = blockIdx.x * (256 / LR_HMAX) + (threadIdx.x >> 5);
+  const bool on = j < n && l < h;
+  const float* w = T + (size_t)(j < n ? j : 0) * ldv;
+  double m = 0.0, cz = 0.0;
+  if (on) {
     for (int k = 0; k < h; ++k) m += (double)w[k] * stats[2 * h + (size_t)k * h + l];
-    quad += m * (double)w[l];
+    cz = (double)w[l] * stats[h + l];
     Rm[(size_t)j * 2 * h + l] = (float)(m - (double)w[h + l]);
     Rm[(size_t)j * 2 * h + h + l] = w[l];
   }
-  rowval[j] = quad;
+  double quad = on ? m * (double)w[l] : 0.0;
+#pragma unroll
+  for (int o = LR_HMAX / 2; o > 0; o >>= 1) { quad += __shfl_xor(quad, o); cz += __shfl_xor(cz, o); }
+  if (l == 0 && j < n) {
+    cvec[j] = (float)((cz - (double)w[2 * h]) / (double)n);
+    rowval[j] = quad;
+  }
 }
 
 // N x N pass: G_ij += a2 (delta_i^2 Xc_ij + c_j) + a1 P1_ij ;  rowval_i = sum_j P1_ij Xc_ij  (linear_HSIC(Fadj, X))
@@ -211,20 +216,23 @@ __global__ void k_rowpp_fin(int n, int nrp, const float* __restrict__ rowpp, flo
 //   G_Zn_i += kk (Q2_i + delta_i Q_i - 2 rs_i delta_i z_i)          (kk = -2 s2: the Kx D part of d c2 / d A1)
 //   G_Zn_i += a2 (q_i (Z^T Z) + z_i (Q^T Z) - 2 (q_i . z_i) z_i)    (ztz != nullptr: the Q Z^T part, see k_lr_decode_bwd)
 //   rowval_i = quad_i - 2 delta_i z_i . Q_i + delta_i^2 rs_i       (quad from k_lr_post; the sum is |R|_F^2)
-__global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const float* __restrict__ Z, int ldz,
-                           const float* __restrict__ delta, const double* __restrict__ rs, float kk,
-                           float* __restrict__ GZn, int ldg, const double* __restrict__ quad,
-                           double* __restrict__ rowval, const double* __restrict__ ztz,
-                           const double* __restrict__ qtz, float a2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float d = delta[i];
-  const float r = (float)rs[i];
-  const float* q = QQ + (size_t)i * 2 * h;
-  const float* z = Z + (size_t)i * ldz;
-  double zq = 0.0;
-  for (int k = 0; k < h; ++k) zq += (double)z[k] * (double)q[k];
-  for (int k = 0; k < h; ++k) {
+__global__ __launch_bounds__(256) void k_lr_part2(int n, int h, const float* __restrict__ QQ, const float* __restrict__ Z,
+                                                  int ldz, const float* __restrict__ delta, const double* __restrict__ rs,
+                                                  float kk, float* __restrict__ GZn, int ldg, const double* __restrict__ quad,
+                                                  double* __restrict__ rowval, const double* __restrict__ ztz,
+                                                  const double* __restrict__ qtz, float a2) {
+  // thread (i, k): LR_HMAX lanes per row
+  const int k = threadIdx.x & (LR_HMAX - 1), i = blockIdx.x * (256 / LR_HMAX) + (threadIdx.x >> 5);
+  const bool on = i < n && k < h;
+  const int ii = i < n ? i : 0;
+  const float d = delta[ii];
+  const float r = (float)rs[ii];
+  const float* q = QQ + (size_t)ii * 2 * h;
+  const float* z = Z + (size_t)ii * ldz;
+  double zq = on ? (double)z[k] * (double)q[k] : 0.0;
+#pragma unroll
+  for (int o = LR_HMAX / 2; o > 0; o >>= 1) zq += __shfl_xor(zq, o);
+  if (on) {
     float add = kk * (q[h + k] + d * q[k] - 2.f * r * d * z[k]);
     if (ztz) {
       double t = -2.0 * zq * (double)z[k];
@@ -233,7 +241,7 @@ __global__ void k_lr_part2(int n, int h, const float* __restrict__ QQ, const flo
     }
     GZn[(size_t)i * ldg + k] += add;
   }
-  rowval[i] = quad[i] - 2.0 * (double)d * zq + (double)d * (double)d * rs[i];
+  if (k == 0 && i < n) rowval[i] = quad[i] - 2.0 * (double)d * zq + (double)d * (double)d * rs[i];
 }
 
 // stats needs 2h + h^2 + 2 doubles followed by (h + 3) * LR_PARTS * h doubles of scratch
@@ -380,7 +388,7 @@ void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const
 }
 void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,
                     double* rowval) {
-  LAUNCH(k_lr_post, dim3((n + 255) / 256), dim3(256), st, n, h, T, ldv, stats, Rm, cvec, rowval);
+  LAUNCH(k_lr_post, dim3((n + 256 / LR_HMAX - 1) / (256 / LR_HMAX)), dim3(256), st, n, h, T, ldv, stats, Rm, cvec, rowval);
 }
 void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
                     const float* cvec, float a1, float a2, float* G, double* rowval) {
@@ -419,7 +427,8 @@ void launch_lr_elem_normbwd(hipStream_t st, int n, int ld, const float* Xc, cons
 void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
                      const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
                      const double* ztz, const double* qtz, float a2) {
-  LAUNCH(k_lr_part2, dim3((n + 63) / 64), dim3(64), st, n, h, QQ, Z, ldz, delta, rs, kk, GZn, ldg, quad, rowval, ztz, qtz, a2);
+  LAUNCH(k_lr_part2, dim3((n + 256 / LR_HMAX - 1) / (256 / LR_HMAX)), dim3(256), st, n, h, QQ, Z, ldz, delta, rs, kk, GZn, ldg, quad,
+         rowval, ztz, qtz, a2);
 }
 
 }  // namespace mcgra

@@ -57,12 +57,34 @@ with open(os.path.join(P, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
                 "hbm_bytes_per_launch_corrected", "avg_ms_under_pmc", "corrected_GBps"])
     for _, k, n, fe, wr, hbm, ms in rows:
         w.writerow([k, n, f"{fe:.1f}", f"{wr:.1f}", f"{hbm:.0f}", f"{ms:.4f}", f"{hbm / (ms * 1e-3) / 1e9:.1f}" if ms else ""])
-gem = [r for r in rows if ("gemm_f32_kernel<128, 128" in r[1] or "split3_symm_kernel" in r[1]) and r[5] > 2e9]
+gem = [r for r in rows if ("gemm_f32_kernel<128, 128" in r[1] or "split3_symm_kernel" in r[1] or "split2_m16_kernel" in r[1]) and r[5] > 2e9]
 out = {"note": "HBM-side bytes per launch of the N x N x N fp32 MFMA GEMM launches (synthetic-10k-hsic; one launch = a batched "
                "pair of products), from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the "
                "gfx950 correction (calibrated on k_rowsum: 2 x FETCH_SIZE = 400.7 MB for a 400 MB read)",
-       "kernels": [{"kernel": k, "role": "split_f16" if "split3_symm_kernel<2" in k else "split" if "split3_symm_kernel" in k else "symm" if ", 2, 2, 1>" in k else "syrk" if ", 2, 1, 1>" in k else "gemm", "launches": n, "fetch_size_kb": fe, "write_size_kb": wr, "hbm_bytes_corrected": hbm,
+       "kernels": [{"kernel": k, "role": "split_f16" if ("split3_symm_kernel<2" in k or "split2_m16_kernel" in k) else "split" if "split3_symm_kernel" in k else "symm" if ", 2, 2, 1>" in k else "syrk" if ", 2, 1, 1>" in k else "gemm", "launches": n, "fetch_size_kb": fe, "write_size_kb": wr, "hbm_bytes_corrected": hbm,
                     "avg_ms": ms} for _, k, n, fe, wr, hbm, ms in gem]}
+# whole-step traffic outside the product: every mcgra kernel launched once per step or more (launch counts are multiples of
+# the timed + warm-up steps of the pass), per step
+steps_in_pass = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+# (set-up and post-loop kernels -- create-time zero fills, set_graph's products, finalize's decode -- are not part of a step:
+#  excluded by name, and a launch count that is not a multiple of the steps is floored)
+NOT_IN_STEP = ("fillBufferAligned grid=65536", "k_dd2_accum", "k_axpby2d", "rankk_nt_kernel<16>", "k_decode_post", "k_unpack_sym",
+               "k_split_absmax", "k_center_cols", "k_rowsum", "copyBuffer")
+step_rows = [(k, float(n // steps_in_pass), hbm, ms) for _, k, n, fe, wr, hbm, ms in rows
+             if ("mcgra::" in k or "rocclr" in k) and n >= steps_in_pass and "gemm_f32_kernel<128, 128" not in k
+             and not any(x in k for x in NOT_IN_STEP)]
+prod = sum(hbm * c for k, c, hbm, ms in step_rows if "split" in k and "k_split3_reduce" not in k)
+rest = sum(hbm * c for k, c, hbm, ms in step_rows if not ("split" in k and "k_split3_reduce" not in k))
+rest_ms = sum(ms * c for k, c, hbm, ms in step_rows if not ("split" in k and "k_split3_reduce" not in k))
+json.dump({"note": "HBM-side bytes per attack step (2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction), summed over the "
+                   "kernels a step launches, from the serialised PMC passes; `outside_product` is everything but the N x N x N "
+                   "product launches", "steps_in_pass": steps_in_pass,
+           "product_bytes_per_step": prod, "outside_product_bytes_per_step": rest, "outside_product_ms_per_step_under_pmc": rest_ms,
+           "outside_product_GBps": rest / (rest_ms * 1e-3) / 1e9 if rest_ms else None,
+           "kernels": [{"kernel": k, "launches_per_step": c, "hbm_bytes_per_launch": hbm, "avg_ms": ms} for k, c, hbm, ms in
+                       sorted(step_rows, key=lambda r: -r[1] * r[2])[:40]]},
+          open(os.path.join(P, f"{tag}_step_traffic.json"), "w"), indent=1)
+print("per step: product", prod / 1e9, "GB; outside", rest / 1e9, "GB in", rest_ms, "ms")
 # entries of other evaluations of the product (earlier passes with MCGRA_SPLIT_BF16=0 / 2) stay in the file
 old_path = os.path.join(P, f"{tag}_gemm_traffic.json")
 if os.path.exists(old_path):

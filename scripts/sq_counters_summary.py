@@ -10,7 +10,7 @@ per = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(dict)
 name = {}
 for r in csv.DictReader(open(src)):
-    if "split3_symm_kernel" not in r["Kernel_Name"]:
+    if "split3_symm_kernel" not in r["Kernel_Name"] and "split2_m16_kernel" not in r["Kernel_Name"]:
         continue
     g = int(r["Grid_Size"])
     per[g][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -30,7 +30,9 @@ for g in sorted(per, reverse=True):
                               "mfma_busy_fraction": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles),
                               "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"],
                               "wait_any_fraction_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                              "wait_lds_fraction_of_wave_cycles": c["SQ_WAIT_INST_LDS"] / c["SQ_WAVE_CYCLES"],
+                              "wait_lds_fraction_of_wave_cycles": c.get("SQ_WAIT_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"],
+                              "wait_inst_any_fraction_of_wave_cycles": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                              "active_inst_any_fraction_of_wave_cycles": c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
                               "counters": c})
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps([{k: v for k, v in d.items() if k != "counters"} for d in out["dispatches"]], indent=1))
