@@ -396,8 +396,10 @@ def test_pgdattack_class_other_victims(pkg, torch_, name, fake):
     assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
 
 
-def _run_cora(pkg, t, name):
+def _run_cora(pkg, t, name, epochs=None):
     z = H.load_cora(name)
+    if epochs is not None:
+        z["epochs"] = np.array(epochs)
     w = O.GCNWeights([z["W0"], z["W1"]], [z["b0"], z["b1"]], z["Wlin"], z["blin"])
     victim, emb = H.FakeGCN(w), H.FakeGCN(w)
     X, adj, lab = z["features"], z["adj"], z["labels"]
@@ -431,14 +433,34 @@ def test_cora_auc_matches_reference(pkg, torch_, name):
     assert abs(final.astype(np.float64).sum() - float(z["final_sum"])) <= 1e-4 * abs(float(z["final_sum"]))
 
 
+CKPT = np.load(os.path.join(H.GOLDEN, "cora_mse_checkpoints.npz"))
+
+
+@pytest.mark.parametrize("epochs", [10, 40])
+def test_cora_mse_checkpoints(pkg, torch_, epochs):
+    """README Cora run at intermediate horizons against the reference's own AUC there
+    (tests/golden/make_adam_noise.py).  The reference, the fp32 oracle and the fp64 oracle -- three evaluations of ONE
+    algorithm on identical inputs -- agree to 1.6e-7 / 6e-6 / 1.2e-4 / 1.4e-3 at 10 / 20 / 40 / 100 epochs
+    (profiles/r02_adam_noise_experiment.json): Adam turns fp32 rounding noise on near-zero gradients into +-lr moves,
+    so the bar of north_star (1e-4) is meaningful up to ~20 epochs; beyond, the engine is held to the measured spread
+    of those three at that horizon (x 2)."""
+    i = list(CKPT["epochs"]).index(epochs)
+    ref, o32, o64 = float(CKPT["auc_reference"][i]), float(CKPT["auc_oracle_fp32"][i]), float(CKPT["auc_oracle_fp64"][i])
+    spread = max(abs(ref - o32), abs(ref - o64), abs(o32 - o64))
+    auc = _run_cora(pkg, torch_, "cora_mse_readme", epochs=epochs)[2]
+    assert abs(auc - ref) <= max(1e-4, 2 * spread), (epochs, auc, ref, spread)
+
+
 def test_cora_readme_100_epochs(pkg, torch_):
-    """README headline run (MSELoss, 100 epochs).  Adam turns fp32 rounding noise on near-zero gradients
-    into +-lr moves, so 100-epoch trajectories agree only statistically: the numpy oracle (same fp32
-    algorithm, different BLAS summation order) gives 0.90221 where the reference gives 0.90315.  The HIP
-    path is held to 2e-3, and to the reference's own spread under a changed thread count when that is larger."""
+    """README headline run (MSELoss, 100 epochs).  Bar: twice the measured spread of the reference, the fp32 oracle and
+    the fp64 oracle at 100 epochs (1.4e-3, see test_cora_mse_checkpoints): no fp32 implementation is reproducible more
+    tightly on that horizon, the float64 evaluation of the reference's own algorithm included."""
     z, final, auc = _run_cora(pkg, torch_, "cora_mse_readme")
-    spread = abs(float(z["auc"]) - float(z["auc_alt_threads"])) if "auc_alt_threads" in z else 0.0
-    assert abs(auc - float(z["auc"])) <= max(2e-3, 3 * spread), (auc, float(z["auc"]), spread)
+    i = list(CKPT["epochs"]).index(100)
+    ref, o32, o64 = float(CKPT["auc_reference"][i]), float(CKPT["auc_oracle_fp32"][i]), float(CKPT["auc_oracle_fp64"][i])
+    assert ref == float(z["auc"])
+    spread = max(abs(ref - o32), abs(ref - o64), abs(o32 - o64))
+    assert abs(auc - ref) <= 2 * spread, (auc, ref, spread)
 
 
 def test_main_entry_end_to_end(pkg, torch_, tmp_path, monkeypatch):
