@@ -134,6 +134,17 @@ int mcgra_hsic_regular(void* stream, int m, int dx, int dy, const float* X, cons
 int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, const float* Y,
                           float sigma, float* out);
 
+/* The rest of hsic.py.  sigma=None (median heuristic, hsic.py:5-17) is estimated by the host mirror
+ * (mc-gra_amd/hsic.py: mcgra_distmat on the device, the median on the host, as the reference does with numpy) and
+ * arrives here as explicit per-operand sigmas.  hsic_normalized_cca (:138-151, two m x m inverses) is not provided. */
+int mcgra_hsic_regular2(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma_x, float sigma_y,
+                        int normalized, float* out);               /* hsic_regular / hsic_normalized, one sigma per operand */
+int mcgra_distmat(void* stream, int m, int d, const float* X, float* out);                      /* hsic.py:20-27 */
+int mcgra_mmd(void* stream, int mx, int my, int d, const float* X, const float* Y, float sx, float sy, float sxy,
+              float* out);                                                                     /* hsic.py:68-89 */
+int mcgra_mmd_pxpy_pxy(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sx, float sy,
+                       float* out);                                                            /* hsic.py:92-114 */
+
 /* torch.nn.MSELoss()(X, Y) over `count` elements, *out device scalar. */
 int mcgra_mse(void* stream, int64_t count, const float* X, const float* Y, float* out);
 

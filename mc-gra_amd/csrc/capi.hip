@@ -215,7 +215,7 @@ int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X, const
 
 // hsic.py hsic_regular (:117-124) with a given sigma; pair = 0: (x,y), used three times by hsic_normalized
 static int hsic_gauss(hipStream_t st, int m, int dx, int dy, const float* X, const float* Y, float sigma, double* out3,
-                      bool normalized) {
+                      bool normalized, float sigma_y = 0.f) {
   const int ld = (m + 3) & ~3;
   Scratch s;
   float* KX = s.get<float>((size_t)m * ld); NEED(KX);
@@ -224,12 +224,13 @@ static int hsic_gauss(hipStream_t st, int m, int dx, int dy, const float* X, con
   double* rx = s.get<double>(ld); double* ry = s.get<double>(ld); double* rr = s.get<double>(ld); NEED(rx); NEED(ry); NEED(rr);
   double* tot = s.get<double>(4); NEED(tot);
   const float inv2s2 = 1.f / (2.f * sigma * sigma);
+  const float inv2s2y = sigma_y > 0.f ? 1.f / (2.f * sigma_y * sigma_y) : inv2s2;     // sigma=None: one estimate per operand
   launch_row_sqnorm(st, m, dx, X, dx, sx);
   launch_row_sqnorm(st, m, dy, Y, dy, sy);
   MCGRA_HIP(sgemm(st, false, true, m, m, dx, 1.f, X, dx, X, dx, 0.f, KX, ld, nullptr, 0));     // X X^T (hsic.py:25)
   MCGRA_HIP(sgemm(st, false, true, m, m, dy, 1.f, Y, dy, Y, dy, 0.f, KY, ld, nullptr, 0));
   launch_gauss_kernel(st, m, ld, KX, sx, inv2s2, rx);
-  launch_gauss_kernel(st, m, ld, KY, sy, inv2s2, ry);
+  launch_gauss_kernel(st, m, ld, KY, sy, inv2s2y, ry);
   launch_hsic_gauss_rows(st, m, ld, KX, KY, rx, ry, rr);
   launch_reduce_rows(st, rr, m, 1, tot + 0);
   if (normalized) {
@@ -263,6 +264,103 @@ int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, c
   int rc = hsic_gauss((hipStream_t)stream, m, dx, dy, X, Y, sigma, v, true);
   if (rc) return rc;
   const float f = (float)(v[0] / (sqrt(v[1]) * sqrt(v[2])));       // Pxy / (Px * Py) (hsic.py:131-134)
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// hsic.py with sigma=None: kernelmat (:30-47) takes one median-heuristic sigma per operand (sigma_estimation(X, X));
+// the estimate itself is host work in the reference too (numpy median, :5-17) and stays in the host mirror.
+int mcgra_hsic_regular2(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma_x, float sigma_y,
+                        int normalized, float* out) {
+  if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out || !(sigma_x > 0.f) || !(sigma_y > 0.f)) { set_error("bad argument"); return MCGRA_EINVAL; }
+  double v[3];
+  int rc = hsic_gauss((hipStream_t)stream, m, dx, dy, X, Y, sigma_x, v, normalized != 0, sigma_y);
+  if (rc) return rc;
+  const float f = normalized ? (float)(v[0] / (sqrt(v[1]) * sqrt(v[2]))) : (float)v[0];
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// hsic.distmat (hsic.py:20-27): out[m x m] = r_i - 2 <x_i, x_j> + r_j
+int mcgra_distmat(void* stream, int m, int d, const float* X, float* out) {
+  if (m < 1 || d < 1 || !X || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  float* sq = s.get<float>(m); NEED(sq);
+  double* rr = s.get<double>(m); NEED(rr);
+  launch_row_sqnorm(st, m, d, X, d, sq);
+  MCGRA_HIP(sgemm(st, false, true, m, m, d, 1.f, X, d, X, d, 0.f, out, m, nullptr, 0));
+  launch_gauss_kernel(st, m, m, out, sq, 0.f, rr);
+  MCGRA_KERNEL_CHECK();
+  MCGRA_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// mean(exp(-D(A, B) * coef)) for A [ma x d], B [mb x d] (B == A: the square form)
+static int gauss_mean(hipStream_t st, int ma, int mb, int d, const float* A, const float* B, float coef, double* mean) {
+  Scratch s;
+  const int ld = (mb + 3) & ~3;
+  float* K = s.get<float>((size_t)ma * ld); NEED(K);
+  float* sa = s.get<float>(ma); float* sb = s.get<float>(mb); NEED(sa); NEED(sb);
+  double* rows = s.get<double>(ma); double* tot = s.get<double>(1); NEED(rows); NEED(tot);
+  launch_row_sqnorm(st, ma, d, A, d, sa);
+  launch_row_sqnorm(st, mb, d, B, d, sb);
+  MCGRA_HIP(sgemm(st, false, true, ma, mb, d, 1.f, A, d, B, d, 0.f, K, ld, nullptr, 0));
+  launch_gauss_kernel(st, ma, ld, K, sa, coef, rows, sb, mb);
+  launch_reduce_rows(st, rows, ma, 1, tot);
+  MCGRA_KERNEL_CHECK();
+  double t;
+  MCGRA_HIP(hipMemcpyAsync(&t, tot, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  *mean = t / ((double)ma * mb);
+  return 0;
+}
+
+// hsic.mmd (hsic.py:68-89): mean(Kx) + mean(Ky) - 2 mean(Kxy), Kx = exp(-Dxx / (2 sx^2)), Ky likewise, Kxy = exp(-Dxy / sxy^2)
+int mcgra_mmd(void* stream, int mx, int my, int d, const float* X, const float* Y, float sx, float sy, float sxy, float* out) {
+  if (mx < 1 || my < 1 || d < 1 || !X || !Y || !out || !(sx > 0.f) || !(sy > 0.f) || !(sxy > 0.f)) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  double a, b, c;
+  int rc = gauss_mean(st, mx, mx, d, X, X, 1.f / (2.f * sx * sx), &a);
+  if (!rc) rc = gauss_mean(st, my, my, d, Y, Y, 1.f / (2.f * sy * sy), &b);
+  if (!rc) rc = gauss_mean(st, mx, my, d, X, Y, 1.f / (sxy * sxy), &c);
+  if (rc) return rc;
+  const float f = (float)(a + b - 2.0 * c);
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// hsic.mmd_pxpy_pxy (hsic.py:92-114): mean(Kx o Ky) - 2 mean(colmean(Kx) o colmean(Ky)) + mean(Kx) mean(Ky)
+int mcgra_mmd_pxpy_pxy(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sx, float sy, float* out) {
+  if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out || !(sx > 0.f) || !(sy > 0.f)) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = (m + 3) & ~3;
+  Scratch s;
+  float* KX = s.get<float>((size_t)m * ld); NEED(KX);
+  float* KY = s.get<float>((size_t)m * ld); NEED(KY);
+  float* qx = s.get<float>(ld); float* qy = s.get<float>(ld); NEED(qx); NEED(qy);
+  double* rx = s.get<double>(ld); double* ry = s.get<double>(ld); double* rr = s.get<double>(ld); double* zero = s.get<double>(ld);
+  NEED(rx); NEED(ry); NEED(rr); NEED(zero);
+  double* tot = s.get<double>(1); NEED(tot);
+  launch_row_sqnorm(st, m, dx, X, dx, qx);
+  launch_row_sqnorm(st, m, dy, Y, dy, qy);
+  MCGRA_HIP(sgemm(st, false, true, m, m, dx, 1.f, X, dx, X, dx, 0.f, KX, ld, nullptr, 0));
+  MCGRA_HIP(sgemm(st, false, true, m, m, dy, 1.f, Y, dy, Y, dy, 0.f, KY, ld, nullptr, 0));
+  launch_gauss_kernel(st, m, ld, KX, qx, 1.f / (2.f * sx * sx), rx);
+  launch_gauss_kernel(st, m, ld, KY, qy, 1.f / (2.f * sy * sy), ry);
+  launch_hsic_gauss_rows(st, m, ld, KX, KY, zero, zero, rr);          // sum_j Kx_ij Ky_ij (no centring)
+  launch_reduce_rows(st, rr, m, 1, tot);
+  MCGRA_KERNEL_CHECK();
+  std::vector<double> hx(m), hy(m);
+  double t;
+  MCGRA_HIP(hipMemcpyAsync(&t, tot, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipMemcpyAsync(hx.data(), rx, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipMemcpyAsync(hy.data(), ry, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  double B = 0, sxm = 0, sym = 0;
+  for (int j = 0; j < m; ++j) { B += (hx[j] / m) * (hy[j] / m); sxm += hx[j]; sym += hy[j]; }   // K symmetric: column means = row means
+  const double A = t / ((double)m * m), Cc = (sxm / ((double)m * m)) * (sym / ((double)m * m));
+  const float f = (float)(A - 2.0 * B / m + Cc);
   MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }

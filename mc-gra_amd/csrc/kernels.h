@@ -33,7 +33,8 @@ void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float 
 void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
                         bool use1, bool use2, bool lower);
 void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, int nstrips, double* cols);
-void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows);
+void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows,
+                         const float* sq2 = nullptr, int m2 = 0);
 void launch_hsic_gauss_rows(hipStream_t st, int m, int ld, const float* KX, const float* KY, const double* rowsx,
                             const double* rowsy, double* rows);
 void launch_row_sqnorm(hipStream_t st, int m, int d, const float* X, int ldx, float* sq);

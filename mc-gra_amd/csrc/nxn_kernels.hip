@@ -852,17 +852,20 @@ __global__ void k_colsum_fin(int n, const double* __restrict__ part, int nstrips
 //   hsic_regular = mean_ij Kxc_ij Kyc_ji.  K is symmetric, so Kyc_ji = Ky_ij - rowmean_y[j].
 // k_gauss_kernel turns the Gram a = X X^T into K in place and leaves row sums of K.
 // ---------------------------------------------------------------------------
+// (sq2 != nullptr, m2 columns: the cross form D_xy of mmd (hsic.py:83-85); inv2s2 == 0: leave the distance matrix itself)
 __global__ __launch_bounds__(ROW_THREADS) void k_gauss_kernel(int m, int ld, float* __restrict__ A,
                                                               const float* __restrict__ sq, float inv2s2,
-                                                              double* __restrict__ rows) {
+                                                              double* __restrict__ rows, const float* __restrict__ sq2, int m2) {
   __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   const float ri = sq[i];
+  const float* sc = sq2 ? sq2 : sq;
+  const int mc = sq2 ? m2 : m;
   double s = 0;
-  for (int j = threadIdx.x; j < m; j += ROW_THREADS) {
-    const float d = ri - 2.f * A[base + j] + sq[j];
-    const float k = expf(-d * inv2s2);
+  for (int j = threadIdx.x; j < mc; j += ROW_THREADS) {
+    const float d = ri - 2.f * A[base + j] + sc[j];
+    const float k = inv2s2 != 0.f ? expf(-d * inv2s2) : d;
     A[base + j] = k;
     s += k;
   }
@@ -966,8 +969,9 @@ void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, 
   LAUNCH(k_colsum_part, dim3((n + 255) / 256, nstrips), dim3(256), st, n, ld, X, rows_per_strip, part);
   LAUNCH(k_colsum_fin, dim3((n + 255) / 256), dim3(256), st, n, part, nstrips, cols);
 }
-void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows) {
-  LAUNCH(k_gauss_kernel, dim3(m), dim3(ROW_THREADS), st, m, ld, A, sq, inv2s2, rows);
+void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows, const float* sq2,
+                         int m2) {
+  LAUNCH(k_gauss_kernel, dim3(m), dim3(ROW_THREADS), st, m, ld, A, sq, inv2s2, rows, sq2, m2);
 }
 void launch_hsic_gauss_rows(hipStream_t st, int m, int ld, const float* KX, const float* KY, const double* rowsx,
                             const double* rowsy, double* rows) {

@@ -175,6 +175,59 @@ def hsic_normalized(x, y, sigma) -> F32:
     return F32(hsic_regular(x, y, sigma) / (np.sqrt(hsic_regular(x, x, sigma)) * np.sqrt(hsic_regular(y, y, sigma))))
 
 
+def hsic_sigma_estimation(X, Y) -> float:
+    """hsic.sigma_estimation (hsic.py:5-17)."""
+    D = hsic_distmat(np.concatenate([X, Y]))
+    tri = D[np.tril_indices(D.shape[0], -1)]
+    med = np.median(tri)
+    if med <= 0:
+        med = np.mean(tri)
+    if med < 1e-2:
+        med = 1e-2
+    return float(med)
+
+
+def hsic_regular_auto(x, y) -> F32:
+    """hsic.hsic_regular with sigma=None: kernelmat estimates one sigma per operand (hsic.py:39-41)."""
+    kx, ky = hsic_kernelmat(x, hsic_sigma_estimation(x, x)), hsic_kernelmat(y, hsic_sigma_estimation(y, y))
+    return F32((kx.astype(np.float64) * ky.T).mean())
+
+
+def hsic_normalized_auto(x, y) -> F32:
+    sx, sy = hsic_sigma_estimation(x, x), hsic_sigma_estimation(y, y)
+    reg = lambda a, sa, b, sb: (hsic_kernelmat(a, sa).astype(np.float64) * hsic_kernelmat(b, sb).T).mean()
+    return F32(reg(x, sx, y, sy) / (np.sqrt(reg(x, sx, x, sx)) * np.sqrt(reg(y, sy, y, sy))))
+
+
+def hsic_distcorr(X, sigma=1.0) -> F32:
+    """hsic.distcorr (hsic.py:50-53)."""
+    return F32(np.exp(-hsic_distmat(X).astype(np.float64) / (2.0 * sigma * sigma)).mean())
+
+
+def hsic_mmd(x, y, sigma=None) -> F32:
+    """hsic.mmd (hsic.py:68-89)."""
+    if sigma:
+        sx = sy = sxy = sigma
+    else:
+        sx, sy, sxy = hsic_sigma_estimation(x, x), hsic_sigma_estimation(y, y), hsic_sigma_estimation(x, y)
+    kx = np.exp(-hsic_distmat(x).astype(np.float64) / (2.0 * sx * sx))
+    ky = np.exp(-hsic_distmat(y).astype(np.float64) / (2.0 * sy * sy))
+    dxy = hsic_distmat(np.concatenate([x, y]))[: x.shape[0], x.shape[0]:]
+    kxy = np.exp(-dxy.astype(np.float64) / (1.0 * sxy * sxy))
+    return F32(kx.mean() + ky.mean() - 2 * kxy.mean())
+
+
+def hsic_mmd_pxpy_pxy(x, y, sigma=None) -> F32:
+    """hsic.mmd_pxpy_pxy (hsic.py:92-114)."""
+    if sigma:
+        sx = sy = sigma
+    else:
+        sx, sy = hsic_sigma_estimation(x, x), hsic_sigma_estimation(y, y)
+    kx = np.exp(-hsic_distmat(x).astype(np.float64) / (2.0 * sx * sx))
+    ky = np.exp(-hsic_distmat(y).astype(np.float64) / (2.0 * sy * sy))
+    return F32((kx * ky).mean() - 2 * (kx.mean(0) * ky.mean(0)).mean() + kx.mean() * ky.mean())
+
+
 def mse_loss(X, Y) -> F32:
     """torch.nn.MSELoss()(X, Y) (topology_attack.py:194-195)."""
     return F32(np.mean((X.astype(np.float64) - Y) ** 2))

@@ -332,6 +332,20 @@ def gen_ops(tmp):
     for sg in (1.0, 5.0):
         out[f"ghsic_reg_{sg}"] = rhsic.hsic_regular(torch.tensor(hx), torch.tensor(hy), sigma=sg).item()
         out[f"ghsic_norm_{sg}"] = rhsic.hsic_normalized(torch.tensor(hx), torch.tensor(hy), sigma=sg).item()
+    # the rest of hsic.py: sigma=None (median heuristic), distmat, distcorr, mmd, mmd_pxpy_pxy
+    tx, ty = torch.tensor(hx), torch.tensor(hy)
+    out["ghsic_sigma_xx"] = float(rhsic.sigma_estimation(tx, tx)); out["ghsic_sigma_yy"] = float(rhsic.sigma_estimation(ty, ty))
+    hz = (hx[:, :5] * 0.3 + rng.randn(45, 5) * 0.5).astype(np.float32)          # same width as y: mmd needs x, y in one space
+    out["ghsic_z"] = hz
+    tz = torch.tensor(hz)
+    out["ghsic_sigma_yz"] = float(rhsic.sigma_estimation(ty, tz))
+    out["ghsic_reg_auto"] = rhsic.hsic_regular(tx, ty).item()
+    out["ghsic_norm_auto"] = rhsic.hsic_normalized(tx, ty).item()
+    out["ghsic_distmat"] = rhsic.distmat(tx).numpy()
+    out["ghsic_distcorr_2.0"] = rhsic.distcorr(tx, sigma=2.0).item()
+    for sg in (None, 1.5):
+        out[f"ghsic_mmd_{sg}"] = rhsic.mmd(ty, tz, sigma=sg).item()
+        out[f"ghsic_mmdp_{sg}"] = rhsic.mmd_pxpy_pxy(tx, ty, sigma=sg, use_cuda=False).item()
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
     print("ops.npz", len(out), "arrays")
 

@@ -165,6 +165,27 @@ def test_gaussian_hsic_ops(pkg, torch_, sg):
         E.hsic_regular(x, y, 0.0)
 
 
+def test_hsic_py_mirror_against_reference(pkg, torch_):
+    """mc-gra_amd/hsic.py (the reference's hsic.py surface on the device) against the reference's own values:
+    sigma=None forms (median heuristic: distance matrix on the device, median on the host as in the reference),
+    distmat, distcorr, mmd, mmd_pxpy_pxy; hsic_normalized_cca refuses loudly."""
+    from mc_gra_amd import hsic as HS
+    x, y, z = dev(torch_, OPS["ghsic_x"]), dev(torch_, OPS["ghsic_y"]), dev(torch_, OPS["ghsic_z"])
+    assert abs(HS.sigma_estimation(x, x) - float(OPS["ghsic_sigma_xx"])) <= 2e-5 * float(OPS["ghsic_sigma_xx"])
+    assert abs(HS.sigma_estimation(y, z) - float(OPS["ghsic_sigma_yz"])) <= 2e-5 * float(OPS["ghsic_sigma_yz"])
+    assert rel(HS.distmat(x).cpu().numpy(), OPS["ghsic_distmat"]) < 2e-6
+    for sg in (1.0, 5.0):
+        assert abs(float(HS.hsic_regular(x, y, sigma=sg)) - float(OPS[f"ghsic_reg_{sg}"])) <= 3e-5 * abs(float(OPS[f"ghsic_reg_{sg}"]))
+    assert abs(float(HS.hsic_regular(x, y)) - float(OPS["ghsic_reg_auto"])) <= 2e-4 * abs(float(OPS["ghsic_reg_auto"]))
+    assert abs(float(HS.hsic_normalized(x, y)) - float(OPS["ghsic_norm_auto"])) <= 3e-4 * abs(float(OPS["ghsic_norm_auto"]))
+    assert abs(float(HS.distcorr(x, 2.0)) - float(OPS["ghsic_distcorr_2.0"])) <= 2e-6
+    for sg in (None, 1.5):
+        assert abs(float(HS.mmd(y, z, sigma=sg)) - float(OPS[f"ghsic_mmd_{sg}"])) <= 3e-5 * abs(float(OPS[f"ghsic_mmd_{sg}"]))
+        assert abs(float(HS.mmd_pxpy_pxy(x, y, sigma=sg)) - float(OPS[f"ghsic_mmdp_{sg}"])) <= 3e-4 * abs(float(OPS[f"ghsic_mmdp_{sg}"])) + 1e-8
+    with pytest.raises(NotImplementedError):
+        HS.hsic_normalized_cca(x, y)
+
+
 def test_ops_edge_cases(pkg, torch_):
     from mc_gra_amd import engine as E
     t = torch_

@@ -43,6 +43,20 @@ def test_gaussian_hsic(sg):
     assert abs(O.hsic_normalized(x, y, sg) - float(OPS[f"ghsic_norm_{sg}"])) <= 2e-4 * abs(float(OPS[f"ghsic_norm_{sg}"]))
 
 
+def test_hsic_py_remainder():
+    """sigma_estimation, the sigma=None forms, distmat, distcorr, mmd, mmd_pxpy_pxy of hsic.py against the reference."""
+    x, y, z = OPS["ghsic_x"], OPS["ghsic_y"], OPS["ghsic_z"]
+    assert abs(O.hsic_sigma_estimation(x, x) - float(OPS["ghsic_sigma_xx"])) <= 1e-5 * float(OPS["ghsic_sigma_xx"])
+    assert abs(O.hsic_sigma_estimation(y, z) - float(OPS["ghsic_sigma_yz"])) <= 1e-5 * float(OPS["ghsic_sigma_yz"])
+    assert rel(O.hsic_distmat(x), OPS["ghsic_distmat"]) < 1e-6
+    assert abs(O.hsic_regular_auto(x, y) - float(OPS["ghsic_reg_auto"])) <= 1e-4 * abs(float(OPS["ghsic_reg_auto"]))
+    assert abs(O.hsic_normalized_auto(x, y) - float(OPS["ghsic_norm_auto"])) <= 2e-4 * abs(float(OPS["ghsic_norm_auto"]))
+    assert abs(O.hsic_distcorr(x, 2.0) - float(OPS["ghsic_distcorr_2.0"])) <= 1e-5
+    for sg in (None, 1.5):
+        assert abs(O.hsic_mmd(y, z, sg) - float(OPS[f"ghsic_mmd_{sg}"])) <= 2e-5 * abs(float(OPS[f"ghsic_mmd_{sg}"]))
+        assert abs(O.hsic_mmd_pxpy_pxy(x, y, sg) - float(OPS[f"ghsic_mmdp_{sg}"])) <= 2e-4 * abs(float(OPS[f"ghsic_mmdp_{sg}"])) + 1e-8
+
+
 def test_info_entropy():
     v, g = O.info_entropy_grad(OPS["ie_in"])
     assert abs(v - OPS["ie_val"]) < 1e-6
