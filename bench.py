@@ -459,12 +459,12 @@ def main():
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12
             # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
-            # (profiles/r01_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
+            # (profiles/r02_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
             # cannot be read from inside the timed process, so the committed profile value is reported.
             traffic = None
             ps = eng_path
             lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
-            tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            tp = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
             role = {2: "split", 3: "split_f16"}.get(pmode, "symm") if lowrank else "symm"
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
                 ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == role or not lowrank]
@@ -498,6 +498,21 @@ def main():
                                                 "frac": 2.0 * n ** 3 / (ams * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                                 "issued_frac": 2.0 * npp * n ** 3 / (ams * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                                 "steps_per_s_without_side_stream": alone["value"]}
+            elif eng.gram_split_steps() > 0:
+                # Gram evaluation (MCGRA_NO_LOWRANK=1, masked or GAT / SAGE steps) on the same 2-plane fp16 kernel: four
+                # launches per step; each counted as the reference's dense n x n x n product (2 n^3 flop) although the two
+                # Gram launches compute only the tiles on or below the diagonal
+                out["roofline"] = {"bound": "mfma",
+                                   "kernel": "split2_m16_kernel (the four N x N x N products of the Gram evaluation of "
+                                             "linear_HSIC as 2-plane fp16 splits: Kx = Xc Xc^T and Ky = Yc Yc^T on lower tiles "
+                                             "with a mirrored store, then G_adjn += Ky' Xc and G_A1 += Kx' Yc)",
+                                   "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                                   "algorithmic_flop_per_launch": st["flops"] / st["launches"],
+                                   "fp32_mfma_peak_multiple": ach / PEAK_F32_MFMA_TFLOPS,
+                                   "traffic": None, "traffic_unit": "bytes/launch",
+                                   "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
+                                   "gemm_share_of_step": st["ms"] / (1e3 * dt)}
             else:
                 what = ("P1 = (H Kf H) Xc, the one N x N x N product of a low-rank linear_HSIC step: SYMM on lower tile "
                         "storage, one launch per step") if lowrank else ("N x N x N products of the Gram evaluation of "
@@ -513,6 +528,17 @@ def main():
                                                 "frac": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         else:
             out["roofline"] = None
+        # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed
+        # profile) over the step time that is not the product (step without the side stream - product alone)
+        sp = os.path.join(ROOT, "profiles", "r02_step_traffic.json")
+        if world == 1 and a.workload == "synthetic-10k-hsic" and os.path.exists(sp) and alone is not None and "value" in alone:
+            bytes_out = json.load(open(sp))["outside_product_bytes_per_step"]
+            ms_out = 1e3 / alone["value"] - alone.get("product_avg_launch_ms", 0.0)
+            if ms_out > 0:
+                out["step_outside_product"] = {"bound": "hbm", "bytes_per_step": bytes_out, "ms_per_step": ms_out,
+                                               "achieved": bytes_out / (ms_out * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                               "frac": bytes_out / (ms_out * 1e-3) / 1e9 / 8000.0,
+                                               "note": "launch- and VALU-bound kernels included: ~75 node-level launches per step"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -278,6 +278,9 @@ int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long lo
  * never stored).  Conditions: measure HSIC, ReLU GCN victim, eps == 0, the split product (n >= 1024 or
  * MCGRA_SPLIT_BF16=2/3), n >= 256, widths <= 32; MCGRA_NO_FUSED_LR=1 disables it. */
 long long mcgra_attack_fused_steps(mcgra_attack_t* h);
+/* Gram-evaluation steps (masked decode, GAT / SAGE chains, MCGRA_NO_LOWRANK) whose four N x N x N products ran on the
+ * 2-plane fp16 kernel instead of fp32 SYMM (n >= 1024, HSIC, eps == 0; MCGRA_GRAM_SPLIT=0 turns it off). */
+long long mcgra_attack_gram_split_steps(mcgra_attack_t* h);
 
 /* Monitoring forward of topology_attack.py:290-296 on the current adjacency:
  * out_logp [n x nclass] = victim(features, normalize(get_modified_adj)),

@@ -30,7 +30,7 @@ SYMBOLS = [
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
     "mcgra_attack_exchange_bytes", "mcgra_attack_bind_exchange", "mcgra_attack_shard_begin", "mcgra_attack_shard_next",
-    "mcgra_attack_shard_scalars", "mcgra_attack_get_rows", "mcgra_attack_path_stats", "mcgra_attack_fused_steps", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
+    "mcgra_attack_shard_scalars", "mcgra_attack_get_rows", "mcgra_attack_path_stats", "mcgra_attack_fused_steps", "mcgra_attack_gram_split_steps", "mcgra_attack_product_mode", "mcgra_ssymm_split_bf16", "mcgra_ssymm_split_f16",
     "mcgra_attack_monitor", "mcgra_attack_finalize", "mcgra_attack_buffer", "mcgra_attack_copy_buffer",
     "mcgra_attack_profile",
     "mcgra_attack_gemm_stats",
@@ -123,6 +123,8 @@ def _load():
         fn.restype = C.c_int
     lib.mcgra_attack_fused_steps.argtypes = [vp]
     lib.mcgra_attack_fused_steps.restype = C.c_longlong
+    lib.mcgra_attack_gram_split_steps.argtypes = [vp]
+    lib.mcgra_attack_gram_split_steps.restype = C.c_longlong
     lib.mcgra_attack_exchange_bytes.argtypes = [vp]
     lib.mcgra_attack_exchange_bytes.restype = C.c_int64
     return lib

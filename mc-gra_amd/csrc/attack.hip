@@ -287,9 +287,23 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     if (!rc && h->lr_ok && cfg->eps == 0.f && es && (es[0] == '2' || es[0] == '3')) {
       h->split_planes = es[0] == '3' ? 2 : 3;
       A_(Apack, split3_pack_bytes((int)n, h->split_planes)); A_(Bpack, split3_pack_bytes((int)n, h->split_planes));
-      A_(amax, 2);
+      A_(amax, 16);
       h->split_on = (rc == 0);
       h->split_mode = 2;
+    }
+    // The Gram evaluation of HSIC (steps the low-rank forms do not cover: a masked decode, GAT / SAGE chains,
+    // MCGRA_NO_LOWRANK) through the 2-plane fp16 kernel as well: Kx = Xc Xc^T and Ky = Yc Yc^T as full matrices, then
+    // G_adjn += Ky' Xc and G_A1 += Kx' Yc -- four products of 2 n^3 instead of 3 n^3 MACs of fp32 SYMM at a third of
+    // their rate.  MCGRA_GRAM_SPLIT=0: fp32 path.
+    const char* eg_ = getenv("MCGRA_GRAM_SPLIT");
+    const bool gram_auto = (es[0] == '3') && !(eg_ && eg_[0] == '0');
+    if (!rc && cfg->measure == MCGRA_MEASURE_HSIC && cfg->eps == 0.f && gram_auto) {
+      if (!h->split_on) { h->split_planes = 2; A_(Bpack, split3_pack_bytes((int)n, 2)); A_(amax, 16); }
+      if (h->split_planes == 2) {
+        const size_t pb = split3_pack_bytes((int)n, 2);
+        A_(Gp0, pb); A_(Gp1, pb); A_(Gp2, pb);
+        h->gram_split = (rc == 0);
+      }
     }
     // The product on the engine's own stream, beside the HBM-bound kernels of the step that do not need it.  On by
     // default with the 2-plane fp16 kernel (64 KB of LDS and 212 VGPRs per CU leave room for them: 9.1 vs 9.4 ms per
@@ -703,7 +717,11 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
     if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
     launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr,
-                       (h->split_mode == 2 && h->split_planes == 2) ? h->amax + 1 : nullptr);
+                       ((h->split_mode == 2 && h->split_planes == 2) || h->gram_split) ? h->amax + 1 : nullptr);
+    // Gram evaluation through the split kernel: planes of Xc^T now (cmean is reused by Yc's centring), unless the
+    // low-rank product below packs them anyway
+    if (h->gram_split && !noise && !(h->lr_ok && !cka && use1 && h->split_on))
+      split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, 2, h->amax + 1);
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
@@ -816,7 +834,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         ++h->general_steps;
         if (use2) {
           launch_rowsum(st, n, ld, h->A1, h->rowsy);
-          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC);
+          const bool gs = h->gram_split && !noise;
+          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC, nullptr, gs ? h->amax + 2 : nullptr);
+          if (gs) split3_pack(st, n, ld, h->A1, h->cmean, false, h->Gp2, 2, h->amax + 2);      // Yc^T (A1 is symmetric)
         }
       }
     }
@@ -837,11 +857,60 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       h->p1_inflight = false;
     }
     if (h->lr_step) {
+    } else if (h->gram_split && !noise && !cka) {
+      // full Kx and Ky from the fp16 planes of Xc and Yc (split_symm_bf16.hip); split-K slabs in G_A, idle until phase 3
+      const size_t slab = sizeof(float) * (size_t)n * ld;
+      const bool big = h->profile;
+      auto pair = [&](int slot, int ia, int ib) -> int {
+        MCGRA_HIP(hipMemcpyAsync(h->amax + 8 + 2 * slot, h->amax + ia, sizeof(float), hipMemcpyDeviceToDevice, st));
+        MCGRA_HIP(hipMemcpyAsync(h->amax + 9 + 2 * slot, h->amax + ib, sizeof(float), hipMemcpyDeviceToDevice, st));
+        return MCGRA_OK;
+      };
+      CHK(pair(0, 1, 1));
+      // Kx and Ky are symmetric: tiles on or below the diagonal, mirrored by the epilogue (MCGRA_GRAM_TRI=0: all tiles)
+      static const int gram_flags = [] { const char* e = getenv("MCGRA_GRAM_TRI"); return (e && e[0] == '0') ? 0 : 2; }();
+      split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
+      CHK(timer_begin(h, st, big));
+      MCGRA_HIP(split3_symm(st, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->G_A, slab, 2, h->amax + 8, 0, -1, gram_flags));
+      CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
+      if (use2) {
+        CHK(pair(1, 2, 2));
+        split3_pack(st, n, ld, h->YC, nullptr, false, h->Gp1, 2, h->amax + 2);
+        CHK(timer_begin(h, st, big));
+        MCGRA_HIP(split3_symm(st, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->G_A, slab, 2, h->amax + 10, 0, -1, gram_flags));
+        CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
+      }
+      ++h->gram_split_steps;
     } else
     if (use2) CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY, t0, t1 - t0));   // H Kx H and H Ky H
     else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
   }
 
+  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && h->gram_split && !noise && !cka) {
+    const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
+    const size_t slab = sizeof(float) * (size_t)n * ld;
+    const bool big = h->profile;
+    MCGRA_HIP(hipMemsetAsync(h->amax + 3, 0, 2 * sizeof(float), st));
+    launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->rowvals + 4 * (size_t)ld, false,
+                        h->amax + 4, h->amax + 3);
+    launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+    // G_adjn += 2 (s1 Kfc + s2 Kyc) Xc ;  G_A1 += 2 s2 Kxc Yc
+    MCGRA_HIP(hipMemcpyAsync(h->amax + 12, h->amax + 3, sizeof(float), hipMemcpyDeviceToDevice, st));
+    MCGRA_HIP(hipMemcpyAsync(h->amax + 13, h->amax + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
+    split3_pack(st, n, ld, h->KY, nullptr, false, h->Gp0, 2, h->amax + 3);
+    CHK(timer_begin(h, st, big));
+    MCGRA_HIP(split3_symm(st, n, h->Gp0, h->Bpack, h->G_ADJN, ld, 0, -1, h->G_A, slab, 2, h->amax + 12, 0, -1, 1));
+    CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
+    if (use2) {
+      MCGRA_HIP(hipMemcpyAsync(h->amax + 14, h->amax + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
+      MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
+      split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp1, 2, h->amax + 4);
+      CHK(timer_begin(h, st, big));
+      MCGRA_HIP(split3_symm(st, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->G_A, slab, 2, h->amax + 14, 0, -1, 1));
+      CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
+    }
+    MCGRA_KERNEL_CHECK();
+  } else
   if (PH(2) && hsic && (use1 || use2) && !h->lr_step) {
     const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
     if (cka) {
@@ -1019,6 +1088,7 @@ int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long lo
 }
 
 long long mcgra_attack_fused_steps(mcgra_attack_t* h) { return h ? (long long)h->fused_steps : 0; }
+long long mcgra_attack_gram_split_steps(mcgra_attack_t* h) { return h ? (long long)h->gram_split_steps : 0; }
 
 int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, double* sparsity) {
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }

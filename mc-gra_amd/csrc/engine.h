@@ -96,6 +96,12 @@ struct mcgra_attack {
   int split_planes = 3;            // 3: bf16 x 3 (six products); 2: fp16 x 2 (three products, operand scales from amax)
   float *amax = 0;                 // [0] max |H Kf H| (per graph), [1] max |Xc| (per step, from the centring pass)
   int64_t split_steps = 0;
+  // Gram evaluation (masked / GAT / MCGRA_NO_LOWRANK steps) through the same kernel: planes of Xc, Yc, the combined
+  // Grams and Yc^T; amax[2] = max |Yc|, [3] = max |2 (s1 Kfc + s2 Kyc)|, [4] = max |2 s2 Kxc|, [8..15] = the
+  // (A, B) scale pairs of the four products
+  bool gram_split = false;
+  unsigned char *Gp0 = 0, *Gp1 = 0, *Gp2 = 0;
+  int64_t gram_split_steps = 0;
   GemmTimer timer;
   // fused low-rank step (attack_fused.hip): everything N x N from M and n-vectors; MCGRA_NO_FUSED_LR=1 disables
   bool fused_ok = false;           // configuration allows it

@@ -21,7 +21,7 @@ void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, 
 void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* mean_scratch,
                         float* out, double* rowsq = nullptr, float* absmax = nullptr);
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
-                         double* rowvals, bool lower);
+                         double* rowvals, bool lower, float* amax_kx = nullptr, float* amax_ky = nullptr);
 void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out);
 void launch_kl_rows(hipStream_t st, int n, int ld, const float* A, const float* B, const float* FS, float k1, float k2,
                     float* GA, float* GB, double* rowvals);

@@ -284,11 +284,12 @@ __global__ __launch_bounds__(ROW_THREADS) void k_center_cols(int n, int ld, cons
 // rowvals[0][i] = sum_j KFC_ij*KX_ij (c1), rowvals[1][i] = sum_j KX_ij*KY_ij (c2).
 __global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
     int n, int ld, float* __restrict__ KX, float* __restrict__ KY, const float* __restrict__ KFC,
-    float s1, float s2, double* __restrict__ rowvals, int lower) {
+    float s1, float s2, double* __restrict__ rowvals, int lower, unsigned* __restrict__ amax_kx, unsigned* __restrict__ amax_ky) {
   __shared__ double shd[16];
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   double v1 = 0, v2 = 0;
+  float mxa = 0.f, mxb = 0.f;     // largest magnitudes of the two results (operand scales of the fp16 split, optional)
   // lower != 0: KX / KY are in lower tile storage (common.h).  Only that region is read and
   // written; tiles left of the diagonal tile stand for their mirror image too (weight 2).
   const int jdiag = lower ? (i / SYM_TILE) * SYM_TILE : 0;
@@ -310,12 +311,22 @@ __global__ __launch_bounds__(ROW_THREADS) void k_hsic_combine(
         b = 2.f * (s1 * kf[t] + s2 * ky[t]);
       }
       ox[t] = a; oy[t] = b;
+      mxa = fmaxf(mxa, fabsf(a)); mxb = fmaxf(mxb, fabsf(b));
     }
     *reinterpret_cast<f32x4*>(KX + base + j) = ox;
     *reinterpret_cast<f32x4*>(KY + base + j) = oy;
   }
   v1 = block_sum_d(v1, shd); v2 = block_sum_d(v2, shd);
   if (threadIdx.x == 0) { rowvals[i] = v1; rowvals[(size_t)n + i] = v2; }
+  if (amax_kx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mxa = fmaxf(mxa, __shfl_xor(mxa, o)); mxb = fmaxf(mxb, __shfl_xor(mxb, o)); }
+    if ((threadIdx.x & 63) == 0) {      // non-negative floats order as unsigned integers
+      const unsigned ba = __float_as_uint(mxa), bb = __float_as_uint(mxb);
+      if (ba > __hip_atomic_load(amax_kx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_kx, ba);
+      if (bb > __hip_atomic_load(amax_ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_ky, bb);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -937,8 +948,9 @@ void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const dou
   LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, mean_scratch, out, rowsq, (unsigned*)absmax);
 }
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
-                         double* rowvals, bool lower) {
-  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals, lower ? 1 : 0);
+                         double* rowvals, bool lower, float* amax_kx, float* amax_ky) {
+  LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals, lower ? 1 : 0, (unsigned*)amax_kx,
+         (unsigned*)amax_ky);
 }
 void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out) {
   LAUNCH(k_row_softmax, dim3(n), dim3(ROW_THREADS), st, n, ld, X, out);

@@ -179,6 +179,30 @@ __device__ __forceinline__ f32x16 plane_mma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// launch flags of the split kernels
+constexpr int SPLIT_BETA = 1;      // C += product (instead of C = product)
+constexpr int SPLIT_TRI = 2;       // A == B (Gram product): only tiles on or below the diagonal are computed; tiles below it
+                                   // are stored twice, as computed and mirrored, so that C is the full, bitwise symmetric matrix
+// linear tile index -> (tile_m, tile_n): 4-panel groups over the tile grid (gemm_f32.hip), or the lower triangle row by row
+__device__ __forceinline__ void split_tile_of(int lin, int tiles_m, int tiles_n, int panel_off, int npanel_off, int flags,
+                                              int& tile_m, int& tile_n) {
+  if (flags & SPLIT_TRI) {
+    int m = (int)((sqrtf(8.f * (float)lin + 1.f) - 1.f) * 0.5f);
+    while ((m + 1) * (m + 2) / 2 <= lin) ++m;
+    while (m * (m + 1) / 2 > lin) --m;
+    tile_m = m; tile_n = lin - m * (m + 1) / 2;
+    return;
+  }
+  constexpr int GROUP_M = 4;
+  const int group_sz = GROUP_M * tiles_n;
+  const int group_id = lin / group_sz;
+  const int first_m = group_id * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  tile_m = first_m + (lin % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
+  tile_n = (lin % group_sz) / gm + npanel_off;              // column-block ranks: this launch starts at column panel npanel_off
+}
+
+
 // NW = 8 waves as 2 x 4 with 128 x 64 wave tiles (the kernel described above), or NW = 4 waves as 2 x 2 with 128 x 128
 // wave tiles: 256 accumulator registers per lane, one wave per SIMD, a third less LDS read traffic per MFMA.
 template <int NP, int KSUB, int NW>
@@ -186,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
                                                                  float* __restrict__ C, int n, int ldc, int nks,
                                                                  int tiles_m, int tiles_n, int panel_off, int tile_base,
                                                                  int ksplit, float* __restrict__ slab,
-                                                                 const float* __restrict__ amax, int npanel_off) {
+                                                                 const float* __restrict__ amax, int npanel_off, int beta) {
   using CF = SplitCfg<NP, KSUB>;
   constexpr int OPB = CF::OPB, STAGE = CF::STAGE;
   constexpr int NJ = NW == 8 ? 2 : 4;                     // 32-column MFMA tiles per wave
@@ -203,13 +227,7 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     part = bid % ksplit;
     lin = tile_base + bid / ksplit;
-    constexpr int GROUP_M = 4;
-    const int group_sz = GROUP_M * tiles_n;
-    const int group_id = lin / group_sz;
-    const int first_m = group_id * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    tile_m = first_m + (lin % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
-    tile_n = (lin % group_sz) / gm + npanel_off;                // column-block ranks: this launch starts at column panel npanel_off
+    split_tile_of(lin, tiles_m, tiles_n, panel_off, npanel_off, beta, tile_m, tile_n);
   }
   const int kper = (nks + ksplit - 1) / ksplit;
   const int kc_begin = part * kper;
@@ -372,7 +390,10 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < n && col < n) C[(size_t)row * ldc + col] = acc[i][j][r];
+        if (row < n && col < n) {
+          C[(size_t)row * ldc + col] = acc[i][j][r] + ((beta & SPLIT_BETA) ? C[(size_t)row * ldc + col] : 0.f);
+          if ((beta & SPLIT_TRI) && tile_m != tile_n) C[(size_t)col * ldc + row] = acc[i][j][r];
+        }
       }
     }
 }
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
                                                             float* __restrict__ C, int n, int ldc, int nks,
                                                             int tiles_m, int tiles_n, int panel_off, int tile_base,
                                                             int ksplit, float* __restrict__ slab,
-                                                            const float* __restrict__ amax, int npanel_off) {
+                                                            const float* __restrict__ amax, int npanel_off, int beta) {
   using CF = SplitCfg<2, 2>;
   constexpr int OPB = CF::OPB, STAGE = CF::STAGE;     // 16 KB per operand and chunk, 64 KB per stage
   constexpr int COPY = 512 * 16, AOPS = 2 * OPB / COPY;   // 4 copies per operand and step
@@ -401,13 +422,7 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     part = bid % ksplit;
     lin = tile_base + bid / ksplit;
-    constexpr int GROUP_M = 4;
-    const int group_sz = GROUP_M * tiles_n;
-    const int group_id = lin / group_sz;
-    const int first_m = group_id * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    tile_m = first_m + (lin % group_sz) % gm + panel_off;
-    tile_n = (lin % group_sz) / gm + npanel_off;
+    split_tile_of(lin, tiles_m, tiles_n, panel_off, npanel_off, beta, tile_m, tile_n);
   }
   const int kper = (nks + ksplit - 1) / ksplit;
   const int kc_begin = part * kper;
@@ -503,7 +518,15 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + i * 16 + 4 * lg + r;
-        if (row < n && col < n) C[(size_t)row * ldc + col] = acc[i][j][r] * inv;
+        if (row < n && col < n) C[(size_t)row * ldc + col] = acc[i][j][r] * inv + ((beta & SPLIT_BETA) ? C[(size_t)row * ldc + col] : 0.f);
+      }
+      if ((beta & SPLIT_TRI) && tile_m != tile_n && col < n) {      // mirrored: the 4 accumulators of a lane are 4 columns of row `col`
+        const int row = m0 + i * 16 + 4 * lg;
+        float* o = C + (size_t)col * ldc + row;
+        if (row + 3 < n && (ldc & 3) == 0) *reinterpret_cast<f32x4v*>(o) = acc[i][j] * inv;
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (row + r < n) o[r] = acc[i][j][r] * inv;
       }
     }
 }
@@ -511,12 +534,10 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
 // C tile = sum over parts of the partial tiles of the split-K tail (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__ slab, int ntile, int ksplit, float* __restrict__ C,
                                                        int n, int ldc, int tiles_m, int tiles_n, int panel_off, int tile_base,
-                                                       int npanel_off) {
+                                                       int npanel_off, int beta) {
   const int t = blockIdx.x, lin = tile_base + t;
-  constexpr int GROUP_M = 4;
-  const int group_sz = GROUP_M * tiles_n, group_id = lin / group_sz, first_m = group_id * GROUP_M;
-  const int gm = min(tiles_m - first_m, GROUP_M);
-  const int tile_m = first_m + (lin % group_sz) % gm + panel_off, tile_n = (lin % group_sz) / gm + npanel_off;
+  int tile_m, tile_n;
+  split_tile_of(lin, tiles_m, tiles_n, panel_off, npanel_off, beta, tile_m, tile_n);
   for (int e = blockIdx.y * 256 + threadIdx.x; e < TB * TB / 4; e += gridDim.y * 256) {
     const int row = e / (TB / 4), c4 = (e % (TB / 4)) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -527,10 +548,14 @@ __global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__
     const int gr = tile_m * TB + row, gc = tile_n * TB + c4;
     if (gr >= n) continue;
     float* o = C + (size_t)gr * ldc + gc;
-    if (gc + 0 < n) o[0] = v.x;
-    if (gc + 1 < n) o[1] = v.y;
-    if (gc + 2 < n) o[2] = v.z;
-    if (gc + 3 < n) o[3] = v.w;
+    const bool acc_c = (beta & SPLIT_BETA) != 0, mir = (beta & SPLIT_TRI) && tile_m != tile_n;
+    const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (gc + q < n) {
+        o[q] = vs[q] + (acc_c ? o[q] : 0.f);
+        if (mir) C[(size_t)(gc + q) * ldc + gr] = vs[q];
+      }
   }
 }
 
@@ -543,14 +568,14 @@ int chunks_of(int n, int planes) {
 template <int NP, int KSUB, int NW = 8>
 hipError_t launch_split(hipStream_t st, int grid, const void* Apack, const void* Bpack, float* C, int n, int ldc, int nkc,
                         int tm, int tiles, int panel_off, int tile_base, int ksplit, float* slab, const float* amax,
-                        int npanel_off) {
+                        int npanel_off, int beta) {
   // the dynamic-LDS limit is a per-device function attribute: set it on every launch (a host-side table write,
   // no device work), so that a second GPU in the same process gets it too
   constexpr int smem = 2 * SplitCfg<NP, KSUB>::STAGE;
   hipError_t e = hipFuncSetAttribute((const void*)split3_symm_kernel<NP, KSUB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((split3_symm_kernel<NP, KSUB, NW>), dim3(grid), dim3(NW * 64), smem, st, (const char*)Apack, (const char*)Bpack,
-                     C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax, npanel_off);
+                     C, n, ldc, nkc / KSUB, tm, tiles, panel_off, tile_base, ksplit, slab, amax, npanel_off, beta);
   return hipSuccess;
 }
 }  // namespace
@@ -592,7 +617,7 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
 // planes == 2: amax[0], amax[1] = the magnitudes the operands were packed with.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax, int npanel_off,
-                       int npanel_cols) {
+                       int npanel_cols, int beta) {
   const int nkc = chunks_of(n, planes), tiles_all = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles_all;
   const int tiles = npanel_cols >= 0 ? npanel_cols : tiles_all;      // column panels of this launch
@@ -609,7 +634,9 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   }
   // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so
   // that it fills the chip too (tiles are 256 x 256 x n: 1600 of them on 256 CUs would otherwise take 7 rounds for 6.25).
-  const int total = tm * tiles;
+  // (SPLIT_TRI: whole square launches only; tiles on or below the diagonal)
+  if ((beta & 2) && (tm != tiles_all || tiles != tiles_all || panel_off || npanel_off)) return hipErrorInvalidValue;
+  const int total = (beta & 2) ? tiles_all * (tiles_all + 1) / 2 : tm * tiles;
   int full = (total / slots) * slots, rem = total - full, ksplit = 1;
   if (rem > 0 && rem * 2 <= slots && slab) {
     ksplit = slots / rem;
@@ -625,12 +652,12 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
       hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(split2_m16_kernel, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc,
-                         nkc / 2, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
+                         nkc / 2, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
       return hipSuccess;
     }
     if (planes == 2)
-      return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
-    return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off);
+      return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
+    return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
   };
   if (full > 0) {
     hipError_t e = launch(full, 0, 1, nullptr);
@@ -640,7 +667,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     hipError_t e = launch(rem * ksplit, full, ksplit, slab);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, full,
-                       npanel_off);
+                       npanel_off, beta);
   }
   return hipGetLastError();
 }

@@ -338,6 +338,10 @@ class AttackEngine:
         """Low-rank steps that ran as the fused step (mcgra_attack_fused_steps)."""
         return int(lib.mcgra_attack_fused_steps(self._h))
 
+    def gram_split_steps(self):
+        """Gram-evaluation steps whose products ran on the fp16 split kernel (mcgra_attack_gram_split_steps)."""
+        return int(lib.mcgra_attack_gram_split_steps(self._h))
+
     def leading_dim(self):
         ptr, r, c, ld = C.c_void_p(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib.mcgra_attack_buffer(self._h, b"M", C.byref(ptr), C.byref(r), C.byref(c), C.byref(ld)))

@@ -159,7 +159,7 @@ def test_lowrank_and_gram_evaluations_agree_at_10k(ctx, monkeypatch):
         for k in ("loss", "c1", "c2", "c6", "c7"):
             assert a[k] == pytest.approx(b[k], rel=3e-4, abs=1e-6), (t, k)
         gram.set_adj_changes(fast.get_adj_changes())
-    assert gram.path_stats()["general_steps"] == 2
+    assert gram.path_stats()["general_steps"] == 2 and gram.gram_split_steps() == 2
 
 
 def test_sharded_ranks_match_monolithic_at_10k(ctx):
@@ -253,7 +253,7 @@ def test_config4_shape_30k_3layer_properties(ctx, monkeypatch):
     monkeypatch.delenv("MCGRA_NO_LOWRANK")
     b = gram.step(want_scalars=True)
     gg = gram.buffer("G_sym")
-    assert gram.path_stats()["general_steps"] == 1
+    assert gram.path_stats()["general_steps"] == 1 and gram.gram_split_steps() == 1
     err = float((gf - gg).abs().max()) / float(gg.abs().max())
     assert err < 1e-4, err
     for k in ("loss", "c1", "c2", "c6", "c7"):

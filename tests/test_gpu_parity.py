@@ -961,6 +961,63 @@ def test_fused_lowrank_adopts_the_monitor_forward_bit_identically(pkg, monkeypat
     assert abs(O.metric_pool(z["adj"], f1, z["idx_attack"]) - O.metric_pool(z["adj"], f3, z["idx_attack"])) < 1e-4
 
 
+@pytest.mark.parametrize("wp", [(0.01, 0.01, 0, 0, 0, 10, 10, 0, 0, 0), (0.01, 0, 0, 0, 0, 10, 10, 0, 0, 0),
+                                (0, 0.01, 0, 0, 0, 0, 10, 10, 0, 0)], ids=["c1c2", "c1only", "c2only"])
+def test_gram_evaluation_on_the_split_kernel_matches_fp32_symm(pkg, monkeypatch, wp):
+    """Steps the low-rank forms do not cover evaluate HSIC from the Grams; for n >= 1024 their four N x N x N products
+    run on the 2-plane fp16 kernel (mcgra_attack_gram_split_steps).  Same gradient, values and update as the fp32 SYMM
+    evaluation of the same step (MCGRA_GRAM_SPLIT=0) to fp32 rounding, and as the oracle."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=21, weight_param=wp)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    split = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_GRAM_SPLIT", "0")
+    f32 = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_GRAM_SPLIT"); monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    o = H.oracle_from(z)
+    for t in range(3):
+        a, b = split.step(want_scalars=True), f32.step(want_scalars=True)
+        o.step()
+        ga, gb = split.buffer("G_sym"), f32.buffer("G_sym")
+        scale = float(gb.abs().max())
+        assert float((ga - gb).abs().max()) / scale < 2e-5, t
+        g_or = torch.from_numpy(o.last["G_sym"]).to(ga.device)
+        assert float((ga - g_or).abs().max()) / scale < 1e-4, t
+        for k in ("loss", "c1", "c2", "c6", "c7"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-7), (t, k)
+        f32.set_adj_changes(split.get_adj_changes())
+        o.set_adj_changes(split.get_adj_changes().cpu().numpy())
+    assert split.gram_split_steps() == 3 and f32.gram_split_steps() == 0
+    assert split.path_stats() == f32.path_stats() == {"lowrank_steps": 0, "general_steps": 3}
+
+
+def test_masked_steps_of_a_large_graph_use_the_split_gram_evaluation(pkg, monkeypatch):
+    """n >= 1024 with a decode that masks pairs: the fused step hands over, the Gram evaluation runs on the split kernel
+    and agrees with the fp32 SYMM evaluation of the same steps."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=9, weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0))
+    w = H.weights_from(z)
+    probe = H.oracle_from(z); probe.step()
+    w.b = [b.copy() for b in w.b]
+    w.b[1] = (w.b[1] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)
+    engs = []
+    for gs in ("1", "0"):
+        monkeypatch.setenv("MCGRA_GRAM_SPLIT", gs)
+        e = H.engine_from(pkg, z)
+        e.set_model(w.W, w.b, w.Wlin, w.b and w.blin, w.Ws)
+        engs.append(e)
+    monkeypatch.delenv("MCGRA_GRAM_SPLIT")
+    for t in range(2):
+        a, b = [e.step(want_scalars=True) for e in engs]
+        ga, gb = engs[0].buffer("G_sym"), engs[1].buffer("G_sym")
+        assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 2e-5, t
+        for k in ("loss", "c1", "c2"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-7), (t, k)
+        engs[1].set_adj_changes(engs[0].get_adj_changes())
+    assert engs[0].gram_split_steps() == 2 and engs[1].gram_split_steps() == 0
+    assert engs[0].path_stats() == {"lowrank_steps": 0, "general_steps": 2} and engs[0].fused_steps() == 0
+
+
 def test_fused_lowrank_hands_masked_steps_to_the_general_path(pkg, monkeypatch):
     """A decode that masks a pair (S_ij <= 0) cannot take the low-rank algebra: the fused step detects it from Zn and
     the general (Gram) path redoes the step -- same result as an engine that never tries the fused step."""
