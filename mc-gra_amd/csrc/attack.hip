@@ -244,6 +244,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   if (cfg->measure == MCGRA_MEASURE_DP) { A_(KY, nn); A_(XC, nn); }
   A_(cmean, ld); A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
   A_(rowmin, ld); A_(rowmax, ld); A_(mm, 4);
+  A_(mask_seq_dev, 1);
   A_(rowsq, 2 * ld); h->rowsum = h->rowsq ? h->rowsq + n : nullptr;
   A_(rowvals, 8 * ld); A_(rowsx, ld); A_(rowsy, ld); A_(scal, S_COUNT);
   A_(labels, n); A_(idx, (size_t)h->na); A_(correct, 4);
@@ -319,9 +320,15 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
       if (hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, pr_least) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+          hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_fork3, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess ||
+          hipHostMalloc((void**)&h->mask_host, 8, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer((void**)&h->mask_host_dev, (void*)h->mask_host, 0) != hipSuccess) {
         set_error("stream / event creation failed"); rc = MCGRA_EHIP;
       }
+      if (h->mask_host) { h->mask_host[0] = 0u; h->mask_host[1] = 0u; }
     }
   }
   {
@@ -363,6 +370,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   }
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
+  h->ws_small_bytes = (size_t)64 * (h->na > h->hmax ? h->na : h->hmax) * h->hmax * sizeof(float);
+  A_(ws_small, h->ws_small_bytes / sizeof(float));
 #undef A_
   // the zero fills of dalloc ran on the null stream: order them in front of whatever stream the caller uses next
   if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed after allocation"); rc = MCGRA_EHIP; }
@@ -378,6 +387,10 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (h->st2) { (void)hipStreamSynchronize(h->st2); (void)hipStreamDestroy(h->st2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->st3) { (void)hipStreamSynchronize(h->st3); (void)hipStreamDestroy(h->st3); }
+  if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
+  if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
+  if (h->mask_host) (void)hipHostFree((void*)h->mask_host);
   delete h;
   return 0;
 }
@@ -488,6 +501,12 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
 int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg,
                       const float* Xc, double k_signed, float* G, int ldg, int slot) {
   const int na = h->na, hm = h->hmax;
+  // (own split-K workspace: the fused step runs this chain on a side stream, beside products that use h->ws)
+  auto eg = [](mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
+               const float* B, int ldb, float beta, float* C, int ldc) -> int {
+    MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws_small, h->ws_small_bytes));
+    return 0;
+  };
   launch_gather_rows(st, na, width, Ysrc, ldy, h->idx, h->Yg, hm);
   if (h->cfg.measure == MCGRA_MEASURE_MSE) {
     launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot);   // sum of squares
@@ -555,6 +574,16 @@ __global__ void k_cn(const double* __restrict__ scal, float coef, float* __restr
   // d/da (coef * |a|_2) = coef * a / |a|, 0 at the origin (torch.norm backward); |a|^2 = sum_{i!=j} M^2 / 2
   const double sq = scal[S_SQ] * 0.5;
   out[0] = sq > 0.0 ? (float)(coef / sqrt(sq)) : 0.f;
+}
+
+// {sequence number, masked?} of the decode into mapped host memory (the host polls the sequence number)
+__global__ void k_post_mask(const unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
+                            unsigned int* __restrict__ seq_dev, unsigned int* __restrict__ host_slot) {
+  const unsigned int masked = count_u32 ? (*count_u32 != 0u) : (*count_f64 != 0.0);
+  const unsigned int seq = ++*seq_dev;
+  __hip_atomic_store(host_slot + 1, masked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(host_slot + 0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // func(x) = clamp(adj_changes - x, 0, 1).sum() (topology_attack.py:398-399), over the strict lower triangle

@@ -160,6 +160,20 @@ int fused_forward(mcgra_attack* h, hipStream_t st) {      // monolithic engines 
   return fused_forward_pt(h, st, nullptr);
 }
 
+// host-side bookkeeping of a fused step that went through (the Adam pass is enqueued)
+static void fused_commit(mcgra_attack* h) {
+  const int n = h->n;
+  const size_t cnt = (size_t)n * fl_tail_tiles(n);
+  const bool may_project = h->cfg.num_edges < 0.5 * (double)n * (double)n;
+  h->lr_step = true;
+  ++h->lr_steps;
+  ++h->fused_steps;
+  h->t += 1;
+  h->prep_valid = !may_project && 3 * cnt + 4 <= (size_t)n * h->ld;
+  h->have_step = true;
+  h->fused_last = true;
+}
+
 // Returns 1 at an exchange point, 0 when the step is done, 2 when the step must be redone by the general path (a
 // relu-masked pair in the decode; every rank then holds the full M / am / av), < 0 on error.
 static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
@@ -176,9 +190,12 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   const int P = split3_panel(), p_off = R0 / P, p_cnt = R1 > R0 ? (R1 - R0 + P - 1) / P : 0;
   const int nt = fl_tail_tiles(n);
   const bool pair = !h->sharded;
+  // side streams: the product on st2, the small-operand terms on st3
+  const bool ovl = h->overlap;
+  hipStream_t s3 = h->st3;
   auto join = [&]() -> int {
     if (h->p1_inflight) {
-      if (h->overlap) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+      if (ovl) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
       h->p1_inflight = false;
     }
     return 0;
@@ -202,30 +219,43 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // kept for the post-loop decode (:300): adj_norm itself is never stored
       MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
                                  hipMemcpyDeviceToDevice, st));
-
-      // ---- planes of Xc^T rows straight from M, |xc_i|^2 from the same pass; P1 (column block of the own rows: Xc^T
-      //      rows = adj_norm rows by symmetry) forked onto the side stream
-      h->p1_inflight = false;
+      // planes of Xc^T rows straight from M, |xc_i|^2 from the same pass
       if (p_cnt > 0) {
-        float* rsq = use2 ? h->A1 : nullptr;
-        split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt, rsq);
+        split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
+                           use2 ? h->A1 : nullptr);
         if (use2)
           hipLaunchKernelGGL(k_rsq_fin, dim3((R1 - R0 + 3) / 4), dim3(256), 0, st, R0, R1, split3_pack_rsq_parts(n, h->split_planes), h->A1, h->lrRs);
-        if (use1) {
-          hipStream_t sp = h->overlap ? h->st2 : st;
-          if (h->overlap) {
-            MCGRA_HIP(hipEventRecord(h->ev_fork, st));
-            MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-          }
-          CHK(timer_begin(h, sp, h->profile));
-          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
-                                h->amax, p_off, p_cnt));
-          CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
-          ++h->split_steps;
-          if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
-          h->p1_inflight = true;
-        }
       }
+
+      // ---- P1 (column block of the own rows: Xc^T rows = adj_norm rows by symmetry) forked onto the side stream
+      h->p1_inflight = false;
+      if (p_cnt > 0 && use1) {
+        hipStream_t sp = ovl ? h->st2 : st;
+        if (ovl) {
+          MCGRA_HIP(hipEventRecord(h->ev_fork, st));
+          MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        }
+        CHK(timer_begin(h, sp, h->profile));
+        MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
+                              h->amax, p_off, p_cnt));
+        CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
+        ++h->split_steps;
+        if (ovl) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
+        h->p1_inflight = true;
+      }
+
+      // ---- small-operand terms c9 (:237-258) and c10 (:259-272): they need only the forward, and at small n their ~16
+      //      tiny launches are a tenth of the step -- forked onto a third stream, joined in front of the backward of em
+      MCGRA_HIP(hipEventRecord(h->ev_fork3, st));
+      MCGRA_HIP(hipStreamWaitEvent(h->st3, h->ev_fork3, 0));
+      MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
+      if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
+      if (w10 != 0) {
+        MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s3));
+        CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
+        launch_softmax_bwd(s3, n, C, h->sm2, h->Gsm, C, h->GZ2);
+      }
+      MCGRA_HIP(hipEventRecord(h->ev_join3, h->st3));
 
       // ---- CE loss (:172) and its gradient into the victim chain
       launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
@@ -255,43 +285,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
       FS_XCHG(h->fs_state, 3, x_allreduce(ex, h->off_sc + 16, 2))
       if (h->sharded) MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 3, sizeof(double), hipMemcpyDeviceToDevice, st));
-      {
-        unsigned int masked = 0;
-        if (use2) {
-          if (h->sharded) {
-            double m = 0;
-            MCGRA_HIP(hipMemcpyAsync(&m, h->SC + 2, sizeof(double), hipMemcpyDeviceToHost, st));
-            MCGRA_HIP(hipStreamSynchronize(st));
-            masked = m != 0.0 ? 1u : 0u;
-          } else {
-            MCGRA_HIP(hipMemcpyAsync(&masked, h->nmask, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-            MCGRA_HIP(hipStreamSynchronize(st));
-          }
-        }
-        if (masked == 0) goto lowrank_ok;
-      }
-      // relu'(0) = 0 masks a pair in the reference's backward: the low-rank algebra does not apply.  A row-block rank
-      // first collects the full M / am / av (own rows through the N x N stage), then every rank redoes the step.
-      CHK(join());
-      for (h->fs_l = 0; h->fs_l < 3; ++h->fs_l) {
-        if (h->sharded && R1 > R0) {
-          float* src = h->fs_l == 0 ? h->M : (h->fs_l == 1 ? h->am : h->av);
-          MCGRA_HIP(hipMemcpyAsync(h->NXS + (size_t)R0 * ld, src + (size_t)R0 * ld, sizeof(float) * (size_t)(R1 - R0) * ld,
-                                   hipMemcpyDeviceToDevice, st));
-        }
-        FS_XCHG(h->fs_state, 4, x_allgather(ex, h->off_nxn, (int64_t)h->rpr * ld * 4))
-        if (h->sharded) {
-          float* dst = h->fs_l == 0 ? h->M : (h->fs_l == 1 ? h->am : h->av);
-          MCGRA_HIP(hipMemcpyAsync(dst, h->NXS, sizeof(float) * (size_t)n * ld, hipMemcpyDeviceToDevice, st));
-        }
-      }
-      h->fs_state = 0;
-      return 2;
-
-    lowrank_ok:
-      h->lr_step = true;
-      ++h->lr_steps;
-      ++h->fused_steps;
+      // A relu-masked pair (S_ij <= 0) voids the low-rank algebra.  The count is posted to mapped host memory now and
+      // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
+      // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
+      // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
+      if (use2)
+        hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, h->sharded ? nullptr : h->nmask, h->sharded ? h->SC + 2 : nullptr,
+                           h->mask_seq_dev, h->mask_host_dev);
 
       // ---- low-rank factors (section 1b) with the products on M (section 1c).  T = Xc^T Vc without the delta^2 column
       //      of V: on a low-rank step every row of Zn has unit norm (a dead row would have masked its pairs), so that
@@ -319,15 +319,6 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         fl_lrq_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 192, h->lrQ, 2 * he);
       MCGRA_KERNEL_CHECK();
 
-      // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
-      MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
-      if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
-      if (w10 != 0) {
-        MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
-        CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
-        launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
-      }
-
       // ---- decode backward (the entropy part is already in GZn), normalisation of em
       if (use2) {
         launch_lr_xtz(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrQtZ);
@@ -335,6 +326,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
                         h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld, h->lrStats + 2 * he, h->lrQtZ, 2.f * (float)(sg * k2));
         launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
       }
+      MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join3, 0));       // c9 / c10: Gem, GZ2 and their scalars
       launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
 
       // ---- backward: modified_adj chain (embedding + output2), products on M
@@ -420,10 +412,46 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
       FS_XCHG(h->fs_state, 10, X_SG(h))
       if (h->sharded) stage_to_rows(h, st, 1, 0, h->gd, 1);
+      // ---- the decision, on the host
+      if (use2) {
+        bool masked;        // (no initialiser: the resumable step jumps into the block below)
+        {
+          const unsigned int want = ++h->mask_seq;
+          unsigned int spins = 0;
+          while (__atomic_load_n(&h->mask_host[0], __ATOMIC_ACQUIRE) != want) {
+            if ((++spins & 0xFFFF) == 0) {
+              const hipError_t q = hipStreamQuery(st);       // an idle stream without the post: something was lost
+              if (q != hipErrorNotReady && __atomic_load_n(&h->mask_host[0], __ATOMIC_ACQUIRE) != want) {
+                set_error("masked-pair post %u never arrived (stream: %s)", want, hipGetErrorString(q));
+                return MCGRA_EHIP;
+              }
+            }
+          }
+          masked = h->mask_host[1] != 0u;
+        }
+        if (masked) {
+          // relu'(0) = 0 masks a pair in the reference's backward: the low-rank algebra does not apply.  A row-block
+          // rank first collects the full M / am / av (own rows through the N x N stage), then every rank redoes the step.
+          for (h->fs_l = 0; h->fs_l < 3; ++h->fs_l) {
+            if (h->sharded && R1 > R0) {
+              float* src = h->fs_l == 0 ? h->M : (h->fs_l == 1 ? h->am : h->av);
+              MCGRA_HIP(hipMemcpyAsync(h->NXS + (size_t)R0 * ld, src + (size_t)R0 * ld, sizeof(float) * (size_t)(R1 - R0) * ld,
+                                       hipMemcpyDeviceToDevice, st));
+            }
+            FS_XCHG(h->fs_state, 4, x_allgather(ex, h->off_nxn, (int64_t)h->rpr * ld * 4))
+            if (h->sharded) {
+              float* dst = h->fs_l == 0 ? h->M : (h->fs_l == 1 ? h->am : h->av);
+              MCGRA_HIP(hipMemcpyAsync(dst, h->NXS, sizeof(float) * (size_t)n * ld, hipMemcpyDeviceToDevice, st));
+            }
+          }
+          h->fs_state = 0;
+          return 2;
+        }
+      }
       {
-        h->t += 1;
         const double b1 = 0.9, b2 = 0.999;
-        const double bc1 = 1.0 - pow(b1, (double)h->t), bc2 = 1.0 - pow(b2, (double)h->t);
+        const int64_t t = h->t + 1;                          // (the host's count moves in fused_commit)
+        const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
         hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
         const bool may_project = c.num_edges < 0.5 * n2;
         const size_t cnt = (size_t)n * nt;
@@ -435,11 +463,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
                      /* the Adam moments are only ever read back through the lower tile pairs (by this kernel and by the general
                         path's tail kernels): their mirrored halves are not written */ 0);
         MCGRA_KERNEL_CHECK();
-        h->prep_valid = emit;
-        h->have_step = true;
-        h->fused_last = true;
-        if (may_project) { CHK(project(h, st)); h->prep_valid = false; }      // (monolithic only: refused at create otherwise)
       }
+      fused_commit(h);
+      if (c.num_edges < 0.5 * n2) { CHK(project(h, st)); h->prep_valid = false; }      // (monolithic only: refused at create otherwise)
       if (h->sharded && h->fs_want) {
         // sum(clamp(adj_changes, 0, 1)) after the update = the row sums the Adam pass just left behind, own rows
         const size_t cnt = (size_t)n * nt;

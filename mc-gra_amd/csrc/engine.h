@@ -87,6 +87,18 @@ struct mcgra_attack {
   // right after the normalisation and runs (MFMA-bound) under the HBM-bound rest of the step
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // third stream of the fused step: the small-operand terms c9 / c10 (a chain of ~16 tiny launches that needs only the
+  // forward) run beside the low-rank factor chain; its products use their own split-K workspace
+  hipStream_t st3 = nullptr;
+  hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
+  float* ws_small = nullptr;
+  size_t ws_small_bytes = 0;
+  // The decode's masked-pair count of the fused step is posted to mapped host memory by k_post_mask together with a
+  // launch sequence number ({seq, masked}); the host polls it in front of the Adam pass (no stream sync).
+  volatile unsigned int* mask_host = nullptr;    // [0] sequence number of the post, [1] masked != 0
+  unsigned int* mask_host_dev = nullptr;         // the same words through the device's address space
+  unsigned int* mask_seq_dev = nullptr;          // device-side counter of the posts
+  unsigned int mask_seq = 0;                     // posts enqueued so far
   bool p1_inflight = false;
   bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
   // P1 through the split kernel of split_symm_bf16.hip instead of the fp32 MFMA SYMM
@@ -155,4 +167,7 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
 int project(mcgra_attack* h, hipStream_t st);
 int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out, bool have_clampsum = false);
 __global__ void k_cn(const double* __restrict__ scal, float coef, float* __restrict__ out);
+__global__ void k_post_mask(const unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
+                            unsigned int* __restrict__ seq_dev, unsigned int* __restrict__ host_slot);
+
 }

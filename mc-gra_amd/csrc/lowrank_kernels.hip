@@ -21,33 +21,31 @@ constexpr int LR_HMAX = 32;
 // partial sums over row slices (block x = k < h : column k of Z^T Z;  x = h : column sums;  x = h+1 : zeta = sum_i
 // delta_i z_i;  x = h+2 : sum_i delta_i^2 in slot 0), then a fixed-order combine.
 constexpr int LR_PARTS = 64;
-__global__ __launch_bounds__(256) void k_lr_colstats_part(int n, int h, const float* __restrict__ Z, int ldz,
-                                                          double* __restrict__ part) {
-  __shared__ double sh[16];
+// One wave per block: lane = (row r of the iteration, column k), one fp64 accumulator per lane, no barriers
+// (64 / hp rows per iteration, hp = h rounded up to a power of two >= 8).
+__global__ __launch_bounds__(64) void k_lr_colstats_part(int n, int h, const float* __restrict__ Z, int ldz,
+                                                         double* __restrict__ part) {
   const int b = blockIdx.x, pz = blockIdx.y;
   const int per = (n + LR_PARTS - 1) / LR_PARTS, i0 = pz * per, i1 = min(n, i0 + per);
-  double acc[LR_HMAX];
-#pragma unroll
-  for (int k = 0; k < LR_HMAX; ++k) acc[k] = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+  int hp = 8;
+  while (hp < h) hp <<= 1;
+  const int lane = threadIdx.x, k = lane & (hp - 1), r = lane / hp, rpi = 64 / hp;
+  double acc = 0.0;
+  for (int i = i0 + r; i < i1; i += rpi) {
     const float* z = Z + (size_t)i * ldz;
     double wgt;
     if (b < h) wgt = (double)z[b];
     else if (b == h) wgt = 1.0;
     else {
       float d = 0.f;
-      for (int k = 0; k < h; ++k) d += z[k] * z[k];
+      for (int q = 0; q < h; ++q) d += z[q] * z[q];
       wgt = (double)d;
     }
-    if (b == h + 2) { acc[0] += wgt * wgt; continue; }
-#pragma unroll
-    for (int k = 0; k < LR_HMAX; ++k)
-      if (k < h) acc[k] += wgt * (double)z[k];
+    if (b == h + 2) { if (k == 0) acc += wgt * wgt; }
+    else if (k < h) acc += wgt * (double)z[k];
   }
-  for (int k = 0; k < h; ++k) {
-    const double t = block_sum_d(acc[k], sh);
-    if (threadIdx.x == 0) part[((size_t)b * LR_PARTS + pz) * h + k] = t;
-  }
+  for (int o = hp; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+  if (r == 0 && k < h) part[((size_t)b * LR_PARTS + pz) * h + k] = acc;
 }
 __global__ void k_lr_colstats_fin(int n, int h, const double* __restrict__ part, double* __restrict__ stats) {
   const int b = blockIdx.x, k = threadIdx.x;
@@ -310,25 +308,18 @@ __global__ __launch_bounds__(256) void k_lr_decode_bwd(int n, int ld, const floa
   if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 // QtZ[b][k] = sum_i X[i][b] Z[i][k] in fp64, two deterministic stages like k_lr_colstats_*
-__global__ __launch_bounds__(256) void k_lr_xtz_part(int n, int h, const float* __restrict__ X, int ldx,
-                                                     const float* __restrict__ Z, int ldz, double* __restrict__ part) {
-  __shared__ double sh[16];
+__global__ __launch_bounds__(64) void k_lr_xtz_part(int n, int h, const float* __restrict__ X, int ldx,
+                                                    const float* __restrict__ Z, int ldz, double* __restrict__ part) {
   const int b = blockIdx.x, pz = blockIdx.y;
   const int per = (n + LR_PARTS - 1) / LR_PARTS, i0 = pz * per, i1 = min(n, i0 + per);
-  double acc[LR_HMAX];
-#pragma unroll
-  for (int k = 0; k < LR_HMAX; ++k) acc[k] = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    const double wgt = (double)X[(size_t)i * ldx + b];
-    const float* z = Z + (size_t)i * ldz;
-#pragma unroll
-    for (int k = 0; k < LR_HMAX; ++k)
-      if (k < h) acc[k] += wgt * (double)z[k];
-  }
-  for (int k = 0; k < h; ++k) {
-    const double t = block_sum_d(acc[k], sh);
-    if (threadIdx.x == 0) part[((size_t)b * LR_PARTS + pz) * h + k] = t;
-  }
+  int hp = 8;
+  while (hp < h) hp <<= 1;
+  const int lane = threadIdx.x, k = lane & (hp - 1), r = lane / hp, rpi = 64 / hp;
+  double acc = 0.0;
+  if (k < h)
+    for (int i = i0 + r; i < i1; i += rpi) acc += (double)X[(size_t)i * ldx + b] * (double)Z[(size_t)i * ldz + k];
+  for (int o = hp; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+  if (r == 0 && k < h) part[((size_t)b * LR_PARTS + pz) * h + k] = acc;
 }
 __global__ void k_lr_xtz_fin(int h, const double* __restrict__ part, double* __restrict__ out) {
   const int b = blockIdx.x, k = threadIdx.x;
@@ -359,7 +350,7 @@ int lr_decode_slabs(int n) {
 size_t lr_qtz_doubles(int h) { return (size_t)h * h + (size_t)h * LR_PARTS * h; }
 void launch_lr_xtz(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, double* qtz) {
   double* part = qtz + (size_t)h * h;
-  LAUNCH(k_lr_xtz_part, dim3(h, LR_PARTS), dim3(256), st, n, h, QQ, 2 * h, Z, ldz, part);
+  LAUNCH(k_lr_xtz_part, dim3(h, LR_PARTS), dim3(64), st, n, h, QQ, 2 * h, Z, ldz, part);
   LAUNCH(k_lr_xtz_fin, dim3(h), dim3(64), st, h, part, qtz);
 }
 int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
@@ -379,7 +370,7 @@ int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, 
 
 void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats) {
   double* part = stats + (size_t)2 * h + (size_t)h * h + 2;
-  LAUNCH(k_lr_colstats_part, dim3(h + 3, LR_PARTS), dim3(256), st, n, h, Z, ldz, part);
+  LAUNCH(k_lr_colstats_part, dim3(h + 3, LR_PARTS), dim3(64), st, n, h, Z, ldz, part);
   LAUNCH(k_lr_colstats_fin, dim3(h + 3), dim3(64), st, n, h, part, stats);
 }
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,

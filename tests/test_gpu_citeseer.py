@@ -3,12 +3,14 @@
 priors H_A + Y, the citeseer branch of dot_product_decode2 (:427-431).  Fixtures: tests/golden/citeseer_gat_*.npz
 (tests/golden/make_golden.py --only citeseer ran the reference's PGDAttack.attack on CPU).
 
-"bf16" in that config line has no counterpart in the reference (its CPU path is fp32 torch) and none here: ELU
-embeddings of width 80 take the Gram evaluation of linear_HSIC (fp32 MFMA SYRK / SYMM), KL is elementwise fp32;
-16-bit matrix-core arithmetic appears on this path only as the 2-plane fp16 split of the low-rank step's one product,
-at fp32-level error."""
+"bf16" in that config line has no counterpart in the reference (its CPU path is fp32 torch): on this path 16-bit
+matrix-core arithmetic appears only as the 2-plane fp16 split of N x N x N products at fp32-level error (DESIGN.md
+section 3) -- the ELU embeddings of width 80 take the Gram evaluation of linear_HSIC, whose four products per step run
+on that kernel (n = 3312 >= 1024); KL is elementwise fp32."""
 import argparse
+import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -98,3 +100,37 @@ def test_citeseer_gat_through_the_pgdattack_class(pkg):
                  label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
     final = model.modified_adj.cpu().numpy()
     assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) <= 1e-4
+
+
+def test_citeseer_gat_hsic_step_time(pkg):
+    """Step time of config[2]'s shape (GAT victim, Gram evaluation on the split kernel).  Written to
+    $MCGRA_REPORT_DIR/citeseer_gat_hsic_step.json when that is set (profiles/ keeps a copy); the bound only catches a
+    fall back to the fp32 products (measured 3.5x slower at this size)."""
+    import torch
+    z = H.load_cora("citeseer_gat_hsic")
+    w = _weights(z)
+    n = z["adj"].shape[0]
+    dims = [w.W[0].shape[0]] + [x.shape[1] for x in w.W]
+    eng = pkg.AttackEngine(n, dims, w.Wlin.shape[0], int(z["emb_nlayer"]), "HSIC", float(z["weight_sup"]),
+                           tuple(float(x) for x in z["weight_param"]), float(z["lr"]), float(z["num_edges"]),
+                           len(z["idx_attack"]), act="elu", head_act="elu", fin_layers=tuple(int(x) for x in z["fin_layers"]))
+    eng.set_model(w.W, w.b, w.Wlin, w.blin)
+    eng.set_graph(z["features"], z["adj"], None, H.cora_feature_adj(z["features"]), z["labels"], z["idx_attack"])
+    for _ in range(3):
+        eng.step(); eng.monitor()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 20
+    for _ in range(steps):
+        eng.step(); eng.monitor()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    assert eng.gram_split_steps() == steps + 3
+    out = {"workload": "citeseer (N = 3312), GAT victim 5 x 16 ELU, HSIC, priors H_A + Y", "ms_per_step": ms,
+           "steps_per_s": 1e3 / ms, "products": "Gram evaluation: 4 split products per step (2-plane fp16)",
+           "monitor_forward": True}
+    d = os.environ.get("MCGRA_REPORT_DIR")
+    if d and os.path.isdir(d):
+        json.dump(out, open(os.path.join(d, "citeseer_gat_hsic_step.json"), "w"))
+    print(out)
+    assert ms < 6.0, ms
