@@ -139,6 +139,11 @@ int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, c
  * arrives here as explicit per-operand sigmas.  hsic_normalized_cca (:138-151, two m x m inverses) is not provided. */
 int mcgra_hsic_regular2(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma_x, float sigma_y,
                         int normalized, float* out);               /* hsic_regular / hsic_normalized, one sigma per operand */
+/* hsic.py:138-151 (= utils.py:732-743 with sigma 5): sum(Rx o Ry^T), R = Kc (Kc + 1e-5 m I)^-1.  fp64 throughout
+ * (kernel matrices from the fp32 inputs, Gauss-Jordan inverses with partial pivoting): the reference's fp32
+ * torch.inverse leaves up to 1e-2 of error on these matrices, this path is the exact value to fp32 output rounding. */
+int mcgra_hsic_normalized_cca(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma_x, float sigma_y,
+                              float* out);
 int mcgra_distmat(void* stream, int m, int d, const float* X, float* out);                      /* hsic.py:20-27 */
 int mcgra_mmd(void* stream, int mx, int my, int d, const float* X, const float* Y, float sx, float sy, float sxy,
               float* out);                                                                     /* hsic.py:68-89 */

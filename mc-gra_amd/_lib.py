@@ -24,7 +24,7 @@ SYMBOLS = [
     "mcgra_version", "mcgra_last_error", "mcgra_device_count", "mcgra_sgemm",
     "mcgra_ssyrk_lower", "mcgra_ssymm_lower",
     "mcgra_get_modified_adj", "mcgra_pack_tril", "mcgra_normalize_adj", "mcgra_info_entropy",
-    "mcgra_dot_product_decode", "mcgra_dot_product_decode2", "mcgra_linear_hsic", "mcgra_hsic_regular", "mcgra_hsic_normalized", "mcgra_hsic_regular2", "mcgra_distmat", "mcgra_mmd",
+    "mcgra_dot_product_decode", "mcgra_dot_product_decode2", "mcgra_linear_hsic", "mcgra_hsic_regular", "mcgra_hsic_normalized", "mcgra_hsic_regular2", "mcgra_hsic_normalized_cca", "mcgra_distmat", "mcgra_mmd",
     "mcgra_mmd_pxpy_pxy", "mcgra_mse",
     "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
@@ -87,6 +87,7 @@ def _load():
         "mcgra_hsic_regular": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp],
         "mcgra_hsic_normalized": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp],
         "mcgra_hsic_regular2": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_int, fp],
+        "mcgra_hsic_normalized_cca": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, fp],
         "mcgra_distmat": [vp, C.c_int, C.c_int, fp, fp],
         "mcgra_mmd": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp],
         "mcgra_mmd_pxpy_pxy": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, fp],

@@ -28,6 +28,98 @@ struct Scratch {
 };
 }  // namespace
 
+// ---- hsic_normalized_cca (hsic.py:138-151): fp64 throughout.  The two regularised kernel matrices have condition
+// numbers ~1 / (1e-5 m) of their largest eigenvalue; the reference's fp32 torch.inverse leaves 1e-3 .. 1e-2 of error in
+// the result (measured against an fp64 evaluation, tests/golden), so this path forms the kernel matrices in fp64 from
+// the fp32 inputs and inverts them by Gauss-Jordan elimination with partial pivoting in fp64.
+namespace {
+// K_ij = exp(-|x_i - x_j|^2 / (2 sigma^2)) in fp64 (distmat's r_i - 2 <x_i, x_j> + r_j, hsic.py:20-27), row sums to rs
+__global__ __launch_bounds__(256) void k_cca_kernelmat(int m, int d, const float* __restrict__ X, double inv2s2,
+                                                       double* __restrict__ K, double* __restrict__ rs) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    double ri = 0, rj = 0, dot = 0;
+    for (int k = 0; k < d; ++k) {
+      const double a = X[(size_t)i * d + k], b = X[(size_t)j * d + k];
+      ri += a * a; rj += b * b; dot += a * b;
+    }
+    const double v = exp(-(ri - 2.0 * dot + rj) * inv2s2);
+    K[(size_t)i * m + j] = v;
+    acc += v;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) rs[i] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// aug = [Kc + eps m I | I] with Kc = K H (row means removed, hsic.py:45-46)
+__global__ __launch_bounds__(256) void k_cca_augment(int m, const double* __restrict__ K, const double* __restrict__ rs, double epsm,
+                                                     double* __restrict__ aug) {
+  const int i = blockIdx.x;
+  const double mean = rs[i] / (double)m;
+  for (int j = threadIdx.x; j < 2 * m; j += 256)
+    aug[(size_t)i * 2 * m + j] = j < m ? K[(size_t)i * m + j] - mean + (i == j ? epsm : 0.0) : (j - m == i ? 1.0 : 0.0);
+}
+// one elimination step: pivot search in column k (rows >= k), row swap, scaling of the pivot row (one block) ...
+__global__ __launch_bounds__(256) void k_gj_pivot(int m, int k, double* __restrict__ aug, int* __restrict__ singular) {
+  __shared__ double bv[256];
+  __shared__ int bi[256];
+  const int w = 2 * m;
+  double best = -1.0; int idx = k;
+  for (int i = k + threadIdx.x; i < m; i += 256) {
+    const double v = fabs(aug[(size_t)i * w + k]);
+    if (v > best) { best = v; idx = i; }
+  }
+  bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o && (bv[threadIdx.x + o] > bv[threadIdx.x] ||
+                            (bv[threadIdx.x + o] == bv[threadIdx.x] && bi[threadIdx.x + o] < bi[threadIdx.x]))) {
+      bv[threadIdx.x] = bv[threadIdx.x + o]; bi[threadIdx.x] = bi[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const int p = bi[0];
+  if (!(bv[0] > 0.0)) { if (threadIdx.x == 0) *singular = 1; return; }
+  const double inv = 1.0 / aug[(size_t)p * w + k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < w; j += 256) {
+    const double a = aug[(size_t)p * w + j], b = aug[(size_t)k * w + j];
+    aug[(size_t)k * w + j] = a * inv;
+    if (p != k) aug[(size_t)p * w + j] = b;
+  }
+}
+// ... and the elimination of column k from every other row (one block per row)
+__global__ __launch_bounds__(256) void k_gj_eliminate(int m, int k, double* __restrict__ aug) {
+  const int i = blockIdx.x, w = 2 * m;
+  if (i == k) return;
+  __shared__ double f;
+  if (threadIdx.x == 0) f = aug[(size_t)i * w + k];
+  __syncthreads();
+  const double fi = f;
+  if (fi == 0.0) return;
+  for (int j = threadIdx.x; j < w; j += 256) aug[(size_t)i * w + j] -= fi * aug[(size_t)k * w + j];
+}
+// rows[i] = sum_j Rx_ij Ry_ji with R = Kc (Kc + eps m I)^-1 = I - eps m (Kc + eps m I)^-1
+__global__ __launch_bounds__(256) void k_cca_rows(int m, double epsm, const double* __restrict__ ax, const double* __restrict__ ay,
+                                                  double* __restrict__ rows) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x, w = 2 * m;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const double rx = (i == j ? 1.0 : 0.0) - epsm * ax[(size_t)i * w + m + j];
+    const double ry = (i == j ? 1.0 : 0.0) - epsm * ay[(size_t)j * w + m + i];
+    acc += rx * ry;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) rows[i] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+}  // namespace
+
 #define NEED(ptr) if (!(ptr)) { set_error("hipMalloc failed"); return MCGRA_ENOMEM; }
 
 extern "C" {
@@ -361,6 +453,44 @@ int mcgra_mmd_pxpy_pxy(void* stream, int m, int dx, int dy, const float* X, cons
   for (int j = 0; j < m; ++j) { B += (hx[j] / m) * (hy[j] / m); sxm += hx[j]; sym += hy[j]; }   // K symmetric: column means = row means
   const double A = t / ((double)m * m), Cc = (sxm / ((double)m * m)) * (sym / ((double)m * m));
   const float f = (float)(A - 2.0 * B / m + Cc);
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// hsic.hsic_normalized_cca (hsic.py:138-151; utils.py:732-743 is the same function with sigma = 5):
+// sum(Rx o Ry^T), R = Kc (Kc + 1e-5 m I)^-1, Kc = exp(-D / (2 sigma^2)) H.  sigma_x / sigma_y as in mcgra_hsic_regular2.
+int mcgra_hsic_normalized_cca(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma_x, float sigma_y,
+                              float* out) {
+  if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out || !(sigma_x > 0.f) || !(sigma_y > 0.f)) { set_error("bad argument"); return MCGRA_EINVAL; }
+  if (m > 8192) { set_error("hsic_normalized_cca: m = %d rows (two dense m x 2m fp64 eliminations) is beyond what this utility is for", m); return MCGRA_ENOSUP; }
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  double* K = s.get<double>((size_t)m * m); NEED(K);
+  double* ax = s.get<double>((size_t)m * 2 * m); double* ay = s.get<double>((size_t)m * 2 * m); NEED(ax); NEED(ay);
+  double* rs = s.get<double>(m); double* tot = s.get<double>(1); NEED(rs); NEED(tot);
+  int* sing = s.get<int>(1); NEED(sing);
+  const double epsm = 1e-5 * (double)m;
+  const float* in[2] = {X, Y};
+  const int dd[2] = {dx, dy};
+  const double sg[2] = {sigma_x, sigma_y};
+  double* aug[2] = {ax, ay};
+  for (int t = 0; t < 2; ++t) {
+    hipLaunchKernelGGL(k_cca_kernelmat, dim3(m), dim3(256), 0, st, m, dd[t], in[t], 1.0 / (2.0 * sg[t] * sg[t]), K, rs);
+    hipLaunchKernelGGL(k_cca_augment, dim3(m), dim3(256), 0, st, m, K, rs, epsm, aug[t]);
+    for (int k = 0; k < m; ++k) {
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, st, m, k, aug[t], sing);
+      hipLaunchKernelGGL(k_gj_eliminate, dim3(m), dim3(256), 0, st, m, k, aug[t]);
+    }
+  }
+  hipLaunchKernelGGL(k_cca_rows, dim3(m), dim3(256), 0, st, m, epsm, ax, ay, rs);
+  launch_reduce_rows(st, rs, m, 1, tot);
+  MCGRA_KERNEL_CHECK();
+  double t = 0; int bad = 0;
+  MCGRA_HIP(hipMemcpyAsync(&t, tot, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipMemcpyAsync(&bad, sing, sizeof(int), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  if (bad) { set_error("hsic_normalized_cca: singular matrix (torch.inverse raises here too)"); return MCGRA_EINVAL; }
+  const float f = (float)t;
   MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }

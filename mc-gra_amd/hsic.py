@@ -3,7 +3,8 @@ tensors in, device scalars out.  The kernel matrices, their centring and every m
 (csrc/capi.hip); what the reference itself does on the host stays on the host: ``sigma_estimation`` takes the median
 of the pairwise distances with numpy (hsic.py:5-17) after the distance matrix has been formed on the device.
 
-Not provided: ``hsic_normalized_cca`` (:138-151, two m x m matrix inverses) -- nothing in the attack calls it.
+``hsic_normalized_cca`` (:138-151) is evaluated in fp64 on the device (its two regularised m x m inverses are
+ill-conditioned: the reference's fp32 result carries up to 1e-2 of error, see csrc/capi.hip).
 ``use_cuda`` / ``to_numpy`` are accepted and ignored (the reference ignores ``to_numpy`` too).
 """
 import ctypes as C
@@ -103,6 +104,14 @@ def hsic_normalized(x, y, sigma=None, use_cuda=True, to_numpy=True):
     return _hsic(x, y, sigma, True)
 
 
+@_on_operand_device
 def hsic_normalized_cca(x, y, sigma=None, use_cuda=True, to_numpy=True):
-    raise NotImplementedError("hsic_normalized_cca (hsic.py:138-151) needs two m x m matrix inverses and is not on the HIP path; "
-                              "nothing in the attack calls it")
+    """hsic.hsic_normalized_cca (:138-151); utils.hsic_normalized_cca (utils.py:732-743) is this with sigma=5.0."""
+    x, y = _f32(x), _f32(y)
+    if sigma:
+        sx = sy = float(sigma)
+    else:
+        sx, sy = sigma_estimation(x, x), sigma_estimation(y, y)
+    out = torch.zeros(1, device=x.device, dtype=torch.float32)
+    check(lib.mcgra_hsic_normalized_cca(_stream(), x.shape[0], x.shape[1], y.shape[1], _p(x), _p(y), sx, sy, _p(out)))
+    return out[0]

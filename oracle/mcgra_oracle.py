@@ -228,6 +228,26 @@ def hsic_mmd_pxpy_pxy(x, y, sigma=None) -> F32:
     return F32((kx * ky).mean() - 2 * (kx.mean(0) * ky.mean(0)).mean() + kx.mean() * ky.mean())
 
 
+def hsic_normalized_cca(x, y, sigma=None, dtype=None):
+    """hsic.hsic_normalized_cca (hsic.py:138-151): sum(Rx o Ry^T), R = Kc inv(Kc + 1e-5 m I).  dtype=np.float64 gives
+    the exact value the fp32 reference approximates (its two inverses are ill-conditioned)."""
+    T = dtype or F32
+    if sigma:
+        sx = sy = sigma
+    else:
+        sx, sy = hsic_sigma_estimation(x, x), hsic_sigma_estimation(y, y)
+    m = x.shape[0]
+
+    def R(X, s_):
+        X = X.astype(T)
+        r = (X * X).sum(1)
+        K = np.exp(-(r[:, None] - T(2) * (X @ X.T) + r[None, :]) / T(2.0 * s_ * s_)).astype(T)
+        Kc = (K @ (np.eye(m, dtype=T) - np.ones((m, m), T) / T(m))).astype(T)
+        return (Kc @ np.linalg.inv(Kc + T(1e-5 * m) * np.eye(m, dtype=T)).astype(T)).astype(T)
+
+    return T((R(x, sx).astype(np.float64) * R(y, sy).T).sum())
+
+
 def mse_loss(X, Y) -> F32:
     """torch.nn.MSELoss()(X, Y) (topology_attack.py:194-195)."""
     return F32(np.mean((X.astype(np.float64) - Y) ** 2))

@@ -346,6 +346,19 @@ def gen_ops(tmp):
     for sg in (None, 1.5):
         out[f"ghsic_mmd_{sg}"] = rhsic.mmd(ty, tz, sigma=sg).item()
         out[f"ghsic_mmdp_{sg}"] = rhsic.mmd_pxpy_pxy(tx, ty, sigma=sg, use_cuda=False).item()
+    # hsic_normalized_cca (hsic.py:138-151): the reference's fp32 value and the same formula in float64 (the two
+    # regularised inverses are ill-conditioned; the fp32 value is up to 1e-2 off)
+    def cca64(x, y, sx, sy):
+        def R(X, s_):
+            X = X.astype(np.float64); m = len(X)
+            r = (X * X).sum(1)
+            Kc = np.exp(-(r[:, None] - 2 * X @ X.T + r[None, :]) / (2 * s_ * s_)) @ (np.eye(m) - np.ones((m, m)) / m)
+            return Kc @ np.linalg.inv(Kc + 1e-5 * m * np.eye(m))
+        return float((R(x, sx) * R(y, sy).T).sum())
+    for sg in (1.0, 5.0, None):
+        out[f"ghsic_cca_{sg}"] = rhsic.hsic_normalized_cca(tx, ty, sigma=sg).item()
+        sxx, syy = (sg, sg) if sg else (out["ghsic_sigma_xx"], out["ghsic_sigma_yy"])
+        out[f"ghsic_cca64_{sg}"] = cca64(hx, hy, sxx, syy)
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
     print("ops.npz", len(out), "arrays")
 

@@ -168,7 +168,7 @@ def test_gaussian_hsic_ops(pkg, torch_, sg):
 def test_hsic_py_mirror_against_reference(pkg, torch_):
     """mc-gra_amd/hsic.py (the reference's hsic.py surface on the device) against the reference's own values:
     sigma=None forms (median heuristic: distance matrix on the device, median on the host as in the reference),
-    distmat, distcorr, mmd, mmd_pxpy_pxy; hsic_normalized_cca refuses loudly."""
+    distmat, distcorr, mmd, mmd_pxpy_pxy, hsic_normalized_cca."""
     from mc_gra_amd import hsic as HS
     x, y, z = dev(torch_, OPS["ghsic_x"]), dev(torch_, OPS["ghsic_y"]), dev(torch_, OPS["ghsic_z"])
     assert abs(HS.sigma_estimation(x, x) - float(OPS["ghsic_sigma_xx"])) <= 2e-5 * float(OPS["ghsic_sigma_xx"])
@@ -182,8 +182,14 @@ def test_hsic_py_mirror_against_reference(pkg, torch_):
     for sg in (None, 1.5):
         assert abs(float(HS.mmd(y, z, sigma=sg)) - float(OPS[f"ghsic_mmd_{sg}"])) <= 3e-5 * abs(float(OPS[f"ghsic_mmd_{sg}"]))
         assert abs(float(HS.mmd_pxpy_pxy(x, y, sigma=sg)) - float(OPS[f"ghsic_mmdp_{sg}"])) <= 3e-4 * abs(float(OPS[f"ghsic_mmdp_{sg}"])) + 1e-8
-    with pytest.raises(NotImplementedError):
-        HS.hsic_normalized_cca(x, y)
+    # hsic_normalized_cca: two ill-conditioned inverses.  The fixture holds the reference's fp32 value and the same
+    # formula in float64; the device path (fp64 throughout) must sit on the float64 value and be no further from the
+    # reference than the reference is from the float64 value.
+    for sg in (1.0, 5.0, None):
+        ref, exact = float(OPS[f"ghsic_cca_{sg}"]), float(OPS[f"ghsic_cca64_{sg}"])
+        got = float(HS.hsic_normalized_cca(x, y, sigma=sg))
+        assert abs(got - exact) <= (2e-6 if sg else 2e-4) * abs(exact), (sg, got, exact)      # (None: sigma from an fp32 median)
+        assert abs(got - ref) <= abs(ref - exact) + (2e-6 if sg else 2e-4) * abs(exact), (sg, got, ref, exact)
 
 
 def test_ops_edge_cases(pkg, torch_):

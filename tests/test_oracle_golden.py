@@ -57,6 +57,16 @@ def test_hsic_py_remainder():
         assert abs(O.hsic_mmd_pxpy_pxy(x, y, sg) - float(OPS[f"ghsic_mmdp_{sg}"])) <= 2e-4 * abs(float(OPS[f"ghsic_mmdp_{sg}"])) + 1e-8
 
 
+@pytest.mark.parametrize("sg", [1.0, 5.0, None])
+def test_hsic_normalized_cca(sg):
+    """hsic.hsic_normalized_cca (:138-151): the restatement in fp32 lands within the reference's own conditioning error
+    (numpy's and torch's LU differ in rounding), the float64 evaluation on the fixture's float64 value."""
+    x, y = OPS["ghsic_x"], OPS["ghsic_y"]
+    ref, exact = float(OPS[f"ghsic_cca_{sg}"]), float(OPS[f"ghsic_cca64_{sg}"])
+    assert abs(float(O.hsic_normalized_cca(x, y, sg, dtype=np.float64)) - exact) <= 1e-7 * abs(exact)
+    assert abs(float(O.hsic_normalized_cca(x, y, sg)) - ref) <= 3 * abs(ref - exact) + 3e-5 * abs(exact)
+
+
 def test_info_entropy():
     v, g = O.info_entropy_grad(OPS["ie_in"])
     assert abs(v - OPS["ie_val"]) < 1e-6
