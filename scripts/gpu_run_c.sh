@@ -1,8 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "hsic_py" 2>&1 | grep -E "passed|failed|FAILED|^tests|^E " | tail -8
-export TMPDIR=/tmp
-R="$GRAFT_REPO_ROOT"
-cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/${TAG}_prof_cora" -o kt -- python3 "$R/bench.py" --workload cora-shape-hsic --steps 20 --warmup 5 --no-cpu-baseline --no-split-probe > "$R/gpurun_out/${TAG}_prof_cora.log" 2>&1
-ls $R/gpurun_out/${TAG}_prof_cora | head
+export MCGRA_REPORT_DIR="$GRAFT_REPO_ROOT/gpurun_out"
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|^tests" | tail -8
+for i in 1 2; do
+python bench.py --workload cora-shape-hsic --no-cpu-baseline --no-split-probe --steps 200 --warmup 10 > gpurun_out/${TAG}_cora.json 2> gpurun_out/${TAG}_cora.err
+python -c "import json;j=json.load(open('gpurun_out/${TAG}_cora.json'));print('cora', j['value'], j['ms_per_step'])"
+python bench.py --no-cpu-baseline --no-split-probe --steps 30 > gpurun_out/${TAG}_10k.json 2>/dev/null
+python -c "import json;j=json.load(open('gpurun_out/${TAG}_10k.json'));print('10k', j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'])"
+done
