@@ -298,7 +298,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     // their rate.  MCGRA_GRAM_SPLIT=0: fp32 path.
     const char* eg_ = getenv("MCGRA_GRAM_SPLIT");
     const bool gram_auto = (es[0] == '3') && !(eg_ && eg_[0] == '0');
-    if (!rc && cfg->measure == MCGRA_MEASURE_HSIC && cfg->eps == 0.f && gram_auto) {
+    if (!rc && (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) && cfg->eps == 0.f && gram_auto) {
       if (!h->split_on) { h->split_planes = 2; A_(Bpack, split3_pack_bytes((int)n, 2)); A_(amax, 16); }
       if (h->split_planes == 2) {
         const size_t pb = split3_pack_bytes((int)n, 2);
@@ -886,7 +886,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       h->p1_inflight = false;
     }
     if (h->lr_step) {
-    } else if (h->gram_split && !noise && !cka) {
+    } else if (h->gram_split && !noise) {
       // full Kx and Ky from the fp16 planes of Xc and Yc (split_symm_bf16.hip); split-K slabs in G_A, idle until phase 3
       const size_t slab = sizeof(float) * (size_t)n * ld;
       const bool big = h->profile;
@@ -915,14 +915,21 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
   }
 
-  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && h->gram_split && !noise && !cka) {
+  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && h->gram_split && !noise) {
     const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
     const size_t slab = sizeof(float) * (size_t)n * ld;
     const bool big = h->profile;
     MCGRA_HIP(hipMemsetAsync(h->amax + 3, 0, 2 * sizeof(float), st));
-    launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->rowvals + 4 * (size_t)ld, false,
-                        h->amax + 4, h->amax + 3);
-    launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+    if (cka) {      // linear_CKA (:486): the same two gradient products with left factors L1 -> KY, L2 -> KX
+      launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, false);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 4, h->scal + S_CK0);
+      launch_cka_coef(st, h->scal + S_CK0, h->cst + 0, use1 ? (float)k1 : 0.f, use2 ? (float)k2 : 0.f, h->coef);
+      launch_cka_lincomb(st, n, ld, h->KX, h->KY, h->KFC, h->coef, use1, use2, false, h->amax + 4, h->amax + 3);
+    } else {
+      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->rowvals + 4 * (size_t)ld, false,
+                          h->amax + 4, h->amax + 3);
+      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+    }
     // G_adjn += 2 (s1 Kfc + s2 Kyc) Xc ;  G_A1 += 2 s2 Kxc Yc
     MCGRA_HIP(hipMemcpyAsync(h->amax + 12, h->amax + 3, sizeof(float), hipMemcpyDeviceToDevice, st));
     MCGRA_HIP(hipMemcpyAsync(h->amax + 13, h->amax + 1, sizeof(float), hipMemcpyDeviceToDevice, st));

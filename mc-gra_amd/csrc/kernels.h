@@ -31,7 +31,7 @@ void launch_cka_sums(hipStream_t st, int n, int ld, const float* KX, const float
                      bool use2, double* rowvals, bool lower);
 void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float k1, float k2, float* coef);
 void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
-                        bool use1, bool use2, bool lower);
+                        bool use1, bool use2, bool lower, float* amax_l2 = nullptr, float* amax_l1 = nullptr);
 void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, int nstrips, double* cols);
 void launch_gauss_kernel(hipStream_t st, int m, int ld, float* A, const float* sq, float inv2s2, double* rows,
                          const float* sq2 = nullptr, int m2 = 0);

@@ -822,17 +822,30 @@ __global__ void k_cka_coef(const double* __restrict__ s, const double* __restric
 
 __global__ __launch_bounds__(ROW_THREADS) void k_cka_lincomb(int n, int ld, float* __restrict__ KX,
                                                              float* __restrict__ KY, const float* __restrict__ KFC,
-                                                             const float* __restrict__ coef, int use1, int use2, int lower) {
+                                                             const float* __restrict__ coef, int use1, int use2, int lower,
+                                                             unsigned* __restrict__ amax_l2, unsigned* __restrict__ amax_l1) {
   const int i = blockIdx.x;
   const size_t base = (size_t)i * ld;
   const int jend = lower ? min(n, (i / SYM_TILE + 1) * SYM_TILE) : n;
   const float af = coef[0], ax = coef[1], ay = coef[2], bx = coef[3], by = coef[4];
+  float m1 = 0.f, m2 = 0.f;       // largest magnitudes of L1 / L2 (operand scales of the fp16 split, optional)
   for (int j = threadIdx.x; j < jend; j += ROW_THREADS) {
     const float kx = KX[base + j];
     const float ky = use2 ? KY[base + j] : 0.f;
     const float kf = use1 ? KFC[base + j] : 0.f;
-    KY[base + j] = af * kf + ax * kx + ay * ky;
-    KX[base + j] = bx * kx + by * ky;
+    const float l1 = af * kf + ax * kx + ay * ky, l2 = bx * kx + by * ky;
+    KY[base + j] = l1;
+    KX[base + j] = l2;
+    m1 = fmaxf(m1, fabsf(l1)); m2 = fmaxf(m2, fabsf(l2));
+  }
+  if (amax_l1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, o)); m2 = fmaxf(m2, __shfl_xor(m2, o)); }
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned b1 = __float_as_uint(m1), b2 = __float_as_uint(m2);
+      if (b1 > __hip_atomic_load(amax_l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_l1, b1);
+      if (b2 > __hip_atomic_load(amax_l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_l2, b2);
+    }
   }
 }
 
@@ -973,8 +986,9 @@ void launch_cka_coef(hipStream_t st, const double* s4, const double* hff, float 
   LAUNCH(k_cka_coef, dim3(1), dim3(1), st, s4, hff, k1, k2, coef);
 }
 void launch_cka_lincomb(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, const float* coef,
-                        bool use1, bool use2, bool lower) {
-  LAUNCH(k_cka_lincomb, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, coef, use1 ? 1 : 0, use2 ? 1 : 0, lower ? 1 : 0);
+                        bool use1, bool use2, bool lower, float* amax_l2, float* amax_l1) {
+  LAUNCH(k_cka_lincomb, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, coef, use1 ? 1 : 0, use2 ? 1 : 0, lower ? 1 : 0,
+         (unsigned*)amax_l2, (unsigned*)amax_l1);
 }
 void launch_colsum(hipStream_t st, int n, int ld, const float* X, double* part, int nstrips, double* cols) {
   const int rows_per_strip = (n + nstrips - 1) / nstrips;

@@ -1000,6 +1000,33 @@ def test_gram_evaluation_on_the_split_kernel_matches_fp32_symm(pkg, monkeypatch,
     assert split.path_stats() == f32.path_stats() == {"lowrank_steps": 0, "general_steps": 3}
 
 
+def test_cka_steps_of_a_large_graph_use_the_split_kernel(pkg, monkeypatch):
+    """linear_CKA (:486) at n >= 1024: the two Grams and the two gradient products of a step on the 2-plane fp16 kernel;
+    same gradient and values as the fp32 SYRK / SYMM evaluation (MCGRA_GRAM_SPLIT=0) and as the oracle."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=33, measure="CKA", weight_param=(1.0, 1.0, 0, 0, 0, 10, 10, 0, 0, 0))
+    split = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_GRAM_SPLIT", "0")
+    f32 = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_GRAM_SPLIT")
+    o = H.oracle_from(z)
+    for t in range(2):
+        a, b = split.step(want_scalars=True), f32.step(want_scalars=True)
+        o.step()
+        ga, gb = split.buffer("G_sym"), f32.buffer("G_sym")
+        scale = float(gb.abs().max())
+        assert float((ga - gb).abs().max()) / scale < 2e-5, t
+        # (the oracle only loosely: the CKA gradient is the difference of two normalised Gram terms that nearly cancel,
+        # numpy's fp32 evaluation of it carries ~1e-3 of noise; the two HIP evaluations agree 100 x closer)
+        g_or = torch.from_numpy(o.last["G_sym"]).to(ga.device)
+        assert float((ga - g_or).abs().max()) / scale < 1e-2, (t, float((ga - g_or).abs().max()) / scale)
+        for k in ("loss", "c1", "c2"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-7), (t, k)
+        f32.set_adj_changes(split.get_adj_changes())
+        o.set_adj_changes(split.get_adj_changes().cpu().numpy())
+    assert split.gram_split_steps() == 2 and f32.gram_split_steps() == 0
+
+
 def test_masked_steps_of_a_large_graph_use_the_split_gram_evaluation(pkg, monkeypatch):
     """n >= 1024 with a decode that masks pairs: the fused step hands over, the Gram evaluation runs on the split kernel
     and agrees with the fp32 SYMM evaluation of the same steps."""
