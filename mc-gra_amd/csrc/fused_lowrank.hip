@@ -278,13 +278,23 @@ __device__ __forceinline__ void ft_stage(float (*dst)[FT], int koff, const float
 }
 
 // acc[a][b] += sum_f alpha_f (L_i . R_j + R_i . L_j) for the thread's 4 x 4 patch of tile (bi, bj).  One staging phase per
-// round puts the four panels it needs in LDS (alpha L and R of the tile's rows, R and alpha L of its columns), then both
-// dot products run without another barrier.  Bitwise symmetric under i <-> j: the two dot products are the same fmaf
-// chains with the roles swapped and are added to each other first, so a diagonal tile, whose two triangles are computed
-// by different threads, stays symmetric.   P: [4][KMAX][64] floats = {alpha L_I, R_J, R_I, alpha L_J}
+// round puts the four panels it needs in LDS (alpha L and R of the tile's rows, R and alpha L of its columns); the two
+// 64 x 64 x K products of a round then run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, one 32 x 32 quadrant per
+// wave, operands straight from the panels: lane = (row, k parity), conflict-free ds_read_b32) -- half the cycles of the
+// 4 x 4 register-tile FMA form, whose LDS operand reads cost as much as its FMAs, and the VALU stays free for the
+// elementwise part.  Bitwise symmetric under i <-> j: the two products are the same k-ordered chains with the roles
+// swapped and are added to each other first, so a diagonal tile, whose two triangles are computed by different
+// lanes, stays symmetric.   P: [4][KMAX][64] floats = {alpha L_I, R_J, R_I, alpha L_J}; T [64][65] receives the sum
+// in the matrix cores' accumulator layout and hands it to the threads' 4 x 4 patches (T may alias P[0..2]).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 template <int KMAX>
-__device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int bj, int n, float (*P)[KMAX][FT], int r0, int c0,
-                                             float (&acc)[4][4]) {
+__device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int bj, int n, float (*P)[KMAX][FT], float (*T)[FT + 1],
+                                             int r0, int c0, float (&acc)[4][4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5, qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
+  f32x16_t tot;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tot[r] = 0.f;
   for (int rd = 0; rd < F.nrounds; ++rd) {
     const int K = F.kround[rd];
     __syncthreads();                       // previous users of the panels are done
@@ -297,28 +307,28 @@ __device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int b
       ft_stage(P[3], F.koff[f], F.L[f], F.ldl[f], bj, n, F.K[f], F.alpha[f], vl);
     }
     __syncthreads();
-    float part[2][4][4];
+    f32x16_t p0, p1;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) part[half][a][b] = 0.f;
-      for (int k = 0; k < K; ++k) {
-        const float4 av4 = *reinterpret_cast<const float4*>(&P[2 * half][k][r0]);
-        const float4 bv4 = *reinterpret_cast<const float4*>(&P[2 * half + 1][k][c0]);
-        const float as_[4] = {av4.x, av4.y, av4.z, av4.w}, bs_[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) part[half][a][b] = fmaf(as_[a], bs_[b], part[half][a][b]);
-      }
+    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
+    for (int k = 0; k < K; k += 2) {
+      const int kk = k + lh;               // A[i][k]: lane = (i = lane & 31, k = lane >> 5); B[k][j] likewise
+      const bool in = kk < K;
+      const float a0 = in ? P[0][kk][qi + l31] : 0.f, b0 = in ? P[1][kk][qj + l31] : 0.f;
+      const float a1 = in ? P[2][kk][qi + l31] : 0.f, b1 = in ? P[3][kk][qj + l31] : 0.f;
+      p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, p0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, p1, 0, 0, 0);
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] += part[0][a][b] + part[1][a][b];
+    tot += p0 + p1;
   }
+  __syncthreads();                         // the panels are dead: T may overwrite them
+  // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[qi + (r & 3) + 8 * (r >> 2) + 4 * lh][qj + l31] = tot[r];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] += T[r0 + a][c0 + b];
 }
 
 // Pass 1 of the tail.  pair != 0: grid (nt, nt), blocks with bj > bi return (their pair block covers them); a block
@@ -356,8 +366,8 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  ft_sym_rankk<KMAX>(F, bi, bj, n, P, r0, c0, acc);
-  __syncthreads();                         // every thread is past its panel reads: T may overwrite them
+  ft_sym_rankk<KMAX>(F, bi, bj, n, P, T, r0, c0, acc);
+  __syncthreads();                         // every thread has its patch: T may be overwritten
   // mirrored P1 tile (J, I) through LDS: T[j local][i local]
   if (P1) {
 #pragma unroll
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  ft_sym_rankk<KMAX>(F, bi, bj, n, P, r0, c0, acc);
+  ft_sym_rankk<KMAX>(F, bi, bj, n, P, T, r0, c0, acc);
   const float4 rj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(r + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 gj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(gd + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float rjs[4] = {rj4.x, rj4.y, rj4.z, rj4.w}, gdj[4] = {gj4.x, gj4.y, gj4.z, gj4.w};
