@@ -318,10 +318,20 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       // the forked MFMA-bound product, which otherwise fills every slot and starves them until it ends
       int pr_least = 0, pr_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-      if (hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, pr_least) != hipSuccess ||
+      // The two side streams are shared by all engines of a device in this process: a process has few hardware queues
+      // (four by default), and engines beyond the first would otherwise multiplex their side streams onto the ones in
+      // use (measured: a second live engine's Cora-size step went from 0.63 to 2.4 ms).  Engines of one process run
+      // one after another, so sharing only adds ordering that is there anyway.
+      static hipStream_t side2[64] = {nullptr}, side3[64] = {nullptr};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev < 0 || dev >= 64) dev = 0;
+      if (!side2[dev] && hipStreamCreateWithPriority(&side2[dev], hipStreamNonBlocking, pr_least) != hipSuccess) side2[dev] = nullptr;
+      if (!side3[dev] && hipStreamCreateWithFlags(&side3[dev], hipStreamNonBlocking) != hipSuccess) side3[dev] = nullptr;
+      h->st2 = side2[dev]; h->st3 = side3[dev];
+      if (!h->st2 || !h->st3 ||
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-          hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork3, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess ||
           hipHostMalloc((void**)&h->mask_host, 8, hipHostMallocMapped) != hipSuccess ||
@@ -384,10 +394,10 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (!h) return 0;
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->timer.ev) (void)hipEventDestroy(e);
-  if (h->st2) { (void)hipStreamSynchronize(h->st2); (void)hipStreamDestroy(h->st2); }
+  if (h->st2) (void)hipStreamSynchronize(h->st2);      // (shared side streams: drained, not destroyed)
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->st3) { (void)hipStreamSynchronize(h->st3); (void)hipStreamDestroy(h->st3); }
+  if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
   if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
   if (h->mask_host) (void)hipHostFree((void*)h->mask_host);

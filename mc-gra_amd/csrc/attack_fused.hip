@@ -192,7 +192,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   const bool pair = !h->sharded;
   // side streams: the product on st2, the small-operand terms on st3
   const bool ovl = h->overlap;
-  hipStream_t s3 = h->st3;
+  static const bool no_st3 = [] { const char* e = getenv("MCGRA_NO_ST3"); return e && e[0] == '1'; }();      // A/B switch
+  hipStream_t s3 = no_st3 ? st : h->st3;
   auto join = [&]() -> int {
     if (h->p1_inflight) {
       if (ovl) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -246,8 +247,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
 
       // ---- small-operand terms c9 (:237-258) and c10 (:259-272): they need only the forward, and at small n their ~16
       //      tiny launches are a tenth of the step -- forked onto a third stream, joined in front of the backward of em
-      MCGRA_HIP(hipEventRecord(h->ev_fork3, st));
-      MCGRA_HIP(hipStreamWaitEvent(h->st3, h->ev_fork3, 0));
+      if (s3 != st) {
+        MCGRA_HIP(hipEventRecord(h->ev_fork3, st));
+        MCGRA_HIP(hipStreamWaitEvent(s3, h->ev_fork3, 0));
+      }
       MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
       if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
       if (w10 != 0) {
@@ -255,7 +258,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
         launch_softmax_bwd(s3, n, C, h->sm2, h->Gsm, C, h->GZ2);
       }
-      MCGRA_HIP(hipEventRecord(h->ev_join3, h->st3));
+      if (s3 != st) MCGRA_HIP(hipEventRecord(h->ev_join3, s3));
 
       // ---- CE loss (:172) and its gradient into the victim chain
       launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
@@ -326,7 +329,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
                         h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld, h->lrStats + 2 * he, h->lrQtZ, 2.f * (float)(sg * k2));
         launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
       }
-      MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join3, 0));       // c9 / c10: Gem, GZ2 and their scalars
+      if (s3 != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join3, 0));       // c9 / c10: Gem, GZ2 and their scalars
       launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
 
       // ---- backward: modified_adj chain (embedding + output2), products on M
