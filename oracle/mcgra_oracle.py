@@ -589,46 +589,6 @@ class PGDAttackOracle:
 
     # -- one iteration of the loop at topology_attack.py:161-298 -------------
     def step(self, noise: Optional[np.ndarray] = None) -> Dict[str, float]:
-        it = self.step_iter(noise)
-        try:
-            while True:
-                next(it)
-        except StopIteration as e:
-            return e.value
-
-    # Row-block sharding of the N x N HSIC products.  With ``shard = (row_begin, row_end)``
-    # and ``exchanged = {"KX","KY","G_adjn","G_A1"}`` ([n_pad, n] arrays owned by the caller) step_iter yields
-    # "gram" after writing its rows of the centred Grams and "grad" after writing its rows of the two gradient
-    # products; the caller all-gathers the row blocks in place before resuming.  Unset (default): no yields.
-    shard = None
-    exchanged = None
-
-    def _hsic_nxn_sharded(self, adj_norm, A1, k1, k2):
-        n = self.n
-        r0, r1 = self.shard
-        r1 = min(r1, n)
-        ex = self.exchanged
-        ctr = lambda Z: (Z - Z.mean(0, dtype=np.float64).astype(F32)[None, :]).astype(F32)
-        Xc, Yc = ctr(adj_norm), ctr(A1)
-        if self._KFc is None:
-            Fc = ctr(self.fadj)
-            self._KFc = (Fc @ Fc.T).astype(F32)
-        if r0 < n:
-            ex["KX"][r0:r1] = Xc[r0:r1] @ Xc.T
-            ex["KY"][r0:r1] = Yc[r0:r1] @ Yc.T
-        yield "gram"
-        KX, KY = ex["KX"][:n], ex["KY"][:n]
-        v1 = F32((self._KFc.astype(np.float64) * KX).sum())
-        v2 = F32((KX.astype(np.float64) * KY).sum())
-        if r0 < n:
-            ex["G_adjn"][r0:r1] = F32(2) * ((F32(k1) * self._KFc[r0:r1] + F32(k2) * KY[r0:r1]) @ Xc)
-            ex["G_A1"][r0:r1] = F32(2 * k2) * (KX[r0:r1] @ Yc)
-        yield "grad"
-        return v1, v2, ex["G_adjn"][:n].copy(), ex["G_A1"][:n].copy()
-
-    _KFc = None
-
-    def step_iter(self, noise: Optional[np.ndarray] = None):
         cfg, w, n, idx = self.cfg, self.w, self.n, self.idx
         w1, w2, _, _, _, w6, w7, w8, w9, w10 = [float(x) for x in cfg.weight_param]
         sign = -1.0 if cfg.measure == "HSIC" else 1.0            # (:217-220 etc.)
@@ -661,14 +621,6 @@ class PGDAttackOracle:
         G_em = np.zeros_like(em)           # d loss / d em (both uses, :185 and :241)
         terms: Dict[str, float] = {}
 
-        if self.shard is not None:
-            assert cfg.measure == "HSIC" and self.fadj_nonconst
-            k1, k2 = sign * w1 * 1000 * AP["c1"], sign * w2 * 100 * AP["c2"]
-            v1, v2, ga, gb = yield from self._hsic_nxn_sharded(adj_norm, A1, k1, k2)
-            terms["c1"] = float(w1 * float(v1) * 1000 * AP["c1"]); terms["c2"] = float(w2 * float(v2) * 100 * AP["c2"])
-            loss += k1 * float(v1) + k2 * float(v2)
-            G_adjn += ga; G_A1 += gb
-            w1 = w2 = 0.0
         if w1 != 0 and self.fadj_nonconst:                       # (:212-220)
             k = sign * w1 * 1000 * AP["c1"]
             v, _, gy = calc(self.fadj, adj_norm, need_x=False, need_y=True)
