@@ -314,8 +314,6 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const char* eo = getenv("MCGRA_OVERLAP");
     h->overlap = (eo && eo[0]) ? eo[0] == '1' : (h->split_mode == 2 && h->split_planes == 2);
     if (!rc && h->lr_ok) {
-      // lowest priority: blocks of the caller's (HBM-bound) kernels take freed CU slots ahead of new tiles of
-      // the forked MFMA-bound product, which otherwise fills every slot and starves them until it ends
       int pr_least = 0, pr_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
       // The two side streams are shared by all engines of a device in this process: a process has few hardware queues
@@ -326,7 +324,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       int dev = 0;
       (void)hipGetDevice(&dev);
       if (dev < 0 || dev >= 64) dev = 0;
-      if (!side2[dev] && hipStreamCreateWithPriority(&side2[dev], hipStreamNonBlocking, pr_least) != hipSuccess) side2[dev] = nullptr;
+      // the product's stream: normal priority (A/B at N = 10 000, same box: low 153.8, normal 154.8, high 154.4 steps/s;
+      // round 1's fp32 SYMM, which left no room beside itself, wanted the lowest).  MCGRA_P1_PRIO=low|normal|high.
+      int pr2 = (pr_least + pr_greatest) / 2;
+      if (const char* ep = getenv("MCGRA_P1_PRIO")) pr2 = ep[0] == 'h' ? pr_greatest : (ep[0] == 'l' ? pr_least : pr2);
+      if (!side2[dev] && hipStreamCreateWithPriority(&side2[dev], hipStreamNonBlocking, pr2) != hipSuccess) side2[dev] = nullptr;
       if (!side3[dev] && hipStreamCreateWithFlags(&side3[dev], hipStreamNonBlocking) != hipSuccess) side3[dev] = nullptr;
       h->st2 = side2[dev]; h->st3 = side3[dev];
       if (!h->st2 || !h->st3 ||
