@@ -486,6 +486,10 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   }
   if (h->cfg.measure == MCGRA_MEASURE_KL && h->cfg.w[0] != 0.f)
     launch_row_softmax(st, n, ld, h->FADJ, h->XC);      // F.softmax(feature_adj) of calc_kl (:484), constant
+  // (small_term's HSIC branch relies on zero pad columns in Q / Q2: see there)
+  MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)h->hmax * h->hmax, st));
+  MCGRA_HIP(hipMemsetAsync(h->Q2, 0, sizeof(float) * (size_t)h->hmax * h->hmax, st));
+  h->t3_zero = false;
   MCGRA_KERNEL_CHECK();
   // feature_adj.max() != feature_adj.min() (topology_attack.py:212) is evaluated by the host layer
   MCGRA_HIP(hipStreamSynchronize(st));
@@ -511,7 +515,7 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
 // calc(X[idx], Y[idx]) on small operands: gradient w.r.t. Y scattered into G (zero-filled by caller).
 // Xg raw gathered constant, Xc its column-centred copy.  Value lands in scal[slot].
 int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg,
-                      const float* Xc, double k_signed, float* G, int ldg, int slot) {
+                      const float* Xc, double k_signed, float* G, int ldg, int slot, bool want_value) {
   const int na = h->na, hm = h->hmax;
   // (own split-K workspace: the fused step runs this chain on a side stream, beside products that use h->ws)
   auto eg = [](mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
@@ -553,10 +557,12 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
     // Y is centred explicitly: Xc^T Y == Xc^T Yc only in exact arithmetic, and with identical rows of Y
     // (adj_changes == 0) the fp32 residue of Xc's column sums would otherwise be the whole "gradient"
     launch_colmean_center(st, na, width, h->Yg, hm);
-    MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
-    CHK(eg(h, st, true, false, width, width, na, 1.f, Xc, hm, h->Yg, hm, 0.f, h->Q, hm));
-    launch_sumsq(st, (size_t)width * hm, h->Q, h->scal + slot);              // pad columns of Q are zero
-    CHK(eg(h, st, false, false, na, width, width, 1.f, Xc, hm, h->Q, hm, 0.f, h->Gg, hm));
+    // one Q per term (c9: Q, c10: Q2): each is only ever written on its term's width x width block, so its pad columns
+    // keep the zeros of the allocation and no fill is needed per step
+    float* Qb = slot == S_C10 ? h->Q2 : h->Q;
+    CHK(eg(h, st, true, false, width, width, na, 1.f, Xc, hm, h->Yg, hm, 0.f, Qb, hm));
+    if (want_value) launch_sumsq(st, (size_t)width * hm, Qb, h->scal + slot);              // pad columns of Q are zero
+    CHK(eg(h, st, false, false, na, width, width, 1.f, Xc, hm, Qb, hm, 0.f, h->Gg, hm));
     launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)(2.0 * k_signed), G, ldg);
   }
   MCGRA_KERNEL_CHECK();
@@ -589,9 +595,10 @@ __global__ void k_cn(const double* __restrict__ scal, float coef, float* __restr
 }
 
 // {sequence number, masked?} of the decode into mapped host memory (the host polls the sequence number)
-__global__ void k_post_mask(const unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
+__global__ void k_post_mask(unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
                             unsigned int* __restrict__ seq_dev, unsigned int* __restrict__ host_slot) {
   const unsigned int masked = count_u32 ? (*count_u32 != 0u) : (*count_f64 != 0.0);
+  if (count_u32) *count_u32 = 0u;          // re-armed for the next decode
   const unsigned int seq = ++*seq_dev;
   __hip_atomic_store(host_slot + 1, masked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
@@ -869,6 +876,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
           launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
           // T = Xc^T [U | D Z | delta^2]: W, W2 and t3 from one pass over Xc
           CHK(eg(h, st, true, false, n, h->lr_ldv, n, 1.f, h->XC, ld, h->lrV, h->lr_ldv, 0.f, h->lrT, h->lr_ldv));
+          h->t3_zero = false;
           launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
         }
       } else {

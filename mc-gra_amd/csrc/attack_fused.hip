@@ -130,9 +130,10 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
       for (h->fs_l = 0; h->fs_l < L; ++h->fs_l) {
         {
           const int l = h->fs_l, w = h->wdt[l];
-          fl_cat_scaled(st, n, w, w, h->Tv + h->off[l], hs, h->r, h->FV, fc, 0);
-          fl_cat_scaled(st, n, w, w, h->Tu + h->off[l], hs, nullptr, h->FV, fc, w);
-          if (l == 0) fl_cat_scaled(st, n, 1, 1, h->r, 1, nullptr, h->FV, fc, 2 * w);
+          const float* Xs[3] = {h->Tv + h->off[l], h->Tu + h->off[l], h->r};
+          const float* rs[3] = {h->r, nullptr, nullptr};
+          const int lds[3] = {hs, hs, 1}, ws[3] = {w, w, 1};
+          fl_cat_segs(st, n, l == 0 ? 3 : 2, Xs, lds, rs, ws, h->FV, fc);      // [r o Tv | Tu (| r)]
           CHK(mm_rows(h, st, 2 * w + (l == 0 ? 1 : 0)));
         }
         FS_XCHG(h->fw_state, 3, X_FY(h))
@@ -192,6 +193,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   const bool pair = !h->sharded;
   // side streams: the product on st2, the small-operand terms on st3
   const bool ovl = h->overlap;
+  // reductions that only feed the returned loss terms are skipped when the caller did not ask for them (a row-block
+  // rank keeps them: they ride in exchanges whose layout is fixed)
+  const bool want_vals = h->sharded || h->fs_want;
   static const bool no_st3 = [] { const char* e = getenv("MCGRA_NO_ST3"); return e && e[0] == '1'; }();      // A/B switch
   hipStream_t s3 = no_st3 ? st : h->st3;
   auto join = [&]() -> int {
@@ -215,7 +219,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (rc == 1) { h->fs_state = 1; return 1; }
         if (rc < 0) return rc;
       }
-      MCGRA_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(double) * (S_COUNT - 2), st));
+      if (want_vals) MCGRA_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(double) * (S_COUNT - 2), st));
       // embedding(features, adj_norm) of this iteration (= the victim chain's activations: shared weights, main.py:190),
       // kept for the post-loop decode (:300): adj_norm itself is never stored
       MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
@@ -252,27 +256,28 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         MCGRA_HIP(hipStreamWaitEvent(s3, h->ev_fork3, 0));
       }
       MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
-      if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
+      if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9, want_vals));
       if (w10 != 0) {
         MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s3));
-        CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
+        CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10, want_vals));
         launch_softmax_bwd(s3, n, C, h->sm2, h->Gsm, C, h->GZ2);
       }
       if (s3 != st) MCGRA_HIP(hipEventRecord(h->ev_join3, s3));
 
       // ---- CE loss (:172) and its gradient into the victim chain
       launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
-      launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
+      if (want_vals) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
       launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
                          h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
       launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
-      MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+      // (monolithic with c2: k_post_mask leaves the counter at zero for the next step)
+      if (h->sharded || !use2) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
       h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
                                h->hmax, h->nmask);
       if (!h->sharded) {
-        launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->scal + S_V7);
+        if (want_vals) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->scal + S_V7);
       } else {
         MCGRA_HIP(hipMemsetAsync(h->SC + 2, 0, 2 * sizeof(double), st));
         hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, h->SC + 2);
@@ -310,7 +315,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
       if (use2) {
         fl_lrt_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // [W | W2] = Xc^T Vc
-        MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));          // t3 = 0
+        if (!h->t3_zero) {                                                                        // t3 = 0
+          MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));
+          h->t3_zero = true;
+        }
         launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
         // [Q | Q2] = Xc [W | W2]
         fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 256);
@@ -327,7 +335,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         launch_lr_xtz(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrQtZ);
         launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->lrRs, -2.f * (float)(sg * k2), h->GZn, h->hmax,
                         h->rowvals + 7 * (size_t)ld, h->rowvals + 5 * (size_t)ld, h->lrStats + 2 * he, h->lrQtZ, 2.f * (float)(sg * k2));
-        launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
+        if (want_vals) launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
       }
       if (s3 != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join3, 0));       // c9 / c10: Gem, GZ2 and their scalars
       launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
@@ -350,8 +358,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         {
           const int lv = h->fs_l, lu = h->fs_l2;
           const int wv = lv >= 1 ? h->wdt[lv] : 0, wu = lu >= 1 ? h->wdt[lu] : 0;
-          if (lv >= 1) fl_cat_scaled(st, n, wv, wv, h->GPv + h->off[lv], hs, h->r, h->FV, fc, 0);
-          if (lu >= 1) fl_cat_scaled(st, n, wu, wu, h->GPu + h->off[lu], hs, nullptr, h->FV, fc, wv);
+          const float* Xs[2] = {h->GPv + h->off[lv >= 1 ? lv : 0], h->GPu + h->off[lu >= 1 ? lu : 0]};
+          const float* rs[2] = {h->r, nullptr};
+          const int lds[2] = {hs, hs}, ws[2] = {wv, wu};
+          if (lv >= 1) fl_cat_segs(st, n, lu >= 1 ? 2 : 1, Xs, lds, rs, ws, h->FV, fc);      // [r o G_P_lv | G_P_lu]
+          else fl_cat_scaled(st, n, wu, wu, h->GPu + h->off[lu], hs, nullptr, h->FV, fc, 0);
           CHK(mm_rows(h, st, wv + wu));
         }
         FS_XCHG(h->fs_state, 8, X_FY(h))
@@ -406,7 +417,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
                                     h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr, a1, a2, (float)(k6 / n2),
                                     h->G_ADJN, ps1, vpart);
         if (h->sharded) MCGRA_HIP(hipMemsetAsync(h->SC + 4, 0, 3 * sizeof(double), st));
-        if (h->fs_nblk > 0) {
+        if (h->fs_nblk > 0 && want_vals) {
           launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? h->SC + 4 : h->scal + S_H1);
           launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? h->SC + 5 : h->scal + S_V6);
         }

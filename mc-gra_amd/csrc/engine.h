@@ -100,6 +100,7 @@ struct mcgra_attack {
   unsigned int* mask_seq_dev = nullptr;          // device-side counter of the posts
   unsigned int mask_seq = 0;                     // posts enqueued so far
   bool p1_inflight = false;
+  bool t3_zero = false;            // column 2 he of lrT (t3 of the low-rank factors) holds zeros (fused step; the general path writes it)
   bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
   // P1 through the split kernel of split_symm_bf16.hip instead of the fp32 MFMA SYMM
   bool split_on = false;
@@ -163,11 +164,11 @@ int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, floa
 double sign_of(const mcgra_attack* h);
 extern "C" {      // (defined inside attack.hip's extern "C" block)
 int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, int ldy, const float* Xg, const float* Xc,
-               double k_signed, float* G, int ldg, int slot);
+               double k_signed, float* G, int ldg, int slot, bool want_value = true);   // want_value: also the term's value (HSIC: not needed for the gradient)
 int project(mcgra_attack* h, hipStream_t st);
 int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out, bool have_clampsum = false);
 __global__ void k_cn(const double* __restrict__ scal, float coef, float* __restrict__ out);
-__global__ void k_post_mask(const unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
+__global__ void k_post_mask(unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
                             unsigned int* __restrict__ seq_dev, unsigned int* __restrict__ host_slot);
 
 }

@@ -29,6 +29,28 @@ __global__ void k_cat_scaled(int n, int w, int wpad, const float* __restrict__ X
   const int i = e / wpad, k = e - i * wpad;
   V[(size_t)i * ldv + col0 + k] = k < w ? (r ? r[i] : 1.f) * X[(size_t)i * ldx + k] : 0.f;
 }
+// up to three such column blocks side by side in one launch: V[i][col0_s + k] = (r_s ? r_s[i] : 1) X_s[i][k], k < w_s
+struct CatSegs {
+  const float* X[3];
+  const float* r[3];
+  int ldx[3], w[3], col0[3];
+  int count, wtot;
+};
+__global__ void k_cat_segs(int n, CatSegs S, float* __restrict__ V, int ldv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * S.wtot) return;
+  const int i = e / S.wtot;
+  int k = e - i * S.wtot;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (s >= S.count) return;
+    if (k < S.w[s]) {
+      V[(size_t)i * ldv + S.col0[s] + k] = (S.r[s] ? S.r[s][i] : 1.f) * S.X[s][(size_t)i * S.ldx[s] + k];
+      return;
+    }
+    k -= S.w[s];
+  }
+}
 // out[i][k] = r_i (Y[i][c0 + k] + Vs[i][c0 + k])          (adj_norm V from Y = M Vs, Vs = r o V)
 __global__ void k_an_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy, int c0,
                           const float* __restrict__ r, float* __restrict__ out, int ldo) {
@@ -612,6 +634,15 @@ static inline dim3 g1(size_t count) { return dim3((unsigned)((count + 255) / 256
 
 void fl_cat_scaled(hipStream_t st, int n, int w, int wpad, const float* X, int ldx, const float* r, float* V, int ldv, int col0) {
   LAUNCH(k_cat_scaled, g1((size_t)n * wpad), dim3(256), st, n, w, wpad, X, ldx, r, V, ldv, col0);
+}
+// count <= 3 column blocks {X, ldx, r or nullptr, w} written side by side from column 0 of V
+void fl_cat_segs(hipStream_t st, int n, int count, const float* const* X, const int* ldx, const float* const* r, const int* w,
+                 float* V, int ldv) {
+  CatSegs S{};
+  S.count = count; S.wtot = 0;
+  for (int s = 0; s < count; ++s) { S.X[s] = X[s]; S.r[s] = r[s]; S.ldx[s] = ldx[s]; S.w[s] = w[s]; S.col0[s] = S.wtot; S.wtot += w[s]; }
+  if (S.wtot <= 0) return;
+  LAUNCH(k_cat_segs, g1((size_t)n * S.wtot), dim3(256), st, n, S, V, ldv);
 }
 void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, int c0, const float* r, float* out, int ldo) {
   LAUNCH(k_an_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, c0, r, out, ldo);

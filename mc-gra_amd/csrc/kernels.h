@@ -117,6 +117,8 @@ void launch_lr_xtz(hipStream_t st, int n, int h, const float* QQ, const float* Z
 
 // ---- fused_lowrank.hip (the low-rank HSIC step evaluated from M directly)
 void fl_cat_scaled(hipStream_t st, int n, int w, int wpad, const float* X, int ldx, const float* r, float* V, int ldv, int col0);
+void fl_cat_segs(hipStream_t st, int n, int count, const float* const* X, const int* ldx, const float* const* r, const int* w,
+                 float* V, int ldv);
 void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, int c0, const float* r, float* out, int ldo);
 void fl_copy_cols(hipStream_t st, int n, int w, const float* Y, int ldy, int c0, float* out, int ldo);
 void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V, int ldy, const float* r, const float* b,
