@@ -82,12 +82,18 @@ int64_t fused_exchange_bytes(const mcgra_attack* h) {
          2 * up((int64_t)h->world * h->rpr * h->rpr * 4) + up((int64_t)h->npad * h->ld * 4);
 }
 
-// Y rows [row0, row1) = M[rows, :] V      (V = FV [n x ncol], result in FY)
+// Y rows [row0, row1) = M[rows, :] V      (V = FV [n x ncol]).  A row-block rank needs the result in FY (it is exchanged);
+// a monolithic engine leaves a split-K product as its slabs and hands its consumers a view of them (h->fy).
 static int mm_rows(mcgra_attack* h, hipStream_t st, int ncol) {
   const int rows = h->row1 - h->row0;
+  h->fy = YView{h->FY, h->fcols, 1, 0};
   if (rows <= 0) return 0;
-  return eg(h, st, false, false, rows, ncol, h->n, 1.f, h->M + (size_t)h->row0 * h->ld, h->ld, h->FV, h->fcols, 0.f,
-            h->FY + (size_t)h->row0 * h->fcols, h->fcols);
+  if (h->sharded)
+    return eg(h, st, false, false, rows, ncol, h->n, 1.f, h->M + (size_t)h->row0 * h->ld, h->ld, h->FV, h->fcols, 0.f,
+              h->FY + (size_t)h->row0 * h->fcols, h->fcols);
+  MCGRA_HIP(sgemm(st, false, false, rows, ncol, h->n, 1.f, h->M, h->ld, h->FV, h->fcols, 0.f, h->FY, h->fcols, h->ws, h->ws_bytes,
+                  &h->fy));
+  return 0;
 }
 
 // Resume points: the code between two FS_XCHG runs without interruption.  `var` is h->fs_state or h->fw_state.
@@ -139,7 +145,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         FS_XCHG(h->fw_state, 3, X_FY(h))
         {
           const int l = h->fs_l, w = h->wdt[l];
-          fl_layer_post(st, n, w, h->FY, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
+          fl_layer_post(st, n, w, h->fy, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
                         h->Hu + h->off[l], hs, l == 0, h->cmean, h->rowsx);
           if (l + 1 < L) {
             launch_rowmat(st, n, w, h->wdt[l + 1], h->Hv + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tv + h->off[l + 1], hs);
@@ -314,7 +320,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
       if (use2) {
-        fl_lrt_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // [W | W2] = Xc^T Vc
+        fl_lrt_post(st, n, 2 * he, h->fy, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // [W | W2] = Xc^T Vc
         if (!h->t3_zero) {                                                                        // t3 = 0
           MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));
           h->t3_zero = true;
@@ -327,7 +333,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
       if (use2) { FS_XCHG(h->fs_state, 7, X_FY(h)) }
       if (use2)
-        fl_lrq_post(st, n, 2 * he, h->FY, h->FV, fc, h->r, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 192, h->lrQ, 2 * he);
+        fl_lrq_post(st, n, 2 * he, h->fy, h->FV, fc, h->r, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 192, h->lrQ, 2 * he);
       MCGRA_KERNEL_CHECK();
 
       // ---- decode backward (the entropy part is already in GZn), normalisation of em
@@ -370,12 +376,12 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           const int lv = h->fs_l, lu = h->fs_l2;
           const int wv = lv >= 1 ? h->wdt[lv] : 0;
           if (lv >= 1) {
-            fl_an_post(st, n, wv, h->FY, h->FV, fc, 0, h->r, h->GT, h->hmax);
+            fl_an_post(st, n, wv, h->fy, h->FV, fc, 0, h->r, h->GT, h->hmax);
             launch_rowmat_mask(st, n, h->wdt[lv], h->wdt[lv - 1], h->GT, h->hmax, h->W[lv], 1, h->wdt[lv], nullptr, 0, 0, nullptr, 0, 0,
                                h->Pv + h->off[lv - 1], hs, h->act, nullptr, 0, h->GPv + h->off[lv - 1], hs);
           }
           if (lu >= 1) {
-            fl_copy_cols(st, n, h->wdt[lu], h->FY, fc, wv, h->GT, h->hmax);
+            fl_copy_cols(st, n, h->wdt[lu], h->fy, wv, h->GT, h->hmax);
             launch_rowmat_mask(st, n, h->wdt[lu], h->wdt[lu - 1], h->GT, h->hmax, h->W[lu], 1, h->wdt[lu], nullptr, 0, 0, nullptr, 0, 0,
                                h->Pu + h->off[lu - 1], hs, h->act, (lu - 1 == Le - 1) ? h->Gem : nullptr, h->hmax,
                                h->GPu + h->off[lu - 1], hs);

@@ -21,9 +21,26 @@ void set_error(const char* fmt, ...);
 #define MCGRA_KERNEL_CHECK() MCGRA_HIP(hipGetLastError())
 
 // gemm_f32.hip
+// A product as its consumer may read it: the matrix itself (nz == 1) or the nz split-K slabs of sgemm, summed in slab
+// order on the fly (the same sum sum_slabs_kernel stores: same bits, one launch and one round trip less).
+struct YView {
+  const float* p;
+  int ld;
+  int nz;
+  size_t stride;
+  __device__ __forceinline__ float at(int i, int c) const {
+    const float* q = p + (size_t)i * ld + c;
+    if (nz <= 1) return *q;
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += q[(size_t)z * stride];
+    return s;
+  }
+};
+// keep != nullptr (beta == 0 only): a split-K product is left as its slabs in ws and described by *keep; the caller's
+// next kernels read it through YView::at and nothing else may touch ws before they ran.
 hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha,
                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
-                 float* ws, size_t ws_bytes);
+                 float* ws, size_t ws_bytes, YView* keep = nullptr);
 
 // rankk_f32.hip: C = beta C + alpha1 A1 B1^T (+ alpha2 A2 B2^T), K1, K2 <= 64 (HBM-bound rank-k updates)
 bool rankk_nt_supported(int M, int N, int K1, int K2);

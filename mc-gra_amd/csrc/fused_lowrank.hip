@@ -52,40 +52,38 @@ __global__ void k_cat_segs(int n, CatSegs S, float* __restrict__ V, int ldv) {
   }
 }
 // out[i][k] = r_i (Y[i][c0 + k] + Vs[i][c0 + k])          (adj_norm V from Y = M Vs, Vs = r o V)
-__global__ void k_an_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy, int c0,
+__global__ void k_an_post(int n, int w, YView Y, const float* __restrict__ Vs, int ldv, int c0,
                           const float* __restrict__ r, float* __restrict__ out, int ldo) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * w) return;
   const int i = e / w, k = e - i * w;
-  const size_t o = (size_t)i * ldy + c0 + k;
-  out[(size_t)i * ldo + k] = r[i] * (Y[o] + Vs[o]);
+  out[(size_t)i * ldo + k] = r[i] * (Y.at(i, c0 + k) + Vs[(size_t)i * ldv + c0 + k]);
 }
 // out[i][k] = Y[i][c0 + k]
-__global__ void k_copy_cols(int n, int w, const float* __restrict__ Y, int ldy, int c0, float* __restrict__ out, int ldo) {
+__global__ void k_copy_cols(int n, int w, YView Y, int c0, float* __restrict__ out, int ldo) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * w) return;
   const int i = e / w, k = e - i * w;
-  out[(size_t)i * ldo + k] = Y[(size_t)i * ldy + c0 + k];
+  out[(size_t)i * ldo + k] = Y.at(i, c0 + k);
 }
 
 // Forward layer l of both chains from ONE product Y = M [r o Tv | Tu | r]:
 //   victim(adj_norm):   Pv = r o (Y_a + r o Tv) + b          embedding / victim(M):   Pu = Y_b + b
 //   with_r (layer 0):   rowsum(adj_norm)_i = r_i (Y_c + r_i)  ->  mean_i = rowsum_i / n
-__global__ void k_fl_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ V, int ldy,
+__global__ void k_fl_post(int n, int w, YView Y, const float* __restrict__ V, int ldv,
                           const float* __restrict__ r, const float* __restrict__ b, float* __restrict__ Pv,
                           float* __restrict__ Hv, float* __restrict__ Pu, float* __restrict__ Hu, int ldo, int with_r,
                           float* __restrict__ mean, double* __restrict__ rowsum) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * w) return;
   const int i = e / w, k = e - i * w;
-  const size_t o = (size_t)i * ldy;
   const float ri = r[i];
-  const float pv = ri * (Y[o + k] + V[o + k]) + b[k];
-  const float pu = Y[o + w + k] + b[k];
+  const float pv = ri * (Y.at(i, k) + V[(size_t)i * ldv + k]) + b[k];
+  const float pu = Y.at(i, w + k) + b[k];
   Pv[(size_t)i * ldo + k] = pv; Hv[(size_t)i * ldo + k] = fmaxf(pv, 0.f);
   Pu[(size_t)i * ldo + k] = pu; Hu[(size_t)i * ldo + k] = fmaxf(pu, 0.f);
   if (with_r && k == 0) {
-    const double rs = (double)ri * ((double)Y[o + 2 * w] + (double)ri);
+    const double rs = (double)ri * ((double)Y.at(i, 2 * w) + (double)ri);
     rowsum[i] = rs;
     mean[i] = (float)(rs / (double)n);
   }
@@ -147,14 +145,13 @@ __global__ __launch_bounds__(256) void k_mean_stats(int n, const float* __restri
 }
 
 // T = Xc^T Vc from Y = M (r o Vc):  T_i = r_i (Y_i + r_i Vc_i) - mean_i (1^T Vc)      (Xc^T = adj_norm - mean 1^T)
-__global__ void k_lrt_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy,
+__global__ void k_lrt_post(int n, int w, YView Y, const float* __restrict__ Vs, int ldv,
                            const float* __restrict__ r, const float* __restrict__ mean, const double* __restrict__ colsum,
                            float* __restrict__ T, int ldt) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * w) return;
   const int i = e / w, k = e - i * w;
-  const size_t o = (size_t)i * ldy + k;
-  T[(size_t)i * ldt + k] = r[i] * (Y[o] + Vs[o]) - (float)((double)mean[i] * colsum[k]);
+  T[(size_t)i * ldt + k] = r[i] * (Y.at(i, k) + Vs[(size_t)i * ldv + k]) - (float)((double)mean[i] * colsum[k]);
 }
 // Vs = r o (W - wbar), wbar_k = colsum_k / n        (right-hand side of Q = Xc [W | W2], column-centred)
 __global__ void k_lrq_pre(int n, int w, const float* __restrict__ W, int ldw, const float* __restrict__ r,
@@ -166,7 +163,7 @@ __global__ void k_lrq_pre(int n, int w, const float* __restrict__ W, int ldw, co
 }
 // Q = Xc W = adj_norm Wc - 1 (mean^T Wc) + n (mean - mbar 1) wbar^T   with Wc = W - 1 wbar^T:
 //   Q_ik = r_i (Y_ik + Vs_ik) - kappa_k + n (mean_i - mbar) wbar_k,   kappa_k = mean^T W_k - (sum mean) wbar_k
-__global__ void k_lrq_post(int n, int w, const float* __restrict__ Y, const float* __restrict__ Vs, int ldy,
+__global__ void k_lrq_post(int n, int w, YView Y, const float* __restrict__ Vs, int ldv,
                            const float* __restrict__ r, const float* __restrict__ mean, const double* __restrict__ colsum,
                            const double* __restrict__ mw, const double* __restrict__ msum, float* __restrict__ Q, int ldq) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,8 +171,7 @@ __global__ void k_lrq_post(int n, int w, const float* __restrict__ Y, const floa
   const int i = e / w, k = e - i * w;
   const double wbar = colsum[k] / (double)n, ms = msum[0];
   const double kappa = mw[k] - ms * wbar;
-  const size_t o = (size_t)i * ldy + k;
-  Q[(size_t)i * ldq + k] = r[i] * (Y[o] + Vs[o]) - (float)kappa + (float)((double)n * ((double)mean[i] - ms / (double)n) * wbar);
+  Q[(size_t)i * ldq + k] = r[i] * (Y.at(i, k) + Vs[(size_t)i * ldv + k]) - (float)kappa + (float)((double)n * ((double)mean[i] - ms / (double)n) * wbar);
 }
 
 // ---------------------------------------------------------------------------------- decode, recomputed per pair
@@ -644,15 +640,15 @@ void fl_cat_segs(hipStream_t st, int n, int count, const float* const* X, const 
   if (S.wtot <= 0) return;
   LAUNCH(k_cat_segs, g1((size_t)n * S.wtot), dim3(256), st, n, S, V, ldv);
 }
-void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, int c0, const float* r, float* out, int ldo) {
-  LAUNCH(k_an_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, c0, r, out, ldo);
+void fl_an_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, int c0, const float* r, float* out, int ldo) {
+  LAUNCH(k_an_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldv, c0, r, out, ldo);
 }
-void fl_copy_cols(hipStream_t st, int n, int w, const float* Y, int ldy, int c0, float* out, int ldo) {
-  LAUNCH(k_copy_cols, g1((size_t)n * w), dim3(256), st, n, w, Y, ldy, c0, out, ldo);
+void fl_copy_cols(hipStream_t st, int n, int w, YView Y, int c0, float* out, int ldo) {
+  LAUNCH(k_copy_cols, g1((size_t)n * w), dim3(256), st, n, w, Y, c0, out, ldo);
 }
-void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V, int ldy, const float* r, const float* b,
+void fl_layer_post(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum) {
-  LAUNCH(k_fl_post, g1((size_t)n * w), dim3(256), st, n, w, Y, V, ldy, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0, mean, rowsum);
+  LAUNCH(k_fl_post, g1((size_t)n * w), dim3(256), st, n, w, Y, V, ldv, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0, mean, rowsum);
 }
 // scratch: 2 * 64 * WC_PARTS doubles
 void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch) {
@@ -663,16 +659,16 @@ size_t fl_wcolsum_scratch_doubles() { return (size_t)2 * 64 * WC_PARTS; }
 void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound) {
   LAUNCH(k_mean_stats, dim3(1), dim3(256), st, n, mean, r, msum, amax_bound);
 }
-void fl_lrt_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+void fl_lrt_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, const float* r, const float* mean,
                  const double* colsum, float* T, int ldt) {
-  LAUNCH(k_lrt_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, r, mean, colsum, T, ldt);
+  LAUNCH(k_lrt_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldv, r, mean, colsum, T, ldt);
 }
 void fl_lrq_pre(hipStream_t st, int n, int w, const float* W, int ldw, const float* r, const double* colsum, float* Vs, int ldv) {
   LAUNCH(k_lrq_pre, g1((size_t)n * w), dim3(256), st, n, w, W, ldw, r, colsum, Vs, ldv);
 }
-void fl_lrq_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, const float* r, const float* mean,
                  const double* colsum, const double* mw, const double* msum, float* Q, int ldq) {
-  LAUNCH(k_lrq_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldy, r, mean, colsum, mw, msum, Q, ldq);
+  LAUNCH(k_lrq_post, g1((size_t)n * w), dim3(256), st, n, w, Y, Vs, ldv, r, mean, colsum, mw, msum, Q, ldq);
 }
 
 // decode recomputed per pair for rows [row0, row1); returns the number of v7 partials (0 and GZn = 0 when kie7 == 0:

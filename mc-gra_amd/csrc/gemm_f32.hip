@@ -533,7 +533,8 @@ static inline bool vec_ok(const float* A, int lda, const float* B, int ldb) {
 // `ws`/`ws_bytes` (optional) enable slab split-K for outputs whose tile grid cannot fill 256 CUs.
 hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha,
                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
-                 float* ws, size_t ws_bytes) {
+                 float* ws, size_t ws_bytes, YView* keep) {
+  if (keep) *keep = YView{C, ldc, 1, 0};
   if (M <= 0 || N <= 0) return hipSuccess;
   if (K <= 0) {  // C = beta * C
     if (beta == 0.f) {
@@ -578,6 +579,7 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     else
       e = launch_big(st, ta, tb, vec, M, N, K, alpha, A, lda, B, ldb, 0.f, ws, N, nsplit, k_per_split, stride);
     if (e != hipSuccess) return e;
+    if (keep && beta == 0.f) { *keep = YView{ws, N, nsplit, stride}; return hipGetLastError(); }
     const int blocks = (int)min((size_t)2048, (stride + 255) / 256);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, stride, nsplit, C, stride, N, ldc, beta);
     return hipGetLastError();

@@ -119,17 +119,17 @@ void launch_lr_xtz(hipStream_t st, int n, int h, const float* QQ, const float* Z
 void fl_cat_scaled(hipStream_t st, int n, int w, int wpad, const float* X, int ldx, const float* r, float* V, int ldv, int col0);
 void fl_cat_segs(hipStream_t st, int n, int count, const float* const* X, const int* ldx, const float* const* r, const int* w,
                  float* V, int ldv);
-void fl_an_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, int c0, const float* r, float* out, int ldo);
-void fl_copy_cols(hipStream_t st, int n, int w, const float* Y, int ldy, int c0, float* out, int ldo);
-void fl_layer_post(hipStream_t st, int n, int w, const float* Y, const float* V, int ldy, const float* r, const float* b,
+void fl_an_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, int c0, const float* r, float* out, int ldo);
+void fl_copy_cols(hipStream_t st, int n, int w, YView Y, int c0, float* out, int ldo);
+void fl_layer_post(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum);
 void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch);
 size_t fl_wcolsum_scratch_doubles();
 void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound);
-void fl_lrt_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+void fl_lrt_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, const float* r, const float* mean,
                  const double* colsum, float* T, int ldt);
 void fl_lrq_pre(hipStream_t st, int n, int w, const float* W, int ldw, const float* r, const double* colsum, float* Vs, int ldv);
-void fl_lrq_post(hipStream_t st, int n, int w, const float* Y, const float* Vs, int ldy, const float* r, const float* mean,
+void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, const float* r, const float* mean,
                  const double* colsum, const double* mw, const double* msum, float* Q, int ldq);
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
                   double* v7part, float* GZn, int ldg, unsigned int* nmask);
