@@ -229,6 +229,10 @@ def gen_small(tmp):
         ("s48_sage_hsic_init", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
         ("s48_sage_kl", 48, 24, 4, 16, 2, "KL", base_wp, 1.0, 0.01, 3, 1e12),
         ("s200_mse_init", 200, 64, 6, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 0.01, 4, 1e12),
+        # eps != 0 at n >= 256: the gated branch of the one-pass tail kernel (rank-k + mirror + Adam) and the asymmetric
+        # normalisation backward at the sizes where they are the default
+        ("s300_hsic_eps", 300, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 2, 1e12),
+        ("s300_mse_eps", 300, 64, 6, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 2, 1e12),
     ]
     for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:
         arch = "gat" if "_gat_" in name else ("sage" if "_sage_" in name else "gcn")
