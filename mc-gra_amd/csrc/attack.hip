@@ -304,6 +304,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         const size_t pb = split3_pack_bytes((int)n, 2);
         A_(Gp0, pb); A_(Gp1, pb); A_(Gp2, pb);
         h->gram_split = (rc == 0);
+        { const char* et = getenv("MCGRA_GRAM_TRI"); h->gram_tri = !(et && et[0] == '0'); }
       }
     }
     // The product on the engine's own stream, beside the HBM-bound kernels of the step that do not need it.  On by
@@ -917,7 +918,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       };
       CHK(pair(0, 1, 1));
       // Kx and Ky are symmetric: tiles on or below the diagonal, mirrored by the epilogue (MCGRA_GRAM_TRI=0: all tiles)
-      static const int gram_flags = [] { const char* e = getenv("MCGRA_GRAM_TRI"); return (e && e[0] == '0') ? 0 : 2; }();
+      const int gram_flags = h->gram_tri ? 2 : 0;
       split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
       CHK(timer_begin(h, st, big));
       MCGRA_HIP(split3_symm(st, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->G_A, slab, 2, h->amax + 8, 0, -1, gram_flags));

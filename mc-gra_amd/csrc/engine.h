@@ -112,7 +112,7 @@ struct mcgra_attack {
   // Gram evaluation (masked / GAT / MCGRA_NO_LOWRANK steps) through the same kernel: planes of Xc, Yc, the combined
   // Grams and Yc^T; amax[2] = max |Yc|, [3] = max |2 (s1 Kfc + s2 Kyc)|, [4] = max |2 s2 Kxc|, [8..15] = the
   // (A, B) scale pairs of the four products
-  bool gram_split = false;
+  bool gram_split = false, gram_tri = true;
   unsigned char *Gp0 = 0, *Gp1 = 0, *Gp2 = 0;
   int64_t gram_split_steps = 0;
   GemmTimer timer;

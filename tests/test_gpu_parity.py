@@ -980,9 +980,15 @@ def test_gram_evaluation_on_the_split_kernel_matches_fp32_symm(pkg, monkeypatch,
     z = _synthetic_case(1100, 11, (16, 16), 4, seed=21, weight_param=wp)
     monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
     split = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_GRAM_TRI", "0")           # all tiles of the two Grams instead of the mirrored lower triangle
+    full = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_GRAM_TRI")
     monkeypatch.setenv("MCGRA_GRAM_SPLIT", "0")
     f32 = H.engine_from(pkg, z)
     monkeypatch.delenv("MCGRA_GRAM_SPLIT"); monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    full.step()
+    full_g = full.buffer("G_sym").clone()
+    del full
     o = H.oracle_from(z)
     for t in range(3):
         a, b = split.step(want_scalars=True), f32.step(want_scalars=True)
@@ -990,6 +996,8 @@ def test_gram_evaluation_on_the_split_kernel_matches_fp32_symm(pkg, monkeypatch,
         ga, gb = split.buffer("G_sym"), f32.buffer("G_sym")
         scale = float(gb.abs().max())
         assert float((ga - gb).abs().max()) / scale < 2e-5, t
+        if t == 0:      # a mirrored tile equals the one the full launch computes up to the order of its two cross terms
+            assert float((ga - full_g).abs().max()) / scale < 2e-6
         # (not for c2 alone: that gradient is a small difference of large Gram sums, any fp32 evaluation of it carries
         # 1e-3 .. 1e-2 of noise -- the two HIP evaluations above agree 100 x closer than either does with numpy's)
         if wp[0] != 0:
