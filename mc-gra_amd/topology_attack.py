@@ -9,7 +9,7 @@ to HBM and drives the engine.  There is no CPU path: without a HIP device or
 without libmcgra_hip.so it raises.
 
 Arguments the reference accepts but this path does not cover yet raise
-NotImplementedError naming the reference line (measure KDE, loss_type 'CW',
+NotImplementedError naming the reference line (measure KDE,
 a non-zero ori_adj, an embedding whose weights differ from
 victim_model.gc).
 """
@@ -171,8 +171,14 @@ class PGDAttack(BaseAttack):
         dev = torch.device(self.device)
         if dev.type != 'cuda':
             raise RuntimeError("mc-gra_amd PGDAttack runs on an MI355X ('cuda:N' device) only; there is no CPU path")
-        if self.loss_type != 'CE':
-            raise NotImplementedError("loss_type 'CW' (topology_attack.py:329-335) is not on the HIP path")
+        if self.loss_type not in ('CE', 'CW'):
+            raise NotImplementedError(f"loss_type {self.loss_type!r} (topology_attack.py:326-335 knows 'CE' and 'CW')")
+        # loss_type 'CW': the reference computes the Carlini-Wagner margin loss and back-propagates it, but only calls
+        # optimizer.step() for 'CE' (:277-280) -- adj_changes never moves, and the run's result is the post-loop
+        # ensemble of the untouched adjacency.  The same happens here: no step is taken.  (With a non-zero starting
+        # adj_changes the reference's per-iteration projection (:282) could still move it; that start is a test hook.)
+        if self.loss_type == 'CW' and self._adj_changes_init is not None:
+            raise NotImplementedError("loss_type 'CW' with a non-zero starting adj_changes (projection without steps, :282)")
         if args.max_eval == 1:                      # (:118-119)
             lr_ori = 10 ** args.lr
         self.args = args
@@ -229,7 +235,8 @@ class PGDAttack(BaseAttack):
         acc_test_list, sparsity_list = [], []
         for t in range(epochs):
             # adding_noise (:474-478): torch.randn_like on the attack device, as the reference draws it
-            eng.step(noise=torch.randn(n, n, device=dev) if eps != 0 else None)
+            if self.loss_type == 'CE':
+                eng.step(noise=torch.randn(n, n, device=dev) if eps != 0 else None)
             if monitor:
                 out2, spars = eng.monitor(want_sparsity=False)       # (:290-296)
                 if idx_test_t is not None:

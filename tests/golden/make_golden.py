@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it
 writes under tests/golden/ are data (inputs + the reference's outputs) and are
-what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cora|bench10k|citeseer]
+what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cw|cora|bench10k|citeseer]
 
 Environment shims applied before importing the reference (none of them is on
 the computed path):
@@ -101,7 +101,7 @@ def weights_of(victim):
 
 def run_reference_attack(adj, features, labels, victim, idx_attack, measure, weight_param,
                          weight_sup, lr, epochs, dataset, use, num_edges, eps=0.0,
-                         capture_steps=True, a0=None):
+                         capture_steps=True, a0=None, loss_type="CE"):
     """Drive topology_attack.PGDAttack.attack exactly as main.objective does
     (main.py:298-307) and capture per-step adj_changes / grads through a global
     optimizer post-hook."""
@@ -132,7 +132,7 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
                               useH_A=use[0], useY_A=use[1], useY=use[2],
                               w1=0, w2=0, w6=0, w7=0, w8=0, w9=0, w10=0)
     model = rta.PGDAttack(model=victim, embedding=embedding, H_A=H_A2, Y_A=Y_A, nnodes=n,
-                          loss_type="CE", device=device).to(device)
+                          loss_type=loss_type, device=device).to(device)
     if a0 is not None:      # start away from the origin: adj_changes is a public Parameter (topology_attack.py:77)
         model.adj_changes.data = torch.tensor(np.asarray(a0, dtype=np.float32))
     steps_a, steps_g, noises = [], [], []
@@ -194,6 +194,28 @@ def make_synth(n, f, c, hid, nlayer, seed, p_edge=0.08, arch="gcn"):
         victim = GCN(nfeat=f, nclass=c, nhid=hid, nlayer=nlayer, dropout=0.5, weight_decay=5e-4, device=device)
     # reference reset_parameters / xavier init (models/gcn.py:28-33, gat.py:27-30); no training
     return torch.FloatTensor(adj), torch.FloatTensor(feats), torch.LongTensor(labels), victim
+
+
+def gen_cw(tmp):
+    """loss_type='CW' (topology_attack.py:329-335): the reference back-propagates the margin loss but never calls
+    optimizer.step() (:277-280); the fixture pins what its run returns."""
+    os.chdir(tmp)
+    os.makedirs("saved_data", exist_ok=True)
+    name, n, f, c, hid, nl = "s48_mse_cw", 48, 24, 4, 16, 2
+    wp = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)
+    adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000, arch="gcn")
+    lab = labels.numpy()
+    np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
+    random.seed(7)
+    idx_attack = np.array(random.sample(range(n), n))
+    res = run_reference_attack(adj, feats, labels, victim, idx_attack, "MSELoss", wp, 1.0, 0.01, 3, "cora",
+                               (True, True, True), 1e12, capture_steps=False, loss_type="CW")
+    out = dict(adj=adj.numpy(), features=feats.numpy(), labels=lab, idx_attack=idx_attack, measure="MSELoss",
+               weight_param=np.array(wp, dtype=np.float64), weight_sup=1.0, lr=0.01, epochs=3, num_edges=1e12, nlayer=nl,
+               final=res["final"], H_A2=res["H_A2"], Y_A=res["Y_A"], feature_adj=res["feature_adj"], auc=res["auc"],
+               **weights_of(victim))
+    np.savez_compressed(os.path.join(OUT, f"cw_{name}.npz"), **out)
+    print(name, "auc", res["auc"])
 
 
 def gen_small(tmp):
@@ -572,6 +594,8 @@ if __name__ == "__main__":
             gen_ops(tmp)
         if a.only in ("all", "small"):
             gen_small(tmp)
+        if a.only in ("all", "cw"):
+            gen_cw(tmp)
         if a.only in ("all", "cora"):
             gen_cora(tmp)
         if a.only in ("citeseer",):         # ~20 min on 8 cores: not part of "all"

@@ -404,6 +404,27 @@ def test_pgdattack_class_small(pkg, torch_):
     assert len(model.history["acc_test"]) == int(z["epochs"])
 
 
+def test_pgdattack_class_loss_type_cw(pkg, torch_):
+    """loss_type='CW': the reference back-propagates the margin loss but calls optimizer.step() only for 'CE'
+    (topology_attack.py:277-280), so its run returns the post-loop ensemble of the untouched adjacency; the fixture is
+    that run (tests/golden/make_golden.py --only cw)."""
+    z = dict(np.load(os.path.join(H.GOLDEN, "cw_s48_mse_cw.npz"), allow_pickle=False))
+    w = H.weights_from(z)
+    victim, emb = H.FakeGCN(w), H.FakeGCN(w)
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=torch_.tensor(z["H_A2"]), Y_A=torch_.tensor(z["Y_A"]),
+                          nnodes=48, loss_type="CW", device="cuda:0")
+    lab = z["labels"]
+    model.attack(_args("MSELoss"), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]),
+                 torch_.tensor(z["feature_adj"]), 0, 0, 0, None, None, np.arange(8), torch_.tensor(z["adj"]),
+                 torch_.tensor(z["features"]), torch_.zeros(48, 48), torch_.tensor(lab), z["idx_attack"],
+                 float(z["num_edges"]), 0, epochs=int(z["epochs"]),
+                 label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    final = model.modified_adj.cpu().numpy()
+    assert np.abs(final - z["final"]).max() < 1e-3
+    assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
+    assert len(model.history["acc_test"]) == int(z["epochs"]) and model.engine.path_stats() == {"lowrank_steps": 0, "general_steps": 0}
+
+
 @pytest.mark.parametrize("name,fake", [("s48_gat_hsic_init", "FakeGAT"), ("s48_sage_kl", "FakeSAGE")])
 def test_pgdattack_class_other_victims(pkg, torch_, name, fake):
     """main.py --arch gat / sage: PGDAttack reads the victim family off the model object."""
