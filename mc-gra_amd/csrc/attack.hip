@@ -815,6 +815,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
   CHK(eg(h, st, false, true, n, n, he, 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->A1, ld));
   MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+  h->nmask_zero = false;
   launch_decode_post(st, n, ld, h->A1, nullptr, h->nmask);
   h->lr_step = false;
 

@@ -278,8 +278,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
       launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
-      // (monolithic with c2: k_post_mask leaves the counter at zero for the next step)
-      if (h->sharded || !use2) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+      // (monolithic with c2: k_post_mask leaves the counter at zero for the next fused step; the general path does not)
+      if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+      h->nmask_zero = false;
       h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
                                h->hmax, h->nmask);
       if (!h->sharded) {
@@ -303,9 +304,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
       // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
       // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
-      if (use2)
+      if (use2) {
         hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, h->sharded ? nullptr : h->nmask, h->sharded ? h->SC + 2 : nullptr,
                            h->mask_seq_dev, h->mask_host_dev);
+        h->nmask_zero = !h->sharded;
+      }
 
       // ---- low-rank factors (section 1b) with the products on M (section 1c).  T = Xc^T Vc without the delta^2 column
       //      of V: on a low-rank step every row of Zn has unit norm (a dead row would have masked its pairs), so that

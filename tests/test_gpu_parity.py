@@ -1084,6 +1084,12 @@ def test_masked_steps_of_a_large_graph_use_the_split_gram_evaluation(pkg, monkey
         engs[1].set_adj_changes(engs[0].get_adj_changes())
     assert engs[0].gram_split_steps() == 2 and engs[1].gram_split_steps() == 0
     assert engs[0].path_stats() == {"lowrank_steps": 0, "general_steps": 2} and engs[0].fused_steps() == 0
+    # once the decode no longer masks a pair the fused step takes over again (the masked-pair counter the general path
+    # leaves behind must not stick)
+    w0 = H.weights_from(z)
+    engs[0].set_model(w0.W, w0.b, w0.Wlin, w0.blin, w0.Ws)
+    engs[0].step(); engs[0].monitor(); engs[0].step()
+    assert engs[0].fused_steps() == 2 and engs[0].path_stats()["general_steps"] == 2
 
 
 def test_fused_lowrank_hands_masked_steps_to_the_general_path(pkg, monkeypatch):
