@@ -410,7 +410,7 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
 
 int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* W, const float* const* b,
                            const float* Wlin, const float* blin, const float* const* Ws) {
-  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;      // whatever the last step / monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = h->skip_fused = false;      // whatever the last step / monitor call left is stale now
   if (!h || !W || !b || !Wlin || !blin) { set_error("null argument"); return MCGRA_EINVAL; }
   if ((h->has_self != 0) != (Ws != nullptr)) { set_error("Ws must be given exactly when has_self is set"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
@@ -499,7 +499,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
 }
 
 int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed) {
-  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;      // whatever the last step / monitor call left is stale now
+  if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = h->skip_fused = false;      // whatever the last step / monitor call left is stale now
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
@@ -719,7 +719,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     set_error("this engine is a row-block rank: drive it with mcgra_attack_shard_begin / mcgra_attack_shard_next");
     return MCGRA_EINVAL;
   }
-  if (phases == 0xF && !noise && !h->sharded && fused_step_possible(h)) {
+  // (after a step whose decode masked a pair the general path goes first: it reads the masked-pair count itself, and
+  // only once that is zero again is the fused step worth enqueueing -- a masked run otherwise pays for both every step)
+  if (phases == 0xF && !noise && !h->sharded && fused_step_possible(h) && !h->skip_fused) {
     const int rc = fused_step(h, st, scalars_out);      // 1: a relu-masked pair in the decode, the general path redoes the step
     if (rc <= 0) return rc;
   }
@@ -864,6 +866,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         MCGRA_HIP(hipStreamSynchronize(st));
       }
       h->lr_step = (masked == 0);
+      if (use2) h->skip_fused = masked != 0;
     }
     // on a low-rank step with c2 the modified_adj1 side (c7 value and gradient) is folded into k_lr_decode_bwd
     const bool y_fused = h->lr_step && use2 && lr_decode_supported(he);

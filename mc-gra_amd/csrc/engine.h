@@ -100,6 +100,7 @@ struct mcgra_attack {
   unsigned int* mask_seq_dev = nullptr;          // device-side counter of the posts
   unsigned int mask_seq = 0;                     // posts enqueued so far
   bool p1_inflight = false;
+  bool skip_fused = false;         // the last step's decode masked a pair: the general path goes first (it re-checks)
   bool nmask_zero = false;         // the decode's masked-pair counter holds 0 (left so by k_post_mask)
   bool t3_zero = false;            // column 2 he of lrT (t3 of the low-rank factors) holds zeros (fused step; the general path writes it)
   bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream
