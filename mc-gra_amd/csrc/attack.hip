@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/mcgra.h"
@@ -764,6 +765,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (adopt) { float* t = h->ADJN; h->ADJN = h->ADJN_next; h->ADJN_next = t; }
   else CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !noise) ? h->rowsx : nullptr));
   h->p1_inflight = false;
+  std::function<int()> fork_p1;       // the forked product of a low-rank step, when its launch is deferred
   if (want_xc) {
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
     if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
@@ -782,25 +784,31 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       const bool split_now = h->split_on && !noise;
       if (split_now)
         split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr);
-      if (h->overlap) {
-        MCGRA_HIP(hipEventRecord(h->ev_fork, st));
-        MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-      }
-      if (split_now) {
-        // planes of Xc^T from the rows of the (symmetric) adj_norm, then the plane-reusing kernel (split_symm_bf16.hip)
-        const int row0 = t0 * SYM_TILE, row1 = t1 * SYM_TILE < n ? t1 * SYM_TILE : n;
-        const bool big = h->profile;
-        CHK(timer_begin(h, sp, big));
-        const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
-        // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
-        MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld,
-                              h->split_planes, h->amax));
-        CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
-        ++h->split_steps;
-      } else
-      CHK(eg_symm(h, sp, true, n, n, h->KFC, ld, h->XC, ld, 0.f, h->KX, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
-      if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
-      h->p1_inflight = true;
+      fork_p1 = [=]() -> int {
+        if (h->overlap) {
+          MCGRA_HIP(hipEventRecord(h->ev_fork, st));
+          MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        }
+        if (split_now) {
+          // planes of Xc^T from the rows of the (symmetric) adj_norm, then the plane-reusing kernel (split_symm_bf16.hip)
+          const int row0 = t0 * SYM_TILE, row1 = t1 * SYM_TILE < n ? t1 * SYM_TILE : n;
+          const bool big = h->profile;
+          CHK(timer_begin(h, sp, big));
+          const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
+          // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
+          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld,
+                                h->split_planes, h->amax));
+          CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
+          ++h->split_steps;
+        } else
+        CHK(eg_symm(h, sp, true, n, n, h->KFC, ld, h->XC, ld, 0.f, h->KX, ld, nullptr, nullptr, nullptr, t0, t1 - t0));
+        if (h->overlap) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
+        h->p1_inflight = true;
+        return 0;
+      };
+      // (in a run whose decode keeps masking pairs the product would be thrown away: it then waits for this step's own
+      // masked-pair count, below)
+      if (!(h->skip_fused && use2)) { CHK(fork_p1()); fork_p1 = nullptr; }
     }
   }
   // ---- victim(features, adj_norm) (:167) and the CE loss (:172)
@@ -867,6 +875,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       }
       h->lr_step = (masked == 0);
       if (use2) h->skip_fused = masked != 0;
+      if (h->lr_step && fork_p1) CHK(fork_p1());
     }
     // on a low-rank step with c2 the modified_adj1 side (c7 value and gradient) is folded into k_lr_decode_bwd
     const bool y_fused = h->lr_step && use2 && lr_decode_supported(he);
