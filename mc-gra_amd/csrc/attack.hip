@@ -322,7 +322,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       // (four by default), and engines beyond the first would otherwise multiplex their side streams onto the ones in
       // use (measured: a second live engine's Cora-size step went from 0.63 to 2.4 ms).  Engines of one process run
       // one after another, so sharing only adds ordering that is there anyway.
-      static hipStream_t side2[64] = {nullptr}, side3[64] = {nullptr};
+      static hipStream_t side2[64] = {nullptr}, side3[64] = {nullptr}, side4[64] = {nullptr};
       int dev = 0;
       (void)hipGetDevice(&dev);
       if (dev < 0 || dev >= 64) dev = 0;
@@ -332,8 +332,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       if (const char* ep = getenv("MCGRA_P1_PRIO")) pr2 = ep[0] == 'h' ? pr_greatest : (ep[0] == 'l' ? pr_least : pr2);
       if (!side2[dev] && hipStreamCreateWithPriority(&side2[dev], hipStreamNonBlocking, pr2) != hipSuccess) side2[dev] = nullptr;
       if (!side3[dev] && hipStreamCreateWithFlags(&side3[dev], hipStreamNonBlocking) != hipSuccess) side3[dev] = nullptr;
-      h->st2 = side2[dev]; h->st3 = side3[dev];
-      if (!h->st2 || !h->st3 ||
+      if (!side4[dev] && hipStreamCreateWithFlags(&side4[dev], hipStreamNonBlocking) != hipSuccess) side4[dev] = nullptr;
+      h->st2 = side2[dev]; h->st3 = side3[dev]; h->st4 = side4[dev];
+      if (!h->st2 || !h->st3 || !h->st4 ||
+          hipEventCreateWithFlags(&h->ev_fork4, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork3, hipEventDisableTiming) != hipSuccess ||
@@ -379,6 +382,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       h->fcols = fc;
       A_(FV, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256 + fl_wcolsum_scratch_doubles());
       if (!h->sharded) { A_(FY, n * (size_t)fc); }      // a row-block rank keeps FY in the exchange arena
+      if (!h->sharded) { A_(ws_dec, (size_t)lr_decode_slabs((int)n) * n * he); }
       h->fused_ok = (rc == 0);
     }
   }
@@ -402,6 +406,9 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->st3) (void)hipStreamSynchronize(h->st3);
+  if (h->st4) (void)hipStreamSynchronize(h->st4);
+  if (h->ev_fork4) (void)hipEventDestroy(h->ev_fork4);
+  if (h->ev_join4) (void)hipEventDestroy(h->ev_join4);
   if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
   if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
   if (h->mask_host) (void)hipHostFree((void*)h->mask_host);

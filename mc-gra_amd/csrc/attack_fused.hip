@@ -278,14 +278,33 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
       launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
-      // (monolithic with c2: k_post_mask leaves the counter at zero for the next fused step; the general path does not)
-      if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
-      h->nmask_zero = false;
-      h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
-                               h->hmax, h->nmask);
       if (!h->sharded) {
-        if (want_vals) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->scal + S_V7);
+        // monolithic, small graphs (where the step is bound by its chain of dependent node-level kernels): the decode -- the
+        // longest of them, and it needs only Zn -- on a fourth stream with its own slabs, beside the low-rank factor chain;
+        // joined in front of the first consumer of G_Zn (n = 2708: 0.60 -> 0.54 ms per step).  At N = 10 000 the chain hides
+        // behind the product anyway and a decode that runs beside more of it only slows the product (6.4 -> 6.9 ms).
+        // The masked-pair count is posted from the decode's stream (see below).
+        hipStream_t s4 = (s3 != st && n < 4096) ? h->st4 : st;
+        if (s4 != st) {
+          MCGRA_HIP(hipEventRecord(h->ev_fork4, st));
+          MCGRA_HIP(hipStreamWaitEvent(s4, h->ev_fork4, 0));
+        }
+        // (with c2, k_post_mask leaves the counter at zero for the next fused step; the general path does not)
+        if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), s4));
+        h->nmask_zero = false;
+        h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask);
+        if (want_vals) launch_reduce_rows(s4, h->rowvals, h->fs_np, 1, h->scal + S_V7);
+        if (use2) {
+          hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, s4, h->nmask, nullptr, h->mask_seq_dev, h->mask_host_dev);
+          h->nmask_zero = true;
+        }
+        if (s4 != st) MCGRA_HIP(hipEventRecord(h->ev_join4, s4));
+        h->fs_dec_forked = s4 != st;
       } else {
+        MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+        h->nmask_zero = false;
+        h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
+                                 h->hmax, h->nmask);
         MCGRA_HIP(hipMemsetAsync(h->SC + 2, 0, 2 * sizeof(double), st));
         hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, h->SC + 2);
         if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->SC + 3);
@@ -304,11 +323,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
       // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
       // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
-      if (use2) {
-        hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, h->sharded ? nullptr : h->nmask, h->sharded ? h->SC + 2 : nullptr,
-                           h->mask_seq_dev, h->mask_host_dev);
-        h->nmask_zero = !h->sharded;
-      }
+      if (use2 && h->sharded)
+        hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, nullptr, h->SC + 2, h->mask_seq_dev, h->mask_host_dev);
 
       // ---- low-rank factors (section 1b) with the products on M (section 1c).  T = Xc^T Vc without the delta^2 column
       //      of V: on a low-rank step every row of Zn has unit norm (a dead row would have masked its pairs), so that
@@ -340,6 +356,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       MCGRA_KERNEL_CHECK();
 
       // ---- decode backward (the entropy part is already in GZn), normalisation of em
+      if (h->fs_dec_forked) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join4, 0)); h->fs_dec_forked = false; }
       if (use2) {
         launch_lr_xtz(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrQtZ);
         launch_lr_part2(st, n, he, h->lrQ, h->Zn, h->hmax, h->lrDelta, h->lrRs, -2.f * (float)(sg * k2), h->GZn, h->hmax,

@@ -93,6 +93,11 @@ struct mcgra_attack {
   hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
   float* ws_small = nullptr;
   size_t ws_small_bytes = 0;
+  // fourth stream of the (monolithic) fused step: the decode recomputed per pair (the longest node-level kernel, needs
+  // only Zn) beside the low-rank factor chain, with its own slab buffer
+  hipStream_t st4 = nullptr;
+  hipEvent_t ev_fork4 = nullptr, ev_join4 = nullptr;
+  float* ws_dec = nullptr;
   // The decode's masked-pair count of the fused step is posted to mapped host memory by k_post_mask together with a
   // launch sequence number ({seq, masked}); the host polls it in front of the Adam pass (no stream sync).
   volatile unsigned int* mask_host = nullptr;    // [0] sequence number of the post, [1] masked != 0
@@ -139,7 +144,7 @@ struct mcgra_attack {
   int sgw = 0;
   // resumable step (protothread state: the step runs to the next exchange point and returns)
   int fs_state = 0, fw_state = 0, fs_l = 0, fs_l2 = 0, fs_what = 0, fs_want = 0, fs_np = 0, fs_nblk = 0;
-  bool fs_active = false, fs_adopted = false;
+  bool fs_active = false, fs_adopted = false, fs_dec_forked = false;
   double fs_scalars[10] = {0};
 };
 
