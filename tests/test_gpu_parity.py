@@ -165,6 +165,20 @@ def test_gaussian_hsic_ops(pkg, torch_, sg):
         E.hsic_regular(x, y, 0.0)
 
 
+@pytest.mark.parametrize("m,dx,dy", [(257, 9, 5), (64, 3, 3), (1, 4, 2)])
+def test_hsic_normalized_cca_against_float64(pkg, torch_, m, dx, dy):
+    """hsic_normalized_cca at sizes beyond the reference fixture (m not a multiple of anything, m = 1): the device path
+    (fp64 kernel matrices, Gauss-Jordan inverses with partial pivoting) against the oracle's float64 evaluation."""
+    from mc_gra_amd import hsic as HS
+    rng = np.random.RandomState(m)
+    x = rng.randn(m, dx).astype(np.float32)
+    y = (x[:, :min(dx, dy)] @ rng.randn(min(dx, dy), dy) * 0.5 + rng.randn(m, dy) * 0.7).astype(np.float32)
+    for sg in (0.8, 3.0):
+        want = float(O.hsic_normalized_cca(x, y, sg, dtype=np.float64))
+        got = float(HS.hsic_normalized_cca(dev(torch_, x), dev(torch_, y), sigma=sg))
+        assert abs(got - want) <= 2e-6 * abs(want) + 1e-7, (m, sg, got, want)
+
+
 def test_hsic_py_mirror_against_reference(pkg, torch_):
     """mc-gra_amd/hsic.py (the reference's hsic.py surface on the device) against the reference's own values:
     sigma=None forms (median heuristic: distance matrix on the device, median on the host as in the reference),
