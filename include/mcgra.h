@@ -13,7 +13,13 @@
  *   - every function returns 0 on success, a negative MCGRA_E* code otherwise;
  *     mcgra_last_error() returns a static description of the last failure on
  *     the calling thread;
- *   - functions enqueue on `stream` and do not synchronise unless documented.
+ *   - functions enqueue on `stream` and do not synchronise unless documented;
+ *   - threads: standalone ops may be called from any thread.  An attack engine
+ *     (mcgra_attack_t) is driven by one thread at a time, and the engines of one
+ *     device in a process share their side streams (the N x N x N product, the
+ *     small-operand terms and the decode run beside the caller's stream): steps of
+ *     different engines of one device, issued from different host threads or on
+ *     different streams, are correct but serialise on those side streams.
  *
  * Reference citations are relative to /root/reference/MC-GRA.
  */
@@ -127,8 +133,8 @@ int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X,
 
 /* hsic.py (Gaussian-kernel HSIC; not called by the attack loop, named by the task's north_star):
  * hsic_regular (hsic.py:117-124) = mean(Kxc * Kyc^T) with K = exp(-distmat / (2 sigma^2)) (:20-38), Kc = K H (:46);
- * hsic_normalized (:127-135) = Pxy / (sqrt(Pxx) sqrt(Pyy)).  X [m x dx], Y [m x dy]; sigma > 0 (sigma=None, the
- * median heuristic of :5-17, is not provided).  *out device scalar; synchronises. */
+ * hsic_normalized (:127-135) = Pxy / (sqrt(Pxx) sqrt(Pyy)).  X [m x dx], Y [m x dy]; sigma > 0 (for sigma=None, the
+ * median heuristic of :5-17, see mcgra_hsic_regular2 below).  *out device scalar; synchronises. */
 int mcgra_hsic_regular(void* stream, int m, int dx, int dy, const float* X, const float* Y,
                        float sigma, float* out);
 int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, const float* Y,
@@ -136,7 +142,7 @@ int mcgra_hsic_normalized(void* stream, int m, int dx, int dy, const float* X, c
 
 /* The rest of hsic.py.  sigma=None (median heuristic, hsic.py:5-17) is estimated by the host mirror
  * (mc-gra_amd/hsic.py: mcgra_distmat on the device, the median on the host, as the reference does with numpy) and
- * arrives here as explicit per-operand sigmas.  hsic_normalized_cca (:138-151, two m x m inverses) is not provided. */
+ * arrives here as explicit per-operand sigmas. */
 int mcgra_hsic_regular2(void* stream, int m, int dx, int dy, const float* X, const float* Y, float sigma_x, float sigma_y,
                         int normalized, float* out);               /* hsic_regular / hsic_normalized, one sigma per operand */
 /* hsic.py:138-151 (= utils.py:732-743 with sigma 5): sum(Rx o Ry^T), R = Kc (Kc + 1e-5 m I)^-1.  fp64 throughout

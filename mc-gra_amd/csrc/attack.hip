@@ -20,6 +20,7 @@
 
 #include <string>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mcgra.h"
@@ -237,6 +238,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn);
   { const char* e = getenv("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
+  { const char* e = getenv("MCGRA_TEST_MUTATE"); h->test_mutate = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }
   if (h->keep_gsym) { A_(GSYM, nn); }
   if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
     A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn);
@@ -323,6 +325,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       // use (measured: a second live engine's Cora-size step went from 0.63 to 2.4 ms).  Engines of one process run
       // one after another, so sharing only adds ordering that is there anyway.
       static hipStream_t side2[64] = {nullptr}, side3[64] = {nullptr}, side4[64] = {nullptr};
+      static std::mutex side_mu;                        // creation from several host threads (include/mcgra.h: "Threads")
+      std::lock_guard<std::mutex> side_lock(side_mu);
       int dev = 0;
       (void)hipGetDevice(&dev);
       if (dev < 0 || dev >= 64) dev = 0;

@@ -181,6 +181,26 @@ static void fused_commit(mcgra_attack* h) {
   h->fused_last = true;
 }
 
+// A fused step that did not reach one of its regular exits (a HIP error, or a row-block step the caller abandoned after a
+// failed collective and began again) leaves work on the side streams, a forked product / decode nobody joined and
+// possibly a masked-pair post the host never looked at.  Everything such a step wrote is scratch (the Adam pass is its
+// last kernel), so the next step only has to drain the streams and take the device's post counter.
+static int fused_resync(mcgra_attack* h, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  if (h->st2) (void)hipStreamSynchronize(h->st2);
+  if (h->st3) (void)hipStreamSynchronize(h->st3);
+  if (h->st4) (void)hipStreamSynchronize(h->st4);
+  (void)hipGetLastError();
+  unsigned int seq = 0;
+  MCGRA_HIP(hipMemcpy(&seq, h->mask_seq_dev, sizeof(seq), hipMemcpyDeviceToHost));
+  h->mask_seq = h->mask_want = seq;
+  h->p1_inflight = h->fs_dec_forked = false;
+  h->nmask_zero = h->t3_zero = false;
+  h->fused_fwd_valid = h->fwd_cached = h->prep_valid = false;
+  h->fs_open = false;
+  return 0;
+}
+
 // Returns 1 at an exchange point, 0 when the step is done, 2 when the step must be redone by the general path (a
 // relu-masked pair in the decode; every rank then holds the full M / am / av), < 0 on error.
 static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
@@ -213,6 +233,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   };
   int rc;
 
+  if (h->fs_state == 0) {
+    if (h->fs_open) CHK(fused_resync(h, st));
+    h->fs_open = true;
+  }
   switch (h->fs_state) {
     case 0:
       h->fs_adopted = h->fused_fwd_valid;
@@ -296,6 +320,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (want_vals) launch_reduce_rows(s4, h->rowvals, h->fs_np, 1, h->scal + S_V7);
         if (use2) {
           hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, s4, h->nmask, nullptr, h->mask_seq_dev, h->mask_host_dev);
+          h->mask_want = ++h->mask_seq;      // the host's count moves with the enqueue: an abandoned step cannot skew it
           h->nmask_zero = true;
         }
         if (s4 != st) MCGRA_HIP(hipEventRecord(h->ev_join4, s4));
@@ -323,8 +348,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
       // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
       // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
-      if (use2 && h->sharded)
+      if (use2 && h->sharded) {
         hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, nullptr, h->SC + 2, h->mask_seq_dev, h->mask_host_dev);
+        h->mask_want = ++h->mask_seq;
+      }
 
       // ---- low-rank factors (section 1b) with the products on M (section 1c).  T = Xc^T Vc without the delta^2 column
       //      of V: on a low-rank step every row of Zn has unit norm (a dead row would have masked its pairs), so that
@@ -415,6 +442,14 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // ---- tail: everything above ran beside the forked product.  A row-block rank holds the column block
       //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
       CHK(join());
+      {
+        // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result,
+        // =c2 drops the low-rank terms of linear_HSIC(adj_norm, modified_adj1) from the gradient -- a parity test that
+        // stays green under either is blind to split2_m16_kernel / the rank-k rounds of k_tail_reduce
+        const int mutate = h->test_mutate;      // (read at create)
+        if (mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
+        if (mutate == 2 && use2) MCGRA_HIP(hipMemsetAsync(h->lrL, 0, sizeof(float) * (size_t)n * 2 * he, st));
+      }
       if (h->sharded && use1) {
         for (int s = 0; s < h->world; ++s) {
           const int sr0 = s * h->rpr, sr1 = sr0 + h->rpr < n ? sr0 + h->rpr : n;
@@ -456,7 +491,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (use2) {
         bool masked;        // (no initialiser: the resumable step jumps into the block below)
         {
-          const unsigned int want = ++h->mask_seq;
+          const unsigned int want = h->mask_want;
           unsigned int spins = 0;
           while (__atomic_load_n(&h->mask_host[0], __ATOMIC_ACQUIRE) != want) {
             if ((++spins & 0xFFFF) == 0) {
@@ -485,6 +520,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
             }
           }
           h->fs_state = 0;
+          h->fs_open = false;
           return 2;
         }
       }
@@ -521,6 +557,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
   }
   h->fs_state = 0;
+  h->fs_open = false;
   return 0;
 }
 
@@ -563,6 +600,9 @@ int mcgra_attack_shard_begin(mcgra_attack_t* h, void* stream, int what, int want
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
   if (!h->sharded || !h->arena) { set_error("not a row-block rank, or no exchange arena bound"); return MCGRA_EINVAL; }
   if (what != MCGRA_SHARD_STEP && what != MCGRA_SHARD_MONITOR) { set_error("what = %d", what); return MCGRA_EINVAL; }
+  // a step that was begun and never ran to XCHG_DONE (the caller gave up on a collective): its leftovers are dropped
+  // by fused_resync at the top of the next step (fs_open is still set); a monitor call holds no such state
+  if (h->fs_active && h->fs_what == MCGRA_SHARD_MONITOR) h->fused_fwd_valid = false;
   h->fs_what = what; h->fs_want = want_scalars ? 1 : 0;
   h->fs_state = 0; h->fw_state = 0;
   h->fs_active = true;

@@ -40,6 +40,7 @@ struct mcgra_attack {
   bool fwd_cached = false, fwd_reuse = true;
   bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
   bool prep_valid = false;         // G_A holds the per-tile row sums of the current M (left by the fused tail kernel)
+  int test_mutate = 0;             // MCGRA_TEST_MUTATE (read at create; TEST-ONLY, see attack_fused.hip): 1 wipes P1, 2 drops the low-rank c2 terms
   bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
   float* ADJN_next = 0;
   bool graph_set = false, model_set = false;
@@ -103,7 +104,8 @@ struct mcgra_attack {
   volatile unsigned int* mask_host = nullptr;    // [0] sequence number of the post, [1] masked != 0
   unsigned int* mask_host_dev = nullptr;         // the same words through the device's address space
   unsigned int* mask_seq_dev = nullptr;          // device-side counter of the posts
-  unsigned int mask_seq = 0;                     // posts enqueued so far
+  unsigned int mask_seq = 0;                     // posts enqueued so far (moves where k_post_mask is launched)
+  unsigned int mask_want = 0;                    // sequence number of the post the step in flight will poll for
   bool p1_inflight = false;
   bool skip_fused = false;         // the last step's decode masked a pair: the general path goes first (it re-checks)
   bool nmask_zero = false;         // the decode's masked-pair counter holds 0 (left so by k_post_mask)
@@ -145,6 +147,7 @@ struct mcgra_attack {
   // resumable step (protothread state: the step runs to the next exchange point and returns)
   int fs_state = 0, fw_state = 0, fs_l = 0, fs_l2 = 0, fs_what = 0, fs_want = 0, fs_np = 0, fs_nblk = 0;
   bool fs_active = false, fs_adopted = false, fs_dec_forked = false;
+  bool fs_open = false;            // a fused step was started and has not reached a regular exit (see fused_resync)
   double fs_scalars[10] = {0};
 };
 

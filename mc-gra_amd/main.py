@@ -145,10 +145,16 @@ def run(args):
         embedding = embedding_gat(nfeat=nfeat, nclass=nclass, nhid=16, nlayer=args.nlayers, dropout=0.5, alpha=0.1,
                                   nheads=5, device=device)
         embedding.attentions = victim_model.attentions
-    victim_model.eval(); embedding.eval()
+    # main.py:233-241, call for call: the victim is in eval mode (fit() leaves it there), the freshly built embedding is
+    # NOT -- embedding_gat.forward therefore applies F.dropout(0.5) and the reference's H_A priors of --arch gat carry
+    # dropout noise (embedding_GCN / embedding_graphsage have no dropout); each call consumes the RNG as the reference's does
+    embedding = embedding.to(device)
     with torch.no_grad():
         fd, ad = features.to(device), adj.to(device)
+        embedding(fd, ad)                                                                  # H_A     main.py:235
         Y_A = victim_model(fd, ad)                                                         # main.py:236
+        embedding.set_layers(1)
+        embedding(fd, ad)                                                                  # H_A1    main.py:238-239
         embedding.set_layers(2)
         H_A2 = embedding(fd, ad)                                                           # main.py:240-241
         out = victim_model(fd, utils.normalize_adj_tensor(ad))

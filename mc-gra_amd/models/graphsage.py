@@ -65,7 +65,8 @@ class graphsage(nn.Module):
         assert device is not None, "Please specify 'device'!"
         self.device, self.nfeat, self.hidden_sizes, self.nclass, self.nlayer = device, nfeat, [nhid], nclass, nlayer
         self.gc = _layers(nfeat, nhid, nlayer, with_bias)
-        self.gc1 = self.gc[0]                      # the only registered layer (graphsage.py:130-131)
+        self.gc1 = self.gc[0]                      # the only registered layer (graphsage.py:126)
+        self.gc2 = self.gc1                        # alias of it (graphsage.py:127): state_dict keys gc1.* and gc2.* as in the reference's checkpoints
         self.linear1 = nn.Linear(nhid, nclass, bias=with_bias)
         self.dropout, self.lr = dropout, lr
         self.weight_decay = weight_decay if with_relu else 0

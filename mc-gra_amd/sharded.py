@@ -37,13 +37,39 @@ class RowBlockPlan:
         self.has_rows = self.row_begin < self.n
 
 
-def run_exchange(ex, arena, plan, dist=None, group=None, clone_input=False, always=False):
+def run_exchange(ex, arena, plan, dist=None, group=None, clone_input=False, always=False, host_staged=False):
     """One collective of the protocol on the rank's arena (uint8 tensor).  dist None / world 1: nothing to move
-    (always=True issues the world-1 collectives anyway: a hardware smoke test of the RCCL calls)."""
+    (always=True issues the world-1 collectives anyway: a hardware smoke test of the RCCL calls).
+
+    host_staged=True: the arena lives on a device but the process group is a host one (gloo) -- the slices a collective
+    touches are copied to host tensors, exchanged there and copied back.  For ranks that SHARE one GPU (RCCL refuses two
+    ranks on one device): the multi-process tests of the engine on a 1-GPU box; never the fast path."""
     kind, count, off, off2, chunk = ex
     if kind == XCHG_DONE or dist is None or (plan.world == 1 and not always):
         return
     w, r = plan.world, plan.rank
+    if host_staged:
+        # (.cpu() orders itself behind the engine's launches on the current stream and waits; the copies back are enqueued
+        # on the same stream, in front of the engine's next launches)
+        if kind == XCHG_ALLGATHER:
+            full = arena[off:off + w * chunk]
+            mine = full[r * chunk:(r + 1) * chunk].cpu()
+            host = torch.empty(w * chunk, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, mine, group=group)
+            full.copy_(host)
+        elif kind == XCHG_ALLREDUCE_F64:
+            dev = arena[off:off + 8 * count].view(torch.float64)
+            host = dev.cpu()
+            dist.all_reduce(host, group=group)
+            dev.copy_(host)
+        elif kind == XCHG_ALLTOALL:
+            send = arena[off:off + w * chunk].cpu()
+            host = torch.empty(w * chunk, dtype=torch.uint8)
+            dist.all_to_all_single(host, send, group=group)
+            arena[off2:off2 + w * chunk].copy_(host)
+        else:
+            raise ValueError(f"exchange kind {kind}")
+        return
     if kind == XCHG_ALLGATHER:
         full = arena[off:off + w * chunk]
         mine = full[r * chunk:(r + 1) * chunk]
@@ -58,12 +84,13 @@ def run_exchange(ex, arena, plan, dist=None, group=None, clone_input=False, alwa
 
 
 class ShardedStepper:
-    def __init__(self, backend, plan=None, dist=None, group=None, clone_input=False, always=False):
+    def __init__(self, backend, plan=None, dist=None, group=None, clone_input=False, always=False, host_staged=False):
         """backend: .arena, .begin(what, want_scalars), .next() -> (kind, count, offset, offset2, chunk_bytes),
         .scalars(); dist: torch.distributed or None (world 1); clone_input: gloo needs a non-aliased all_gather
-        input."""
+        input; host_staged: device arena, host process group (see run_exchange)."""
         self.b, self.plan = backend, plan or backend.plan
         self.dist, self.group, self.clone_input, self.always = dist, group, clone_input, always
+        self.host_staged = host_staged
         self.exchanges = 0
 
     def _run(self, what, want_scalars):
@@ -72,7 +99,7 @@ class ShardedStepper:
             ex = self.b.next()
             if ex[0] == XCHG_DONE:
                 break
-            run_exchange(ex, self.b.arena, self.plan, self.dist, self.group, self.clone_input, self.always)
+            run_exchange(ex, self.b.arena, self.plan, self.dist, self.group, self.clone_input, self.always, self.host_staged)
             self.exchanges += 1
         return self.b.scalars() if want_scalars else None
 

@@ -21,7 +21,7 @@ ti, tj = torch.as_tensor(pi, device=dev), torch.as_tensor(pj, device=dev)
 for name in ["run"] + sorted({k[:4] for k in z.files if k.startswith("one")}):
     sd, sc = int(z[f"{name}_a0_seed"]), float(z[f"{name}_a0_scale"])
     eng, inp, adj_dev = bench.build_engine(pkg, torch, dev, WL, int(z["seed"]))
-    if (sd, sc) != (int(z["seed"]), 0.05):
+    if (sd, sc) != (int(z["seed"]), bench.start_scale(WL, n)):
         eng.set_adj_changes(torch.as_tensor(bench.make_a0(n, sd, sc), device=dev))
     G, A = z[f"{name}_g"], z[f"{name}_a"]
     for t in range(G.shape[0]):
@@ -35,7 +35,7 @@ for name in ["run"] + sorted({k[:4] for k in z.files if k.startswith("one")}):
             g64 = z64[f"{name}_g64"]
             line += f" | hip-vs-f64 {np.abs(g - g64).max()/gmax:.3e} ref-vs-f64 {np.abs(G[t] - g64).max()/gmax:.3e}"
         a = eng.buffer("M")[ti, tj].cpu().numpy()
-        moved = np.abs(a - np.clip(A[t], 0, 1)) > 0.05 * 0.01
+        moved = np.abs(a - np.clip(A[t], 0, 1)) > 0.05 * float(z["lr"])
         line += f" | moved {moved.mean():.4f} loss {sc_['loss']:.6e} c1 {sc_['c1']:.4e} c2 {sc_['c2']:.4e}"
         print(line, flush=True)
     lab = torch.as_tensor(inp["labels"], device=dev)

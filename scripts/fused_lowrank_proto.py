@@ -10,7 +10,7 @@ from oracle import mcgra_oracle as O
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 f, c, hid, nl = 128, 7, 16, 2
 inp = B.make_inputs(n, f, c, hid, nl, 0)
-a0 = B.make_a0(n, 0)
+a0 = B.make_a0(n, 0, 0.05)      # the dense start of rounds 1-2
 M = O.unpack_sym(a0, n).astype(np.float32)
 w = O.GCNWeights(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
 T0 = inp["features"] @ inp["W"][0]

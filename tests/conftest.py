@@ -10,8 +10,26 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _start_clean_process_factory():
+    """tests/test_gpu_multiproc.py runs several ranks of one attack as separate processes on the box's GPU.  A process
+    that has initialised the GPU must not fork + exec others (the GPU box refuses that), so the factory of those ranks --
+    a multiprocessing fork server, a process that never touches the GPU and forks its children WITHOUT exec -- is started
+    here, before anything in this pytest process initialises the device (torch.cuda.device_count() does not)."""
+    try:
+        import torch
+        if torch.cuda.device_count() == 0:
+            return
+    except Exception:
+        return
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    mp.set_forkserver_preload([])
+    forkserver.ensure_running()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    _start_clean_process_factory()
 
 
 @pytest.fixture(scope="session")

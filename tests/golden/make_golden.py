@@ -529,14 +529,17 @@ def gen_citeseer_gat(tmp, train_iters=6):
         print(name, "auc", res["auc"], "seconds", round(_t.time() - t0, 1), flush=True)
 
 
-def gen_bench(tmp, workload="synthetic-10k-hsic", tag="bench10k_hsic", seed=0, epochs=4, single_starts=((1, 0.2), (2, 0.6))):
+def gen_bench(tmp, workload="synthetic-10k-hsic", tag="bench10k_hsic", seed=0, epochs=4, single_starts=((1, 0.5), (2, 2.0))):
     """The bench's OWN workload (bench.WORKLOADS[workload], bench.make_inputs, bench.make_a0) through the
     reference's PGDAttack.attack on CPU (topology_attack.py:161-324).  The inputs are regenerated from the seed by
     the test, so the fixture holds only the reference's outputs: per-step gradient / adj_changes on a fixed sample
     of packed positions, fp64 step sums, a sample of the final ensemble and the AUC.  Besides the `epochs`-step
     run from bench.make_a0(n, seed), `single_starts` = ((seed offset, scale), ...) are one-step runs from other
     seeded starts: each is a step whose starting state the test can rebuild exactly (the 50 M-entry adj_changes of
-    later steps of a run cannot be stored), i.e. teacher forcing by construction."""
+    later steps of a run cannot be stored), i.e. teacher forcing by construction.  Scales are multiples of the
+    workload's own start scale bench.start_scale (kappa / N): the run starts where the loss's N x N terms and its
+    small-operand terms both carry the gradient (scripts/nxn_share.py), `one0` at half of it (N x N terms in charge),
+    `one1` at twice (small-operand terms in charge); lr is the workload's (bench.workload_lr)."""
     os.chdir(tmp)
     os.makedirs("saved_data", exist_ok=True)
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
@@ -556,14 +559,15 @@ def gen_bench(tmp, workload="synthetic-10k-hsic", tag="bench10k_hsic", seed=0, e
     rng = np.random.RandomState(99)
     pk = np.unique(np.concatenate([np.arange(0, npk, max(1, npk // 4096)), rng.randint(0, npk, 4096)])).astype(np.int64)
     samp = rng.randint(0, n, size=(8192, 2))
-    out = dict(workload=workload, seed=seed, epochs=epochs, packed_pos=pk, sample_pos=samp, lr=0.01, weight_sup=1.0,
-               weight_param=np.array(wp, dtype=np.float64), measure=measure)
+    lr, sc0 = B.workload_lr(workload, n), B.start_scale(workload, n)
+    out = dict(workload=workload, seed=seed, epochs=epochs, packed_pos=pk, sample_pos=samp, lr=lr, weight_sup=1.0,
+               weight_param=np.array(wp, dtype=np.float64), measure=measure, start_scale=sc0)
     import time as _t
-    runs = [("run", seed, 0.05, epochs)] + [(f"one{k}", seed + off, sc, 1) for k, (off, sc) in enumerate(single_starts)]
+    runs = [("run", seed, sc0, epochs)] + [(f"one{k}", seed + off, sc0 * mul, 1) for k, (off, mul) in enumerate(single_starts)]
     for name, sd, sc, ep in runs:
         a0 = B.make_a0(n, sd, sc)
         t0 = _t.time()
-        res = run_reference_attack(adj, feats, labels, victim, inp["idx_attack"], measure, wp, 1.0, 0.01, ep,
+        res = run_reference_attack(adj, feats, labels, victim, inp["idx_attack"], measure, wp, 1.0, lr, ep,
                                    "cora", (True, True, True), 1e30, a0=a0)
         sa = np.stack(res["steps_a"]); sg = np.stack(res["steps_g"])
         out.update({f"{name}_a0_seed": sd, f"{name}_a0_scale": sc,

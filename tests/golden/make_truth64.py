@@ -32,7 +32,7 @@ def main(workload="synthetic-10k-hsic", tag="bench10k_hsic"):
     fadj = 1.0 / (1.0 + np.exp(-np.maximum(X @ X.T - np.eye(n), 0)))
     w = O.GCNWeights([x.astype(np.float64) for x in inp["W"]], [x.astype(np.float64) for x in inp["b"]],
                      inp["Wlin"].astype(np.float64), inp["blin"].astype(np.float64))
-    cfg = O.AttackConfig(measure=measure, weight_sup=1.0, weight_param=wp, lr=0.01, num_edges=float("inf"))
+    cfg = O.AttackConfig(measure=measure, weight_sup=1.0, weight_param=wp, lr=float(z["lr"]), num_edges=float("inf"))
     pk = z["packed_pos"]
     i = ((1.0 + np.sqrt(1.0 + 8.0 * pk.astype(np.float64))) / 2.0).astype(np.int64)
     i = np.where(i * (i - 1) // 2 > pk, i - 1, i)

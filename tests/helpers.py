@@ -90,6 +90,28 @@ def cora_feature_adj(feats):
     return (1.0 / (1.0 + np.exp(-Z.astype(np.float64)))).astype(np.float32)
 
 
+def synthetic_case(n, nfeat, widths, nclass, seed, measure="HSIC", weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)):
+    rng = np.random.RandomState(seed)
+    dims = [nfeat] + list(widths)
+    z = {"measure": np.array(measure), "weight_sup": np.array(1.0), "weight_param": np.array(weight_param, np.float64),
+         "lr": np.array(0.01), "num_edges": np.array(1e30), "nlayer": np.array(len(widths)),
+         "emb_nlayer": np.array(min(2, len(widths))), "a0_seed": np.array(7), "a0_scale": np.array(0.05)}
+    for l in range(len(widths)):
+        s = 1.0 / np.sqrt(dims[l + 1])
+        z[f"W{l}"] = rng.uniform(-s, s, (dims[l], dims[l + 1])).astype(np.float32)
+        z[f"b{l}"] = rng.uniform(0, s, dims[l + 1]).astype(np.float32)
+    s = 1.0 / np.sqrt(widths[-1])
+    z["Wlin"] = rng.uniform(-s, s, (nclass, widths[-1])).astype(np.float32)
+    z["blin"] = rng.uniform(-s, s, nclass).astype(np.float32)
+    z["features"] = (rng.rand(n, nfeat) < 0.3).astype(np.float32)
+    a = (rng.rand(n, n) < 0.08).astype(np.float32)
+    a = np.triu(a, 1); z["adj"] = a + a.T
+    z["feature_adj"] = cora_feature_adj(z["features"])
+    z["labels"] = rng.randint(0, nclass, n)
+    z["idx_attack"] = rng.permutation(n)[: n - 5]
+    return z
+
+
 # ---------------------------------------------------------------- GPU-side helpers
 def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None, **kw):
     """AttackEngine (C-ABI handle) set up from a golden attack case."""

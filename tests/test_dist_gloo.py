@@ -1,6 +1,7 @@
-"""N > 1 plumbing of bench.py on CPU: two gloo ranks run the timing contract (barrier, exactly K timed steps,
-MAX over ranks, whole-job aggregate).  The per-rank work is a stand-in sleep: the HIP step itself cannot run
-here, and round 1 ships independent replicas per rank (no data-path collective to test)."""
+"""N > 1 plumbing on CPU (gloo): (i) bench.py's timing contract on two ranks (barrier, exactly K timed steps, MAX over
+ranks) with a stand-in sleep as the per-rank work; (ii) the product's ShardedStepper / run_exchange over gloo at world
+2 / 3 / 4 with a numpy rank that walks the engine's arena conventions.  The HIP row-block engine itself under a real
+process group runs on the GPU box: tests/test_gpu_multiproc.py."""
 import os
 import socket
 import sys
