@@ -442,14 +442,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // ---- tail: everything above ran beside the forked product.  A row-block rank holds the column block
       //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
       CHK(join());
-      {
-        // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result,
-        // =c2 drops the low-rank terms of linear_HSIC(adj_norm, modified_adj1) from the gradient -- a parity test that
-        // stays green under either is blind to split2_m16_kernel / the rank-k rounds of k_tail_reduce
-        const int mutate = h->test_mutate;      // (read at create)
-        if (mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
-        if (mutate == 2 && use2) MCGRA_HIP(hipMemsetAsync(h->lrL, 0, sizeof(float) * (size_t)n * 2 * he, st));
-      }
+      // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result, =c2 drops
+      // the low-rank term of linear_HSIC(adj_norm, modified_adj1) from the gradient -- a parity test that stays green under
+      // either is blind to split2_m16_kernel / the rank-k rounds of k_tail_reduce
+      if (h->test_mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
       if (h->sharded && use1) {
         for (int s = 0; s < h->world; ++s) {
           const int sr0 = s * h->rpr, sr1 = sr0 + h->rpr < n ? sr0 + h->rpr : n;
@@ -473,10 +469,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         const float* Ls[2] = {h->GPv, h->lrL};
         const float* Rs[2] = {h->Tv, h->lrR};
         const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
-        const float al[2] = {1.f, a2};
-        h->fs_nblk = fl_tail_reduce(st, n, ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->M, use1 ? h->KX : nullptr, h->r,
-                                    h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr, a1, a2, (float)(k6 / n2),
-                                    h->G_ADJN, ps1, vpart);
+        const float al[2] = {1.f, h->test_mutate == 2 ? 0.f : a2};
+        h->fs_nblk = fl_tail_reduce(st, n, ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, hs, h->M,
+                                    use1 ? h->KX : nullptr, h->r, h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
+                                    a1, a2, (float)(k6 / n2), h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf);
         if (h->sharded) MCGRA_HIP(hipMemsetAsync(h->SC + 4, 0, 3 * sizeof(double), st));
         if (h->fs_nblk > 0 && want_vals) {
           launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? h->SC + 4 : h->scal + S_H1);
@@ -532,7 +528,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         const bool may_project = c.num_edges < 0.5 * n2;
         const size_t cnt = (size_t)n * nt;
         const bool emit = !may_project && 3 * cnt + 4 <= (size_t)n * ld;
-        fl_tail_adam(st, n, ld, pair, R0, R1, h->GPu, hs, h->Tu, hs, hs, h->G_ADJN, h->r, h->gd, h->M, h->am, h->av, h->mm + 2,
+        fl_tail_adam(st, n, ld, pair, R0, R1, h->G_ADJN, h->gd, h->M, h->am, h->av, h->mm + 2,
                      (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
                      h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,
                      emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr,

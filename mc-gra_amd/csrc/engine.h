@@ -132,6 +132,7 @@ struct mcgra_attack {
   int fcols = 0;                   // leading dimension of FV / FY
   float *FV = 0, *FY = 0;          // right-hand sides / results of the skinny products on M  [n x fcols]
   mcgra::YView fy{nullptr, 0, 1, 0};      // the last such product as its consumers read it (FY, or the split-K slabs in ws)
+  char* rkbuf = 0;                 // packed fp16 planes of the tail's rank-k panels (fl_tail_pack_bytes)
   float *em_last = 0;              // embedding(features, adj_norm) of the last iteration (:300), = its victim-chain activations
   double *fstat = 0;               // small fp64 vectors: colsum(V) [64] | colsum(W) [64] | mean^T W [64] | sum(mean) [2]
   int64_t fused_steps = 0;

@@ -8,11 +8,13 @@
 //   G_adjn_ij   = ie'(adj_norm_ij) + sum_k GPv_ik Tv_jk + a2 sum_k L_ik R_jk + a1 P1_ij + a2 (delta_i^2 Xc_ij + c_j)
 //
 // Only G_adjn + G_adjn^T reaches the optimiser (the packed gradient is mirrored and adj_norm is symmetric), so the tail
-// is two passes over 64 x 64 tile pairs: k_tail_reduce forms Gs = G + G^T per pair (rank-k terms as VALU FMAs on LDS
-// panels, P1 tile and its mirror), stores it and reduces the row sums of the normalisation backward;
-// k_tail_adam turns Gs into the packed gradient, adds the rank-k term of the modified_adj chain and runs Adam on the
-// pair, writing both halves of the state.  A row-block rank (row range [row0, row1), all columns: `pair == 0`) runs
-// the same code without mirrored writes.
+// is two passes over 64 x 64 tile pairs:
+//   k_tail_reduce  Gs = G + G^T per pair: every rank-k term of the step (fp16-split products on the 16-bit matrix cores,
+//                  fragments straight from pre-packed panels: no staging, no barriers), the P1 tile and its mirror (through
+//                  LDS), the entropy / delta^2 / c terms; reduces the row sums of the normalisation backward; stores
+//                  G2 = Gs r_i r_j + (rank-k term of the modified_adj chain)
+//   k_tail_adam    packed gradient g = G2 + gd_i + gd_j + cn M_ij, Adam, clamp, both halves of the state: elementwise
+// A row-block rank (row range [row0, row1), all columns: `pair == 0`) runs the same code without mirrored writes.
 #include "common.h"
 #include "kernels.h"
 
@@ -258,87 +260,126 @@ __global__ void k_sum_slabs_rows(int n, int row0, int row1, int h, int nslab, co
 
 // -------------------------------------------------------------------------------------------------- the tail
 constexpr int FT = 64;           // tile edge
-// Symmetrised rank-k terms sum_f alpha_f (L_f,i . R_f,j + R_f,i . L_f,j).  The terms are concatenated along k into
-// rounds of at most KMAX columns (host side: make_factors), so that e.g. the victim-chain term (K = 32) and the
-// low-rank term (K = 32) of a 2-layer GCN cost one pair of staged products instead of two.
-struct TailFactors {
-  const float* L[4];
-  const float* R[4];
-  int ldl[4], ldr[4], K[4], koff[4], round[4];
-  float alpha[4];
-  int count, nrounds, kround[4];
+// The rank-k terms of the tail, sum_f alpha_f (L_f,i . R_f,j + R_f,i . L_f,j), on the 16-bit matrix cores at fp32-level
+// accuracy -- the arithmetic of the N x N x N product (split_symm_bf16.hip) applied to 64-row panels: every factor is cut
+// into rounds of at most 32 columns and every (round, 64-row tile) panel is packed ONCE per step by k_pack_rk as two fp16
+// planes, x 2^(15 - e) = x0 + x1 with e the panel's own exponent (largest magnitude in [2^14, 2^15): 22 significant bits,
+// the residual exact), in the LDS image the kernels read: [k step of 16][plane][k half][row][8 k] = 8 KB per panel.
+// fp32 MFMA runs at 1/16 of the 16-bit rate: the three plane products x0 y0 + x0 y1 + x1 y0 cost 3/16 of the fp32 form
+// (measured: k_tail_reduce's two fp32 rounds were 210 of its 424 us, and beside the N x N x N product they took the
+// matrix pipe from it one for one).
+constexpr int RK_KMAX = 32;                          // columns per round
+constexpr int RK_PANEL = FT * RK_KMAX * 2 * 2;       // 8192 bytes: two fp16 planes of a 64 x 32 panel
+constexpr int RK_MAXR = 4;                           // rounds per term group (K <= 128)
+struct RkRounds {
+  const char* L[RK_MAXR];         // packed panels of alpha L, [tile][RK_PANEL]
+  const char* R[RK_MAXR];
+  const int* eL[RK_MAXR];         // panel exponents, [tile]
+  const int* eR[RK_MAXR];
+  int ksteps[RK_MAXR];            // 16-k steps of the round (1 or 2)
+  int count;
 };
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-// stage rows [r0, r0 + 64) x [0, K) of a row-major panel, scaled, into LDS as dst[koff + k][64].  Lane = row, so the four
-// scalar stores of a lane's float4 go to 64 consecutive floats per k across the wave: no bank conflicts (a lane = k
-// mapping put 8 lanes on one bank).  The panels are a few KB and L2-resident; the row-strided 16-byte loads are cheap.
-__device__ __forceinline__ void ft_stage(float (*dst)[FT], int koff, const float* __restrict__ src, int ld, int r0, int nrows,
-                                         int K, float scale, bool vec) {
-  const int kq = (K + 3) >> 2;
-  for (int e = threadIdx.x; e < FT * kq; e += 256) {
-    const int m = e & (FT - 1), k4 = (e / FT) << 2;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (r0 + m < nrows) {
-      const float* p = src + (size_t)(r0 + m) * ld + k4;
-      if (vec && k4 + 3 < K) {
-        const float4 q = *reinterpret_cast<const float4*>(p);
-        v[0] = scale * q.x; v[1] = scale * q.y; v[2] = scale * q.z; v[3] = scale * q.w;
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (k4 + t < K) v[t] = scale * p[t];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (k4 + t < K) dst[koff + k4 + t][m] = v[t];
-  }
+__device__ __forceinline__ int rk_exp(float amax) {       // amax = f 2^e, f in [0.5, 1); 0 for amax == 0 / inf / nan
+  int e = 0;
+  if (amax > 0.f && amax < 3.0e38f) frexpf(amax, &e);
+  return e;
 }
 
-// acc[a][b] += sum_f alpha_f (L_i . R_j + R_i . L_j) for the thread's 4 x 4 patch of tile (bi, bj).  One staging phase per
-// round puts the four panels it needs in LDS (alpha L and R of the tile's rows, R and alpha L of its columns); the two
-// 64 x 64 x K products of a round then run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, one 32 x 32 quadrant per
-// wave, operands straight from the panels: lane = (row, k parity), conflict-free ds_read_b32) -- half the cycles of the
-// 4 x 4 register-tile FMA form, whose LDS operand reads cost as much as its FMAs, and the VALU stays free for the
-// elementwise part.  Bitwise symmetric under i <-> j: the two products are the same k-ordered chains with the roles
-// swapped and are added to each other first, so a diagonal tile, whose two triangles are computed by different
-// lanes, stays symmetric.   P: [4][KMAX][64] floats = {alpha L_I, R_J, R_I, alpha L_J}; T [64][65] receives the sum
-// in the matrix cores' accumulator layout and hands it to the threads' 4 x 4 patches (T may alias P[0..2]).
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-template <int KMAX>
-__device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int bj, int n, float (*P)[KMAX][FT], float (*T)[FT + 1],
-                                             int r0, int c0, float (&acc)[4][4]) {
+// One block per (64-row tile, job): job = one round of one factor.  256 threads: thread = (row, k octet).
+struct RkPackJobs {
+  const float* src[2 * RK_MAXR * 2];     // factor matrix, row-major
+  int ld[2 * RK_MAXR * 2], c0[2 * RK_MAXR * 2], kw[2 * RK_MAXR * 2];      // columns [c0, c0 + kw) of it
+  float alpha[2 * RK_MAXR * 2];
+  char* out[2 * RK_MAXR * 2];
+  int* eout[2 * RK_MAXR * 2];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_pack_rk(int n, RkPackJobs J) {
+  __shared__ float shm[4];
+  const int t = blockIdx.x, q = blockIdx.y;
+  const int row = t * FT + (threadIdx.x >> 2), oct = threadIdx.x & 3;
+  const int kw = J.kw[q];
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = oct * 8 + j;
+    v[j] = (row < n && k < kw) ? J.alpha[q] * J.src[q][(size_t)row * J.ld[q] + J.c0[q] + k] : 0.f;
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  const int e = rk_exp(m);
+  if (threadIdx.x == 0) J.eout[q][t] = e;
+  const float sc = ldexpf(1.f, 15 - e);
+  f16x8_t p0, p1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * sc;                 // exact
+    p0[j] = (_Float16)x;
+    p1[j] = (_Float16)(x - (float)p0[j]);      // the residual is exact in fp32
+  }
+  // [k step][plane][k half][row][8]
+  char* base = J.out[q] + (size_t)t * RK_PANEL + ((size_t)((oct >> 1) * 2) * 2 + (oct & 1)) * (FT * 16) + (size_t)(threadIdx.x >> 2) * 16;
+  *reinterpret_cast<f16x8_t*>(base) = p0;
+  *reinterpret_cast<f16x8_t*>(base + 2 * (FT * 16)) = p1;
+}
+
+// acc[a][b] += sum over the rounds of (L_i . R_j + R_i . L_j) for the thread's 4 x 4 patch of tile (ti, tj).  Per round two
+// products on v_mfma_f32_32x32x16_f16 (one 32 x 32 quadrant per wave): p0 = L_I R_J^T and p1 = R_I L_J^T.  The packed
+// panels ARE the fragment layout -- lane (row l & 31, k half l >> 5) of [k step][plane][k half][row][8] is one 16-byte
+// load, 512 contiguous bytes per half wave -- so the operands go from L2 (the panels of a step are 7.5 MB) straight into
+// registers: no LDS staging and no barrier inside the rounds (four waves per SIMD cover the load latency).  Bitwise symmetric under i <-> j: per product the x0 y0 terms and the cross terms x0 y1, x1 y0 are kept in two
+// accumulators, and p1 issues its cross terms in the opposite order of p0 -- so p1 of the mirrored element is, MFMA for
+// MFMA, p0 of this one (the planes swap roles with the operands), and p0 + p1 are added to each other before anything else.
+// T [64][65] receives the sum in the matrix cores' accumulator layout and hands it to the threads' 4 x 4 patches.
+__device__ __forceinline__ void rk_sym(const RkRounds& F, int ti, int tj, float (*T)[FT + 1], int r0, int c0, float (&acc)[4][4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5, qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
   f32x16_t tot;
 #pragma unroll
   for (int r = 0; r < 16; ++r) tot[r] = 0.f;
-  for (int rd = 0; rd < F.nrounds; ++rd) {
-    const int K = F.kround[rd];
-    __syncthreads();                       // previous users of the panels are done
-    for (int f = 0; f < F.count; ++f) {
-      if (F.round[f] != rd) continue;
-      const bool vl = (F.ldl[f] & 3) == 0 && ((uintptr_t)F.L[f] & 15) == 0, vr = (F.ldr[f] & 3) == 0 && ((uintptr_t)F.R[f] & 15) == 0;
-      ft_stage(P[0], F.koff[f], F.L[f], F.ldl[f], bi, n, F.K[f], F.alpha[f], vl);
-      ft_stage(P[1], F.koff[f], F.R[f], F.ldr[f], bj, n, F.K[f], 1.f, vr);
-      ft_stage(P[2], F.koff[f], F.R[f], F.ldr[f], bi, n, F.K[f], 1.f, vr);
-      ft_stage(P[3], F.koff[f], F.L[f], F.ldl[f], bj, n, F.K[f], F.alpha[f], vl);
-    }
-    __syncthreads();
-    f32x16_t p0, p1;
+  const size_t oi = (size_t)ti * RK_PANEL + (size_t)lh * (FT * 16) + (size_t)(qi + l31) * 16;
+  const size_t oj = (size_t)tj * RK_PANEL + (size_t)lh * (FT * 16) + (size_t)(qj + l31) * 16;
+  // fragment (k step s, plane p) of a panel: + (s * 2 + p) * 2 * 1024 bytes
+  auto ld = [&](const char* base, size_t o, int s, int p) {
+    return __builtin_bit_cast(f16x8_t, *reinterpret_cast<const u32x4_t*>(base + o + (size_t)((s * 2 + p) * 2) * (FT * 16)));
+  };
+#pragma unroll 1
+  for (int rd = 0; rd < F.count; ++rd) {
+    const int ks = F.ksteps[rd];
+    // undo the panel scales 2^(15 - e): exact
+    const float i0 = ldexpf(1.f, F.eL[rd][ti] + F.eR[rd][tj] - 30), i1 = ldexpf(1.f, F.eR[rd][ti] + F.eL[rd][tj] - 30);
+    f32x16_t c00, cx;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
-    for (int k = 0; k < K; k += 2) {
-      const int kk = k + lh;               // A[i][k]: lane = (i = lane & 31, k = lane >> 5); B[k][j] likewise
-      const bool in = kk < K;
-      const float a0 = in ? P[0][kk][qi + l31] : 0.f, b0 = in ? P[1][kk][qj + l31] : 0.f;
-      const float a1 = in ? P[2][kk][qi + l31] : 0.f, b1 = in ? P[3][kk][qj + l31] : 0.f;
-      p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, p0, 0, 0, 0);
-      p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, p1, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; cx[r] = 0.f; }
+    for (int s = 0; s < ks; ++s) {         // p0 = L_I R_J^T: cross terms x0 y1 then x1 y0
+      const f16x8_t a0 = ld(F.L[rd], oi, s, 0), a1 = ld(F.L[rd], oi, s, 1), b0 = ld(F.R[rd], oj, s, 0), b1 = ld(F.R[rd], oj, s, 1);
+      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, cx, 0, 0, 0);
+      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, cx, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c00, 0, 0, 0);
     }
-    tot += p0 + p1;
+    const f32x16_t p0 = (c00 + cx) * i0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; cx[r] = 0.f; }
+    for (int s = 0; s < ks; ++s) {         // p1 = R_I L_J^T: x1 y0 then x0 y1 (the mirrored order)
+      const f16x8_t a0 = ld(F.R[rd], oi, s, 0), a1 = ld(F.R[rd], oi, s, 1), b0 = ld(F.L[rd], oj, s, 0), b1 = ld(F.L[rd], oj, s, 1);
+      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, cx, 0, 0, 0);
+      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, cx, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c00, 0, 0, 0);
+    }
+    const f32x16_t sum = p0 + (c00 + cx) * i1;
+    tot += sum;
   }
-  __syncthreads();                         // the panels are dead: T may overwrite them
+  __syncthreads();                         // previous users of T are done
   // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int r = 0; r < 16; ++r) T[qi + (r & 3) + 8 * (r >> 2) + 4 * lh][qj + l31] = tot[r];
@@ -351,41 +392,41 @@ __device__ __forceinline__ void ft_sym_rankk(const TailFactors& F, int bi, int b
 
 // Pass 1 of the tail.  pair != 0: grid (nt, nt), blocks with bj > bi return (their pair block covers them); a block
 // handles tile (I, J) and its mirror.  pair == 0: grid (nt, tile rows of [row0, row1)), every block its own tile only.
-//   GS[i][j] = G_adjn_ij + G_adjn_ji                      (pair: tiles on or below the diagonal only)
-//   ps[i][J] = sum_{j in tile J} GS_ij mx_ij r_j          (S_i = sum_J ps[i][J] = rowpart_i + colpart_i of the
+//   Gs[i][j] = G_adjn_ij + G_adjn_ji
+//   G2[i][j] = Gs_ij r_i r_j + sum_k (GPu_ik Tu_jk + Tu_ik GPu_jk)      (pair: tiles on or below the diagonal only)
+//   ps[i][J] = sum_{j in tile J} Gs_ij mx_ij r_j          (S_i = sum_J ps[i][J] = rowpart_i + colpart_i of the
 //                                                          normalisation backward, mx = M + I)
-//   vpart[block] = { sum P1 o Xc over the block's elements (both orientations when pair), sum ie_value(adj_norm) }
-template <int KMAX>
-__global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, int tile_row0, TailFactors F,
+//   WANT_V: vpart[block] = { sum P1 o Xc over the block's elements (both orientations when pair), sum ie_value(adj_norm) }
+//           -- the values of the c1 / c6 terms, only when the caller asked for the loss terms
+template <bool WANT_V>
+__global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair, int tile_row0, RkRounds F, RkRounds FU,
                                                      const float* __restrict__ M, const float* __restrict__ P1,
                                                      const float* __restrict__ r, const float* __restrict__ mean,
                                                      const float* __restrict__ delta, const float* __restrict__ cvec,
-                                                     float a1, float a2, float kie6, float* __restrict__ GS,
+                                                     float a1, float a2, float kie6, float* __restrict__ G2,
                                                      float* __restrict__ ps, double* __restrict__ vpart) {
-  // 32 KB of panels (KMAX = 32); the transposed P1 tile T [64][65] reuses panels 0..2 once the rank-k rounds are done,
-  // the column sums use panel 3: 33 KB per block, four blocks per CU
-  __shared__ float P[4][KMAX][FT];
-  static_assert(sizeof(float) * 3 * KMAX * FT >= sizeof(float) * FT * (FT + 1), "T fits in three panels");
-  float (*T)[FT + 1] = reinterpret_cast<float (*)[FT + 1]>(&P[0][0][0]);
+  // T: hand-over of the rank-k sums, then the transposed P1 tile, then the column sums: 16.6 KB per block
+  __shared__ float T[FT][FT + 1];
   __shared__ double shd[16];
   const int nt = gridDim.x;
   const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
   const size_t vslot = (size_t)blockIdx.y * nt + blockIdx.x, vtot = (size_t)gridDim.y * nt;   // v1 partials, then v6 partials
   if (pair && tj > ti) {
-    if (threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; }
+    if (WANT_V && threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; }
     return;
   }
   const int bi = ti * FT, bj = tj * FT;
   const bool offdiag = ti != tj;
   const bool mirror = pair && offdiag;
   const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;
-  float acc[4][4];
+  float acc[4][4], accu[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  ft_sym_rankk<KMAX>(F, bi, bj, n, P, T, r0, c0, acc);
-  __syncthreads();                         // every thread has its patch: T may be overwritten
+    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.f; accu[a][b] = 0.f; }
+  rk_sym(F, ti, tj, T, r0, c0, acc);
+  if (FU.count > 0) rk_sym(FU, ti, tj, T, r0, c0, accu);
+  __syncthreads();                         // every thread has its patches: T may be overwritten
   // mirrored P1 tile (J, I) through LDS: T[j local][i local]
   if (P1) {
 #pragma unroll
@@ -424,32 +465,37 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int j = j0 + b;
-      float g = 0.f;
+      float g2 = 0.f;
       if (rowin && j < n) {
         const float mx = ms[b] + (i == j ? 1.f : 0.f);
-        // every term below is bitwise symmetric under i <-> j (see ft_sym_rankk): adj_norm_ij as mx (r_i r_j)
-        const float an = mx * (ri * rjs[b]);
+        // every term below is bitwise symmetric under i <-> j (see rk_sym): adj_norm_ij as mx (r_i r_j)
+        const float rr = ri * rjs[b];
+        const float an = mx * rr;
         const float xij = an - mjs[b], xji = an - mi;        // Xc_ij, Xc_ji
         const float pt = P1 ? T[c0 + b][r0 + a] : 0.f;       // P1_ji
         float val, g6;
         ie_term(an, kie6, val, g6);
-        g = acc[a][b] + 2.f * g6 + a1 * (pd[b] + pt) + a2 * (fmaf(di * di, xij, cjs[b]) + fmaf(djs[b] * djs[b], xji, ci));
+        const float g = acc[a][b] + 2.f * g6 + a1 * (pd[b] + pt) + a2 * (fmaf(di * di, xij, cjs[b]) + fmaf(djs[b] * djs[b], xji, ci));
         const float w = g * mx;
         rowacc += w * rjs[b];
         cs[b] += w * ri;
-        v1 += (double)pd[b] * (double)xij;
-        if (mirror) v1 += (double)pt * (double)xji;
-        v6 += mirror ? 2.0 * (double)val : (double)val;
+        if (WANT_V) {
+          v1 += (double)pd[b] * (double)xij;
+          if (mirror) v1 += (double)pt * (double)xji;
+          v6 += mirror ? 2.0 * (double)val : (double)val;
+        }
+        g2 = fmaf(g, rr, accu[a][b]);
       }
-      gs[b] = g;
+      gs[b] = g2;
     }
-    if (rowin) *reinterpret_cast<float4*>(GS + o) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    if (rowin) *reinterpret_cast<float4*>(G2 + o) = make_float4(gs[0], gs[1], gs[2], gs[3]);
 #pragma unroll
     for (int o2 = 1; o2 < 16; o2 <<= 1) rowacc += __shfl_xor(rowacc, o2);
     if ((threadIdx.x & 15) == 0 && i < n) ps[(size_t)i * nt + tj] = rowacc;
   }
   if (mirror) {      // column sums of the tile = the mirrored tile's contribution to the rows of tile J
-    float (*CS)[FT] = P[3];
+    float (*CS)[FT] = reinterpret_cast<float (*)[FT]>(&T[0][0]);
+    __syncthreads();                       // (every thread has read its part of the transposed P1 tile)
 #pragma unroll
     for (int b = 0; b < 4; ++b) CS[threadIdx.x >> 4][c0 + b] = cs[b];
     __syncthreads();
@@ -461,9 +507,11 @@ __global__ __launch_bounds__(256) void k_tail_reduce(int n, int ld, int pair, in
       if (j < n) ps[(size_t)j * nt + ti] = s;
     }
   }
-  v1 = block_sum_d(v1, shd);
-  v6 = block_sum_d(v6, shd);
-  if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; }
+  if (WANT_V) {
+    v1 = block_sum_d(v1, shd);
+    v6 = block_sum_d(v6, shd);
+    if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; }
+  }
 }
 
 // gd_i = -1/2 d_i^-3/2 sum_J ps[i][J]      (k_normbwd_gd with rowpart + colpart already merged per tile)
@@ -480,20 +528,20 @@ __global__ __launch_bounds__(256) void k_tail_gd(int n, int row0, int row1, int 
   }
 }
 
-// Pass 2 of the tail: g_ij = GS_ij r_i r_j + gd_i + gd_j + sum_k (GPu_ik Tu_jk + Tu_ik GPu_jk) + cn M_ij, Adam, clamp
-// (:274-283).  pair: both halves of the state are written from the lower pair; otherwise only rows of the row block.
+// Last pass of the tail: g_ij = G2_ij + gd_i + gd_j + cn M_ij, Adam, clamp (:274-283) -- elementwise.
+// pair: both halves of the state are written from the lower pair; otherwise only rows of the row block.
 // ps_out / pq_out: per-tile row sums of the new M (and of its squares) for the next normalisation (k_prep_fin).
-template <int KMAX>
-__global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int tile_row0, TailFactors F,
-                                                   const float* __restrict__ GS, const float* __restrict__ r,
+__global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int tile_row0,
+                                                   const float* __restrict__ G2,
                                                    const float* __restrict__ gd, float* __restrict__ M,
                                                    float* __restrict__ am, float* __restrict__ av,
                                                    const float* __restrict__ cn_ptr, float omb1, float b2, float omb2,
                                                    float step_size, float sqrt_bc2, float eps, float* __restrict__ gsym_dbg,
                                                    int do_clamp, float* __restrict__ ps_out, double* __restrict__ pq_out,
                                                    int mirror_moments) {
-  __shared__ float P[4][KMAX][FT];
   __shared__ float T[FT][FT + 1];
+  __shared__ float CS[16][FT];
+  __shared__ double CQ[16][FT];
   const int nt = gridDim.x;
   const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
   if (pair && tj > ti) return;
@@ -501,15 +549,8 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
   const bool mirror = pair && ti != tj;
   const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;
   const float cn = cn_ptr[0];
-  float acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  ft_sym_rankk<KMAX>(F, bi, bj, n, P, T, r0, c0, acc);
-  const float4 rj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(r + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 gj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(gd + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float rjs[4] = {rj4.x, rj4.y, rj4.z, rj4.w}, gdj[4] = {gj4.x, gj4.y, gj4.z, gj4.w};
+  const float gdj[4] = {gj4.x, gj4.y, gj4.z, gj4.w};
   float pn_[4][4], m_[4][4], v_[4][4], g_[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -521,9 +562,9 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
       p4 = *reinterpret_cast<const float4*>(M + o);
       m4 = *reinterpret_cast<const float4*>(am + o);
       v4 = *reinterpret_cast<const float4*>(av + o);
-      s4 = *reinterpret_cast<const float4*>(GS + o);
+      s4 = *reinterpret_cast<const float4*>(G2 + o);
     }
-    const float ri = rowin ? r[i] : 0.f, gdi = rowin ? gd[i] : 0.f;
+    const float gdi = rowin ? gd[i] : 0.f;
     float ps[4] = {p4.x, p4.y, p4.z, p4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
     const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
     float gsv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -532,7 +573,7 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
       const int j = j0 + b;
       if (rowin && j < n && i != j) {
         const float p = ps[b];
-        const float g = (fmaf(ss[b], ri * rjs[b], gdi + gdj[b]) + acc[a][b]) + cn * p;     // symmetric under i <-> j
+        const float g = (ss[b] + (gdi + gdj[b])) + cn * p;     // symmetric under i <-> j
         float m = ms[b], v = vs[b];
         m = m + omb1 * (g - m);            // exp_avg.lerp_(grad, 1 - beta1)
         v = v * b2 + omb2 * g * g;         // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
@@ -580,9 +621,6 @@ __global__ __launch_bounds__(256) void k_tail_adam(int n, int ld, int pair, int 
     }
   }
   if (!mirror) return;
-  float (*CS)[FT] = P[0];                                           // [16][64] floats, panels are dead by now
-  double (*CQ)[FT] = reinterpret_cast<double (*)[FT]>(&P[1][0][0]); // [16][64] doubles = 8 KB <= one panel
-  __syncthreads();
   if (ps_out) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) { CS[threadIdx.x >> 4][c0 + b] = cs[b]; CQ[threadIdx.x >> 4][c0 + b] = cq[b]; }
@@ -685,67 +723,63 @@ int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float*
   return nb * js;
 }
 
-// terms packed greedily, in order, into rounds of at most kmax concatenated columns
-static TailFactors make_factors(int count, const float* const* L, const int* ldl, const float* const* R, const int* ldr,
-                                const int* K, const float* alpha, int kmax) {
-  TailFactors F;
-  F.count = count; F.nrounds = 0;
-  for (int f = 0; f < 4; ++f) {
-    F.L[f] = F.R[f] = nullptr; F.ldl[f] = F.ldr[f] = F.K[f] = F.koff[f] = F.round[f] = 0; F.alpha[f] = 0.f; F.kround[f] = 0;
-  }
-  int used = 0;
-  for (int f = 0; f < count; ++f) {
-    if (f == 0 || used + K[f] > kmax) { ++F.nrounds; used = 0; }
-    F.L[f] = L[f]; F.R[f] = R[f]; F.ldl[f] = ldl[f]; F.ldr[f] = ldr[f]; F.K[f] = K[f]; F.alpha[f] = alpha[f];
-    F.koff[f] = used; F.round[f] = F.nrounds - 1;
-    used += K[f];
-    F.kround[F.nrounds - 1] = used;
-  }
-  return F;
-}
 int fl_tail_tiles(int n) { return (n + FT - 1) / FT; }
 bool fl_tail_supported(int n, int ld, int kmax) { return kmax > 0 && kmax <= 64 && (ld % 4) == 0 && n >= 256; }
+// scratch of the packed rank-k panels of one step: up to 6 rounds x 2 sides x (tiles x 8 KB planes + tiles exponents)
+size_t fl_tail_pack_bytes(int n) {
+  const size_t nt = fl_tail_tiles(n);
+  return (size_t)2 * 3 * RK_MAXR / 2 * (nt * RK_PANEL + ((nt * sizeof(int) + 255) & ~(size_t)255));
+}
 
-// vpart: nblk v1 partials followed by nblk v6 partials, nblk = nt * (tile rows) = the return value
+// vpart (nullable): nblk v1 partials followed by nblk v6 partials, nblk = nt * (tile rows) = the return value.  The rank-k
+// terms {L, R, K, alpha} (K <= 64 each, at most two) feed Gs; {Lu, Ru, Ku} (the modified_adj chain) is added to G2 unscaled.
+// rkbuf: fl_tail_pack_bytes(n) of scratch for the packed panels.
 int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
-                   const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha, const float* M,
-                   const float* P1, const float* r, const float* mean, const float* delta, const float* cvec, float a1,
-                   float a2, float kie6, float* GS, float* ps, double* vpart) {
+                   const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha,
+                   const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
+                   const float* r, const float* mean, const float* delta, const float* cvec,
+                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf) {
   const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
   if (t1 <= t0) return 0;
-  int ktot = 0, kbig = 1;
-  for (int f = 0; f < nfac; ++f) { ktot += K[f]; kbig = K[f] > kbig ? K[f] : kbig; }
-  (void)ktot;
-  const int kmax = kbig <= 32 ? 32 : 64;       // LDS panel depth of the kernel instance: 32 KB of panels (3 blocks per CU) when it fits
-  const TailFactors F = make_factors(nfac, L, ldl, R, ldr, K, alpha, kmax);
+  RkPackJobs J{};
+  RkRounds F{}, FU{};
+  const size_t slot = (size_t)nt * RK_PANEL, eslot = ((size_t)nt * sizeof(int) + 255) & ~(size_t)255;
+  char* cur = rkbuf;
+  auto add = [&](RkRounds& G, const float* Lm, int ll, const float* Rm, int lr_, int Kf, float al) {
+    for (int c0 = 0; c0 < Kf; c0 += RK_KMAX) {
+      const int kw = Kf - c0 < RK_KMAX ? Kf - c0 : RK_KMAX, g = G.count++;
+      for (int side = 0; side < 2; ++side) {
+        const int q = J.count++;
+        J.src[q] = side ? Rm : Lm; J.ld[q] = side ? lr_ : ll; J.c0[q] = c0; J.kw[q] = kw; J.alpha[q] = side ? 1.f : al;
+        J.out[q] = cur; cur += slot;
+        J.eout[q] = reinterpret_cast<int*>(cur); cur += eslot;
+        (side ? G.R[g] : G.L[g]) = J.out[q];
+        (side ? G.eR[g] : G.eL[g]) = J.eout[q];
+      }
+      G.ksteps[g] = (kw + 15) / 16;
+    }
+  };
+  for (int f = 0; f < nfac; ++f) add(F, L[f], ldl[f], R[f], ldr[f], K[f], alpha[f]);
+  if (Ku > 0) add(FU, Lu, ldlu, Ru, ldru, Ku, 1.f);
+  LAUNCH(k_pack_rk, dim3(nt, J.count), dim3(256), st, n, J);
   dim3 grid(nt, t1 - t0);
-  if (kmax <= 32)
-    LAUNCH(k_tail_reduce<32>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, M, P1, r, mean, delta, cvec, a1, a2, kie6, GS, ps, vpart);
+  if (vpart)
+    LAUNCH(k_tail_reduce<true>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, M, P1, r, mean, delta, cvec, a1, a2, kie6, G2, ps, vpart);
   else
-    LAUNCH(k_tail_reduce<64>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, M, P1, r, mean, delta, cvec, a1, a2, kie6, GS, ps, vpart);
+    LAUNCH(k_tail_reduce<false>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, M, P1, r, mean, delta, cvec, a1, a2, kie6, G2, ps, nullptr);
   return nt * (t1 - t0);
 }
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd) {
   if (row1 <= row0) return;
   LAUNCH(k_tail_gd, dim3((row1 - row0 + 3) / 4), dim3(256), st, n, row0, row1, fl_tail_tiles(n), ps, d, gd);
 }
-void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* GPu, int ldp, const float* Tu,
-                  int ldt, int K, const float* GS, const float* r, const float* gd, float* M, float* am, float* av,
-                  const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
-                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments) {
+void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* G2, const float* gd, float* M,
+                  float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
+                  float eps, float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments) {
   const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
   if (t1 <= t0) return;
-  const float* Ls[1] = {GPu}; const float* Rs[1] = {Tu};
-  const int ll[1] = {ldp}, lr_[1] = {ldt}, Ks[1] = {K};
-  const float al[1] = {1.f};
-  const TailFactors F = make_factors(1, Ls, ll, Rs, lr_, Ks, al, K <= 32 ? 32 : 64);
-  dim3 grid(nt, t1 - t0);
-  if (K <= 32)
-    LAUNCH(k_tail_adam<32>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, GS, r, gd, M, am, av, cn, omb1, b2, omb2, step_size,
-           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out, mirror_moments);
-  else
-    LAUNCH(k_tail_adam<64>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, GS, r, gd, M, am, av, cn, omb1, b2, omb2, step_size,
-           sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out, mirror_moments);
+  LAUNCH(k_tail_adam, dim3(nt, t1 - t0), dim3(256), st, n, ld, pair ? 1 : 0, t0, G2, gd, M, am, av, cn, omb1, b2, omb2, step_size,
+         sqrt_bc2, eps, gsym_dbg, do_clamp, ps_out, pq_out, mirror_moments);
 }
 
 }  // namespace mcgra

@@ -136,13 +136,14 @@ int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float*
 int fl_tail_tiles(int n);
 bool fl_tail_supported(int n, int ld, int kmax);
 int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
-                   const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha, const float* M,
-                   const float* P1, const float* r, const float* mean, const float* delta, const float* cvec, float a1,
-                   float a2, float kie6, float* GS, float* ps, double* vpart);
+                   const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha,
+                   const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
+                   const float* r, const float* mean, const float* delta, const float* cvec,
+                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf);
+size_t fl_tail_pack_bytes(int n);
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd);
-void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* GPu, int ldp, const float* Tu,
-                  int ldt, int K, const float* GS, const float* r, const float* gd, float* M, float* am, float* av,
-                  const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2, float eps,
-                  float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments = 1);
+void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* G2, const float* gd, float* M,
+                  float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
+                  float eps, float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments);
 
 }  // namespace mcgra
