@@ -238,7 +238,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn);
   { const char* e = getenv("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
-  { const char* e = getenv("MCGRA_TEST_MUTATE"); h->test_mutate = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }
+  { const char* e = getenv("MCGRA_TEST_MUTATE"); h->test_mutate = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'r' ? 2 : 0)); }
   if (h->keep_gsym) { A_(GSYM, nn); }
   if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
     A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn);

@@ -442,9 +442,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // ---- tail: everything above ran beside the forked product.  A row-block rank holds the column block
       //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
       CHK(join());
-      // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result, =c2 drops
-      // the low-rank term of linear_HSIC(adj_norm, modified_adj1) from the gradient -- a parity test that stays green under
-      // either is blind to split2_m16_kernel / the rank-k rounds of k_tail_reduce
+      // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result, =rk drops
+      // the rank-k terms of the tail (both GCN chains' backward and the low-rank term of c2) from the gradient -- a parity
+      // test that stays green under either is blind to split2_m16_kernel / the fp16-split rank-k rounds of k_tail_reduce
       if (h->test_mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
       if (h->sharded && use1) {
         for (int s = 0; s < h->world; ++s) {
@@ -469,8 +469,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         const float* Ls[2] = {h->GPv, h->lrL};
         const float* Rs[2] = {h->Tv, h->lrR};
         const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
-        const float al[2] = {1.f, h->test_mutate == 2 ? 0.f : a2};
-        h->fs_nblk = fl_tail_reduce(st, n, ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, hs, h->M,
+        const bool no_rk = h->test_mutate == 2;
+        const float al[2] = {no_rk ? 0.f : 1.f, no_rk ? 0.f : a2};
+        h->fs_nblk = fl_tail_reduce(st, n, ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M,
                                     use1 ? h->KX : nullptr, h->r, h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
                                     a1, a2, (float)(k6 / n2), h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf);
         if (h->sharded) MCGRA_HIP(hipMemsetAsync(h->SC + 4, 0, 3 * sizeof(double), st));

@@ -40,7 +40,7 @@ struct mcgra_attack {
   bool fwd_cached = false, fwd_reuse = true;
   bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
   bool prep_valid = false;         // G_A holds the per-tile row sums of the current M (left by the fused tail kernel)
-  int test_mutate = 0;             // MCGRA_TEST_MUTATE (read at create; TEST-ONLY, see attack_fused.hip): 1 wipes P1, 2 drops the low-rank c2 terms
+  int test_mutate = 0;             // MCGRA_TEST_MUTATE (read at create; TEST-ONLY, see attack_fused.hip): 1 wipes P1, 2 drops the tail's rank-k terms
   bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
   float* ADJN_next = 0;
   bool graph_set = false, model_set = false;

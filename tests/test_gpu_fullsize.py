@@ -72,15 +72,19 @@ def _reference_run_errors(ctx, z, z64, name, steps=None, check=True):
         gmax = float(z[f"{name}_g_absmax"][t])
         err_ref = np.abs(g - G[t]).max() / gmax
         err_true = ref_true = None
+        ref_flips = 0.0
         if t == 0 and f"{name}_g64" in z64.files:
             g64 = z64[f"{name}_g64"]
             err_true = np.abs(g - g64).max() / gmax
             ref_true = np.abs(G[t] - g64).max() / gmax
+            # entries whose gradient has another sign in the reference's fp32 evaluation than in exact arithmetic: Adam's
+            # first step is lr * sign(g), so the reference itself moves these the "wrong" way
+            ref_flips = float((np.sign(G[t]) != np.sign(g64)).mean())
         errs.append((err_ref, err_true, ref_true))
         if not check:
             continue
         if err_true is not None:
-            assert abs(float(z64[f"{name}_g64_absmax"]) - gmax) <= 2e-3 * gmax
+            assert abs(float(z64[f"{name}_g64_absmax"]) - gmax) <= (ref_true + 2e-3) * gmax
             assert err_true <= 3e-4, (name, t, err_true)
             assert err_ref <= ref_true + 3e-4, (name, t, err_ref, ref_true)
         else:
@@ -88,13 +92,13 @@ def _reference_run_errors(ctx, z, z64, name, steps=None, check=True):
         # whole-matrix sums (fp64): the packed gradient is half of the mirrored matrix
         gsum = float(Gs.double().sum()) * 0.5
         ref_l1 = float(np.sqrt(z[f"{name}_g_sqsum"][t]) * np.sqrt(n * (n - 1) / 2))     # >= sum |g|
-        assert abs(gsum - float(z[f"{name}_g_sum"][t])) <= 2e-3 * ref_l1, (name, t, gsum, float(z[f"{name}_g_sum"][t]))
-        assert abs(float(Gs.abs().max()) - gmax) <= 2e-3 * gmax
+        assert abs(gsum - float(z[f"{name}_g_sum"][t])) <= ((ref_true or 0.0) + 2e-3) * ref_l1, (name, t, gsum, float(z[f"{name}_g_sum"][t]))
+        assert abs(float(Gs.abs().max()) - gmax) <= ((ref_true or 0.0) + 2e-3) * gmax
         M = eng.buffer("M")
         a = M[ti, tj].cpu().numpy()
         # (the reference's hook sees adj_changes after optimizer.step(), before the clamp of :283)
         moved = np.abs(a - np.clip(A[t], 0, 1)) > 0.05 * lr
-        assert moved.mean() <= (0.002 if t == 0 else 0.01), (name, t, moved.mean())
+        assert moved.mean() <= (ref_flips + 0.002 if t == 0 else 0.01), (name, t, moved.mean(), ref_flips)
         asum = float(M.double().sum()) * 0.5
         ref_sum = float(z[f"{name}_a_clip_sum"][t])
         assert abs(asum - ref_sum) <= 1e-4 * ref_sum, (name, t, asum, ref_sum)
@@ -112,15 +116,22 @@ def test_bench_workload_matches_reference_at_10k(ctx):
     construction (a 50 M-entry adj_changes per step cannot be stored, so the later steps of `run` free-run: Adam moves
     an entry whose gradient sits at the fp32 noise level by +-lr on its sign alone; such entries are counted).
     What this pins at N = 10 000 against topology_attack.py:161-324: the forward chains, the fp16-split product
-    (split2_m16_kernel) through c1, the low-rank factors and rank-k rounds of k_tail_reduce through c2, the
-    small-operand terms, the normalisation backward, Adam, the post-loop ensemble and the AUC.
-    test_mutations_turn_the_10k_reference_test_red checks that it does: with P1 wiped or the low-rank terms dropped the
-    same comparison fails by orders of magnitude.
+    (split2_m16_kernel) through c1, the fp16-split rank-k rounds of k_tail_reduce (backward of both GCN chains, i.e.
+    the CE loss, c9, c10 and c2's path through the embedding), the small-operand terms, the normalisation backward, Adam,
+    the post-loop ensemble and the AUC.  test_mutations_turn_the_10k_reference_test_red checks that it does: with P1
+    wiped or the rank-k terms dropped the same comparison fails by orders of magnitude.  (Not visible at this size, by the
+    loss's own weights: the Info_entropy terms c6 / c7 -- k_decode_fly's gradient -- at 1e-5 ... 1e-6 of the gradient, and
+    the low-rank term of c2 that acts on adj_norm directly, 4e-5; these are pinned against the oracle with the other terms
+    switched off, tests/test_gpu_parity.py.)
 
-    Bars.  AUC: north_star's 1e-4.  Gradient: the engine is held to 3e-4 of the EXACT gradient (float64 evaluation of
-    the same algorithm, tests/golden/bench10k_hsic_fp64.npz, make_truth64.py) -- the bar the small goldens hold against
-    the reference -- and to the reference within the reference's own distance from the exact gradient plus 3e-4;
-    free-running steps, which have no float64 truth, to 2e-3."""
+    Bars.  AUC: north_star's 1e-4.  Gradient: at this size and state the reference's OWN fp32 gradient is 1.2e-2 / 1.2e-2 /
+    3.5e-3 of the gradient's largest magnitude away from a float64 evaluation of the same algorithm
+    (tests/golden/bench10k_hsic_fp64.npz, make_truth64.py: its Gram-then-centre evaluation of linear_HSIC on the
+    all-positive feature_adj cancels three digits) and has the other SIGN than the exact gradient on 0.2 % of the
+    entries.  So the engine is held to 3e-4 of the EXACT gradient (measured: 4e-6 ... 4e-5) -- the bar the small goldens
+    hold against the reference -- to the reference within the reference's own distance from the exact gradient plus
+    3e-4, and its first Adam step to the reference's within the reference's own sign flips plus 0.2 %; free-running
+    steps, which have no float64 truth, to 2e-3."""
     pkg, torch, bench, dev = ctx
     z = np.load(os.path.join(ROOT, "tests", "golden", "bench10k_hsic.npz"))
     z64 = np.load(os.path.join(ROOT, "tests", "golden", "bench10k_hsic_fp64.npz"))
@@ -144,12 +155,12 @@ def test_bench_workload_matches_reference_at_10k(ctx):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("mutation,name", [("p1", "run"), ("p1", "one0"), ("c2", "run"), ("c2", "one0")])
+@pytest.mark.parametrize("mutation,name", [("p1", "run"), ("p1", "one0"), ("p1", "one1"), ("rk", "run"), ("rk", "one1")])
 def test_mutations_turn_the_10k_reference_test_red(ctx, monkeypatch, mutation, name):
     """Mutation guard of the test above (with the old dense start it would have passed with P1 = 0).
-    MCGRA_TEST_MUTATE=p1 wipes the result of split2_m16_kernel before the tail reads it, =c2 drops the low-rank terms of
-    linear_HSIC(adj_norm, modified_adj1) from the gradient: the first-step comparison against the reference must then
-    fail its 3e-4 bar by a wide margin -- i.e. the kernels are visible to the fixture at this size."""
+    MCGRA_TEST_MUTATE=p1 wipes the result of split2_m16_kernel before the tail reads it, =rk drops the rank-k terms of
+    k_tail_reduce (fp16-split products) from the gradient: the first-step comparison against the exact gradient must
+    then fail its 3e-4 bar by a wide margin -- i.e. the kernels are visible to the fixture at this size."""
     pkg, torch, bench, dev = ctx
     z = np.load(os.path.join(ROOT, "tests", "golden", "bench10k_hsic.npz"))
     z64 = np.load(os.path.join(ROOT, "tests", "golden", "bench10k_hsic_fp64.npz"))
@@ -158,7 +169,7 @@ def test_mutations_turn_the_10k_reference_test_red(ctx, monkeypatch, mutation, n
     monkeypatch.delenv("MCGRA_TEST_MUTATE")
     err_ref, err_true, _ = errs[0]
     assert eng.fused_steps() == 1
-    assert err_true > 30 * 3e-4 and err_ref > 30 * 3e-4, (mutation, name, err_ref, err_true)
+    assert err_true > 30 * 3e-4, (mutation, name, err_ref, err_true)
     del eng
     torch.cuda.empty_cache()
 
