@@ -405,6 +405,7 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
 // step, one barrier per 32 k.  On a power-limited chip the 16 x 16 shape holds a higher clock than 32 x 32
 // (MI355X_MICROARCH.md: 1.12-1.15 x the FLOP/s at equal cycles on random operands).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
                                                             float* __restrict__ C, int n, int ldc, int nks,
                                                             int tiles_m, int tiles_n, int panel_off, int tile_base,
@@ -461,8 +462,11 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
   const int a_off = k_off + (wm * 128 + l15) * 16;                 // + i * 256 (row tile of 16) + plane * PLANE
   const int b_off = 2 * OPB + k_off + (wn * 64 + l15) * 16;        // + j * 256 + plane * PLANE
   auto frag = [&](const char* s, int off) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(s + off)); };
-  auto multiply = [&](int stage, auto&& after_first_reads) {
+  auto multiply = [&](int stage, auto&& before_reads) {
     const char* s = smem + stage * STAGE;
+    // MODE 2: the copies of the next tile go out first (with them between the head reads and the first MFMAs the compiler
+    // waits for all ten reads, lgkmcnt(0): it does not count past an LDS-DMA; with the reads last it waits for six)
+    if constexpr (MODE == 2) before_reads();
     f16x8 b0[4], b1[4];
     f16x8 a1 = frag(s, a_off + PLANE);
 #pragma unroll
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     f16x8 a0 = frag(s, a_off);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1[j] = frag(s, b_off + j * 256 + PLANE);
-    after_first_reads();
+    if constexpr (MODE != 2) before_reads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f16x8 n0 = a0, n1 = a1;
@@ -492,9 +496,22 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
   if (nk > 0) {
     stage_tile(0, 0);
     __syncthreads();                      // (waits for the copies of this wave, then for everybody's)
-    for (int kc = 0; kc < nk; ++kc) {
-      multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
+    if constexpr (MODE == 0) {
+      for (int kc = 0; kc < nk; ++kc) {
+        multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
+        __syncthreads();
+      }
+    } else {
+    int kc = 0;
+    // steady state without a condition around the staging: the head reads, the copies and the first MFMAs then sit in
+    // ONE basic block and the compiler waits for the fragments it needs (counted lgkmcnt) instead of for all ten reads at
+    // a block entry
+    for (; kc + 1 < nk; ++kc) {
+      multiply(kc & 1, [&]() { stage_tile(kc + 1, (kc + 1) & 1); });
       __syncthreads();
+    }
+    multiply(kc & 1, [&]() {});
+    __syncthreads();
     }
   }
   const float inv = ldexpf(1.f, amax_exp(amax[0]) + amax_exp(amax[1]) - 30);      // undo the operand scales: exact
@@ -649,11 +666,23 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2 && m16) {
       constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;
-      hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(split2_m16_kernel, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc,
-                         nkc / 2, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
-      return hipSuccess;
+      // MCGRA_SPLIT_LOOP=2: the K loop with its last step peeled and the copies of the next tile issued ahead of the head
+      // reads (one basic block: counted lgkmcnt waits).  Measured on one box, three alternating runs each: the product ALONE
+      // 4.48-4.51 ms against 4.58-4.60 ms of the default, but 5.14-5.21 against 4.99-5.04 ms beside the step's other
+      // kernels (153-154 against 157-158 steps/s): the default loop stays.
+      static const int mode = [] { const char* e = getenv("MCGRA_SPLIT_LOOP"); return e && e[0] == '2' ? 2 : 0; }();
+      constexpr int smem_ = smem;
+#define MCGRA_LAUNCH_M16(MODE_)                                                                                              \
+      {                                                                                                                       \
+        hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel<MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
+        if (e != hipSuccess) return e;                                                                                        \
+        hipLaunchKernelGGL(split2_m16_kernel<MODE_>, dim3(grid), dim3(512), smem_, st, (const char*)Apack, (const char*)Bpack, C, n, \
+                           ldc, nkc / 2, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);                     \
+        return hipSuccess;                                                                                                    \
+      }
+      if (mode == 0) MCGRA_LAUNCH_M16(0)
+      MCGRA_LAUNCH_M16(2)
+#undef MCGRA_LAUNCH_M16
     }
     if (planes == 2)
       return launch_split<2, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
