@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it
 writes under tests/golden/ are data (inputs + the reference's outputs) and are
-what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cw|cora|bench10k|citeseer]
+what travels to the GPU box.  Usage:  python tests/golden/make_golden.py [--only small|ops|cw|cora|cora_sparse|mid|bench10k|citeseer]
 
 Environment shims applied before importing the reference (none of them is on
 the computed path):
@@ -389,7 +389,7 @@ def gen_ops(tmp):
     print("ops.npz", len(out), "arrays")
 
 
-def gen_cora(tmp):
+def gen_cora(tmp, only=None):
     """Cora through the reference's own data path and victim training
     (main.py:148-190), README headline MSELoss config + an HSIC config."""
     os.chdir(tmp)
@@ -435,7 +435,12 @@ def gen_cora(tmp):
         # HSIC: at adj_changes == 0 every c1/c2 gradient is >= 0 (PSD Gram), the origin is a fixed point in exact
         # arithmetic and the reference leaves it on rounding noise only; start from a seeded random adj_changes.
         ("cora_hsic", "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 10 ** -2, 8, (123, 0.05)),
+        # the same from the bench's start rule (adj_changes_0 = U[0, 1) / n, lr = 1 / (50 n)), where the N x N terms carry
+        # the gradient (from the dense start above they are 5e-13 of it: VERDICT round 2, item 1c)
+        ("cora_hsic_sparse", "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), 1.0, 1.0 / (50 * 2708), 4, (123, 1.0 / 2708)),
     ]
+    if only is not None:
+        runs = [r for r in runs if r[0] in only]
     for name, measure, wp, wsup, lr, epochs, init in runs:
         a0 = init_adj_changes(adj.shape[0], *init) if init else None
         res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs,
@@ -458,6 +463,44 @@ def gen_cora(tmp):
                    **common)
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
         print(name, "auc", res["auc"])
+
+
+def gen_mid(tmp):
+    """A reference run at a size where the default path is the fused low-rank step with the fp16-split product (n >= 1024)
+    and from a start where the N x N terms carry the gradient: n = 1200, the bench's start
+    rule (adj_changes_0 = U[0, 1) / n, lr = 1 / (50 n)).  Per-step gradient / adj_changes on 8k sampled packed positions,
+    fp64 sums, a sample of the final ensemble, AUC; the graph travels as bits."""
+    os.chdir(tmp)
+    os.makedirs("saved_data", exist_ok=True)
+    name, n, f, c, hid, nl = "s1200_hsic_sparse", 1200, 64, 6, 16, 2
+    wp = (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)
+    adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000, p_edge=0.01)
+    lab = labels.numpy()
+    np.save("saved_data/cora.npy", (lab[:, None] == lab[None, :]).astype(np.float32))
+    random.seed(7)
+    idx_attack = np.array(random.sample(range(n), n))
+    scale, lr, epochs = 1.0 / n, 1.0 / (50.0 * n), 3
+    a0 = init_adj_changes(n, 123, scale)
+    res = run_reference_attack(adj, feats, labels, victim, idx_attack, "HSIC", wp, 1.0, lr, epochs, "cora",
+                               (True, True, True), 1e12, a0=a0)
+    npk = n * (n - 1) // 2
+    rng = np.random.RandomState(99)
+    pk = np.unique(np.concatenate([np.arange(0, npk, max(1, npk // 4096)), rng.randint(0, npk, 4096)])).astype(np.int64)
+    samp = rng.randint(0, n, size=(8192, 2))
+    sa = np.stack(res["steps_a"]); sg = np.stack(res["steps_g"])
+    fx = feats.numpy()
+    assert set(np.unique(fx)) <= {0.0, 1.0}
+    ei = np.argwhere(np.triu(adj.numpy(), 1) > 0).astype(np.int32)
+    out = dict(features_bits=np.packbits(fx.astype(np.uint8), axis=1), nfeat=fx.shape[1], adj_edges=ei, labels=lab,
+               idx_attack=idx_attack, measure="HSIC", weight_param=np.array(wp, dtype=np.float64), weight_sup=1.0, lr=lr,
+               epochs=epochs, num_edges=1e12, nlayer=nl, a0_seed=123, a0_scale=scale, packed_pos=pk, sample_pos=samp,
+               step_a=sa[:, pk], step_g=sg[:, pk], step_g_absmax=np.abs(sg).max(1),
+               step_g_sum=sg.astype(np.float64).sum(1), step_g_sqsum=(sg.astype(np.float64) ** 2).sum(1),
+               step_a_clip_sum=np.clip(sa, 0, 1).astype(np.float64).sum(1),
+               final_sample=res["final"][samp[:, 0], samp[:, 1]], final_sum=float(res["final"].astype(np.float64).sum()),
+               H_A2=res["H_A2"], Y_A=res["Y_A"], auc=res["auc"], **weights_of(victim))
+    np.savez_compressed(os.path.join(OUT, f"mid_{name}.npz"), **out)
+    print(name, "auc", res["auc"], "gmax per step", np.abs(sg).max(1), flush=True)
 
 
 def gen_citeseer_gat(tmp, train_iters=6):
@@ -602,6 +645,10 @@ if __name__ == "__main__":
             gen_cw(tmp)
         if a.only in ("all", "cora"):
             gen_cora(tmp)
+        if a.only in ("cora_sparse",):
+            gen_cora(tmp, only=("cora_hsic_sparse",))
+        if a.only in ("all", "mid"):
+            gen_mid(tmp)
         if a.only in ("citeseer",):         # ~20 min on 8 cores: not part of "all"
             gen_citeseer_gat(tmp)
         if a.only in ("bench10k",):         # ~25 min and ~20 GB on 8 cores: not part of "all"

@@ -5,6 +5,7 @@ own float32 run is from the exact gradient at N = 10 000 (its Gram evaluation of
 O(1) Gram entries in fp32), which bounds what "equal to the reference" can mean per entry at that size.
 
     python tests/golden/make_truth64.py          (~10 min and ~30 GB per start on 8 cores)
+    python tests/golden/make_truth64.py mid      (the n = 1200 fixture, seconds)
 
 Writes tests/golden/bench10k_hsic_fp64.npz: for each start of the fixture (`run`, `one0`, ...) `<name>_g64` = the
 mirrored packed gradient of its first step at `packed_pos`, plus its largest magnitude over the whole vector."""
@@ -57,5 +58,35 @@ def main(workload="synthetic-10k-hsic", tag="bench10k_hsic"):
         np.savez_compressed(os.path.join(OUT, f"{tag}_fp64.npz"), **out)
 
 
+def mid(tag="mid_s1200_hsic_sparse"):
+    """The same for the n = 1200 reference fixture (make_golden.py --only mid): first-step gradient of the float64 oracle
+    at the fixture's packed positions -> tests/golden/<tag>_fp64.npz (seconds)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests import helpers as H
+    z = H.load_cora(tag)
+    n = z["adj"].shape[0]
+    O.F32 = np.float64
+    f8 = lambda x: np.asarray(x).astype(np.float64)
+    w0 = H.weights_from(z)
+    w = O.GCNWeights([f8(x) for x in w0.W], [f8(x) for x in w0.b], f8(w0.Wlin), f8(w0.blin))
+    cfg = O.AttackConfig(measure=str(z["measure"]), weight_sup=float(z["weight_sup"]),
+                         weight_param=tuple(float(x) for x in z["weight_param"]), lr=float(z["lr"]), num_edges=float(z["num_edges"]))
+    X = f8(z["features"])
+    fadj = 1.0 / (1.0 + np.exp(-np.maximum(X @ X.T - np.eye(n), 0)))
+    orc = O.PGDAttackOracle(w, X, f8(z["adj"]), np.zeros((n, n)), fadj, z["labels"], z["idx_attack"], cfg)
+    orc.w = w
+    orc.set_adj_changes(f8(H.init_adj_changes(n, z["a0_seed"], z["a0_scale"])))
+    orc.step()
+    pi, pj = H.tril_pos(z["packed_pos"])
+    G = orc.last["G_sym"]
+    g64 = G[pi, pj].astype(np.float64)
+    gmax = float(np.abs(G).max())
+    print(tag, "reference fp32 vs float64 oracle: max err / gmax =", np.abs(z["step_g"][0] - g64).max() / gmax, flush=True)
+    np.savez_compressed(os.path.join(OUT, f"{tag}_fp64.npz"), packed_pos=z["packed_pos"], step0_g64=g64, step0_g64_absmax=gmax)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        mid()
+    else:
+        main()

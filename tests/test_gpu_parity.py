@@ -513,7 +513,7 @@ def _run_cora(pkg, t, name, epochs=None):
     return z, final, O.metric_pool(adj, final, z["idx_attack"])
 
 
-@pytest.mark.parametrize("name", ["cora_mse_short", "cora_hsic"])
+@pytest.mark.parametrize("name", ["cora_mse_short", "cora_hsic", "cora_hsic_sparse"])
 def test_cora_auc_matches_reference(pkg, torch_, name):
     """BASELINE configs[0]/[1]: Cora, 2-layer GCN trained by the reference, priors H_A+Y_A+Y.
     north_star bar: recovered-adjacency AUC within 1e-4 of the reference CPU path, on horizons where the
@@ -528,6 +528,64 @@ def test_cora_auc_matches_reference(pkg, torch_, name):
 
 
 CKPT = np.load(os.path.join(H.GOLDEN, "cora_mse_checkpoints.npz"))
+
+
+def _engine_from_bits(pkg, z):
+    """AttackEngine from a fixture that carries its graph as bits (tests.helpers.load_cora layout) and its own start."""
+    w = H.weights_from(z)
+    n = z["adj"].shape[0]
+    dims = [w.W[0].shape[0]] + [x.shape[1] for x in w.W]
+    eng = pkg.AttackEngine(n, dims, w.Wlin.shape[0], 2, str(z["measure"]), float(z["weight_sup"]),
+                           tuple(float(x) for x in z["weight_param"]), float(z["lr"]), float(z["num_edges"]),
+                           len(z["idx_attack"]))
+    eng.set_model(w.W, w.b, w.Wlin, w.blin)
+    eng.set_graph(z["features"], z["adj"], None, H.cora_feature_adj(z["features"]), z["labels"], z["idx_attack"])
+    eng.set_adj_changes(H.init_adj_changes(n, z["a0_seed"], z["a0_scale"]))
+    return eng
+
+
+def test_mid_size_reference_run_on_the_fused_path(pkg, torch_):
+    """A REFERENCE run (not the oracle) at a size where the default path is the fused low-rank step with the fp16-split
+    product (n = 1200 >= 1024), from the bench's start rule, where the N x N terms carry the gradient (from the dense
+    start of the other fixtures they are rounded away at n >= 300: VERDICT round 2, item 1c).  Step 0 starts from the
+    reference's own state; there the reference's own fp32 gradient is 4.6e-4 of the gradient's largest magnitude away from
+    a float64 evaluation of the same algorithm (tests/golden/make_truth64.py mid), so -- as at N = 10 000 -- the engine is
+    held to 3e-4 of the EXACT gradient and to the reference within the reference's own distance from it plus 3e-4; later
+    steps free-run."""
+    z = H.load_cora("mid_s1200_hsic_sparse")
+    z64 = np.load(os.path.join(H.GOLDEN, "mid_s1200_hsic_sparse_fp64.npz"))
+    assert np.array_equal(z64["packed_pos"], z["packed_pos"])
+    n = z["adj"].shape[0]
+    eng = _engine_from_bits(pkg, z)
+    assert eng.product_mode() == 3
+    assert np.abs(eng.buffer("YA").cpu().numpy() - z["Y_A"]).max() <= 5e-5
+    pi, pj = H.tril_pos(z["packed_pos"])
+    ti, tj = torch_.as_tensor(pi, device="cuda:0"), torch_.as_tensor(pj, device="cuda:0")
+    lr = float(z["lr"])
+    for t in range(int(z["epochs"])):
+        eng.step(); eng.monitor()
+        Gs = eng.buffer("G_sym")
+        g = Gs[ti, tj].cpu().numpy()
+        gmax = float(z["step_g_absmax"][t])
+        err = np.abs(g - z["step_g"][t]).max() / gmax
+        ref_flips = 0.0
+        if t == 0:
+            g64 = z64["step0_g64"]
+            err_true, ref_true = np.abs(g - g64).max() / gmax, np.abs(z["step_g"][0] - g64).max() / gmax
+            ref_flips = float((np.sign(z["step_g"][0]) != np.sign(g64)).mean())
+            assert err_true <= 3e-4 and err <= ref_true + 3e-4, (err_true, err, ref_true)
+        else:
+            assert err <= 2e-3, (t, err)
+        assert abs(float(Gs.abs().max()) - gmax) <= 1e-3 * gmax
+        a = eng.buffer("M")[ti, tj].cpu().numpy()
+        moved = np.abs(a - np.clip(z["step_a"][t], 0, 1)) > 0.05 * lr
+        assert moved.mean() <= (ref_flips + 0.001 if t == 0 else 0.01), (t, moved.mean(), ref_flips)
+    assert eng.fused_steps() == int(z["epochs"]) and eng.path_stats()["general_steps"] == 0
+    lab = z["labels"]
+    final = eng.finalize(0, z["H_A2"], z["Y_A"], (lab[:, None] == lab[None, :]).astype(np.float32)).cpu().numpy()
+    assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) <= 1e-4
+    sp = z["sample_pos"]
+    assert np.mean(np.abs(final[sp[:, 0], sp[:, 1]] - z["final_sample"]) > 1e-3 * max(1.0, np.abs(z["final_sample"]).max())) < 0.01
 
 
 @pytest.mark.parametrize("epochs", [10, 40])
