@@ -217,9 +217,13 @@ int mcgra_attack_set_model(mcgra_attack_t* h, void* stream, const float* const* 
 
 /* constant inputs of PGDAttack.attack (topology_attack.py:95-98): ori_features
  * [n x nfeat], adj (true graph, used only for the H_A / Y_A priors :177-182),
- * ori_adj (init_adj; NULL = zeros, the only value dataset.py:433 produces),
+ * ori_adj (init_adj [n x n]; NULL = zeros, the only value dataset.py:433 produces),
  * feature_adj [n x n], labels [n] int32, idx_attack [n_attack] int32.
- * Computes T0 = X W0, H_A_cur and Y_A once.  Synchronises. */
+ * Computes T0 = X W0, H_A_cur and Y_A once.  Synchronises.
+ * A non-NULL ori_adj takes the general step for every measure (modified_adj =
+ * clamp(adj_changes + ori_adj) with its gradient gate :164-165 / :474-478, the embedding
+ * on modified_adj - ori_adj :185 in a chain of its own, + ori_adj in modified_adj1 :188 and
+ * in the adjacency of the post-loop ensemble :302); not available on a row-block rank. */
 int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* features,
                            const float* adj, const float* ori_adj, const float* feature_adj,
                            const int32_t* labels, const int32_t* idx_attack);

@@ -444,12 +444,25 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;      // whatever the last step / monitor call left is stale now
   if (!h || !features || !adj || !feature_adj || !labels || !idx_attack) { set_error("null argument"); return MCGRA_EINVAL; }
   if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
-  if (ori_adj) {
-    set_error("ori_adj != zeros is not implemented on the HIP path yet (dataset.py:433 only produces zeros)");
-    return MCGRA_ENOSUP;
-  }
   hipStream_t st = (hipStream_t)stream;
   const int n = h->n, ld = h->ld, hs = h->hsum;
+  if (ori_adj) {
+    // general path only: the fused / low-rank forms assume modified_adj == M and modified_adj1 == offdiag relu(Zn Zn^T)
+    if (h->sharded) { set_error("a non-zero ori_adj is not supported on a row-block rank"); return MCGRA_ENOSUP; }
+    const size_t nn = (size_t)n * ld, nh = (size_t)n * hs;
+    int rc = 0;
+#define A1_(p, cnt) if (!rc && !h->p) rc = dalloc(h, &h->p, (cnt))
+    A1_(ORI, nn); A1_(Bbuf, nn); A1_(Abuf, nn); A1_(gate, nn); A1_(Te, nh); A1_(Pe, nh); A1_(He, nh); A1_(GPe, nh);
+    if (h->has_self) { A1_(Se, nh); }
+#undef A1_
+    if (rc) return rc;
+    MCGRA_HIP(hipMemcpy2DAsync(h->ORI, (size_t)ld * 4, ori_adj, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+    h->has_ori = true;
+    h->lr_ok = h->fused_ok = h->gram_split = false;
+    h->fwd_reuse = false;          // the monitoring forward (:290-293) runs on the UNclamped M + ori: nothing to adopt
+  } else {
+    h->has_ori = false;
+  }
   MCGRA_HIP(hipMemcpy2DAsync(h->FADJ, (size_t)ld * 4, feature_adj, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
   MCGRA_HIP(hipMemcpyAsync(h->labels, labels, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
   MCGRA_HIP(hipMemcpyAsync(h->idx, idx_attack, sizeof(int) * h->na, hipMemcpyDeviceToDevice, st));
@@ -458,6 +471,8 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   // T0 = X @ W_0 : the only use of the features inside the loop (models/gcn.py:41)
   CHK(eg(h, st, false, false, n, h->wdt[0], h->cfg.dims[0], 1.f, features, h->cfg.dims[0], h->W[0], h->wdt[0], 0.f, h->Tv, hs));
   MCGRA_HIP(hipMemcpy2DAsync(h->Tu, (size_t)hs * 4, h->Tv, (size_t)hs * 4, (size_t)h->wdt[0] * 4, n, hipMemcpyDeviceToDevice, st));
+  if (h->has_ori)
+    MCGRA_HIP(hipMemcpy2DAsync(h->Te, (size_t)hs * 4, h->Tv, (size_t)hs * 4, (size_t)h->wdt[0] * 4, n, hipMemcpyDeviceToDevice, st));
   if (h->has_self)   // S0 = X @ Ws_0: the self half of the first GraphSAGE layer, adjacency independent
     CHK(eg(h, st, false, false, n, h->wdt[0], h->cfg.dims[0], 1.f, features, h->cfg.dims[0], h->Ws[0], h->wdt[0], 0.f, h->S0,
            h->hmax));
@@ -587,17 +602,29 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
 int forward_common(mcgra_attack* h, hipStream_t st, float* adjn_out, const float* noise,
                           double* adjn_rowsum = nullptr) {
   const int n = h->n, ld = h->ld;
-  const bool general = noise != nullptr;
+  const bool general = noise != nullptr || h->has_ori;      // (ori != 0: clamp(M + ori) even without noise, :474-478)
   if (!general && h->prep_valid) {
     // d, r and the norm / sparsity sums from the row sums the Adam pass left behind: no pass over M
     const size_t cnt = (size_t)n * rankk_apply_adam_tiles(n);
     prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
                        h->rowsum);
   } else
-  launch_prep(st, general, n, ld, h->M, nullptr, noise, h->cfg.eps, h->Abuf, h->gate, h->d, h->r, h->rowsq, h->rowsum);
+  launch_prep(st, general, n, ld, h->M, h->has_ori ? h->ORI : nullptr, noise, h->cfg.eps, h->Abuf, h->gate, h->d, h->r, h->rowsq, h->rowsum);
   launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
   launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
   launch_adjn(st, n, ld, general ? h->Abuf : h->M, h->r, adjn_out, adjn_rowsum);
+  MCGRA_KERNEL_CHECK();
+  return 0;
+}
+
+// ori != 0, places that use get_modified_adj(ori_adj) WITHOUT adding_noise's clamp: the monitoring forward (:290-293) and
+// the adj_norm of an attack without steps (:142).  adj_norm((1 - I) o M + ori) -> adjn_out; d, r, S_SUM as forward_common.
+static int forward_ori_unclamped(mcgra_attack* h, hipStream_t st, float* adjn_out) {
+  const int n = h->n, ld = h->ld;
+  launch_axpby2d(st, n, h->M, ld, 1.f, h->ORI, ld, 1.f, h->Bbuf, ld);
+  launch_prep(st, false, n, ld, h->Bbuf, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum);
+  launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
+  launch_adjn(st, n, ld, h->Bbuf, h->r, adjn_out, nullptr);
   MCGRA_KERNEL_CHECK();
   return 0;
 }
@@ -749,9 +776,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const double n2 = (double)n * n;
   const bool cka = c.measure == MCGRA_MEASURE_CKA;
   const bool hsic = c.measure == MCGRA_MEASURE_HSIC || cka;      // both run the centred-Gram path
-  const float* A = noise ? h->Abuf : h->M;   // modified_adj == M when ori == 0, eps == 0
-  const unsigned char* gate = noise ? h->gate : nullptr;
-  const float* em = h->Hu + h->off[Le - 1];
+  const bool gen = noise != nullptr || h->has_ori;      // modified_adj = clamp(M + ori + eps noise) with its gate
+  const float* A = gen ? h->Abuf : h->M;     // modified_adj == M when ori == 0, eps == 0
+  const unsigned char* gate = gen ? h->gate : nullptr;
+  const float* em = (h->has_ori ? h->He : h->Hu) + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
   const bool use1 = (w1 != 0), use2 = (w2 != 0);
   const bool sym = h->use_sym;
@@ -762,7 +790,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const bool sharded = false;
 
   if (PH(0)) {
-  const bool adopt = h->fwd_cached && !noise;       // forward of this iteration already done by the last monitor call
+  const bool adopt = h->fwd_cached && !gen;         // forward of this iteration already done by the last monitor call
   h->fwd_cached = false;
   // (S_SQ, S_SUM are the first two slots: written by forward_common, kept when its results are adopted)
   MCGRA_HIP(hipMemsetAsync(h->scal + (adopt ? 2 : 0), 0, sizeof(double) * (S_COUNT - (adopt ? 2 : 0)), st));
@@ -775,17 +803,20 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const bool want_xc = hsic && (use1 || use2);
   // adj_norm is symmetric when eps == 0 (ori == 0): its column means are its row sums / n, which k_adjn emits
   if (adopt) { float* t = h->ADJN; h->ADJN = h->ADJN_next; h->ADJN_next = t; }
-  else CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !noise) ? h->rowsx : nullptr));
+  else CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !gen) ? h->rowsx : nullptr));
   h->p1_inflight = false;
   std::function<int()> fork_p1;       // the forked product of a low-rank step, when its launch is deferred
   if (want_xc) {
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
-    if (noise) launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);   // asymmetric: true column sums
+    if (gen) {                               // possibly asymmetric: true column sums
+      if (!h->colpart_d) CHK(dalloc(h, &h->colpart_d, (size_t)h->nstrips * ld));
+      launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);
+    }
     launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr,
                        ((h->split_mode == 2 && h->split_planes == 2) || h->gram_split) ? h->amax + 1 : nullptr);
     // Gram evaluation through the split kernel: planes of Xc^T now (cmean is reused by Yc's centring), unless the
     // low-rank product below packs them anyway
-    if (h->gram_split && !noise && !(h->lr_ok && !cka && use1 && h->split_on))
+    if (h->gram_split && !gen && !(h->lr_ok && !cka && use1 && h->split_on))
       split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, 2, h->amax + 1);
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
@@ -793,7 +824,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       hipStream_t sp = h->overlap ? h->st2 : st;
       // bf16 planes of Xc^T (opt-in split path) on the caller's stream, ahead of the fork: cmean is reused later
       // (row blocks of a sharded step must start on a 256-row panel for the split kernel; otherwise fp32 SYMM)
-      const bool split_now = h->split_on && !noise;
+      const bool split_now = h->split_on && !gen;
       if (split_now)
         split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr);
       fork_p1 = [=]() -> int {
@@ -833,12 +864,16 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // ---- embedding(features, modified_adj - ori_adj) (:185) == first Le layers of victim(features, modified_adj) (:259)
   CHK(chain_forward(h, st, A, ld, L, h->Tu, h->Pu, h->Hu, h->Su));
   CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
+  if (h->has_ori) {      // embedding(features, modified_adj - ori_adj) (:185) no longer shares the chain of output2 (:259)
+    launch_axpby2d(st, n, A, ld, 1.f, h->ORI, ld, -1.f, h->Bbuf, ld);
+    CHK(chain_forward(h, st, h->Bbuf, ld, Le, h->Te, h->Pe, h->He, h->Se));
+  }
   // ---- dot_product_decode + get_modified_adj_after (:187-188)
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
   CHK(eg(h, st, false, true, n, n, he, 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->A1, ld));
   MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
   h->nmask_zero = false;
-  launch_decode_post(st, n, ld, h->A1, nullptr, h->nmask);
+  launch_decode_post(st, n, ld, h->A1, h->has_ori ? h->ORI : nullptr, h->nmask);
   h->lr_step = false;
 
   // ---- N x N loss terms (:212-236)
@@ -909,7 +944,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         ++h->general_steps;
         if (use2) {
           launch_rowsum(st, n, ld, h->A1, h->rowsy);
-          const bool gs = h->gram_split && !noise;
+          const bool gs = h->gram_split && !gen;
           launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC, nullptr, gs ? h->amax + 2 : nullptr);
           if (gs) split3_pack(st, n, ld, h->A1, h->cmean, false, h->Gp2, 2, h->amax + 2);      // Yc^T (A1 is symmetric)
         }
@@ -932,7 +967,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       h->p1_inflight = false;
     }
     if (h->lr_step) {
-    } else if (h->gram_split && !noise) {
+    } else if (h->gram_split && !gen) {
       // full Kx and Ky from the fp16 planes of Xc and Yc (split_symm_bf16.hip); split-K slabs in G_A, idle until phase 3
       const size_t slab = sizeof(float) * (size_t)n * ld;
       const bool big = h->profile;
@@ -961,7 +996,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
   }
 
-  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && h->gram_split && !noise) {
+  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && h->gram_split && !gen) {
     const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
     const size_t slab = sizeof(float) * (size_t)n * ld;
     const bool big = h->profile;
@@ -1049,7 +1084,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                                         h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->lrQtZ);
     if (np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, np, 1, h->scal + S_V7);
   } else {
-    launch_sym_mask(st, n, ld, h->G_A1, h->A1, nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
+    launch_sym_mask(st, n, ld, h->G_A1, h->A1, h->has_ori ? h->ORI : nullptr, h->G_A);    // G_A used as scratch for (G + G^T) * [S > 0]
     CHK(eg(h, st, false, false, n, he, n, 1.f, h->G_A, ld, h->Zn, h->hmax, 0.f, h->GZn, h->hmax));
   }
   if (hsic && h->lr_step && use2) {   // the -2 s2 KX D part of d c2 / d A1, applied to Zn directly
@@ -1063,6 +1098,21 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
 
   // ---- backward: modified_adj chain (embedding + output2) -> G_A
   int ltop;
+  if (h->has_ori) {
+    // two chains: output2 on modified_adj (only c10 reaches it) and the embedding on modified_adj - ori (em)
+    MCGRA_HIP(hipMemsetAsync(h->GPu, 0, sizeof(float) * (size_t)n * hs, st));
+    MCGRA_HIP(hipMemsetAsync(h->GPe, 0, sizeof(float) * (size_t)n * hs, st));
+    if (w10 != 0) {
+      if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z2, h->GZ2);
+      launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
+                         h->Pu + h->off[L - 1], hs, h->act, nullptr, 0, h->GPu + h->off[L - 1], hs);
+      CHK(chain_backward(h, st, A, ld, L - 1, h->Pu, h->GPu, -1, nullptr, 0));
+    }
+    launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
+                       h->Pe + h->off[Le - 1], hs, h->act, h->Gem, h->hmax, h->GPe + h->off[Le - 1], hs);
+    CHK(chain_backward(h, st, h->Bbuf, ld, Le - 1, h->Pe, h->GPe, -1, nullptr, 0));
+    ltop = L - 1;
+  } else {
   if (w10 != 0) {
     ltop = L - 1;
     if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z2, h->GZ2);
@@ -1076,6 +1126,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                        h->Pu + h->off[Le - 1], hs, h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
   }
   CHK(chain_backward(h, st, A, ld, ltop, h->Pu, h->GPu, Le - 1, h->Gem, h->hmax));
+  }
   bool normbwd_parts = false;
   float* nb_colpart = h->colpart;       // column partials of the normalisation backward: [nb_strips][n]
   int nb_strips = h->nstrips;
@@ -1111,20 +1162,20 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const bool may_project = c.num_edges < 0.5 * n2;
   bool adam_done = false;
   // normalisation backward writes G_A (beta = 0), then the chain's outer products accumulate
-  if (h->fuse_tail && rankk_apply_adam_supported(n, ld, hs)) {
+  if (h->fuse_tail && rankk_apply_adam_supported(n, ld, hs) && !h->has_ori) {
     // one pass over the lower tile pairs: apply step + rank-k update + gradient mirror + Adam, no G_A in between
     launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
     // (its row sums of the new M go to G_A, which this path leaves unused; not with a projection still to come)
     const size_t cnt = (size_t)n * rankk_apply_adam_tiles(n);
     static const bool no_partials = [] { const char* e = getenv("MCGRA_NO_PREP_PARTIALS"); return e && e[0] == '1'; }();
-    const bool emit = !may_project && !noise && !no_partials && 3 * cnt + 4 <= (size_t)n * ld;
+    const bool emit = !may_project && !gen && !no_partials && 3 * cnt + 4 <= (size_t)n * ld;
     MCGRA_HIP(rankk_apply_adam(st, n, ld, hs, h->GPu, hs, h->Tu, hs, h->G_ADJN, h->r, h->gd, gate, h->M, h->am, h->av, h->mm + 2,
                                (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
                                h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,
                                emit ? reinterpret_cast<double*>(h->G_A + ((cnt + 1) & ~(size_t)1)) : nullptr));
     h->prep_valid = emit;
     adam_done = true;
-  } else if (rankk_nt_supported(n, n, hs, 0)) {
+  } else if (rankk_nt_supported(n, n, hs, 0) && !h->has_ori) {
     // one pass: G_A = GPu Tu^T + (G_adjn_ij r_i r_j + gd_i), the apply step of the normalisation backward as the
     // epilogue of the rank-k update
     launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
@@ -1133,6 +1184,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   } else {
     launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, h->G_A, normbwd_parts);
     CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPu, hs, h->Tu, hs, 1.f, h->G_A, ld));
+    if (h->has_ori) CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPe, hs, h->Te, hs, 1.f, h->G_A, ld));   // d / d (modified_adj - ori)
   }
 
   // ---- packed-gradient mirror + Adam + projection + clamp (:274-283)
@@ -1197,6 +1249,8 @@ int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, doubl
   const bool want_xc = (h->cfg.measure == MCGRA_MEASURE_HSIC || h->cfg.measure == MCGRA_MEASURE_CKA) &&
                        (h->cfg.w[0] != 0 || h->cfg.w[1] != 0);
   float* dst = h->fwd_reuse ? h->ADJN_next : h->A1;
+  if (h->has_ori) CHK(forward_ori_unclamped(h, st, dst));
+  else
   CHK(forward_common(h, st, dst, nullptr, (h->fwd_reuse && want_xc) ? h->rowsx : nullptr));
   CHK(chain_forward(h, st, dst, h->ld, h->L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->fwd_reuse ? h->sm : nullptr));
@@ -1235,7 +1289,10 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   if (decode_mode < 0 || decode_mode > 6) { set_error("decode_mode %d", decode_mode); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
-  if (!h->have_step) CHK(forward_common(h, st, h->ADJN, nullptr));   // epochs == 0: adj_norm of :142
+  if (!h->have_step) {               // epochs == 0: adj_norm of :142
+    if (h->has_ori) CHK(forward_ori_unclamped(h, st, h->ADJN));
+    else CHK(forward_common(h, st, h->ADJN, nullptr));
+  }
   // M is overwritten below (:301): the forward a monitor call left for the next step and the row sums the Adam pass
   // left for the next normalisation describe the old M
   h->fwd_cached = h->prep_valid = h->fused_fwd_valid = false;
@@ -1249,11 +1306,16 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
     launch_row_normalize(st, n, h->wdt[Le - 1], h->Hu + h->off[Le - 1], hs, h->Zn, h->hmax, h->nrm, 2.f);
   }
   CHK(eg(h, st, false, true, n, n, h->wdt[Le - 1], 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->M, ld));
-  launch_decode_post(st, n, ld, h->M, nullptr);            // modified_adj = get_modified_adj (:302)
+  launch_decode_post(st, n, ld, h->M, nullptr);            // adj_changes <- the decode (:301); M stays the state
+  const float* mod = h->M;                                 // modified_adj = get_modified_adj(ori_adj) (:302)
+  if (h->has_ori) {
+    launch_axpby2d(st, n, h->M, ld, 1.f, h->ORI, ld, 1.f, h->Bbuf, ld);
+    mod = h->Bbuf;
+  }
   // out = modified_adj + feature_adj (:314)
-  launch_axpby2d(st, n, h->M, ld, 1.f, h->FADJ, ld, 1.f, out, n);
+  launch_axpby2d(st, n, mod, ld, 1.f, h->FADJ, ld, 1.f, out, n);
   // H_A1, H_A2 = embedding(features, modified_adj) with 1 / 2 layers; Y_A2 = victim (:304-308)
-  CHK(chain_forward(h, st, h->M, ld, L, h->Tu, h->Pu, h->Hu, h->Su));
+  CHK(chain_forward(h, st, mod, ld, L, h->Tu, h->Pu, h->Hu, h->Su));
   CHK(head_forward(h, st, h->Hu, h->Z2, h->logp, nullptr));
   CHK(dd2(h, st, decode_mode, h->Hu + h->off[h->fin0 - 1], h->wdt[h->fin0 - 1], hs, out));   // H_A1 (:304-305)
   CHK(dd2(h, st, decode_mode, h->Hu + h->off[h->fin1 - 1], h->wdt[h->fin1 - 1], hs, out));   // H_A2 (:306-307)
@@ -1275,7 +1337,7 @@ int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr, int* r
       {"G_adjn", h->G_ADJN, n, n, ld}, {"G_A1", h->G_A1, n, n, ld}, {"G_A", h->G_A, n, n, ld},
       {"G_sym", h->GSYM, n, n, ld}, {"adam_m", h->am, n, n, ld}, {"adam_v", h->av, n, n, ld},
       {"d", h->d, 1, n, ld}, {"r", h->r, 1, n, ld}, {"logp", h->logp, n, h->C, h->C}, {"sm2", h->sm2, n, h->C, h->C},
-      {"em", h->Hu + h->off[le], n, h->wdt[le], h->hsum}, {"G_em", h->Gem, n, h->wdt[le], h->hmax},
+      {"em", (h->has_ori ? h->He : h->Hu) + h->off[le], n, h->wdt[le], h->hsum}, {"G_em", h->Gem, n, h->wdt[le], h->hmax},
       {"HA", h->HA, n, h->wdt[le], h->hmax}, {"YA", h->YA, n, h->C, h->C}, {"T0", h->Tv, n, h->wdt[0], h->hsum},
       {"KFC", h->KFC, n, n, ld},
   };

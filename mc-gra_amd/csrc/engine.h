@@ -67,7 +67,12 @@ struct mcgra_attack {
   float *Zn = 0, *GZn = 0, *Gem = 0;
   float *HA = 0, *YA = 0, *HAg = 0, *HAc = 0, *YAg = 0, *YAc = 0, *Yg = 0, *Gg = 0, *Q = 0;
   float *Q2 = 0, *Gg2 = 0, *coef = 0;
-  float* Abuf = 0;                 // modified_adj after adding_noise (only when eps != 0; otherwise it is M itself)
+  // A non-zero ori_adj (never produced by main.py, accepted by the class: topology_attack.py:164, :185, :188, :302): the
+  // general path only.  modified_adj = clamp(M + ori + eps noise) lives in Abuf (with its clamp gate), the embedding runs
+  // on Bbuf = modified_adj - ori in its own chain (Te / Pe / He / GPe) while output2 keeps the chain on modified_adj.
+  bool has_ori = false;
+  float *ORI = 0, *Bbuf = 0, *Te = 0, *Pe = 0, *He = 0, *GPe = 0, *Se = 0;
+  float* Abuf = 0;                 // modified_adj after adding_noise (only when eps != 0 or ori != 0; otherwise it is M itself)
   unsigned char* gate = 0;         // clamp pass-through mask of adding_noise's torch.clamp
   double* colpart_d = 0;
   double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)

@@ -10,8 +10,7 @@ without libmcgra_hip.so it raises.
 
 Arguments the reference accepts but this path does not cover yet raise
 NotImplementedError naming the reference line (measure KDE,
-a non-zero ori_adj, an embedding whose weights differ from
-victim_model.gc).
+an embedding whose weights differ from victim_model.gc).
 """
 import os
 
@@ -196,9 +195,10 @@ class PGDAttack(BaseAttack):
 
         n = self.nnodes
         adj_np = _dense_np(adj)
+        # ori_adj: zeros from main.py (dataset.init_matrix, dataset.py:433-437); anything else takes the engine's general
+        # path (modified_adj = clamp(adj_changes + ori_adj), embedding on modified_adj - ori_adj: :164-165, :185)
         ori_np = _dense_np(ori_adj)
-        if np.any(ori_np != 0):
-            raise NotImplementedError("ori_adj != 0: dataset.init_matrix (dataset.py:433-437) only produces zeros")
+        ori_np = ori_np if np.any(ori_np != 0) else None
         fadj = _dense_np(feature_adj)
         if w1 != 0 and not (fadj.max() != fadj.min()):            # (:212)
             w1 = 0
@@ -223,7 +223,7 @@ class PGDAttack(BaseAttack):
                            (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev,
                            act=act, head_act=head_act, has_self=Ws is not None, fin_layers=fin_layers)
         eng.set_model(W, b, Wlin, blin, Ws)
-        eng.set_graph(_dense_np(ori_features), adj_np, None, fadj, lab, idx)
+        eng.set_graph(_dense_np(ori_features), adj_np, ori_np, fadj, lab, idx)
         if self._adj_changes_init is not None:
             eng.set_adj_changes(self._adj_changes_init)
         self.engine = eng

@@ -101,7 +101,7 @@ def weights_of(victim):
 
 def run_reference_attack(adj, features, labels, victim, idx_attack, measure, weight_param,
                          weight_sup, lr, epochs, dataset, use, num_edges, eps=0.0,
-                         capture_steps=True, a0=None, loss_type="CE"):
+                         capture_steps=True, a0=None, loss_type="CE", ori_adj=None):
     """Drive topology_attack.PGDAttack.attack exactly as main.objective does
     (main.py:298-307) and capture per-step adj_changes / grads through a global
     optimizer post-hook."""
@@ -128,6 +128,8 @@ def run_reference_attack(adj, features, labels, victim, idx_attack, measure, wei
     embedding.set_layers(2); H_A2 = embedding(features, adj)            # main.py:238-241
     feature_adj = ref_dot_product_decode_main(features, dataset)        # main.py:165
     init_adj = torch.zeros(n, n)                                        # dataset.init_matrix (dataset.py:433)
+    if ori_adj is not None:     # a non-zero ori_adj (never produced by main.py; the class accepts it: :164, :185, :188, :302)
+        init_adj = torch.tensor(np.asarray(ori_adj, dtype=np.float32))
     args = argparse.Namespace(max_eval=100, lr=0, dataset=dataset, eps=eps, measure=measure,
                               useH_A=use[0], useY_A=use[1], useY=use[2],
                               w1=0, w2=0, w6=0, w7=0, w8=0, w9=0, w10=0)
@@ -218,7 +220,7 @@ def gen_cw(tmp):
     print(name, "auc", res["auc"])
 
 
-def gen_small(tmp):
+def gen_small(tmp, only=None):
     os.chdir(tmp)
     os.makedirs("saved_data", exist_ok=True)
     cases = []
@@ -255,7 +257,14 @@ def gen_small(tmp):
         # normalisation backward at the sizes where they are the default
         ("s300_hsic_eps", 300, 64, 6, 16, 2, "HSIC", base_wp, 1.0, 0.01, 2, 1e12),
         ("s300_mse_eps", 300, 64, 6, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 2, 1e12),
+        # a non-zero ori_adj (random symmetric 0/1): modified_adj = clamp(adj_changes + ori_adj) gates the gradient where
+        # it saturates, the embedding runs on modified_adj - ori_adj (:185) while output2 runs on modified_adj (:259), and
+        # modified_adj1 / the post-loop adjacency carry + ori_adj (:188, :302)
+        ("s48_hsic_ori", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_mse_ori", 48, 24, 4, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
     ]
+    if only is not None:
+        spec = [c for c in spec if c[0] in only]
     for (name, n, f, c, hid, nl, measure, wp, wsup, lr, epochs, ne) in spec:
         arch = "gat" if "_gat_" in name else ("sage" if "_sage_" in name else "gcn")
         adj, feats, labels, victim = make_synth(n, f, c, hid, nl, seed=zlib.crc32(name.encode()) % 10000, arch=arch)
@@ -270,13 +279,20 @@ def gen_small(tmp):
             extra.update(arch=arch, emb_nlayer=nl, fin_layers=np.array([nl, nl]))
         elif arch == "sage":
             extra.update(arch=arch)
+        ori = None
+        if name.endswith("_ori"):
+            rs = np.random.RandomState(zlib.crc32(name.encode()) % 10000 + 1)
+            up = np.triu(rs.rand(n, n) < 0.06, 1)
+            ori = (up | up.T).astype(np.float32)
+            extra.update(ori_adj=ori, a0_seed=123, a0_scale=0.3)
+            a0 = init_adj_changes(n, 123, 0.3)
         if name.endswith("_init") or name.endswith("_eps"):
             extra.update(a0_seed=123, a0_scale=0.05)
             a0 = init_adj_changes(n, 123, 0.05)
         if name.endswith("_eps"):
             eps = 0.02
         res = run_reference_attack(adj, feats, labels, victim, idx_attack, measure, wp, wsup, lr,
-                                   epochs, "cora", (True, True, True), ne, a0=a0, eps=eps)
+                                   epochs, "cora", (True, True, True), ne, a0=a0, eps=eps, ori_adj=ori)
         if eps != 0:
             extra.update(eps=eps, noise=np.stack(res["noises"]))
         out = dict(adj=adj.numpy(), **extra, features=feats.numpy(), labels=lab, idx_attack=idx_attack,
@@ -645,6 +661,8 @@ if __name__ == "__main__":
             gen_cw(tmp)
         if a.only in ("all", "cora"):
             gen_cora(tmp)
+        if a.only in ("ori",):
+            gen_small(tmp, only=("s48_hsic_ori", "s48_mse_ori"))
         if a.only in ("cora_sparse",):
             gen_cora(tmp, only=("cora_hsic_sparse",))
         if a.only in ("all", "mid"):

@@ -53,7 +53,8 @@ def noise_of(z, t):
 
 def oracle_from(z):
     n = z["adj"].shape[0]
-    orc = O.PGDAttackOracle(weights_from(z), z["features"], z["adj"], np.zeros((n, n), np.float32),
+    ori = z["ori_adj"] if "ori_adj" in z else np.zeros((n, n), np.float32)
+    orc = O.PGDAttackOracle(weights_from(z), z["features"], z["adj"], ori,
                             z["feature_adj"], z["labels"], z["idx_attack"], cfg_from(z))
     if a0_of(z) is not None:
         orc.set_adj_changes(a0_of(z))
@@ -124,7 +125,7 @@ def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None, **kw):
                            len(z["idx_attack"]), eps=cfg.eps, device=device, act=w.act, head_act=w.head_act,
                            has_self=w.Ws is not None, fin_layers=cfg.fin_layers, **kw)
     eng.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
-    eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
+    eng.set_graph(z["features"], z["adj"], z["ori_adj"] if "ori_adj" in z else None, z["feature_adj"], z["labels"], z["idx_attack"])
     if a0_of(z) is not None:
         eng.set_adj_changes(a0_of(z))
     return eng

@@ -447,6 +447,26 @@ def test_pgdattack_class_small(pkg, torch_):
     assert len(model.history["acc_test"]) == int(z["epochs"])
 
 
+def test_pgdattack_class_nonzero_ori_adj(pkg, torch_):
+    """A non-zero ori_adj through the class (topology_attack.py:164-165, :185, :188, :302; main.py only ever passes zeros):
+    modified_adj = clamp(adj_changes + ori_adj) with its gradient gate, the embedding on modified_adj - ori_adj, + ori_adj
+    in modified_adj1 and in the returned adjacency.  Reference fixture with a random symmetric 0/1 ori_adj."""
+    z = H.load_case("s48_hsic_ori")
+    w = H.weights_from(z)
+    victim, emb = H.FakeGCN(w), H.FakeGCN(w)
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=torch_.tensor(z["H_A2"]), Y_A=torch_.tensor(z["Y_A"]),
+                          nnodes=48, loss_type="CE", device="cuda:0")
+    model.adj_changes = H.a0_of(z)
+    lab = z["labels"]
+    model.attack(_args("HSIC"), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]),
+                 torch_.tensor(z["feature_adj"]), 0, 0, 0, None, None, np.arange(8), torch_.tensor(z["adj"]),
+                 torch_.tensor(z["features"]), torch_.tensor(z["ori_adj"]), torch_.tensor(lab), z["idx_attack"],
+                 float(z["num_edges"]), 0, epochs=int(z["epochs"]), label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    final = model.modified_adj.cpu().numpy()
+    assert np.abs(final - z["final"]).max() < 1e-3 * max(1.0, np.abs(z["final"]).max())
+    assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
+
+
 def test_pgdattack_class_loss_type_cw(pkg, torch_):
     """loss_type='CW': the reference back-propagates the margin loss but calls optimizer.step() only for 'CE'
     (topology_attack.py:277-280), so its run returns the post-loop ensemble of the untouched adjacency; the fixture is

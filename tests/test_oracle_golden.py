@@ -184,3 +184,30 @@ def test_oracle_cora_auc(name):
     final = orc.finalize("cora", True, True, True, (lab[:, None] == lab[None, :]).astype(np.float32), Hs[-1], YA)
     auc = O.metric_pool(adj, final, z["idx_attack"])
     assert abs(auc - float(z["auc"])) <= 1e-4, (auc, float(z["auc"]))
+
+
+def test_oracle_against_the_reference_at_n1200_where_the_nxn_terms_carry_the_gradient():
+    """tests/golden/mid_s1200_hsic_sparse.npz: the reference's own run at n = 1200 from the sparse start rule (where c1 / c2
+    are not rounded away in the gradient's fp32 sum).  First step, 8k sampled entries: the fp32 oracle against the
+    reference and against the float64 evaluation of the same algorithm (mid_..._fp64.npz) -- two fp32 evaluations with
+    different summation orders, each a few 1e-4 of the gradient's largest magnitude from the exact one."""
+    z = H.load_cora("mid_s1200_hsic_sparse")
+    z64 = np.load(os.path.join(H.GOLDEN, "mid_s1200_hsic_sparse_fp64.npz"))
+    n = z["adj"].shape[0]
+    cfg = O.AttackConfig(measure=str(z["measure"]), weight_sup=float(z["weight_sup"]),
+                         weight_param=tuple(float(x) for x in z["weight_param"]), lr=float(z["lr"]), num_edges=float(z["num_edges"]))
+    orc = O.PGDAttackOracle(H.weights_from(z), z["features"], z["adj"], np.zeros((n, n), np.float32),
+                            H.cora_feature_adj(z["features"]), z["labels"], z["idx_attack"], cfg)
+    orc.set_adj_changes(H.init_adj_changes(n, z["a0_seed"], z["a0_scale"]))
+    orc.step()
+    pi, pj = H.tril_pos(z["packed_pos"])
+    g = orc.last["G_sym"][pi, pj].astype(np.float64)
+    gmax = float(z["step_g_absmax"][0])
+    ref_true = np.abs(z["step_g"][0] - z64["step0_g64"]).max() / gmax
+    assert abs(float(np.abs(orc.last["G_sym"]).max()) - gmax) <= 1e-3 * gmax
+    assert np.abs(g - z64["step0_g64"]).max() / gmax <= 5e-4
+    assert np.abs(g - z["step_g"][0]).max() / gmax <= ref_true + 5e-4
+    assert (np.tril(orc.last["S"], -1)[np.tril_indices(n, -1)] > 0).all(), "no relu-masked decode pair at this state"
+    a = O.pack_tril(orc.M)[z["packed_pos"]]
+    moved = np.abs(a - np.clip(z["step_a"][0], 0, 1)) > 0.05 * float(z["lr"])
+    assert moved.mean() <= float((np.sign(z["step_g"][0]) != np.sign(z64["step0_g64"])).mean()) + 2e-3
