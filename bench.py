@@ -502,12 +502,12 @@ def main(argv=None):
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12
             # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
-            # (profiles/r02_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
+            # (profiles/r03_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
             # cannot be read from inside the timed process, so the committed profile value is reported.
             traffic = None
             ps = eng_path
             lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
-            tp = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+            tp = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
             role = {2: "split", 3: "split_f16"}.get(pmode, "symm") if lowrank else "symm"
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
                 ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == role or not lowrank]
@@ -573,7 +573,7 @@ def main(argv=None):
             out["roofline"] = None
         # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed
         # profile) over the step time that is not the product (step without the side stream - product alone)
-        sp = os.path.join(ROOT, "profiles", "r02_step_traffic.json")
+        sp = os.path.join(ROOT, "profiles", "r03_step_traffic.json")
         if world == 1 and a.workload == "synthetic-10k-hsic" and os.path.exists(sp) and alone is not None and "value" in alone:
             bytes_out = json.load(open(sp))["outside_product_bytes_per_step"]
             ms_out = 1e3 / alone["value"] - alone.get("product_avg_launch_ms", 0.0)
