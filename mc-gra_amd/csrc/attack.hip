@@ -366,6 +366,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                   lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
                   (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
     h->row0 = 0; h->row1 = (int)n;
+    { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
     if (cfg->shard_world > 0) {
       // row-block rank: only the fused step is sharded, and the host-driven bisection of the projection is not
       if (!h->fused_ok || cfg->num_edges < 0.5 * (double)n * (double)n) {

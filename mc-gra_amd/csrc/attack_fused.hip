@@ -48,6 +48,33 @@ __global__ void k_stage_to_rows(int n, int w, const float* __restrict__ stage, i
   dst[(size_t)i * ldd + k] = stage[(size_t)i * sgw + c0 + k];
 }
 __global__ void k_u32_to_f64(const unsigned int* __restrict__ a, double* __restrict__ out) { out[0] = (double)a[0]; }
+// late mean: from the pack's per-block row sums / sums of squares of adj_norm (uncentred): rowsum_i = sum_p psum[i][p],
+// mean_i = rowsum_i / n, |xc_i|^2 = sum_p psq[i][p] - rowsum_i^2 / n        (fp64)
+__global__ __launch_bounds__(256) void k_mean_fin(int n, int np, const float* __restrict__ psum, const float* __restrict__ psq,
+                                                  float* __restrict__ mean, double* __restrict__ rowsum, double* __restrict__ rsq) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double s = 0.0, q = 0.0;
+  for (int p = lane; p < np; p += 64) { s += (double)psum[(size_t)i * np + p]; if (psq) q += (double)psq[(size_t)i * np + p]; }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    rowsum[i] = s;
+    mean[i] = (float)(s / (double)n);
+    if (rsq) rsq[i] = q - s * s / (double)n;
+  }
+}
+// operand-scale bound of the uncentred adj_norm: |r_i (M_ij + [i == j]) r_j| <= max r^2   (M in [0, 1], zero diagonal)
+__global__ __launch_bounds__(256) void k_rmax2(int n, const float* __restrict__ r, float* __restrict__ out) {
+  __shared__ float shm[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, r[i] * r[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+}
 }  // namespace mcgra
 
 static inline dim3 g1(size_t count) { return dim3((unsigned)((count + 255) / 256)); }
@@ -139,14 +166,15 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
           const float* Xs[3] = {h->Tv + h->off[l], h->Tu + h->off[l], h->r};
           const float* rs[3] = {h->r, nullptr, nullptr};
           const int lds[3] = {hs, hs, 1}, ws[3] = {w, w, 1};
-          fl_cat_segs(st, n, l == 0 ? 3 : 2, Xs, lds, rs, ws, h->FV, fc);      // [r o Tv | Tu (| r)]
-          CHK(mm_rows(h, st, 2 * w + (l == 0 ? 1 : 0)));
+          const bool with_r = l == 0 && !h->late_mean;         // (late mean: the means come out of the pack)
+          fl_cat_segs(st, n, with_r ? 3 : 2, Xs, lds, rs, ws, h->FV, fc);      // [r o Tv | Tu (| r)]
+          CHK(mm_rows(h, st, 2 * w + (with_r ? 1 : 0)));
         }
         FS_XCHG(h->fw_state, 3, X_FY(h))
         {
           const int l = h->fs_l, w = h->wdt[l];
           fl_layer_post(st, n, w, h->fy, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
-                        h->Hu + h->off[l], hs, l == 0, h->cmean, h->rowsx);
+                        h->Hu + h->off[l], hs, l == 0 && !h->late_mean, h->cmean, h->rowsx);
           if (l + 1 < L) {
             launch_rowmat(st, n, w, h->wdt[l + 1], h->Hv + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tv + h->off[l + 1], hs);
             launch_rowmat(st, n, w, h->wdt[l + 1], h->Hu + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tu + h->off[l + 1], hs);
@@ -155,7 +183,8 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
       }
       CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
       CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
-      fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
+      if (h->late_mean) { if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, st, n, h->r, h->amax + 1); }
+      else fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
       MCGRA_KERNEL_CHECK();
   }
   h->fw_state = 0;
@@ -255,6 +284,17 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
                                  hipMemcpyDeviceToDevice, st));
       // planes of Xc^T rows straight from M, |xc_i|^2 from the same pass
+      if (h->late_mean) {
+        // uncentred planes ((H Kf H) 1 = 0: the product does not see the centring vector), row sums and sums of squares of
+        // adj_norm from the same pass -> the column means (adj_norm is symmetric) and |xc_i|^2
+        const int np = split3_pack_rsq_parts(n, h->split_planes);
+        float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
+        split3_pack_from_m(st, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
+                           use2 ? h->A1 : nullptr, psum);
+        hipLaunchKernelGGL(k_mean_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, np, psum, use2 ? h->A1 : nullptr, h->cmean, h->rowsx,
+                           use2 ? h->lrRs : nullptr);
+        fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->mm + 3);      // sum(mean); (the operand-scale bound stays max r^2)
+      } else
       if (p_cnt > 0) {
         split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
                            use2 ? h->A1 : nullptr);

@@ -78,7 +78,7 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
                  const float* amax = nullptr);
 int split3_pack_rsq_parts(int n, int planes);
 void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
-                        const float* amax, int panel_off, int panel_rows, float* rsq_part);
+                        const float* amax, int panel_off, int panel_rows, float* rsq_part, float* rsum_part = nullptr);
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr,
                        int npanel_off = 0, int npanel_cols = -1, int flags = 0);     // flags: 1 = C += product; 2 = Gram product (A == B): lower tiles computed, mirrored into the upper half

@@ -140,6 +140,11 @@ struct mcgra_attack {
   char* rkbuf = 0;                 // packed fp16 planes of the tail's rank-k panels (fl_tail_pack_bytes)
   float *em_last = 0;              // embedding(features, adj_norm) of the last iteration (:300), = its victim-chain activations
   double *fstat = 0;               // small fp64 vectors: colsum(V) [64] | colsum(W) [64] | mean^T W [64] | sum(mean) [2]
+  // Monolithic fused step: the column means of adj_norm come out of the PACK of the product's operand (row sums of the
+  // packed values) instead of out of a 33rd column (M r) of the first forward product; the product's operand is then
+  // packed uncentred -- (H Kf H) 1 = 0, so P1 is the same up to 1e-7 -- and the means are only needed behind the pack.
+  // MCGRA_LATE_MEAN=0 disables (A/B).
+  bool late_mean = false;
   int64_t fused_steps = 0;
   // row-block sharding (mcgra_attack_shard_*): this rank owns rows [row0, row1) of M / am / av
   bool sharded = false;

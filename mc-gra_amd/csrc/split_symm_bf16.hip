@@ -72,11 +72,12 @@ __device__ __forceinline__ void split3(float x, __hip_bfloat16& p0, __hip_bfloat
 // rvec != nullptr: X is the learnable adjacency M and the packed value is the centred normalised adjacency formed on
 // the fly, (r_row (M[row][k] + [row == k])) r_k - sub[row] (adj_norm is never stored: fused low-rank step); rows of the
 // grid start at row_base.  rsq_part != nullptr: rsq_part[row][blockIdx.x] = sum of the squares of the block's 64 values
-// of that row (|xc_row|^2 = diag(Xc Xc^T) once summed over the blocks of the row).
+// of that row (|xc_row|^2 = diag(Xc Xc^T) once summed over the blocks of the row); rsum_part likewise their plain sums.
 template <int NP>
 __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
                                               int sym, int nkc, char* __restrict__ out, const float* __restrict__ amax,
-                                              const float* __restrict__ rvec, int row_base, float* __restrict__ rsq_part) {
+                                              const float* __restrict__ rvec, int row_base, float* __restrict__ rsq_part,
+                                              float* __restrict__ rsum_part) {
   // block: 32 rows x 8 (k chunk pairs of 8): thread (r, c): row = blockIdx.y * 32 + r, k0 = (blockIdx.x * 8 + c) * 8
   const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
   const int row = row_base + blockIdx.y * 32 + r;
@@ -107,6 +108,13 @@ __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __rest
       for (int j = 0; j < 8; ++j) s = fmaf(v[j], v[j], s);
       s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
       if (c == 0 && row < n) rsq_part[(size_t)row * gridDim.x + blockIdx.x] = s;
+    }
+    if (rsum_part) {      // row sums of the packed values (mean of the row once summed over the row's blocks and divided by n)
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      if (c == 0 && row < n) rsum_part[(size_t)row * gridDim.x + blockIdx.x] = s;
     }
   } else
   if (!sym && row < n && k0 + 7 < n && (ld & 3) == 0) {      // interior: two 16-byte loads
@@ -610,23 +618,23 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
   const int nkc = chunks_of(n, planes), panels = (n + TB - 1) / TB;
   dim3 grid((nkc * 2 + 7) / 8, panels * (TB / 32));
   if (planes == 2)
-    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr, nullptr);
 }
 // Panels [panel_off, panel_off + panel_rows) of the centred normalised adjacency formed from M on the fly (see k_pack);
 // rsq_part [n][split3_pack_rsq_parts(n, planes)] receives the per-block sums of squares of each packed row.
 int split3_pack_rsq_parts(int n, int planes) { return (chunks_of(n, planes) * 2 + 7) / 8; }
 void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
-                        const float* amax, int panel_off, int panel_rows, float* rsq_part) {
+                        const float* amax, int panel_off, int panel_rows, float* rsq_part, float* rsum_part) {
   const int nkc = chunks_of(n, planes), panels = (n + TB - 1) / TB;
   const int pr = panel_rows >= 0 ? panel_rows : panels;
   if (pr <= 0) return;
   dim3 grid((nkc * 2 + 7) / 8, pr * (TB / 32));
   if (planes == 2)
-    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part);
+    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part, rsum_part);
   else
-    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part);
+    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part, rsum_part);
 }
 // C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
 // (panel_rows < 0: all panels).  Tiles are independent; a row range gives the same bits as the full launch except for
