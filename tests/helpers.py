@@ -113,6 +113,18 @@ def synthetic_case(n, nfeat, widths, nclass, seed, measure="HSIC", weight_param=
     return z
 
 
+def masked_weights(z):
+    """Weights of a golden / synthetic case whose embedding-layer bias kills about half of em (the bias minus the median
+    of the relu output at the first step): the decode then masks pairs (S_ij <= 0), which voids the low-rank forms."""
+    w = weights_from(z)
+    le = cfg_from(z).emb_nlayer - 1
+    probe = oracle_from(z)
+    probe.step()
+    w.b = [b.copy() for b in w.b]
+    w.b[le] = (w.b[le] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)
+    return w
+
+
 # ---------------------------------------------------------------- GPU-side helpers
 def engine_from(pkg, z, device="cuda:0", measure=None, weight_param=None, **kw):
     """AttackEngine (C-ABI handle) set up from a golden attack case."""

@@ -753,10 +753,7 @@ def test_sharded_ranks_hand_masked_steps_to_the_general_path(pkg, monkeypatch):
     from mc_gra_amd import sharded as S
     z = _synthetic_case(600, 11, (16, 16), 4, seed=9, weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0))
     monkeypatch.setenv("MCGRA_SPLIT_BF16", "3")
-    w = H.weights_from(z)
-    probe = H.oracle_from(z); probe.step()
-    w.b = [b.copy() for b in w.b]
-    w.b[1] = (w.b[1] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)      # about half of em dies
+    w = H.masked_weights(z)      # about half of em dies: the decode masks pairs
     mono = H.engine_from(pkg, z)
     mono.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
     plans, bks = _shard_engines(pkg, z, 2)
@@ -1231,10 +1228,7 @@ def test_masked_steps_of_a_large_graph_use_the_split_gram_evaluation(pkg, monkey
     and agrees with the fp32 SYMM evaluation of the same steps."""
     import torch
     z = _synthetic_case(1100, 11, (16, 16), 4, seed=9, weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0))
-    w = H.weights_from(z)
-    probe = H.oracle_from(z); probe.step()
-    w.b = [b.copy() for b in w.b]
-    w.b[1] = (w.b[1] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)
+    w = H.masked_weights(z)      # about half of em dies: the decode masks pairs
     engs = []
     for gs in ("1", "0"):
         monkeypatch.setenv("MCGRA_GRAM_SPLIT", gs)
@@ -1265,10 +1259,7 @@ def test_fused_lowrank_hands_masked_steps_to_the_general_path(pkg, monkeypatch):
     import torch
     z = _synthetic_case(300, 11, (16, 16), 4, seed=9, weight_param=(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 0))
     monkeypatch.setenv("MCGRA_SPLIT_BF16", "3")
-    w = H.weights_from(z)
-    probe = H.oracle_from(z); probe.step()
-    w.b = [b.copy() for b in w.b]
-    w.b[1] = (w.b[1] - np.quantile(probe.last["em"], 0.5, axis=0)).astype(np.float32)      # about half of em dies
+    w = H.masked_weights(z)      # about half of em dies: the decode masks pairs
     engs = []
     for no_fused in ("0", "1"):
         monkeypatch.setenv("MCGRA_NO_FUSED_LR", no_fused)
