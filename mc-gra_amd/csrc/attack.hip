@@ -367,6 +367,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                   (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
     h->row0 = 0; h->row1 = (int)n;
     { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
+    {
+      const char* ep = getenv("MCGRA_PLANES_MM");
+      h->planes_mm_on = h->late_mean && h->split_planes == 2 && planes_mm_supported((int)n, 32) && !(ep && ep[0] == '0');
+      if (h->planes_mm_on) { A_(pm_scratch, planes_mm_scratch_bytes((int)n)); }
+    }
     if (cfg->shard_world > 0) {
       // row-block rank: only the fused step is sharded, and the host-driven bisection of the projection is not
       if (!h->fused_ok || cfg->num_edges < 0.5 * (double)n * (double)n) {

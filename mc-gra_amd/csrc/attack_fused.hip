@@ -118,6 +118,11 @@ static int mm_rows(mcgra_attack* h, hipStream_t st, int ncol) {
   if (h->sharded)
     return eg(h, st, false, false, rows, ncol, h->n, 1.f, h->M + (size_t)h->row0 * h->ld, h->ld, h->FV, h->fcols, 0.f,
               h->FY + (size_t)h->row0 * h->fcols, h->fcols);
+  if (h->planes_valid && planes_mm_supported(h->n, ncol)) {      // beside the N x N x N product: from its own operand planes
+    MCGRA_HIP(planes_mm(st, h->n, h->Bpack, split3_chunks(h->n, 2), h->amax + 1, h->FV, h->fcols, ncol, h->r, h->ws, h->ws_bytes, &h->fy,
+                        h->pm_scratch));
+    return 0;
+  }
   MCGRA_HIP(sgemm(st, false, false, rows, ncol, h->n, 1.f, h->M, h->ld, h->FV, h->fcols, 0.f, h->FY, h->fcols, h->ws, h->ws_bytes,
                   &h->fy));
   return 0;
@@ -199,6 +204,7 @@ int fused_forward(mcgra_attack* h, hipStream_t st) {      // monolithic engines 
 // host-side bookkeeping of a fused step that went through (the Adam pass is enqueued)
 static void fused_commit(mcgra_attack* h) {
   const int n = h->n;
+  h->planes_valid = false;          // the Adam pass is enqueued: Bpack no longer describes M
   const size_t cnt = (size_t)n * fl_tail_tiles(n);
   const bool may_project = h->cfg.num_edges < 0.5 * (double)n * (double)n;
   h->lr_step = true;
@@ -265,6 +271,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   if (h->fs_state == 0) {
     if (h->fs_open) CHK(fused_resync(h, st));
     h->fs_open = true;
+    h->planes_valid = false;
   }
   switch (h->fs_state) {
     case 0:
@@ -294,6 +301,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         hipLaunchKernelGGL(k_mean_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, np, psum, use2 ? h->A1 : nullptr, h->cmean, h->rowsx,
                            use2 ? h->lrRs : nullptr);
         fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->mm + 3);      // sum(mean); (the operand-scale bound stays max r^2)
+        h->planes_valid = h->planes_mm_on;
       } else
       if (p_cnt > 0) {
         split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
@@ -558,6 +566,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           }
           h->fs_state = 0;
           h->fs_open = false;
+          h->planes_valid = false;
           return 2;
         }
       }

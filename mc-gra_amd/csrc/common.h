@@ -42,6 +42,12 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                  float* ws, size_t ws_bytes, YView* keep = nullptr);
 
+// planes_mm.hip: Y = M W (skinny) from the packed fp16 planes of adj_norm, as split-K slabs described by *out
+size_t planes_mm_scratch_bytes(int n);
+bool planes_mm_supported(int n, int nc);
+hipError_t planes_mm(hipStream_t st, int n, const void* Ap, int nchunks, const float* amaxA, const float* W, int ldw, int nc,
+                     const float* r, float* ws, size_t ws_bytes, YView* out, void* scratch);
+
 // rankk_f32.hip: C = beta C + alpha1 A1 B1^T (+ alpha2 A2 B2^T), K1, K2 <= 64 (HBM-bound rank-k updates)
 bool rankk_nt_supported(int M, int N, int K1, int K2);
 hipError_t rankk_nt(hipStream_t st, int M, int N, int K1, float alpha1, const float* A1, int lda1, const float* B1,
@@ -77,6 +83,7 @@ void split_absmax(hipStream_t st, int n, int ld, const float* X, const float* su
 void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out, int planes = 3,
                  const float* amax = nullptr);
 int split3_pack_rsq_parts(int n, int planes);
+int split3_chunks(int n, int planes);   // 16-k chunks per panel of a packed operand
 void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
                         const float* amax, int panel_off, int panel_rows, float* rsq_part, float* rsum_part = nullptr);
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,

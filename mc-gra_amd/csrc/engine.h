@@ -145,6 +145,10 @@ struct mcgra_attack {
   // packed uncentred -- (H Kf H) 1 = 0, so P1 is the same up to 1e-7 -- and the means are only needed behind the pack.
   // MCGRA_LATE_MEAN=0 disables (A/B).
   bool late_mean = false;
+  // ... and with uncentred planes of the CURRENT M in Bpack (between the pack of a step and its Adam pass) the skinny
+  // products on M that run beside the N x N x N product read those planes (planes_mm.hip).  MCGRA_PLANES_MM=0 disables.
+  bool planes_mm_on = false, planes_valid = false;
+  char* pm_scratch = nullptr;
   int64_t fused_steps = 0;
   // row-block sharding (mcgra_attack_shard_*): this rank owns rows [row0, row1) of M / am / av
   bool sharded = false;

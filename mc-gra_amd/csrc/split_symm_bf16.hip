@@ -709,5 +709,6 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   return hipGetLastError();
 }
 int split3_panel() { return TB; }
+int split3_chunks(int n, int planes) { return chunks_of(n, planes); }
 
 }  // namespace mcgra

@@ -1069,12 +1069,15 @@ def test_fused_tail_matches_separate_kernels(pkg, n, measure, monkeypatch):
     the mirrored gradient agrees to rounding of the final sum and the state stays symmetric bit for bit."""
     import torch
     z = _synthetic_case(n, 11, (16, 8), 4, seed=n, measure=measure)
+    monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")       # both through the general path (n >= 1024 would take the fused step)
     a = H.engine_from(pkg, z)
     monkeypatch.setenv("MCGRA_NO_FUSED_TAIL", "1")
     b = H.engine_from(pkg, z)
     monkeypatch.delenv("MCGRA_NO_FUSED_TAIL")
+    monkeypatch.delenv("MCGRA_NO_FUSED_LR")
     for t in range(3):
         a.step(); b.step()
+        assert a.fused_steps() == 0 and b.fused_steps() == 0
         ga, gb = a.buffer("G_sym"), b.buffer("G_sym")
         assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max()), t
         ma = a.buffer("M")
