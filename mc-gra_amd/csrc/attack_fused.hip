@@ -147,8 +147,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         launch_prep(st, false, n, ld, h->M, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum, R0, R1);
       }
       if (!h->sharded) {
-        launch_reduce_rows(st, h->rowsq, n, 1, h->scal + S_SQ);
-        launch_reduce_rows(st, h->rowsum, n, 1, h->scal + S_SUM);
+        launch_reduce_rows(st, h->rowsq, n, 2, h->scal + S_SQ);      // rowsq | rowsum are adjacent, and so are S_SQ | S_SUM
       } else {
         MCGRA_HIP(hipMemsetAsync(h->SC, 0, 2 * sizeof(double), st));
         if (R1 > R0) {
@@ -236,6 +235,23 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   return 0;
 }
 
+// k_tail_reduce of the step (phase 1: only its rank-k panels are packed -- their inputs are ready before the N x N x N
+// product is joined; 2: the pass itself).  Returns the number of blocks (partials of the loss-term values).
+static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pair, int R0, int R1, bool use1, bool use2, float a1,
+                            float a2, float kie6, bool want_vals) {
+  const int n = h->n, hs = h->hsum, he = h->wdt[h->Le - 1], nt = fl_tail_tiles(n);
+  float* ps1 = h->KY;                                            // [n][nt]: idle (the product's split-K slabs are done)
+  double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
+  const float* Ls[2] = {h->GPv, h->lrL};
+  const float* Rs[2] = {h->Tv, h->lrR};
+  const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
+  const bool no_rk = h->test_mutate == 2;      // (TEST-ONLY mutation, see the join below)
+  const float al[2] = {no_rk ? 0.f : 1.f, no_rk ? 0.f : a2};
+  return fl_tail_reduce(st, n, h->ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M,
+                        use1 ? h->KX : nullptr, h->r, h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr, a1, a2, kie6,
+                        h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf, phase);
+}
+
 // Returns 1 at an exchange point, 0 when the step is done, 2 when the step must be redone by the general path (a
 // relu-masked pair in the decode; every rank then holds the full M / am / av), < 0 on error.
 static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
@@ -285,11 +301,6 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (rc == 1) { h->fs_state = 1; return 1; }
         if (rc < 0) return rc;
       }
-      if (want_vals) MCGRA_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(double) * (S_COUNT - 2), st));
-      // embedding(features, adj_norm) of this iteration (= the victim chain's activations: shared weights, main.py:190),
-      // kept for the post-loop decode (:300): adj_norm itself is never stored
-      MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
-                                 hipMemcpyDeviceToDevice, st));
       // planes of Xc^T rows straight from M, |xc_i|^2 from the same pass
       if (h->late_mean) {
         // uncentred planes ((H Kf H) 1 = 0: the product does not see the centring vector), row sums and sums of squares of
@@ -326,6 +337,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (ovl) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
         h->p1_inflight = true;
       }
+
+      // (behind the fork: nothing in front of the product needs them)
+      if (want_vals) MCGRA_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(double) * (S_COUNT - 2), st));
+      // embedding(features, adj_norm) of this iteration (= the victim chain's activations: shared weights, main.py:190),
+      // kept for the post-loop decode (:300): adj_norm itself is never stored
+      MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
+                                 hipMemcpyDeviceToDevice, st));
 
       // ---- small-operand terms c9 (:237-258) and c10 (:259-272): they need only the forward, and at small n their ~16
       //      tiny launches are a tenth of the step -- forked onto a third stream, joined in front of the backward of em
@@ -487,8 +505,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
       MCGRA_KERNEL_CHECK();
 
-      // ---- tail: everything above ran beside the forked product.  A row-block rank holds the column block
+      // ---- tail: everything above ran beside the forked product; so do the two tiny launches of the tail that need
+      //      nothing of it (the rank-k panels, the coefficient of the norm term).  A row-block rank holds the column block
       //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
+      (void)tail_reduce_call(h, st, 1, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
+      hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
       CHK(join());
       // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result, =rk drops
       // the rank-k terms of the tail (both GCN chains' backward and the low-rank term of c2) from the gradient -- a parity
@@ -512,16 +533,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         }
       }
       {
-        float* ps1 = h->KY;                                            // [n][nt]: idle (the product's split-K slabs are done)
+        float* ps1 = h->KY;
         double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
-        const float* Ls[2] = {h->GPv, h->lrL};
-        const float* Rs[2] = {h->Tv, h->lrR};
-        const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
-        const bool no_rk = h->test_mutate == 2;
-        const float al[2] = {no_rk ? 0.f : 1.f, no_rk ? 0.f : a2};
-        h->fs_nblk = fl_tail_reduce(st, n, ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M,
-                                    use1 ? h->KX : nullptr, h->r, h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr,
-                                    a1, a2, (float)(k6 / n2), h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf);
+        h->fs_nblk = tail_reduce_call(h, st, 2, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
         if (h->sharded) MCGRA_HIP(hipMemsetAsync(h->SC + 4, 0, 3 * sizeof(double), st));
         if (h->fs_nblk > 0 && want_vals) {
           launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? h->SC + 4 : h->scal + S_H1);
@@ -574,7 +588,6 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         const double b1 = 0.9, b2 = 0.999;
         const int64_t t = h->t + 1;                          // (the host's count moves in fused_commit)
         const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
-        hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
         const bool may_project = c.num_edges < 0.5 * n2;
         const size_t cnt = (size_t)n * nt;
         const bool emit = !may_project && 3 * cnt + 4 <= (size_t)n * ld;

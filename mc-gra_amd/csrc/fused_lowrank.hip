@@ -733,12 +733,13 @@ size_t fl_tail_pack_bytes(int n) {
 
 // vpart (nullable): nblk v1 partials followed by nblk v6 partials, nblk = nt * (tile rows) = the return value.  The rank-k
 // terms {L, R, K, alpha} (K <= 64 each, at most two) feed Gs; {Lu, Ru, Ku} (the modified_adj chain) is added to G2 unscaled.
-// rkbuf: fl_tail_pack_bytes(n) of scratch for the packed panels.
+// rkbuf: fl_tail_pack_bytes(n) of scratch for the packed panels.  phase: 0 = pack the panels and run the pass, 1 = pack
+// only, 2 = the pass only (same arguments as the phase-1 call).
 int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
                    const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha,
                    const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
-                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf) {
+                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase) {
   const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
   if (t1 <= t0) return 0;
   RkPackJobs J{};
@@ -761,7 +762,9 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
   };
   for (int f = 0; f < nfac; ++f) add(F, L[f], ldl[f], R[f], ldr[f], K[f], alpha[f]);
   if (Ku > 0) add(FU, Lu, ldlu, Ru, ldru, Ku, 1.f);
-  LAUNCH(k_pack_rk, dim3(nt, J.count), dim3(256), st, n, J);
+  // phase 1: only the panels are packed (their inputs are ready before the N x N x N product is joined); 2: only the pass
+  if (phase != 2) LAUNCH(k_pack_rk, dim3(nt, J.count), dim3(256), st, n, J);
+  if (phase == 1) return nt * (t1 - t0);
   dim3 grid(nt, t1 - t0);
   if (vpart)
     LAUNCH(k_tail_reduce<true>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, M, P1, r, mean, delta, cvec, a1, a2, kie6, G2, ps, vpart);

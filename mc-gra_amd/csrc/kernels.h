@@ -139,7 +139,7 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
                    const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha,
                    const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
-                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf);
+                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase = 0);
 size_t fl_tail_pack_bytes(int n);
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd);
 void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* G2, const float* gd, float* M,
