@@ -309,10 +309,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
         split3_pack_from_m(st, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
                            use2 ? h->A1 : nullptr, psum);
-        hipLaunchKernelGGL(k_mean_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, np, psum, use2 ? h->A1 : nullptr, h->cmean, h->rowsx,
-                           use2 ? h->lrRs : nullptr);
-        fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->mm + 3);      // sum(mean); (the operand-scale bound stays max r^2)
-        h->planes_valid = h->planes_mm_on;
+        h->planes_valid = h->planes_mm_on;          // (the means themselves: behind the fork, below)
       } else
       if (p_cnt > 0) {
         split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
@@ -339,6 +336,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
 
       // (behind the fork: nothing in front of the product needs them)
+      if (h->late_mean) {
+        const int np = split3_pack_rsq_parts(n, h->split_planes);
+        const float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
+        hipLaunchKernelGGL(k_mean_fin, dim3((n + 3) / 4), dim3(256), 0, st, n, np, psum, use2 ? h->A1 : nullptr, h->cmean, h->rowsx,
+                           use2 ? h->lrRs : nullptr);
+        fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->mm + 3);      // sum(mean); (the operand-scale bound stays max r^2)
+      }
       if (want_vals) MCGRA_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(double) * (S_COUNT - 2), st));
       // embedding(features, adj_norm) of this iteration (= the victim chain's activations: shared weights, main.py:190),
       // kept for the post-loop decode (:300): adj_norm itself is never stored
