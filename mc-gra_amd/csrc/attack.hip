@@ -369,7 +369,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
     {
       const char* ep = getenv("MCGRA_PLANES_MM");
-      h->planes_mm_on = h->late_mean && h->split_planes == 2 && planes_mm_supported((int)n, 32) && !(ep && ep[0] == '0');
+      // default from n = 8192: on smaller graphs the step is bound by its chain of launches, and the two extra launches per
+      // product (magnitude + pack of the right-hand side) cost more than the matrix-pipe time they free (Cora-shape step
+      // 0.51 -> 0.56 ms, N = 4096 0.86 -> 0.92 ms with it); MCGRA_PLANES_MM=1 forces it on (tests), =0 off
+      const bool want_pm = (ep && ep[0]) ? ep[0] == '1' : n >= 8192;
+      h->planes_mm_on = h->late_mean && h->split_planes == 2 && planes_mm_supported((int)n, 32) && want_pm;
       if (h->planes_mm_on) { A_(pm_scratch, planes_mm_scratch_bytes((int)n)); }
     }
     if (cfg->shard_world > 0) {

@@ -1087,6 +1087,32 @@ def test_fused_tail_matches_separate_kernels(pkg, n, measure, monkeypatch):
 
 
 # ---- the fused low-rank step (attack_fused.hip): N x N quantities from M and n-vectors only -------------------------
+@pytest.mark.parametrize("n,widths", [(1100, (16, 16)), (1283, (16, 8)), (1030, (16, 16, 16))])
+def test_skinny_products_from_the_operand_planes(pkg, n, widths, monkeypatch):
+    """planes_mm.hip (default from n = 8192, forced on here): the skinny products of the fused step that run beside the
+    N x N x N product read the fp16 planes of its operand, M W = R^-1 adj_norm (R^-1 W) - W at 22 significant bits, instead
+    of M through the fp32 kernel.  Same step, same start: the mirrored gradient agrees to 1e-5 of its largest magnitude,
+    the loss terms to 1e-6, the state stays symmetric bit for bit."""
+    import torch
+    z = _synthetic_case(n, 11, widths, 4, seed=n)
+    monkeypatch.setenv("MCGRA_PLANES_MM", "1")
+    a = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_PLANES_MM", "0")
+    b = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_PLANES_MM")
+    for t in range(3):
+        sa = a.step(want_scalars=True); a.monitor()
+        sb = b.step(want_scalars=True); b.monitor()
+        ga, gb = a.buffer("G_sym"), b.buffer("G_sym")
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()), t
+        for k in ("loss", "c1", "c2", "c9", "c10"):
+            assert sa[k] == pytest.approx(sb[k], rel=1e-6, abs=1e-6 * abs(sb["loss"])), (t, k)
+        M = a.buffer("M")
+        assert torch.equal(M, M.t())
+        b.set_adj_changes(a.get_adj_changes())
+    assert a.fused_steps() == 3 and b.fused_steps() == 3
+
+
 @pytest.mark.parametrize("n,widths,wp,split", [
     (1100, (16, 16), None, None), (1283, (16, 8), NXN_ONLY, None), (700, (16, 16), NXN_ONLY, "3"),
     (1100, (16, 16, 16), None, None), (515, (8, 8), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), "2"),
