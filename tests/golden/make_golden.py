@@ -601,7 +601,12 @@ def gen_bench(tmp, workload="synthetic-10k-hsic", tag="bench10k_hsic", seed=0, e
     `one1` at twice (small-operand terms in charge); lr is the workload's (bench.workload_lr)."""
     os.chdir(tmp)
     os.makedirs("saved_data", exist_ok=True)
-    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    # bench.py of the repository (the generator and the start scale are its): beside this script's tests/golden, or -- for
+    # a copy of this script run elsewhere -- $MCGRA_REPO, or /root/repo
+    for root in (os.path.dirname(os.path.dirname(OUT)), os.environ.get("MCGRA_REPO", ""), "/root/repo"):
+        if root and os.path.exists(os.path.join(root, "bench.py")):
+            sys.path.insert(0, root)
+            break
     import bench as B
     n, f, c, hid, nl, measure, wp = B.WORKLOADS[workload]
     inp = B.make_inputs(n, f, c, hid, nl, seed)
