@@ -501,6 +501,100 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     }
   };
 
+  if constexpr (MODE == 3) {
+    // ---- staggered wave groups (MCGRA_SPLIT_LOOP=3).  A step is cut into four phases of two row tiles (24 MFMAs per wave)
+    // with a raw s_barrier behind each; the waves of row group wm = 1 run ONE PHASE behind those of wm = 0 (they take one
+    // barrier more in front of the loop, the others one more behind it).  Each SIMD holds one wave of either group, so the
+    // head of a step -- ten fragment reads with nothing to multiply yet -- of one wave sits under the last / second phase
+    // of the other wave's MFMAs instead of idling the matrix pipe.  Staging by region, counted waits, never vmcnt(0) in
+    // the steady state:
+    //   A rows of the own group (16 KB, read all step long by the own group only): stage s+1 issued in phase 0 of step s
+    //     (the barrier just passed ended the own group's reads of that buffer), awaited in front of the barrier that ends
+    //     phase 3 (vmcnt(4): the copies of B issued behind it may stay in flight), read from phase 0 of step s+1;
+    //   B (32 KB, read by both groups in their phase 0 only -- the eight B fragments stay in registers): stage s+2 issued in
+    //     phase 2 of step s (both groups read stage s at least one barrier ago), awaited in front of the barrier that ends
+    //     phase 2 of step s+1 (vmcnt(8)), i.e. two barriers ahead of the other group's read: a wait retires copies for
+    //     the waiting wave only, the barrier behind it publishes them.
+    const int gw = wave & 3;
+    auto load_a = [&](int kc, int stage) {
+      const char* src = Ap + ((size_t)tile_m * nks + kc_begin + kc) * (2 * OPB);
+      char* dst = smem + stage * STAGE;
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) {
+        const int piece = gw * 4 + p4, seg = piece >> 1;       // segment (chunk, plane, k half): 128 rows x 16 B of this group
+        const int off = (seg >> 2) * OPB + ((seg >> 1) & 1) * PLANE + (seg & 1) * (PLANE / 2) + wm * 2048 + (piece & 1) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + off + lane * 16), (lptr_t)(dst + off), 16, 0, 0);
+      }
+    };
+    auto load_b = [&](int kc, int stage) {
+      const char* src = Bp + ((size_t)tile_n * nks + kc_begin + kc) * (2 * OPB) + wave * 4096;
+      char* dst = smem + stage * STAGE + 2 * OPB + wave * 4096;
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + p4 * 1024 + lane * 16), (lptr_t)(dst + p4 * 1024), 16, 0, 0);
+    };
+    auto bar = [&]() {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    if (nk > 0) {
+      load_a(0, 0);
+      load_b(0, 0);
+      if (nk > 1) load_b(1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      const bool late = __builtin_amdgcn_readfirstlane(wm) != 0;
+      if (late) bar();
+      f16x8 b0[4], b1[4], a0, a1;
+      for (int kc = 0; kc < nk; ++kc) {
+        const char* s = smem + (kc & 1) * STAGE;
+        auto rows2 = [&](int i0) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = i0 + ii;
+            f16x8 n0 = a0, n1 = a1;
+            if (i + 1 < 8) {
+              n0 = frag(s, a_off + (i + 1) * 256);
+              n1 = frag(s, a_off + (i + 1) * 256 + PLANE);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc[i][j], 0, 0, 0);
+            a0 = n0; a1 = n1;
+          }
+        };
+        // phase 0
+        if (kc + 1 < nk) load_a(kc + 1, (kc + 1) & 1);
+        a1 = frag(s, a_off + PLANE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = frag(s, b_off + j * 256);
+        a0 = frag(s, a_off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = frag(s, b_off + j * 256 + PLANE);
+        rows2(0);
+        bar();
+        // phase 1
+        rows2(2);
+        bar();
+        // phase 2
+        if (kc + 2 < nk) load_b(kc + 2, kc & 1);
+        rows2(4);
+        if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        bar();
+        // phase 3
+        rows2(6);
+        if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bar();
+      }
+      if (!late) bar();
+    }
+  } else
   if (nk > 0) {
     stage_tile(0, 0);
     __syncthreads();                      // (waits for the copies of this wave, then for everybody's)
@@ -509,6 +603,8 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
         multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
         __syncthreads();
       }
+    } else if constexpr (MODE == 3) {
+      // (unreachable: MODE 3 has its own loop below)
     } else {
     int kc = 0;
     // steady state without a condition around the staging: the head reads, the copies and the first MFMAs then sit in
@@ -678,7 +774,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
       // reads (one basic block: counted lgkmcnt waits).  Measured on one box, three alternating runs each: the product ALONE
       // 4.48-4.51 ms against 4.58-4.60 ms of the default, but 5.14-5.21 against 4.99-5.04 ms beside the step's other
       // kernels (153-154 against 157-158 steps/s): the default loop stays.
-      static const int mode = [] { const char* e = getenv("MCGRA_SPLIT_LOOP"); return e && e[0] == '2' ? 2 : 0; }();
+      static const int mode = [] { const char* e = getenv("MCGRA_SPLIT_LOOP"); return e && e[0] == '2' ? 2 : (e && e[0] == '3' ? 3 : 0); }();
       constexpr int smem_ = smem;
 #define MCGRA_LAUNCH_M16(MODE_)                                                                                              \
       {                                                                                                                       \
@@ -689,6 +785,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
         return hipSuccess;                                                                                                    \
       }
       if (mode == 0) MCGRA_LAUNCH_M16(0)
+      if (mode == 3) MCGRA_LAUNCH_M16(3)
       MCGRA_LAUNCH_M16(2)
 #undef MCGRA_LAUNCH_M16
     }

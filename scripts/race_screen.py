@@ -32,6 +32,8 @@ for n in (257, 1000, 2708, 4100, 6000, 10000):
         if not torch.equal(out, first):
             mism += 1
     bad += mism + (err > 1e-6)
-    print(f"n={n}: err vs fp64 {err:.2e}, {mism} of {reps} repetitions differ", flush=True)
+    import hashlib
+    digest = hashlib.sha1(first.cpu().numpy().tobytes()).hexdigest()[:16]      # (same bits for every MCGRA_SPLIT_LOOP)
+    print(f"n={n}: err vs fp64 {err:.2e}, {mism} of {reps} repetitions differ, sha1 {digest}", flush=True)
 print("RACE SCREEN", "FAILED" if bad else "clean")
 sys.exit(1 if bad else 0)

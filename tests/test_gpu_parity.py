@@ -1035,6 +1035,45 @@ def test_split_bf16_product_against_fp64(pkg, torch_, n, arith):
     assert err.max() <= 4 * (np.abs(f32 - ref) / scale).max() + 2e-7
 
 
+_SPLIT_LOOP_PROBE = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.environ["MCGRA_TEST_ROOT"])
+import numpy as np
+import torch
+import mcgra_loader
+mcgra_loader.load()
+from mc_gra_amd import engine as E
+for n in (1000, 2708, 4100):
+    rng = np.random.RandomState(n)
+    F = rng.randn(n, 24).astype(np.float32)
+    S = (F @ F.T).astype(np.float32); S = (S + S.T) * 0.5
+    X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1
+    sub = rng.rand(n).astype(np.float32) * 0.05
+    outs = [E.ssymm_split_f16(torch.tensor(S, device="cuda"), torch.tensor(X, device="cuda"), torch.tensor(sub, device="cuda")).cpu().numpy()
+            for _ in range(3)]
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
+    print("DIGEST", n, hashlib.sha1(outs[0].tobytes()).hexdigest())
+"""
+
+
+def test_split_loop_variants_give_the_default_loops_bits(pkg):
+    """MCGRA_SPLIT_LOOP=2 (peeled loop, copies first) and =3 (two wave groups one phase apart, four raw barriers per
+    step, counted vmcnt waits) keep the MFMA order of every accumulator: their results are the default loop's, bit for
+    bit, at sizes with a split-K tail and with padded chunks -- a lost copy or an early fragment read would show here
+    (the switch is read once per process: one child per value)."""
+    import subprocess
+    import sys
+    digests = {}
+    for mode in ("0", "2", "3"):
+        env = dict(os.environ, MCGRA_SPLIT_LOOP=mode, MCGRA_TEST_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", _SPLIT_LOOP_PROBE], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[mode] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+        assert len(digests[mode]) == 3
+    assert digests["2"] == digests["0"]
+    assert digests["3"] == digests["0"]
+
+
 @pytest.mark.parametrize("scale", [1.0, 3.0e-12, 7.0e11])
 def test_split_f16_product_operand_scales(pkg, torch_, scale):
     """The fp16 planes live in [2^-24, 2^16): the kernel's exact power-of-two operand scales must make the result
