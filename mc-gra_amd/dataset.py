@@ -50,6 +50,9 @@ class Dataset():
         assert np.abs(adj - adj.T).sum() == 0, "Input graph is not symmetric"
         return adj, features, labels
 
+    # lines of <name>_A.txt the reference reads (dataset.py:255, :295): usair's file holds 13 599, the last 17 are never seen
+    EDGE_LINES = {'usair': 13582, 'brazil': 1074}
+
     def _load_edge_list(self, name):
         f = np.loadtxt(osp.join(self.root, name, f'{name}_lable.txt'))
         ids, labels = f[:, 0], f[:, 1]
@@ -57,10 +60,8 @@ class Dataset():
         n = len(ids)
         g = np.zeros((n, n))
         with open(osp.join(self.root, name, f'{name}_A.txt')) as fh:
-            for line in fh:
-                row = line.strip().split()
-                if len(row) < 2:
-                    continue
+            for _ in range(self.EDGE_LINES[name]):
+                row = fh.readline().strip().split()
                 i, j = int(row[0]), int(row[1])
                 g[pos[i], pos[j]] = 1
                 g[pos[j], pos[i]] = 1

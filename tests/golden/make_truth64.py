@@ -6,6 +6,7 @@ O(1) Gram entries in fp32), which bounds what "equal to the reference" can mean 
 
     python tests/golden/make_truth64.py          (~10 min and ~30 GB per start on 8 cores)
     python tests/golden/make_truth64.py mid      (the n = 1200 fixture, seconds)
+    python tests/golden/make_truth64.py readme   (the README-line fixtures on brazil / usair / polblogs / AIDS, ~2 min)
 
 Writes tests/golden/bench10k_hsic_fp64.npz: for each start of the fixture (`run`, `one0`, ...) `<name>_g64` = the
 mirrored packed gradient of its first step at `packed_pos`, plus its largest magnitude over the whole vector."""
@@ -85,8 +86,43 @@ def mid(tag="mid_s1200_hsic_sparse"):
     np.savez_compressed(os.path.join(OUT, f"{tag}_fp64.npz"), packed_pos=z["packed_pos"], step0_g64=g64, step0_g64_absmax=gmax)
 
 
+def readme():
+    """The same for the README-line fixtures (make_golden.py --only readme): first-step gradient of the float64 oracle at each
+    fixture's packed positions -> tests/golden/readme_fp64.npz (`<fixture>_g64` as float32, `<fixture>_gmax`); ~2 min."""
+    from tests import helpers as H
+    O.F32 = np.float64
+    f8 = lambda x: np.asarray(x).astype(np.float64)
+    out = {}
+    for name in H.readme_cases():
+        z = H.load_readme(name)
+        n = len(z["labels"])
+        w0 = H.weights_from(z)
+        w = O.GCNWeights([f8(x) for x in w0.W], [f8(x) for x in w0.b], f8(w0.Wlin), f8(w0.blin))
+        X = f8(z["features"])
+        if str(z["dataset"]) in ("cora", "citeseer", "AIDS"):                      # main.dot_product_decode (main.py:44-55)
+            fadj = 1.0 / (1.0 + np.exp(-np.maximum(X @ X.T - np.eye(n), 0)))
+        else:
+            Xn = X / np.maximum(np.sqrt((X ** 2).sum(1, keepdims=True)), 1e-12)
+            fadj = np.maximum(Xn @ Xn.T - np.eye(n), 0)
+        orc = O.PGDAttackOracle(w, X, f8(z["adj"]), np.zeros((n, n)), fadj, z["labels"], z["idx_attack"], H.cfg_from(z))
+        orc.w = w
+        if H.a0_of(z) is not None:
+            orc.set_adj_changes(f8(H.a0_of(z)))
+        nz = H.noise_of(z, 0)
+        orc.step(noise=f8(nz)) if nz is not None else orc.step()
+        pi, pj = H.tril_pos(z["packed_pos"])
+        G = orc.last["G_sym"]
+        g64, gmax = G[pi, pj].astype(np.float64), float(np.abs(G).max())
+        out[f"{name}_g64"] = g64.astype(np.float32)
+        out[f"{name}_gmax"] = gmax
+        print(name, "reference fp32 vs float64 oracle: max err / gmax =", np.abs(z["step_g"][0] - g64).max() / gmax, flush=True)
+    np.savez_compressed(os.path.join(OUT, "readme_fp64.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mid":
         mid()
+    elif len(sys.argv) > 1 and sys.argv[1] == "readme":
+        readme()
     else:
         main()

@@ -75,6 +75,38 @@ def load_cora(name):
     return z
 
 
+def readme_cases():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "readme_*.npz")) if not p.endswith("_fp64.npz"))
+
+
+def main_feature_adj(feats, dataset):
+    """main.dot_product_decode (main.py:44-55): sigmoid(relu(X X^T - I)) for cora / citeseer / AIDS, relu(Xn Xn^T - I) on
+    row-normalised attributes for the other datasets."""
+    X = np.asarray(feats, np.float32)
+    if dataset in ("cora", "citeseer", "AIDS"):
+        return cora_feature_adj(X)
+    nrm = np.maximum(np.sqrt((X.astype(np.float64) ** 2).sum(1, keepdims=True)), 1e-12)
+    Xn = (X / nrm).astype(np.float32)
+    return np.maximum(Xn @ Xn.T - np.eye(X.shape[0], dtype=np.float32), 0).astype(np.float32)
+
+
+def load_readme(name):
+    """A README-line fixture of tests/golden/make_golden.py:gen_readme in the layout of load_case: the graph rebuilt from
+    its edges and diagonal, identity attributes from their flag, feature_adj by the dataset's rule."""
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    z = {k: z[k] for k in z.files}
+    n = len(z["labels"])
+    adj = np.zeros((n, n), np.float32)
+    e = z["adj_edges"]
+    adj[e[:, 0], e[:, 1]] = 1
+    adj[e[:, 1], e[:, 0]] = 1
+    adj[np.arange(n), np.arange(n)] = z["adj_diag"].astype(np.float32)
+    z["adj"] = adj
+    z["features"] = np.eye(n, dtype=np.float32) if int(z["features_identity"]) else z["features_f32"]
+    z["feature_adj"] = main_feature_adj(z["features"], str(z["dataset"]))
+    return z
+
+
 def tril_pos(p):
     """packed position (torch.tril_indices(n, n, -1) order, topology_attack.py:369) -> (row, col)"""
     p = np.asarray(p, dtype=np.int64)
