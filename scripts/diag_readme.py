@@ -1,6 +1,6 @@
-"""GPU box: the reference's README lines on brazil / usair / polblogs / AIDS (tests/golden/readme_*.npz) through the engine:
-first-step gradient against the float64 truth and the reference, AUC against the reference's, which step implementation ran,
-time per step.  -> profiles/r03_readme_lines.txt"""
+"""GPU box: the reference's README lines (tests/golden/readme_*.npz: cora, citeseer, polblogs, usair, brazil, AIDS) through the
+engine: first-step gradient against the float64 truth and the reference, AUC against the reference's (and the reference's
+own distance from the float64 run), which step implementation ran, time per step.  -> profiles/r03_readme_lines.txt"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +12,7 @@ from oracle import mcgra_oracle as O
 from mc_gra_amd.topology_attack import _decode_mode
 
 TRUTH = np.load(os.path.join(H.GOLDEN, "readme_fp64.npz"))
-print(f"{'fixture':34s} {'n':>5s} {'README':>6s} {'measure':8s} {'lr':>8s} {'g0 vs fp64':>10s} {'ref vs fp64':>11s} {'AUC ref':>9s} {'AUC diff':>9s} {'fused':>5s} {'ms/step':>8s}")
+print(f"{'fixture':34s} {'n':>5s} {'README':>6s} {'measure':8s} {'lr':>8s} {'g0 vs fp64':>10s} {'ref vs fp64':>11s} {'AUC ref':>9s} {'AUC diff':>9s} {'ref-fp64':>9s} {'fused':>5s} {'ms/step':>8s}")
 for name in H.readme_cases():
     z = H.load_readme(name)
     n = len(z["labels"])
@@ -42,5 +42,5 @@ for name in H.readme_cases():
     for _ in range(20):
         eng.step(noise=torch.randn(n, n, device="cuda:0") if float(z["eps"]) != 0 else None)
     torch.cuda.synchronize(); ms = (time.time() - t0) / 20 * 1e3
-    print(f"{name:34s} {n:5d} {int(z['readme_line']):6d} {str(z['measure']):8s} {float(z['lr']):8.1e} {e0:10.1e} {r0:11.1e} {float(z['auc']):9.6f} {abs(auc - float(z['auc'])):9.1e} {fused:5d} {ms:8.3f}")
+    print(f"{name:34s} {n:5d} {int(z['readme_line']):6d} {str(z['measure']):8s} {float(z['lr']):8.1e} {e0:10.1e} {r0:11.1e} {float(z['auc']):9.6f} {abs(auc - float(z['auc'])):9.1e} {abs(float(TRUTH[name + '_auc64']) - float(z['auc'])):9.1e} {fused:5d} {ms:8.3f}")
     eng.close()

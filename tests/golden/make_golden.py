@@ -519,20 +519,25 @@ def gen_mid(tmp):
     print(name, "auc", res["auc"], "gmax per step", np.abs(sg).max(1), flush=True)
 
 
-# README.md command lines on the reference's other datasets (dataset.py: brazil / usair edge lists with identity features,
-# polblogs.npz without attributes, AIDS with 4 real-valued attributes): (tag, README line, measure, use flags, weight_sup,
-# lr exponent, eps, w1..w10 by position, start).  `start` None = the README's own start (adj_changes = 0); (seed, kappa) =
-# a seeded start U[0, 1) * kappa / n (scripts/nxn_share.py: where the N x N terms carry the gradient).  KDE lines cannot
-# run on the reference's CPU path (utils.py:990 hard-codes cuda:0).
+# README.md command lines of the reference, every one its CPU path can run: (tag, README line number, measure, use flags
+# (H_A, Y_A, Y), weight_sup, lr exponent, eps, w1..w10 by position, start).  `start` None = the README's own start
+# (adj_changes = 0); (seed, kappa) = a seeded start U[0, 1) * kappa / n with lr = kappa / (50 n) (scripts/nxn_share.py: where
+# the N x N terms carry the gradient).  Not here: the three --measure=KDE lines (13, 133 and brazil's: utils.py:990
+# hard-codes cuda:0); the eps != 0 lines at n > 1000 (104, 112, 120: the recorded noise is 5.6 - 29 MB per step; eps != 0 is
+# pinned on brazil's line 149 and at n <= 300); line 29 (tests/golden/cora_mse_*.npz).  Lines 116 and 120 sit in the README's
+# usair section but name no dataset: they run on cora, as written.
 README_RUNS = {
     "brazil": [
         ("kl_h", 125, "KL", (1, 0, 0), 0.0, -1.0, 0.0, {1: 0.001, 2: 0.1, 6: 100, 7: 1000, 9: 0.01}, None),
+        ("mse_y", 129, "MSELoss", (0, 1, 0), 0.0, -1.5, 0.0, {1: 0.0001, 6: 0.1, 10: 1}, None),
         ("mse_hy", 137, "MSELoss", (1, 1, 0), 0.0, -2.5, 0.0, {1: 0.0001, 2: 1, 6: 0.0001, 7: 0.001, 9: 100, 10: 1000}, None),
+        ("kl_hY", 141, "KL", (1, 0, 1), 1.0, -2.0, 0.0, {1: 0.001, 2: 100, 7: 0.01, 9: 0.001}, None),
         ("dp_yy", 145, "DP", (0, 1, 1), 1.0, -1.0, 0.0, {6: 10000, 10: 1}, None),
         ("kl_all_eps", 149, "KL", (1, 1, 1), 1.0, 0.0, 0.077458886396933, {1: 10, 2: 0.001, 6: 0.1, 9: 0.1, 10: 100}, None),
     ],
     "usair": [
         ("mse_h", 96, "MSELoss", (1, 0, 0), 0.0, -3.0, 0.0, {2: 100, 6: 100, 7: 10000, 9: 100}, None),
+        ("mse_y", 100, "MSELoss", (0, 1, 0), 0.0, -2.0, 0.0, {1: 1000, 6: 0.01, 10: 0.001}, None),
         # line 108 from the sparse start.  From its own start (adj_changes = 0) the reference's c9 / c10 gradients are
         # rounding noise on this dataset: with identity attributes and an empty graph H_A-vs-em and Y_A-vs-softmax HSIC
         # are 1e-18 / 1e-11 in float64, the fp32 Gram evaluation returns a gradient of largest magnitude 88 where the
@@ -542,6 +547,8 @@ README_RUNS = {
     "polblogs": [
         ("kl_h", 65, "KL", (1, 0, 0), 0.0, -2.5, 0.0, {1: 0.0001, 7: 100, 9: 1000}, None),
         ("dp_y", 69, "DP", (0, 1, 0), 0.0, -2.5, 0.0, {6: 100, 10: 1}, None),
+        ("mse_Y", 73, "MSELoss", (0, 0, 1), 1.0, -2.5, 0.0, {1: 10, 6: 1000}, None),
+        ("mse_hy", 77, "MSELoss", (1, 1, 0), 0.0, -3.0, 0.0, {1: 100, 2: 1, 6: 0.1, 7: 0.01, 9: 1000}, None),
         ("hsic_hY", 81, "HSIC", (1, 0, 1), 1.0, -1.0, 0.0, {1: 0.1, 2: 0.01, 6: 100, 7: 10000, 9: 0.001}, None),
         ("cka_yy", 85, "CKA", (0, 1, 1), 1.0, 0.0, 0.0, {1: 0.01, 6: 100}, None),
         # line 90 from the sparse start (c2 through the fused low-rank step at n = 1490; c1 is off on this dataset: identity
@@ -552,21 +559,42 @@ README_RUNS = {
     ],
     "AIDS": [
         ("kl_h", 154, "KL", (1, 0, 0), 0.0, -3.0, 0.0, {1: 1, 2: 1000, 6: 10000, 7: 0.01, 9: 1000}, None),
+        ("mse_y", 158, "MSELoss", (0, 1, 0), 0.0, -2.5, 0.0, {1: 1, 6: 1, 10: 0.01}, None),
         ("cka_Y", 162, "CKA", (0, 0, 1), 1.0, -2.5, 0.0, {1: 1, 6: 0.0001}, None),
         ("mse_hy", 166, "MSELoss", (1, 1, 0), 0.0, 0.0, 0.0, {6: 0.001, 7: 10, 9: 1, 10: 100}, None),
         ("mse_hY", 170, "MSELoss", (1, 0, 1), 1.0, -1.0, 0.0, {1: 10, 6: 0.0001, 7: 1, 9: 0.1}, None),
+        ("mse_yY", 174, "MSELoss", (0, 1, 1), 1.0, -2.5, 0.0, {1: 100}, None),
+        ("kl_all", 179, "KL", (1, 1, 1), 1.0, -3.0, 0.0, {1: 0.0001, 2: 1, 7: 100, 9: 1000, 10: 0.0001}, None),
         # not a README line: HSIC with the Cora weights on the one small dataset whose attributes make feature_adj
         # non-constant, from the sparse start -- the N x N x N product on real data at n = 1429
         ("hsic_all_sparse", 0, "HSIC", (1, 1, 1), 1.0, None, 0.0, {1: 0.01, 2: 0.01, 6: 10, 7: 10, 9: 10, 10: 1000}, (123, 1.0)),
+    ],
+    "cora": [
+        ("mse_h", 5, "MSELoss", (1, 0, 0), 0.0, -2.5, 0.0, {1: 0.1, 2: 0.1, 6: 10000, 7: 100, 9: 1000}, None),
+        ("kl_y", 9, "KL", (0, 1, 0), 0.0, -2.5, 0.0, {6: 100, 10: 0.1}, None),
+        ("mse_hy", 17, "MSELoss", (1, 1, 0), 0.0, -2.0, 0.0, {1: 1000, 2: 0.001, 6: 0.1, 7: 0.1, 9: 100, 10: 100}, None),
+        ("mse_hY", 21, "MSELoss", (1, 0, 1), 1.0, -2.0, 0.0, {1: 100, 2: 0.0001, 6: 0.0001, 7: 1, 9: 10}, None),
+        ("mse_yY", 25, "MSELoss", (0, 1, 1), 1.0, -3.0, 0.0, {1: 0.1, 6: 10, 10: 0.01}, None),
+        ("cka_yY", 116, "CKA", (0, 1, 1), 1.0, -2.0, 0.0, {1: 1000, 6: 1000, 10: 0.01}, None),
+    ],
+    "citeseer": [
+        ("kl_h", 35, "KL", (1, 0, 0), 0.0, -2.5, 0.0, {1: 10, 2: 0.1, 6: 0.01, 7: 0.001, 9: 10}, None),
+        ("kl_y", 39, "KL", (0, 1, 0), 0.0, -1.5, 0.0, {1: 0.0001, 10: 1}, None),
+        ("mse_Y", 43, "MSELoss", (0, 0, 1), 1.0, -3.0, 0.0, {1: 100, 6: 100}, None),
+        ("mse_hy", 47, "MSELoss", (1, 1, 0), 0.0, -2.5, 0.0, {1: 100, 2: 0.001, 6: 10, 7: 100, 9: 100, 10: 0.001}, None),
+        ("kl_hY", 51, "KL", (1, 0, 1), 1.0, -1.0, 0.0, {1: 0.001, 2: 10000, 6: 0.0001, 7: 100, 9: 100}, None),
+        ("kl_yY", 55, "KL", (0, 1, 1), 1.0, -2.0, 0.0, {1: 10, 6: 1, 10: 10000}, None),
+        ("kl_all", 59, "KL", (1, 1, 1), 1.0, -1.5, 0.0, {1: 100, 2: 0.0001, 6: 0.001, 9: 1000, 10: 0.001}, None),
     ],
 }
 
 
 def gen_readme(tmp, only=None, epochs=6):
-    """The reference on its README.md lines for brazil / usair / polblogs / AIDS, through its own Dataset, preprocess and
-    GCN.fit (main.py:147-190), `epochs` steps each.  The fixture carries what the loader produced (edges, diagonal --
-    brazil has self loops --, attributes or the identity flag, labels, the three index splits), the trained weights, per-step
-    gradient / adj_changes at sampled packed positions, a sample of the post-loop ensemble, its sum and the AUC."""
+    """The reference on its README.md lines, through its own Dataset, preprocess and GCN.fit (main.py:147-190), `epochs`
+    steps each.  Per dataset one `readme_<dataset>_graph.npz` with what the loader produced (edges, diagonal -- brazil has
+    self loops --, attributes as bits / the identity flag / float32, labels, the three index splits, idx_attack) and the
+    trained weights; per line one `readme_<dataset>_<tag>.npz` with the per-step gradient at sampled packed positions,
+    adj_changes there after the last step, a sample of the post-loop ensemble, its sum and the AUC."""
     os.chdir(tmp)
     if not os.path.exists("dataset"):
         os.symlink(os.path.join(REF, "dataset"), "dataset")
@@ -599,12 +627,15 @@ def gen_readme(tmp, only=None, epochs=6):
         samp = rng.randint(0, n, size=(8192, 2))
         npk = n * (n - 1) // 2
         pk = np.unique(np.concatenate([np.arange(0, npk, max(1, npk // 4096)), rng.randint(0, npk, 4096)])).astype(np.int64)
-        common = dict(dataset=ds, idx_attack=idx_attack, idx_train=idx_train, idx_val=idx_val, idx_test=idx_test,
-                      num_edges=float(num_edges), sample_pos=samp, packed_pos=pk, features_identity=int(ident),
-                      adj_edges=np.argwhere(np.triu(a, 1) > 0).astype(np.int32), adj_diag=np.diag(a).astype(np.uint8).copy(),
-                      labels=lab, nlayer=2, **weights_of(victim))
-        if not ident:
-            common["features_f32"] = fx
+        graph = dict(dataset=ds, idx_attack=idx_attack, idx_train=idx_train, idx_val=idx_val, idx_test=idx_test,
+                     num_edges=float(num_edges), sample_pos=samp, packed_pos=pk, features_identity=int(ident),
+                     adj_edges=np.argwhere(np.triu(a, 1) > 0).astype(np.int32), adj_diag=np.diag(a).astype(np.uint8).copy(),
+                     labels=lab, nlayer=2, **weights_of(victim))
+        if not ident and set(np.unique(fx)) <= {0.0, 1.0}:
+            graph.update(features_bits=np.packbits(fx.astype(np.uint8), axis=1), nfeat=fx.shape[1])
+        elif not ident:
+            graph["features_f32"] = fx
+        H_A2 = Y_A = None
         for (tag, line, measure, use, wsup, lrexp, eps, w, start) in runs:
             name = f"readme_{ds.lower()}_{tag}"
             if only is not None and not (f"{ds.lower()}_{tag}" in only or ds.lower() in only):
@@ -622,17 +653,21 @@ def gen_readme(tmp, only=None, epochs=6):
                                        tuple(bool(u) for u in use), num_edges, eps=eps, a0=a0)
             if eps != 0:
                 extra.update(noise=np.stack(res["noises"]))
+            if H_A2 is None:
+                H_A2, Y_A = res["H_A2"], res["Y_A"]
+            assert np.array_equal(H_A2, res["H_A2"]) and np.array_equal(Y_A, res["Y_A"])
             sa = np.stack(res["steps_a"]); sg = np.stack(res["steps_g"])
-            out = dict(readme_line=line, measure=measure, use=np.array(use), weight_param=np.array(wp, dtype=np.float64),
+            out = dict(dataset=ds, readme_line=line, measure=measure, use=np.array(use), weight_param=np.array(wp, dtype=np.float64),
                        weight_sup=wsup, lr=lr, eps=eps, epochs=epochs, auc=res["auc"], **extra,
-                       step_a=sa[:, pk], step_g=sg[:, pk], step_g_absmax=np.abs(sg).max(1),
+                       step_g=sg[:, pk], step_g_absmax=np.abs(sg).max(1), last_a=sa[-1, pk],
                        step_g_sum=sg.astype(np.float64).sum(1), step_g_sqsum=(sg.astype(np.float64) ** 2).sum(1),
                        step_a_clip_sum=np.clip(sa, 0, 1).astype(np.float64).sum(1),
                        final_sample=res["final"][samp[:, 0], samp[:, 1]],
-                       final_sum=float(res["final"].astype(np.float64).sum()),
-                       H_A2=res["H_A2"], Y_A=res["Y_A"], **common)
+                       final_sum=float(res["final"].astype(np.float64).sum()))
             np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
             print(name, "auc", res["auc"], "gmax per step", np.abs(sg).max(1), flush=True)
+        if H_A2 is not None:
+            np.savez_compressed(os.path.join(OUT, f"readme_{ds.lower()}_graph.npz"), H_A2=H_A2, Y_A=Y_A, **graph)
 
 
 def gen_citeseer_gat(tmp, train_iters=6):

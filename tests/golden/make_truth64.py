@@ -6,7 +6,7 @@ O(1) Gram entries in fp32), which bounds what "equal to the reference" can mean 
 
     python tests/golden/make_truth64.py          (~10 min and ~30 GB per start on 8 cores)
     python tests/golden/make_truth64.py mid      (the n = 1200 fixture, seconds)
-    python tests/golden/make_truth64.py readme   (the README-line fixtures on brazil / usair / polblogs / AIDS, ~2 min)
+    python tests/golden/make_truth64.py readme   (the README-line fixtures, ~10 min)
 
 Writes tests/golden/bench10k_hsic_fp64.npz: for each start of the fixture (`run`, `one0`, ...) `<name>_g64` = the
 mirrored packed gradient of its first step at `packed_pos`, plus its largest magnitude over the whole vector."""
@@ -88,7 +88,8 @@ def mid(tag="mid_s1200_hsic_sparse"):
 
 def readme():
     """The same for the README-line fixtures (make_golden.py --only readme): first-step gradient of the float64 oracle at each
-    fixture's packed positions -> tests/golden/readme_fp64.npz (`<fixture>_g64` as float32, `<fixture>_gmax`); ~2 min."""
+    fixture's packed positions and the AUC of the float64 run to its end -> tests/golden/readme_fp64.npz (`<fixture>_g64` as
+    float32, `<fixture>_gmax`, `<fixture>_auc64`); ~10 min."""
     from tests import helpers as H
     O.F32 = np.float64
     f8 = lambda x: np.asarray(x).astype(np.float64)
@@ -108,14 +109,24 @@ def readme():
         orc.w = w
         if H.a0_of(z) is not None:
             orc.set_adj_changes(f8(H.a0_of(z)))
-        nz = H.noise_of(z, 0)
-        orc.step(noise=f8(nz)) if nz is not None else orc.step()
         pi, pj = H.tril_pos(z["packed_pos"])
-        G = orc.last["G_sym"]
-        g64, gmax = G[pi, pj].astype(np.float64), float(np.abs(G).max())
-        out[f"{name}_g64"] = g64.astype(np.float32)
-        out[f"{name}_gmax"] = gmax
-        print(name, "reference fp32 vs float64 oracle: max err / gmax =", np.abs(z["step_g"][0] - g64).max() / gmax, flush=True)
+        for t in range(int(z["epochs"])):
+            nz = H.noise_of(z, t)
+            orc.step(noise=f8(nz)) if nz is not None else orc.step()
+            if t == 0:
+                G = orc.last["G_sym"]
+                g64, gmax = G[pi, pj].astype(np.float64), float(np.abs(G).max())
+                out[f"{name}_g64"] = g64.astype(np.float32)
+                out[f"{name}_gmax"] = gmax
+        # the run to its end in float64: how far the reference's own AUC is from the exact dynamics on this line (Adam turns
+        # rounding noise on near-zero gradients into +-lr moves, and the ensemble's entries sit within 1e-6 of each other on
+        # some lines: AIDS line 174 differs by 2.7e-3)
+        use = [bool(u) for u in z["use"]]
+        lab = z["labels"]
+        final = orc.finalize(str(z["dataset"]), use[0], use[1], use[2], f8(lab[:, None] == lab[None, :]), f8(z["H_A2"]), f8(z["Y_A"]))
+        out[f"{name}_auc64"] = O.metric_pool(z["adj"], np.asarray(final, np.float64), z["idx_attack"])
+        print(name, "reference fp32 vs float64 oracle: first gradient, max err / gmax =", np.abs(z["step_g"][0] - g64).max() / gmax,
+              " AUC", float(z["auc"]), "vs", out[f"{name}_auc64"], flush=True)
     np.savez_compressed(os.path.join(OUT, "readme_fp64.npz"), **out)
 
 

@@ -76,7 +76,8 @@ def load_cora(name):
 
 
 def readme_cases():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "readme_*.npz")) if not p.endswith("_fp64.npz"))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "readme_*.npz"))
+                  if not p.endswith("_fp64.npz") and not p.endswith("_graph.npz"))
 
 
 def main_feature_adj(feats, dataset):
@@ -90,21 +91,39 @@ def main_feature_adj(feats, dataset):
     return np.maximum(Xn @ Xn.T - np.eye(X.shape[0], dtype=np.float32), 0).astype(np.float32)
 
 
+_README_GRAPHS = {}
+
+
+def load_readme_graph(dataset):
+    """readme_<dataset>_graph.npz of tests/golden/make_golden.py:gen_readme: the graph rebuilt from its edges and diagonal,
+    attributes from bits / the identity flag / float32, feature_adj by the dataset's rule, the trained weights (cached)."""
+    key = str(dataset).lower()
+    if key not in _README_GRAPHS:
+        g = np.load(os.path.join(GOLDEN, f"readme_{key}_graph.npz"), allow_pickle=False)
+        g = {k: g[k] for k in g.files}
+        n = len(g["labels"])
+        adj = np.zeros((n, n), np.float32)
+        e = g["adj_edges"]
+        adj[e[:, 0], e[:, 1]] = 1
+        adj[e[:, 1], e[:, 0]] = 1
+        adj[np.arange(n), np.arange(n)] = g["adj_diag"].astype(np.float32)
+        g["adj"] = adj
+        if int(g["features_identity"]):
+            g["features"] = np.eye(n, dtype=np.float32)
+        elif "features_bits" in g:
+            g["features"] = np.unpackbits(g["features_bits"], axis=1)[:, :int(g["nfeat"])].astype(np.float32)
+        else:
+            g["features"] = g["features_f32"]
+        g["feature_adj"] = main_feature_adj(g["features"], str(g["dataset"]))
+        _README_GRAPHS[key] = g
+    return _README_GRAPHS[key]
+
+
 def load_readme(name):
-    """A README-line fixture of tests/golden/make_golden.py:gen_readme in the layout of load_case: the graph rebuilt from
-    its edges and diagonal, identity attributes from their flag, feature_adj by the dataset's rule."""
+    """A README-line fixture in the layout of load_case: its dataset's graph file merged with the line's own results."""
     z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
     z = {k: z[k] for k in z.files}
-    n = len(z["labels"])
-    adj = np.zeros((n, n), np.float32)
-    e = z["adj_edges"]
-    adj[e[:, 0], e[:, 1]] = 1
-    adj[e[:, 1], e[:, 0]] = 1
-    adj[np.arange(n), np.arange(n)] = z["adj_diag"].astype(np.float32)
-    z["adj"] = adj
-    z["features"] = np.eye(n, dtype=np.float32) if int(z["features_identity"]) else z["features_f32"]
-    z["feature_adj"] = main_feature_adj(z["features"], str(z["dataset"]))
-    return z
+    return {**load_readme_graph(str(z["dataset"])), **z}
 
 
 def tril_pos(p):

@@ -217,8 +217,9 @@ README_TRUTH = np.load(os.path.join(H.GOLDEN, "readme_fp64.npz"))
 
 
 @pytest.mark.parametrize("name", H.readme_cases())
-def test_oracle_on_the_readme_lines_of_the_other_datasets(name):
-    """The reference's README lines on brazil / usair / polblogs / AIDS (tests/golden/make_golden.py:gen_readme): the oracle's
+def test_oracle_on_the_reference_readme_lines(name):
+    """Every README.md line the reference's CPU path can run, on cora / citeseer / polblogs / usair / brazil / AIDS
+    (tests/golden/make_golden.py:gen_readme, 37 fixtures): the oracle's
     first gradient against the reference's (within the reference's own distance from a float64 evaluation + 3e-4); the small
     graph (brazil: self loops, decode branch 2, KL / MSELoss / DP, an eps != 0 line at lr = 1) also runs to the end: every
     step's gradient, the post-loop ensemble and the AUC."""
