@@ -486,7 +486,9 @@ def main(argv=None):
                        "forward_reuse": bool(monitor and os.environ.get("MCGRA_NO_FWD_REUSE") != "1"),
                        "parallelism": (f"row-block x{world}: one attack, rows of the learnable adjacency and of every N x N pass "
                                        f"split over the ranks ({plan.rows_per_rank} rows each); per step one all-to-all of "
-                                       "P1 tile blocks, all-gathers of n x c node arrays, all-reduces of scalars (RCCL)"
+                                       "P1 tile blocks, all-gathers of n x c node arrays, all-reduces of scalars "
+                                       + ("(gloo, host-staged: the ranks share ONE GPU -- a test mode, not a measurement)"
+                                          if shared_gpu else "(RCCL)")
                                        if world > 1 else "single")},
             "auc": auc,
         }
