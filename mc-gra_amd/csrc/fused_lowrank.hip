@@ -337,9 +337,10 @@ __global__ __launch_bounds__(256) void k_pack_rk(int n, RkPackJobs J) {
 // products on v_mfma_f32_32x32x16_f16 (one 32 x 32 quadrant per wave): p0 = L_I R_J^T and p1 = R_I L_J^T.  The packed
 // panels ARE the fragment layout -- lane (row l & 31, k half l >> 5) of [k step][plane][k half][row][8] is one 16-byte
 // load, 512 contiguous bytes per half wave -- so the operands go from L2 (the panels of a step are 7.5 MB) straight into
-// registers: no LDS staging and no barrier inside the rounds (four waves per SIMD cover the load latency).  Bitwise symmetric under i <-> j: per product the x0 y0 terms and the cross terms x0 y1, x1 y0 are kept in two
-// accumulators, and p1 issues its cross terms in the opposite order of p0 -- so p1 of the mirrored element is, MFMA for
-// MFMA, p0 of this one (the planes swap roles with the operands), and p0 + p1 are added to each other before anything else.
+// registers: no LDS staging and no barrier inside the rounds (four waves per SIMD cover the load latency).  Bitwise symmetric
+// under i <-> j: the second product issues its cross terms in the opposite order of the first -- so d of the mirrored
+// element is, MFMA for MFMA, c of this one (the planes swap roles with the operands) -- and the two scaled products are
+// added to each other before anything else.
 // T [64][65] receives the sum in the matrix cores' accumulator layout and hands it to the threads' 4 x 4 patches.
 __device__ __forceinline__ void rk_sym(const RkRounds& F, int ti, int tj, float (*T)[FT + 1], int r0, int c0, float (&acc)[4][4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -358,26 +359,25 @@ __device__ __forceinline__ void rk_sym(const RkRounds& F, int ti, int tj, float 
     const int ks = F.ksteps[rd];
     // undo the panel scales 2^(15 - e): exact
     const float i0 = ldexpf(1.f, F.eL[rd][ti] + F.eR[rd][tj] - 30), i1 = ldexpf(1.f, F.eR[rd][ti] + F.eL[rd][tj] - 30);
-    f32x16_t c00, cx;
+    f32x16_t c, d;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; cx[r] = 0.f; }
-    for (int s = 0; s < ks; ++s) {         // p0 = L_I R_J^T: cross terms x0 y1 then x1 y0
+    for (int r = 0; r < 16; ++r) { c[r] = 0.f; d[r] = 0.f; }
+    // Both products of a k step read the same four panels: their eight fragments go out as ONE batch of loads (the rounds are
+    // a chain of L2 round trips -- a block spends most of its life in them -- and one batch per k step instead of one per
+    // product halves the chain), then c = L_I R_J^T with the cross terms x0 y1, x1 y0 ahead of x0 y0, and d = R_I L_J^T with
+    // them in the mirrored order x1 y0, x0 y1.
+    for (int s = 0; s < ks; ++s) {
       const f16x8_t a0 = ld(F.L[rd], oi, s, 0), a1 = ld(F.L[rd], oi, s, 1), b0 = ld(F.R[rd], oj, s, 0), b1 = ld(F.R[rd], oj, s, 1);
-      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, cx, 0, 0, 0);
-      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, cx, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c00, 0, 0, 0);
+      const f16x8_t e0 = ld(F.R[rd], oi, s, 0), e1 = ld(F.R[rd], oi, s, 1), f0 = ld(F.L[rd], oj, s, 0), f1 = ld(F.L[rd], oj, s, 1);
+      __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks half of the loads between the MFMAs: one round trip each)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, f0, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, f1, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, f0, d, 0, 0, 0);
     }
-    const f32x16_t p0 = (c00 + cx) * i0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; cx[r] = 0.f; }
-    for (int s = 0; s < ks; ++s) {         // p1 = R_I L_J^T: x1 y0 then x0 y1 (the mirrored order)
-      const f16x8_t a0 = ld(F.R[rd], oi, s, 0), a1 = ld(F.R[rd], oi, s, 1), b0 = ld(F.L[rd], oj, s, 0), b1 = ld(F.L[rd], oj, s, 1);
-      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, cx, 0, 0, 0);
-      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, cx, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c00, 0, 0, 0);
-    }
-    const f32x16_t sum = p0 + (c00 + cx) * i1;
-    tot += sum;
+    tot += c * i0 + d * i1;
   }
   __syncthreads();                         // previous users of T are done
   // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -424,43 +424,69 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) { acc[a][b] = 0.f; accu[a][b] = 0.f; }
+  // the tile's row-side n-vectors (r, mean, delta, cvec of rows bi ..): one load per thread into LDS now, read back in the
+  // element pass (published by the barriers of rk_sym) -- as four global loads per row inside that pass they were four
+  // more dependent round trips
+  __shared__ float rowv[4][FT];
+  {
+    const int q = threadIdx.x >> 6, t = threadIdx.x & 63, i = bi + t;
+    const float* src = q == 0 ? r : (q == 1 ? mean : (q == 2 ? delta : cvec));
+    rowv[q][t] = (src && i < n) ? src[i] : 0.f;
+  }
   rk_sym(F, ti, tj, T, r0, c0, acc);
   if (FU.count > 0) rk_sym(FU, ti, tj, T, r0, c0, accu);
+  // Every HBM operand of the element pass goes out in ONE batch, ahead of the barriers (the registers of the rank-k rounds
+  // are free again): the mirrored P1 tile, and the block's own rows of M and P1 -- one memory round trip instead of two.
+  float pts[4][4], mss[4][4], pds[4][4], rjs[4], mjs[4], djs[4], cjs[4];
+  {
+    // (branch-free: clamped, always in-bounds addresses and per-component selects afterwards -- loads under a divergent
+    //  condition are each waited for at the end of their own block, and a select between float4 objects goes through scratch)
+    const float* P1s = P1 ? P1 : M;
+    const int colt = min(bi + c0, ld - 4), colo = min(bj + c0, ld - 4);         // ld % 4 == 0: aligned, inside the row's padding
+    float4 pt4[4], m4s[4], p4s[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int rowt = min(bj + r0 + a, n - 1), rowo = min(bi + r0 + a, n - 1);
+      pt4[a] = *reinterpret_cast<const float4*>(P1s + (size_t)rowt * ld + colt);
+      m4s[a] = *reinterpret_cast<const float4*>(M + (size_t)rowo * ld + colo);
+      p4s[a] = *reinterpret_cast<const float4*>(P1s + (size_t)rowo * ld + colo);
+    }
+    // the column-side n-vectors of the thread's four columns (as before: a quad that starts inside n is read whole)
+    const int jq = min(bj + c0, ((n + 3) & ~3) - 4);
+    const float4 rj4 = *reinterpret_cast<const float4*>(r + jq), mj4 = *reinterpret_cast<const float4*>(mean + jq);
+    const float4 dj4 = *reinterpret_cast<const float4*>((delta ? delta : r) + jq), cj4 = *reinterpret_cast<const float4*>((delta ? cvec : r) + jq);
+    const bool jin = bj + c0 < n, jd = jin && delta != nullptr;
+    rjs[0] = jin ? rj4.x : 0.f; rjs[1] = jin ? rj4.y : 0.f; rjs[2] = jin ? rj4.z : 0.f; rjs[3] = jin ? rj4.w : 0.f;
+    mjs[0] = jin ? mj4.x : 0.f; mjs[1] = jin ? mj4.y : 0.f; mjs[2] = jin ? mj4.z : 0.f; mjs[3] = jin ? mj4.w : 0.f;
+    djs[0] = jd ? dj4.x : 0.f; djs[1] = jd ? dj4.y : 0.f; djs[2] = jd ? dj4.z : 0.f; djs[3] = jd ? dj4.w : 0.f;
+    cjs[0] = jd ? cj4.x : 0.f; cjs[1] = jd ? cj4.y : 0.f; cjs[2] = jd ? cj4.z : 0.f; cjs[3] = jd ? cj4.w : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const bool tin = P1 && bj + r0 + a < n && bi + c0 < n, oin = bi + r0 + a < n && bj + c0 < n, pin = oin && P1;
+      pts[a][0] = tin ? pt4[a].x : 0.f; pts[a][1] = tin ? pt4[a].y : 0.f; pts[a][2] = tin ? pt4[a].z : 0.f; pts[a][3] = tin ? pt4[a].w : 0.f;
+      mss[a][0] = oin ? m4s[a].x : 0.f; mss[a][1] = oin ? m4s[a].y : 0.f; mss[a][2] = oin ? m4s[a].z : 0.f; mss[a][3] = oin ? m4s[a].w : 0.f;
+      pds[a][0] = pin ? p4s[a].x : 0.f; pds[a][1] = pin ? p4s[a].y : 0.f; pds[a][2] = pin ? p4s[a].z : 0.f; pds[a][3] = pin ? p4s[a].w : 0.f;
+    }
+  }
   __syncthreads();                         // every thread has its patches: T may be overwritten
   // mirrored P1 tile (J, I) through LDS: T[j local][i local]
   if (P1) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const int row = bj + r0 + a, col = bi + c0;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < n && col < n) v = *reinterpret_cast<const float4*>(P1 + (size_t)row * ld + col);   // ld % 4 == 0: in bounds
-      T[r0 + a][c0] = v.x; T[r0 + a][c0 + 1] = v.y; T[r0 + a][c0 + 2] = v.z; T[r0 + a][c0 + 3] = v.w;
+      T[r0 + a][c0] = pts[a][0]; T[r0 + a][c0 + 1] = pts[a][1]; T[r0 + a][c0 + 2] = pts[a][2]; T[r0 + a][c0 + 3] = pts[a][3];
     }
   }
   __syncthreads();
   double v1 = 0.0, v6 = 0.0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  const float4 rj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(r + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 mj4 = (bj + c0 < n) ? *reinterpret_cast<const float4*>(mean + bj + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float rjs[4] = {rj4.x, rj4.y, rj4.z, rj4.w}, mjs[4] = {mj4.x, mj4.y, mj4.z, mj4.w};
-  float djs[4] = {0.f, 0.f, 0.f, 0.f}, cjs[4] = {0.f, 0.f, 0.f, 0.f};
-  if (delta && bj + c0 < n) {
-    const float4 d4 = *reinterpret_cast<const float4*>(delta + bj + c0), c4 = *reinterpret_cast<const float4*>(cvec + bj + c0);
-    djs[0] = d4.x; djs[1] = d4.y; djs[2] = d4.z; djs[3] = d4.w; cjs[0] = c4.x; cjs[1] = c4.y; cjs[2] = c4.z; cjs[3] = c4.w;
-  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int i = bi + r0 + a, j0 = bj + c0;
     const bool rowin = i < n && j0 < n;
-    float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), p4 = m4;
     const size_t o = (size_t)i * ld + j0;
-    if (rowin) {
-      m4 = *reinterpret_cast<const float4*>(M + o);
-      if (P1) p4 = *reinterpret_cast<const float4*>(P1 + o);
-    }
-    const float ms[4] = {m4.x, m4.y, m4.z, m4.w}, pd[4] = {p4.x, p4.y, p4.z, p4.w};
-    const float ri = rowin ? r[i] : 0.f, mi = rowin ? mean[i] : 0.f;
-    const float di = (delta && rowin) ? delta[i] : 0.f, ci = (delta && rowin) ? cvec[i] : 0.f;
+    const float (&ms)[4] = mss[a], (&pd)[4] = pds[a];
+    const float ri = rowin ? rowv[0][r0 + a] : 0.f, mi = rowin ? rowv[1][r0 + a] : 0.f;
+    const float di = (delta && rowin) ? rowv[2][r0 + a] : 0.f, ci = (delta && rowin) ? rowv[3][r0 + a] : 0.f;
     float gs[4], rowacc = 0.f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {

@@ -30,12 +30,15 @@ __device__ __forceinline__ int pm_exp(float amax) {
   return e;
 }
 
-// largest |W[k][c] / r[k]|: ONE block (n x nc is a few 10^5 elements), plain store -- no fill, no atomics
-__global__ __launch_bounds__(1024) void k_pm_absmax(int n, int nc, const float* __restrict__ W, int ldw, const float* __restrict__ r,
-                                                    float* __restrict__ amax) {
-  __shared__ float shm[16];
+// largest |W[k][c] / r[k]|: PM_ABS blocks leave their partial maxima in the first 256 bytes of the scratch (plain stores: no
+// fill, no atomics); the consumers take the largest of them (pm_amax).  (One block of 1024 threads took 132 us at
+// n = 10 000 -- a serial chain of 312 dependent loads per thread, three times per step on the side chain.)
+constexpr int PM_ABS = 64;
+__global__ __launch_bounds__(256) void k_pm_absmax(int n, int nc, const float* __restrict__ W, int ldw, const float* __restrict__ r,
+                                                   float* __restrict__ part) {
+  __shared__ float shm[4];
   float m = 0.f;
-  for (size_t e = threadIdx.x; e < (size_t)n * nc; e += 1024) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n * nc; e += (size_t)PM_ABS * 256) {
     const int k = (int)(e / nc), c = (int)(e - (size_t)k * nc);
     m = fmaxf(m, fabsf(W[(size_t)k * ldw + c] / r[k]));
   }
@@ -43,12 +46,16 @@ __global__ __launch_bounds__(1024) void k_pm_absmax(int n, int nc, const float* 
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+}
+__device__ __forceinline__ float pm_amax(const float* __restrict__ part) {
+  float m = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t = fmaxf(t, shm[w]);
-    amax[0] = t;
+  for (int q = 0; q < PM_ABS / 4; ++q) {
+    const float4 v = reinterpret_cast<const float4*>(part)[q];
+    m = fmaxf(fmaxf(m, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
   }
+  return m;
 }
 
 // right-hand side W / r as two fp16 planes in fragment order: [k step of 32][plane][k octet (4)][column (NC)][8 k]
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void k_pm_vpack(int n, int nc, int NC, const f
   const int col = e % NC, oct = e / NC;
   const int k0 = oct * 8, nsteps = (n + 31) / 32;
   if (oct >= nsteps * 4) return;
-  const float sc = ldexpf(1.f, 15 - pm_exp(*amax));
+  const float sc = ldexpf(1.f, 15 - pm_exp(pm_amax(amax)));
   f16x8p p0, p1;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(512) void k_planes_mm(const char* __restrict__ Ap, 
       }
   }
   // undo the operand scales (exact), R^-1 from the left, - W in slab 0.  C/D layout: col = lane & 15, row = 4 (lane >> 4) + q
-  const float inv = ldexpf(1.f, pm_exp(amaxA[0]) + pm_exp(amaxV[0]) - 30);
+  const float inv = ldexpf(1.f, pm_exp(amaxA[0]) + pm_exp(pm_amax(amaxV)) - 30);
   float* o = slabs + (size_t)ks * slab_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(512) void k_planes_mm(const char* __restrict__ Ap, 
 }
 }  // namespace
 
-// scratch for the packed right-hand side (+ one float for its magnitude)
+// scratch for the packed right-hand side (+ 256 bytes: the partial maxima of its magnitude)
 size_t planes_mm_scratch_bytes(int n) { return (size_t)((n + 31) / 32) * (2 * 4 * 64 * 16) + 256; }
 bool planes_mm_supported(int n, int nc) { return nc >= 1 && nc <= 64 && n >= 1024; }
 
@@ -152,7 +159,7 @@ hipError_t planes_mm(hipStream_t st, int n, const void* Ap, int nchunks, const f
   if ((size_t)ksplit * stride * sizeof(float) > ws_bytes) return hipErrorInvalidValue;
   const int kper = (nks + ksplit - 1) / ksplit;
   ksplit = (nks + kper - 1) / kper;
-  hipLaunchKernelGGL(k_pm_absmax, dim3(1), dim3(1024), 0, st, n, nc, W, ldw, r, amaxV);
+  hipLaunchKernelGGL(k_pm_absmax, dim3(PM_ABS), dim3(256), 0, st, n, nc, W, ldw, r, amaxV);
   const int octs = ((n + 31) / 32) * 4;
   hipLaunchKernelGGL(k_pm_vpack, dim3((octs * NC + 255) / 256), dim3(256), 0, st, n, nc, NC, W, ldw, r, amaxV, vp);
   dim3 grid(panels, ksplit);
