@@ -366,6 +366,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                   lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
                   (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
     h->row0 = 0; h->row1 = (int)n;
+    { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
     { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
     {
       const char* ep = getenv("MCGRA_PLANES_MM");

@@ -136,7 +136,8 @@ static int mm_rows(mcgra_attack* h, hipStream_t st, int ncol) {
 // d, r, both chains, heads, the means of adj_norm's columns and the operand-scale bound of the current M.
 // Returns 1 at an exchange point (ex filled), 0 when done, < 0 on error.
 static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
-  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, fc = h->fcols, R0 = h->row0, R1 = h->row1;
+  const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, C = h->C, fc = h->fcols, R0 = h->row0, R1 = h->row1;
+  const bool fused_post = h->fused_post;
   switch (h->fw_state) {
     case 0:
       if (h->prep_valid) {
@@ -171,22 +172,40 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
           const float* rs[3] = {h->r, nullptr, nullptr};
           const int lds[3] = {hs, hs, 1}, ws[3] = {w, w, 1};
           const bool with_r = l == 0 && !h->late_mean;         // (late mean: the means come out of the pack)
-          fl_cat_segs(st, n, with_r ? 3 : 2, Xs, lds, rs, ws, h->FV, fc);      // [r o Tv | Tu (| r)]
+          // [r o Tv | Tu (| r)] -- already in FV when the previous layer's post pass wrote it (fl_layer_post_next)
+          if (!(l >= 1 && fused_post && fl_layer_post_fused_supported(h->wdt[l - 1], w)))
+            fl_cat_segs(st, n, with_r ? 3 : 2, Xs, lds, rs, ws, h->FV, fc);
           CHK(mm_rows(h, st, 2 * w + (with_r ? 1 : 0)));
         }
         FS_XCHG(h->fw_state, 3, X_FY(h))
         {
           const int l = h->fs_l, w = h->wdt[l];
-          fl_layer_post(st, n, w, h->fy, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
-                        h->Hu + h->off[l], hs, l == 0 && !h->late_mean, h->cmean, h->rowsx);
-          if (l + 1 < L) {
-            launch_rowmat(st, n, w, h->wdt[l + 1], h->Hv + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tv + h->off[l + 1], hs);
-            launch_rowmat(st, n, w, h->wdt[l + 1], h->Hu + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tu + h->off[l + 1], hs);
+          const bool wr = l == 0 && !h->late_mean;
+          // the post pass and what follows it on the same rows in ONE launch where the widths allow (<= 32): the next
+          // layer's T of both chains + the next product's right-hand side, or -- last layer -- both linear heads with their
+          // log-softmax (same operations in the same order as the separate kernels)
+          if (l + 1 < L && fused_post && fl_layer_post_fused_supported(w, h->wdt[l + 1])) {
+            fl_layer_post_next(st, n, w, h->fy, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
+                               h->Hu + h->off[l], hs, wr, h->cmean, h->rowsx, h->wdt[l + 1], h->W[l + 1], h->Tv + h->off[l + 1],
+                               h->Tu + h->off[l + 1]);
+          } else if (l + 1 == L && fused_post && fl_layer_post_fused_supported(w, C)) {
+            fl_layer_post_head(st, n, w, h->fy, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
+                               h->Hu + h->off[l], hs, wr, h->cmean, h->rowsx, C, h->Wlin, h->blin, h->Z, h->logp, h->sm, h->Z2, h->sm2,
+                               h->head_act);
+          } else {
+            fl_layer_post(st, n, w, h->fy, h->FV, fc, h->r, h->b[l], h->Pv + h->off[l], h->Hv + h->off[l], h->Pu + h->off[l],
+                          h->Hu + h->off[l], hs, wr, h->cmean, h->rowsx);
+            if (l + 1 < L) {
+              launch_rowmat(st, n, w, h->wdt[l + 1], h->Hv + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tv + h->off[l + 1], hs);
+              launch_rowmat(st, n, w, h->wdt[l + 1], h->Hu + h->off[l], hs, h->W[l + 1], h->wdt[l + 1], 1, nullptr, h->Tu + h->off[l + 1], hs);
+            }
           }
         }
       }
-      CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
-      CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
+      if (!(fused_post && fl_layer_post_fused_supported(h->wdt[L - 1], C))) {
+        CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
+        CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
+      }
       if (h->late_mean) { if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, st, n, h->r, h->amax + 1); }
       else fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
       MCGRA_KERNEL_CHECK();

@@ -148,6 +148,7 @@ struct mcgra_attack {
   // ... and with uncentred planes of the CURRENT M in Bpack (between the pack of a step and its Adam pass) the skinny
   // products on M that run beside the N x N x N product read those planes (planes_mm.hip).  MCGRA_PLANES_MM=0 disables.
   bool planes_mm_on = false, planes_valid = false;
+  bool fused_post = true;          // forward: post pass + next layer's T / heads in one launch (MCGRA_NO_FUSED_POST=1: separate kernels)
   char* pm_scratch = nullptr;
   int64_t fused_steps = 0;
   // row-block sharding (mcgra_attack_shard_*): this rank owns rows [row0, row1) of M / am / av

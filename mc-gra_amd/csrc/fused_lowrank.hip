@@ -91,6 +91,81 @@ __global__ void k_fl_post(int n, int w, YView Y, const float* __restrict__ V, in
   }
 }
 
+// k_fl_post and what follows it on the same rows, in one launch (the forward is a chain of dependent launches of a few
+// microseconds each: at n = 2708 they are the step, at n = 10 000 they sit in front of the N x N x N product):
+//   HEAD == 0: the next layer's T = H W_next of both chains (k_rowmat twice) and the right-hand side of the next product,
+//              [r o Tv_next | Tu_next] (k_cat_segs);
+//   HEAD == 1: the linear head Z = H Wlin^T + blin and its log-softmax of both chains (k_rowmat + k_log_softmax, twice).
+// Same operations in the same order as the separate kernels (bit-identical results).  A block: FP_ROWS rows, widths <= 32.
+constexpr int FP_ROWS = 8;
+template <int HEAD>
+__global__ __launch_bounds__(256) void k_fl_post_fused(int n, int w, YView Y, const float* __restrict__ V, int ldv,
+                                                       const float* __restrict__ r, const float* __restrict__ b,
+                                                       float* __restrict__ Pv, float* __restrict__ Hv, float* __restrict__ Pu,
+                                                       float* __restrict__ Hu, int ldo, int with_r, float* __restrict__ mean,
+                                                       double* __restrict__ rowsum,
+                                                       int wn, const float* __restrict__ Wn, const float* __restrict__ bn,
+                                                       float* __restrict__ On_v, float* __restrict__ On_u, int ldn,
+                                                       float* __restrict__ Vout, int ldvo,
+                                                       float* __restrict__ logp_v, float* __restrict__ sm_v,
+                                                       float* __restrict__ sm_u, int head_act) {
+  __shared__ float hs[2][FP_ROWS][32];
+  __shared__ float zs[2][FP_ROWS][32];
+  const int row0 = blockIdx.x * FP_ROWS, t = threadIdx.x;
+  if (t < FP_ROWS * w) {                                   // k_fl_post
+    const int ri = t / w, k = t - ri * w, i = row0 + ri;
+    if (i < n) {
+      const float rr = r[i];
+      const float pv = rr * (Y.at(i, k) + V[(size_t)i * ldv + k]) + b[k];
+      const float pu = Y.at(i, w + k) + b[k];
+      const float hv = fmaxf(pv, 0.f), hu = fmaxf(pu, 0.f);
+      Pv[(size_t)i * ldo + k] = pv; Hv[(size_t)i * ldo + k] = hv;
+      Pu[(size_t)i * ldo + k] = pu; Hu[(size_t)i * ldo + k] = hu;
+      hs[0][ri][k] = hv; hs[1][ri][k] = hu;
+      if (with_r && k == 0) {
+        const double rs = (double)rr * ((double)Y.at(i, 2 * w) + (double)rr);
+        rowsum[i] = rs;
+        mean[i] = (float)(rs / (double)n);
+      }
+    }
+  }
+  __syncthreads();                                         // (V's rows of this block are read: they may be overwritten below)
+  for (int e = t; e < 2 * FP_ROWS * wn; e += 256) {        // k_rowmat of both chains
+    const int ch = e / (FP_ROWS * wn), q = e - ch * (FP_ROWS * wn), ri = q / wn, c = q - ri * wn, i = row0 + ri;
+    if (i >= n) continue;
+    float acc = 0.f;
+    if (HEAD) {
+      for (int k = 0; k < w; ++k) acc = fmaf(hs[ch][ri][k], Wn[(size_t)k + (size_t)c * w], acc);      // Wlin [C][w]
+      acc += bn[c];
+      zs[ch][ri][c] = acc;
+    } else {
+      for (int k = 0; k < w; ++k) acc = fmaf(hs[ch][ri][k], Wn[(size_t)k * wn + c], acc);             // W_next [w][wn]
+      (ch == 0 ? On_v : On_u)[(size_t)i * ldn + c] = acc;
+      Vout[(size_t)i * ldvo + ch * wn + c] = ch == 0 ? r[i] * acc : acc;                              // k_cat_segs
+    }
+  }
+  if (!HEAD) return;
+  __syncthreads();
+  if (t < 2 * FP_ROWS) {                                   // k_log_softmax, one thread per (chain, row)
+    const int ch = t / FP_ROWS, ri = t - ch * FP_ROWS, i = row0 + ri;
+    if (i < n) {
+      const float* z = zs[ch][ri];
+      float* Zo = ch == 0 ? On_v : On_u;
+      float mx = -INFINITY;
+      for (int k = 0; k < wn; ++k) mx = fmaxf(mx, head_act ? (z[k] > 0.f ? z[k] : expm1f(z[k])) : z[k]);
+      float sum = 0.f;
+      for (int k = 0; k < wn; ++k) sum += expf((head_act ? (z[k] > 0.f ? z[k] : expm1f(z[k])) : z[k]) - mx);
+      const float ls = logf(sum);
+      for (int k = 0; k < wn; ++k) {
+        const float l = (head_act ? (z[k] > 0.f ? z[k] : expm1f(z[k])) : z[k]) - mx - ls;
+        Zo[(size_t)i * ldn + k] = z[k];                    // Z keeps the linear output
+        if (ch == 0) { logp_v[(size_t)i * ldn + k] = l; sm_v[(size_t)i * ldn + k] = expf(l); }
+        else sm_u[(size_t)i * ldn + k] = expf(l);
+      }
+    }
+  }
+}
+
 // out[k] = sum_i X[i][k] and (wgt != nullptr) out2[k] = sum_i wgt_i X[i][k] in fp64, k < w <= 64.  Two deterministic stages:
 // WC_PARTS row slices (thread = (row group, column): coalesced along the columns), then a fixed-order combine.
 constexpr int WC_PARTS = 64;
@@ -713,6 +788,21 @@ void fl_copy_cols(hipStream_t st, int n, int w, YView Y, int c0, float* out, int
 void fl_layer_post(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum) {
   LAUNCH(k_fl_post, g1((size_t)n * w), dim3(256), st, n, w, Y, V, ldv, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0, mean, rowsum);
+}
+bool fl_layer_post_fused_supported(int w, int wn) { return w >= 1 && w <= 32 && wn >= 1 && wn <= 32 && FP_ROWS * w <= 256; }
+// k_fl_post + the next layer's T of both chains + the next product's right-hand side [r o Tv_next | Tu_next] in V
+void fl_layer_post_next(hipStream_t st, int n, int w, YView Y, float* V, int ldv, const float* r, const float* b, float* Pv, float* Hv,
+                        float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum, int wn, const float* Wn,
+                        float* Tv_next, float* Tu_next) {
+  LAUNCH(k_fl_post_fused<0>, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, w, Y, V, ldv, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0,
+         mean, rowsum, wn, Wn, nullptr, Tv_next, Tu_next, ldo, V, ldv, nullptr, nullptr, nullptr, 0);
+}
+// k_fl_post + the linear head and its log-softmax of both chains (Z, logp, sm of the victim chain; Z2, sm2 of the other)
+void fl_layer_post_head(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b, float* Pv,
+                        float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum, int C, const float* Wlin,
+                        const float* blin, float* Z, float* logp, float* sm, float* Z2, float* sm2, int head_act) {
+  LAUNCH(k_fl_post_fused<1>, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, w, Y, V, ldv, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0,
+         mean, rowsum, C, Wlin, blin, Z, Z2, C, nullptr, 0, logp, sm, sm2, head_act);
 }
 // scratch: 2 * 64 * WC_PARTS doubles
 void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch) {

@@ -123,6 +123,13 @@ void fl_an_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv,
 void fl_copy_cols(hipStream_t st, int n, int w, YView Y, int c0, float* out, int ldo);
 void fl_layer_post(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum);
+bool fl_layer_post_fused_supported(int w, int wn);
+void fl_layer_post_next(hipStream_t st, int n, int w, YView Y, float* V, int ldv, const float* r, const float* b, float* Pv, float* Hv,
+                        float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum, int wn, const float* Wn,
+                        float* Tv_next, float* Tu_next);
+void fl_layer_post_head(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b, float* Pv,
+                        float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum, int C, const float* Wlin,
+                        const float* blin, float* Z, float* logp, float* sm, float* Z2, float* sm2, int head_act);
 void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch);
 size_t fl_wcolsum_scratch_doubles();
 void fl_mean_stats(hipStream_t st, int n, const float* mean, const float* r, double* msum, float* amax_bound);

@@ -1152,6 +1152,29 @@ def test_skinny_products_from_the_operand_planes(pkg, n, widths, monkeypatch):
     assert a.fused_steps() == 3 and b.fused_steps() == 3
 
 
+@pytest.mark.parametrize("n,widths", [(1100, (16, 16)), (1283, (16, 8)), (1100, (16, 16, 16))])
+def test_forward_post_pass_in_one_launch_gives_the_separate_kernels_bits(pkg, n, widths, monkeypatch):
+    """The forward of the fused step runs a layer's post pass together with what follows it on the same rows -- the next
+    layer's T of both chains and the next product's right-hand side, or both linear heads with their log-softmax -- in one
+    launch (k_fl_post_fused).  Same operations in the same order as the separate kernels (MCGRA_NO_FUSED_POST=1): the whole
+    state after three free-running steps, every loss term and the monitoring forward's output are identical bit for bit,
+    also with three layers and unequal widths."""
+    import torch
+    z = _synthetic_case(n, 11, widths, 4, seed=n)
+    a = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_FUSED_POST", "1")
+    b = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_FUSED_POST")
+    for t in range(3):
+        sa = a.step(want_scalars=True); oa, _ = a.monitor()
+        sb = b.step(want_scalars=True); ob, _ = b.monitor()
+        assert sa == sb, (t, sa, sb)
+        assert torch.equal(oa, ob)
+        for name in ("M", "G_sym", "em"):
+            assert torch.equal(a.buffer(name), b.buffer(name)), (t, name)
+    assert a.fused_steps() == 3 and b.fused_steps() == 3
+
+
 @pytest.mark.parametrize("n,widths,wp,split", [
     (1100, (16, 16), None, None), (1283, (16, 8), NXN_ONLY, None), (700, (16, 16), NXN_ONLY, "3"),
     (1100, (16, 16, 16), None, None), (515, (8, 8), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), "2"),
