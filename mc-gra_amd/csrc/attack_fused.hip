@@ -511,6 +511,12 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         {
           const int lv = h->fs_l, lu = h->fs_l2;
           const int wv = lv >= 1 ? h->wdt[lv] : 0;
+          if (lv >= 1 && lu >= 1 && h->fused_post && fl_bwd_level_supported(wv, h->wdt[lu], h->wdt[lv - 1], h->wdt[lu - 1])) {
+            // both chains' level in one launch (k_an_post + k_copy_cols + two k_rowmat_mask: same operations, same order)
+            fl_bwd_level(st, n, wv, h->wdt[lu], h->fy, h->FV, fc, h->r, h->wdt[lv - 1], h->W[lv], h->Pv + h->off[lv - 1],
+                         h->GPv + h->off[lv - 1], h->wdt[lu - 1], h->W[lu], h->Pu + h->off[lu - 1], h->GPu + h->off[lu - 1], hs,
+                         (lu - 1 == Le - 1) ? h->Gem : nullptr, h->hmax);
+          } else {
           if (lv >= 1) {
             fl_an_post(st, n, wv, h->fy, h->FV, fc, 0, h->r, h->GT, h->hmax);
             launch_rowmat_mask(st, n, h->wdt[lv], h->wdt[lv - 1], h->GT, h->hmax, h->W[lv], 1, h->wdt[lv], nullptr, 0, 0, nullptr, 0, 0,
@@ -521,6 +527,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
             launch_rowmat_mask(st, n, h->wdt[lu], h->wdt[lu - 1], h->GT, h->hmax, h->W[lu], 1, h->wdt[lu], nullptr, 0, 0, nullptr, 0, 0,
                                h->Pu + h->off[lu - 1], hs, h->act, (lu - 1 == Le - 1) ? h->Gem : nullptr, h->hmax,
                                h->GPu + h->off[lu - 1], hs);
+          }
           }
           if (lv >= 1) --h->fs_l;
           if (lu >= 1) --h->fs_l2;

@@ -166,6 +166,42 @@ __global__ __launch_bounds__(256) void k_fl_post_fused(int n, int w, YView Y, co
   }
 }
 
+// One level of the backward of both chains behind the product Y = M [r o G_P_lv | G_P_lu], in one launch instead of four
+// (k_an_post + k_rowmat_mask for the victim(adj_norm) chain, k_copy_cols + k_rowmat_mask for the modified_adj chain):
+//   G_T_v = r o (Y_a + r o G_P_lv),  G_P_{lv-1} = (G_T_v W_lv^T) o relu'(P_v,lv-1)
+//   G_T_u = Y_b,                      G_P_{lu-1} = (G_T_u W_lu^T [+ Add]) o relu'(P_u,lu-1)
+// Same operations in the same order as the separate kernels (bit-identical).  Widths <= 32, FP_ROWS rows per block.
+__global__ __launch_bounds__(256) void k_fl_bwd_level(int n, int wv, int wu, YView Y, const float* __restrict__ Vs, int ldv,
+                                                      const float* __restrict__ r,
+                                                      int cv, const float* __restrict__ Wv, const float* __restrict__ Pv, float* __restrict__ GPv,
+                                                      int cu, const float* __restrict__ Wu, const float* __restrict__ Pu, float* __restrict__ GPu,
+                                                      int ldp, const float* __restrict__ Add, int lda) {
+  __shared__ float gt[2][FP_ROWS][32];
+  const int row0 = blockIdx.x * FP_ROWS, t = threadIdx.x;
+  for (int e = t; e < FP_ROWS * (wv + wu); e += 256) {
+    const int ri = e / (wv + wu), k = e - ri * (wv + wu), i = row0 + ri;
+    if (i >= n) continue;
+    if (k < wv) gt[0][ri][k] = r[i] * (Y.at(i, k) + Vs[(size_t)i * ldv + k]);       // k_an_post
+    else gt[1][ri][k - wv] = Y.at(i, k);                                               // k_copy_cols
+  }
+  __syncthreads();
+  for (int e = t; e < FP_ROWS * (cv + cu); e += 256) {                                 // k_rowmat_mask, both chains
+    const int ri = e / (cv + cu), q = e - ri * (cv + cu), i = row0 + ri;
+    if (i >= n) continue;
+    if (q < cv) {
+      float s = 0.f;
+      for (int k = 0; k < wv; ++k) s = fmaf(gt[0][ri][k], Wv[(size_t)k + (size_t)q * wv], s);
+      GPv[(size_t)i * ldp + q] = s * (Pv[(size_t)i * ldp + q] > 0.f ? 1.f : 0.f);
+    } else {
+      const int c = q - cv;
+      float s = 0.f;
+      for (int k = 0; k < wu; ++k) s = fmaf(gt[1][ri][k], Wu[(size_t)k + (size_t)c * wu], s);
+      if (Add) s += Add[(size_t)i * lda + c];
+      GPu[(size_t)i * ldp + c] = s * (Pu[(size_t)i * ldp + c] > 0.f ? 1.f : 0.f);
+    }
+  }
+}
+
 // out[k] = sum_i X[i][k] and (wgt != nullptr) out2[k] = sum_i wgt_i X[i][k] in fp64, k < w <= 64.  Two deterministic stages:
 // WC_PARTS row slices (thread = (row group, column): coalesced along the columns), then a fixed-order combine.
 constexpr int WC_PARTS = 64;
@@ -803,6 +839,12 @@ void fl_layer_post_head(hipStream_t st, int n, int w, YView Y, const float* V, i
                         const float* blin, float* Z, float* logp, float* sm, float* Z2, float* sm2, int head_act) {
   LAUNCH(k_fl_post_fused<1>, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, w, Y, V, ldv, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0,
          mean, rowsum, C, Wlin, blin, Z, Z2, C, nullptr, 0, logp, sm, sm2, head_act);
+}
+bool fl_bwd_level_supported(int wv, int wu, int cv, int cu) { return wv >= 1 && wu >= 1 && wv <= 32 && wu <= 32 && cv >= 1 && cu >= 1 && cv <= 32 && cu <= 32; }
+void fl_bwd_level(hipStream_t st, int n, int wv, int wu, YView Y, const float* Vs, int ldv, const float* r, int cv, const float* Wv,
+                  const float* Pv, float* GPv, int cu, const float* Wu, const float* Pu, float* GPu, int ldp, const float* Add, int lda) {
+  LAUNCH(k_fl_bwd_level, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, wv, wu, Y, Vs, ldv, r, cv, Wv, Pv, GPv, cu, Wu, Pu, GPu, ldp,
+         Add, lda);
 }
 // scratch: 2 * 64 * WC_PARTS doubles
 void fl_wcolsum(hipStream_t st, int n, int w, const float* X, int ldx, const float* wgt, double* out, double* out_w, double* scratch) {
