@@ -448,9 +448,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       //      which keeps the product at 32 columns (one column tile of the skinny kernel)
       if (use2) {
         launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
-        launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta);
+        // (the right-hand side r o V of the product below comes out of the same launch: fl_cat_scaled's values)
+        launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta, h->fused_post ? h->r : nullptr,
+                       h->fused_post ? h->FV : nullptr, fc);
         fl_wcolsum(st, n, 2 * he, h->lrV, h->lr_ldv, nullptr, h->fstat, nullptr, h->fstat + 256);
-        fl_cat_scaled(st, n, 2 * he, 2 * he, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
+        if (!h->fused_post) fl_cat_scaled(st, n, 2 * he, 2 * he, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
         CHK(mm_rows(h, st, 2 * he));
       }
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
@@ -539,7 +541,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       //      nothing of it (the rank-k panels, the coefficient of the norm term).  A row-block rank holds the column block
       //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
       (void)tail_reduce_call(h, st, 1, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
-      hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
+      // (the coefficient of the norm term comes out of k_tail_gd's launch; a rank without rows has no Adam pass to feed)
+      if (!(h->fused_post && R1 > R0)) hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
       CHK(join());
       // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result, =rk drops
       // the rank-k terms of the tail (both GCN chains' backward and the low-rank term of c2) from the gradient -- a parity
@@ -571,7 +574,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? h->SC + 4 : h->scal + S_H1);
           launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? h->SC + 5 : h->scal + S_V6);
         }
-        fl_tail_gd(st, n, R0, R1, ps1, h->d, h->gd);
+        {
+          const bool cn_in_gd = h->fused_post && R1 > R0;
+          fl_tail_gd(st, n, R0, R1, ps1, h->d, h->gd, cn_in_gd ? h->scal + S_SQ : nullptr, (float)(c.weight_sup * 0.001),
+                     cn_in_gd ? h->mm + 2 : nullptr);
+        }
         if (h->sharded) rows_to_stage(h, st, 1, h->gd, 1, 0);
       }
       FS_XCHG(h->fs_state, 10, X_SG(h))

@@ -652,8 +652,15 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
 }
 
 // gd_i = -1/2 d_i^-3/2 sum_J ps[i][J]      (k_normbwd_gd with rowpart + colpart already merged per tile)
+// cn_out != nullptr: also the coefficient of the norm term, d/da (coef |a|_2) = coef a / |a| with |a|^2 = sum_{i != j} M^2 / 2
+// from *sq (0 at the origin: torch.norm's backward) -- k_cn's launch
 __global__ __launch_bounds__(256) void k_tail_gd(int n, int row0, int row1, int nt, const float* __restrict__ ps,
-                                                 const float* __restrict__ d, float* __restrict__ gd) {
+                                                 const float* __restrict__ d, float* __restrict__ gd,
+                                                 const double* __restrict__ sq, float coef, float* __restrict__ cn_out) {
+  if (cn_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double s2 = sq[0] * 0.5;
+    cn_out[0] = s2 > 0.0 ? (float)(coef / sqrt(s2)) : 0.f;
+  }
   const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= row1) return;
   float s = 0.f;
@@ -930,9 +937,10 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
     LAUNCH(k_tail_reduce<false>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, M, P1, r, mean, delta, cvec, a1, a2, kie6, G2, ps, nullptr);
   return nt * (t1 - t0);
 }
-void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd) {
+void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd, const double* sq, float coef,
+                float* cn_out) {
   if (row1 <= row0) return;
-  LAUNCH(k_tail_gd, dim3((row1 - row0 + 3) / 4), dim3(256), st, n, row0, row1, fl_tail_tiles(n), ps, d, gd);
+  LAUNCH(k_tail_gd, dim3((row1 - row0 + 3) / 4), dim3(256), st, n, row0, row1, fl_tail_tiles(n), ps, d, gd, sq, coef, cn_out);
 }
 void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* G2, const float* gd, float* M,
                   float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,

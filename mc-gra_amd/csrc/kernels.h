@@ -100,7 +100,7 @@ int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, 
                          float kie7, float* slabs, double* v7part, float* GZn, int ldg, double* qtz);
 void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats);
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
-                    int ldv, float* delta);
+                    int ldv, float* delta, const float* rs = nullptr, float* Vs = nullptr, int ldvs = 0);
 void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,
                     double* rowval);
 void launch_lr_elem(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
@@ -151,7 +151,8 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
                    float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase = 0);
 size_t fl_tail_pack_bytes(int n);
-void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd);
+void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd, const double* sq = nullptr,
+                float coef = 0.f, float* cn_out = nullptr);
 void fl_tail_adam(hipStream_t st, int n, int ld, bool pair, int row0, int row1, const float* G2, const float* gd, float* M,
                   float* am, float* av, const float* cn, float omb1, float b2, float omb2, float step_size, float sqrt_bc2,
                   float eps, float* gsym_dbg, int do_clamp, float* ps_out, double* pq_out, int mirror_moments);

@@ -63,20 +63,26 @@ __global__ void k_lr_colstats_fin(int n, int h, const double* __restrict__ part,
 // changes nothing in exact arithmetic; in fp32 it removes a cancellation: the rows of Zn are nearly equal (the
 // embedding aggregates over a dense adjacency), so Xc^T (delta z) is the small difference of large partial sums
 // otherwise (scripts/fused_lowrank_proto.py: error of W2 against float64 1.5e-3 -> 5.7e-5 at n = 2048).
+// rs / Vs != nullptr: also Vs[i][k] = rs_i V[i][k], k < 2h -- the right-hand side of the product M (r o V) that follows in the
+// fused step (fl_cat_scaled's launch)
 __global__ void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, const double* __restrict__ stats,
-                          float* __restrict__ Lf, float* __restrict__ V, int ldv, float* __restrict__ delta) {
+                          float* __restrict__ Lf, float* __restrict__ V, int ldv, float* __restrict__ delta,
+                          const float* __restrict__ rs, float* __restrict__ Vs, int ldvs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* z = Z + (size_t)i * ldz;
   float d = 0.f;
   for (int k = 0; k < h; ++k) d += z[k] * z[k];
   delta[i] = d;
+  const float ri = Vs ? rs[i] : 0.f;
   for (int k = 0; k < h; ++k) {
     const float u = z[k] - (float)stats[k];
     Lf[(size_t)i * 2 * h + k] = u;
     Lf[(size_t)i * 2 * h + h + k] = -d * z[k];
+    const float v2 = d * z[k] - (float)(stats[h + k] / (double)n);
     V[(size_t)i * ldv + k] = u;
-    V[(size_t)i * ldv + h + k] = d * z[k] - (float)(stats[h + k] / (double)n);
+    V[(size_t)i * ldv + h + k] = v2;
+    if (Vs) { Vs[(size_t)i * ldvs + k] = ri * u; Vs[(size_t)i * ldvs + h + k] = ri * v2; }
   }
   V[(size_t)i * ldv + 2 * h] = d * d - (float)stats[2 * h + (size_t)h * h];
   for (int k = 2 * h + 1; k < ldv; ++k) V[(size_t)i * ldv + k] = 0.f;
@@ -374,8 +380,8 @@ void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, d
   LAUNCH(k_lr_colstats_fin, dim3(h + 3), dim3(64), st, n, h, part, stats);
 }
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
-                    int ldv, float* delta) {
-  LAUNCH(k_lr_prep, dim3((n + 255) / 256), dim3(256), st, n, h, Z, ldz, stats, Lf, V, ldv, delta);
+                    int ldv, float* delta, const float* rs, float* Vs, int ldvs) {
+  LAUNCH(k_lr_prep, dim3((n + 255) / 256), dim3(256), st, n, h, Z, ldz, stats, Lf, V, ldv, delta, rs, Vs, ldvs);
 }
 void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,
                     double* rowval) {
