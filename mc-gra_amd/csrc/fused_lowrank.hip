@@ -99,14 +99,14 @@ __global__ void k_fl_post(int n, int w, YView Y, const float* __restrict__ V, in
 // Same operations in the same order as the separate kernels (bit-identical results).  A block: FP_ROWS rows, widths <= 32.
 constexpr int FP_ROWS = 8;
 template <int HEAD>
-__global__ __launch_bounds__(256) void k_fl_post_fused(int n, int w, YView Y, const float* __restrict__ V, int ldv,
+__global__ __launch_bounds__(256) void k_fl_post_fused(int n, int w, YView Y, const float* V, int ldv,      // (V may be Vout)
                                                        const float* __restrict__ r, const float* __restrict__ b,
                                                        float* __restrict__ Pv, float* __restrict__ Hv, float* __restrict__ Pu,
                                                        float* __restrict__ Hu, int ldo, int with_r, float* __restrict__ mean,
                                                        double* __restrict__ rowsum,
                                                        int wn, const float* __restrict__ Wn, const float* __restrict__ bn,
                                                        float* __restrict__ On_v, float* __restrict__ On_u, int ldn,
-                                                       float* __restrict__ Vout, int ldvo,
+                                                       float* Vout, int ldvo,
                                                        float* __restrict__ logp_v, float* __restrict__ sm_v,
                                                        float* __restrict__ sm_u, int head_act) {
   __shared__ float hs[2][FP_ROWS][32];
