@@ -384,10 +384,16 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (s3 != st) MCGRA_HIP(hipEventRecord(h->ev_join3, s3));
 
       // ---- CE loss (:172) and its gradient into the victim chain
+      if (h->fused_post && fl_head_bwd_supported(C, h->wdt[L - 1], he)) {      // k_nll_grad + k_rowmat_mask in one launch
+        fl_head_bwd_nll(st, n, C, h->wdt[L - 1], h->Wlin, h->Pv + h->off[L - 1], h->GPv + h->off[L - 1], hs, h->logp, h->sm, h->labels,
+                        h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
+        if (want_vals) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
+      } else {
       launch_nll_grad(st, n, C, h->logp, h->sm, C, h->labels, h->cnt, (float)(c.weight_sup / h->na), h->GZ, h->rowvals + 6 * (size_t)ld);
       if (want_vals) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, n, 1, h->scal + S_NLL);
       launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
                          h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
+      }
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
       launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
@@ -482,9 +488,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (want_vals) launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
       }
       if (s3 != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join3, 0));       // c9 / c10: Gem, GZ2 and their scalars
-      launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
-
       // ---- backward: modified_adj chain (embedding + output2), products on M
+      if (w10 != 0 && h->fused_post && fl_head_bwd_supported(C, h->wdt[L - 1], he)) {
+        // k_row_normalize_bwd (G_em += ...) + the head's mask pass in one launch
+        fl_head_bwd_em(st, n, C, h->wdt[L - 1], h->Wlin, h->Pu + h->off[L - 1], h->GPu + h->off[L - 1], hs, h->GZ2, he, h->GZn, h->Zn,
+                       h->hmax, h->nrm, h->Gem, h->hmax, L - 1 == Le - 1);
+      } else {
+      launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
       if (w10 != 0) {
         launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ2, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
                            h->Pu + h->off[L - 1], hs, h->act, (L - 1 == Le - 1) ? h->Gem : nullptr, h->hmax, h->GPu + h->off[L - 1], hs);
@@ -492,6 +502,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (L > Le) MCGRA_HIP(hipMemsetAsync(h->GPu, 0, sizeof(float) * (size_t)n * hs, st));
         launch_rowmat_mask(st, n, 0, he, h->Gem, h->hmax, h->Wlin, 0, 0, nullptr, 0, 0, nullptr, 0, 0, h->Pu + h->off[Le - 1], hs,
                            h->act, h->Gem, h->hmax, h->GPu + h->off[Le - 1], hs);
+      }
       }
       // Backward of both chains, one product on M per level: columns [r o G_P_lv of the victim(adj_norm) chain | G_P_lu of
       // the modified_adj chain] (M symmetric: M^T G = M G; adj_norm^T G = r o (M (r o G) + r o G)), then

@@ -166,6 +166,67 @@ __global__ __launch_bounds__(256) void k_fl_post_fused(int n, int w, YView Y, co
   }
 }
 
+// The head's backward of a chain in ONE launch: the kernel that produces G_Z with the mask pass behind it,
+//   G_P_{L-1} = (G_Z Wlin [+ Add]) o relu'(P_{L-1})        (k_rowmat_mask)
+// WHICH == 0: G_Z = scale cnt_i (softmax - onehot) and the per-row CE value (k_nll_grad), no Add;
+// WHICH == 1: G_Z given (softmax backward of the c10 term), Add = G_em after the backward of F.normalize has been added
+//             to it (k_row_normalize_bwd: G_em += (G_Zn - Zn <Zn, G_Zn>) / |em|; Add only where the embedding is the
+//             chain's last layer).
+// Same operations in the same order as the separate kernels (bit-identical).  FP_ROWS rows per block, widths <= 32.
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_fl_head_bwd(int n, int C, int w, const float* __restrict__ Wlin,
+                                                     const float* __restrict__ P, float* __restrict__ GP, int ldp,
+                                                     // WHICH == 0
+                                                     const float* __restrict__ logp, const float* __restrict__ sm,
+                                                     const int* __restrict__ labels, const float* __restrict__ cnt, float scale,
+                                                     float* __restrict__ GZ, double* __restrict__ rownll,
+                                                     // WHICH == 1
+                                                     const float* __restrict__ GZin, int he, const float* __restrict__ GZn,
+                                                     const float* __restrict__ Zn, int ldz, const float* __restrict__ nrm,
+                                                     float* __restrict__ Gem, int ldg, int add_em) {
+  __shared__ float gz[FP_ROWS][32];
+  __shared__ float ge[FP_ROWS][32];
+  const int row0 = blockIdx.x * FP_ROWS, t = threadIdx.x;
+  if (t < FP_ROWS) {
+    const int i = row0 + t;
+    if (i < n) {
+      if (WHICH == 0) {                                    // k_nll_grad
+        const int y = labels[i];
+        const float wgt = cnt[i];
+        for (int k = 0; k < C; ++k) {
+          const float g = scale * wgt * (sm[(size_t)i * C + k] - (k == y ? 1.f : 0.f));
+          GZ[(size_t)i * C + k] = g;
+          gz[t][k] = g;
+        }
+        rownll[i] = -(double)logp[(size_t)i * C + y] * wgt;
+      } else {                                             // k_row_normalize_bwd
+        for (int k = 0; k < C; ++k) gz[t][k] = GZin[(size_t)i * C + k];
+        const float nr = nrm[i];
+        const float den = fmaxf(nr, 1e-12f);
+        float pr = 0.f;
+        if (nr >= 1e-12f)
+          for (int k = 0; k < he; ++k) pr += Zn[(size_t)i * ldz + k] * GZn[(size_t)i * ldz + k];
+        for (int k = 0; k < he; ++k) {
+          const float g = GZn[(size_t)i * ldz + k];
+          const float v = Gem[(size_t)i * ldg + k] + (nr >= 1e-12f ? g - Zn[(size_t)i * ldz + k] * pr : g) / den;
+          Gem[(size_t)i * ldg + k] = v;
+          ge[t][k] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (t < FP_ROWS * w) {                                   // k_rowmat_mask
+    const int ri = t / w, c = t - ri * w, i = row0 + ri;
+    if (i < n) {
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s = fmaf(gz[ri][k], Wlin[(size_t)k * w + c], s);
+      if (WHICH == 1 && add_em) s += ge[ri][c];
+      GP[(size_t)i * ldp + c] = s * (P[(size_t)i * ldp + c] > 0.f ? 1.f : 0.f);
+    }
+  }
+}
+
 // One level of the backward of both chains behind the product Y = M [r o G_P_lv | G_P_lu], in one launch instead of four
 // (k_an_post + k_rowmat_mask for the victim(adj_norm) chain, k_copy_cols + k_rowmat_mask for the modified_adj chain):
 //   G_T_v = r o (Y_a + r o G_P_lv),  G_P_{lv-1} = (G_T_v W_lv^T) o relu'(P_v,lv-1)
@@ -846,6 +907,17 @@ void fl_layer_post_head(hipStream_t st, int n, int w, YView Y, const float* V, i
                         const float* blin, float* Z, float* logp, float* sm, float* Z2, float* sm2, int head_act) {
   LAUNCH(k_fl_post_fused<1>, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, w, Y, V, ldv, r, b, Pv, Hv, Pu, Hu, ldo, with_r ? 1 : 0,
          mean, rowsum, C, Wlin, blin, Z, Z2, C, nullptr, 0, logp, sm, sm2, head_act);
+}
+bool fl_head_bwd_supported(int C, int w, int he) { return C >= 1 && C <= 32 && w >= 1 && w <= 32 && he >= 1 && he <= 32; }
+void fl_head_bwd_nll(hipStream_t st, int n, int C, int w, const float* Wlin, const float* P, float* GP, int ldp, const float* logp,
+                     const float* sm, const int* labels, const float* cnt, float scale, float* GZ, double* rownll) {
+  LAUNCH(k_fl_head_bwd<0>, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, C, w, Wlin, P, GP, ldp, logp, sm, labels, cnt, scale, GZ,
+         rownll, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0);
+}
+void fl_head_bwd_em(hipStream_t st, int n, int C, int w, const float* Wlin, const float* P, float* GP, int ldp, const float* GZ2, int he,
+                    const float* GZn, const float* Zn, int ldz, const float* nrm, float* Gem, int ldg, bool add_em) {
+  LAUNCH(k_fl_head_bwd<1>, dim3((n + FP_ROWS - 1) / FP_ROWS), dim3(256), st, n, C, w, Wlin, P, GP, ldp, nullptr, nullptr, nullptr, nullptr,
+         0.f, nullptr, nullptr, GZ2, he, GZn, Zn, ldz, nrm, Gem, ldg, add_em ? 1 : 0);
 }
 bool fl_bwd_level_supported(int wv, int wu, int cv, int cu) { return wv >= 1 && wu >= 1 && wv <= 32 && wu <= 32 && cv >= 1 && cu >= 1 && cv <= 32 && cu <= 32; }
 void fl_bwd_level(hipStream_t st, int n, int wv, int wu, YView Y, const float* Vs, int ldv, const float* r, int cv, const float* Wv,

@@ -123,6 +123,11 @@ void fl_an_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv,
 void fl_copy_cols(hipStream_t st, int n, int w, YView Y, int c0, float* out, int ldo);
 void fl_layer_post(hipStream_t st, int n, int w, YView Y, const float* V, int ldv, const float* r, const float* b,
                    float* Pv, float* Hv, float* Pu, float* Hu, int ldo, bool with_r, float* mean, double* rowsum);
+bool fl_head_bwd_supported(int C, int w, int he);
+void fl_head_bwd_nll(hipStream_t st, int n, int C, int w, const float* Wlin, const float* P, float* GP, int ldp, const float* logp,
+                     const float* sm, const int* labels, const float* cnt, float scale, float* GZ, double* rownll);
+void fl_head_bwd_em(hipStream_t st, int n, int C, int w, const float* Wlin, const float* P, float* GP, int ldp, const float* GZ2, int he,
+                    const float* GZn, const float* Zn, int ldz, const float* nrm, float* Gem, int ldg, bool add_em);
 bool fl_bwd_level_supported(int wv, int wu, int cv, int cu);
 void fl_bwd_level(hipStream_t st, int n, int wv, int wu, YView Y, const float* Vs, int ldv, const float* r, int cv, const float* Wv,
                   const float* Pv, float* GPv, int cu, const float* Wu, const float* Pu, float* GPu, int ldp, const float* Add, int lda);
