@@ -463,12 +463,17 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
       if (use2) {
-        fl_lrt_post(st, n, 2 * he, h->fy, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // [W | W2] = Xc^T Vc
         if (!h->t3_zero) {                                                                        // t3 = 0
           MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));
           h->t3_zero = true;
         }
-        launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
+        if (h->fused_post && he <= 32) {      // [W | W2] = Xc^T Vc and the per-column terms behind it in one launch
+          launch_lrt_lr_post(st, n, he, h->fy, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC,
+                             h->rowvals + 7 * (size_t)ld);
+        } else {
+          fl_lrt_post(st, n, 2 * he, h->fy, h->FV, fc, h->r, h->cmean, h->fstat, h->lrT, h->lr_ldv);  // [W | W2] = Xc^T Vc
+          launch_lr_post(st, n, he, h->lrT, h->lr_ldv, h->lrStats, h->lrR, h->lrC, h->rowvals + 7 * (size_t)ld);
+        }
         // [Q | Q2] = Xc [W | W2]
         fl_wcolsum(st, n, 2 * he, h->lrT, h->lr_ldv, h->cmean, h->fstat + 64, h->fstat + 128, h->fstat + 256);
         fl_lrq_pre(st, n, 2 * he, h->lrT, h->lr_ldv, h->r, h->fstat + 64, h->FV, fc);

@@ -109,6 +109,8 @@ size_t lr_elem_normbwd_scratch_floats(int n);
 void launch_lr_elem_normbwd(hipStream_t st, int n, int ld, const float* Xc, const float* P1, const float* delta,
                             const float* cvec, float a1, float a2, float* G, const float* A, const float* r,
                             float* scratch, float* rowpart, float** colpart, int* nstrips, double** v1part, int* v1count);
+void launch_lrt_lr_post(hipStream_t st, int n, int h, YView Y, const float* Vs, int ldvs, const float* r, const float* mean,
+                        const double* colsum, float* T, int ldv, const double* stats, float* Rm, float* cvec, double* rowval);
 void launch_lr_part2(hipStream_t st, int n, int h, const float* QQ, const float* Z, int ldz, const float* delta,
                      const double* rs, float kk, float* GZn, int ldg, const double* quad, double* rowval,
                      const double* ztz = nullptr, const double* qtz = nullptr, float a2 = 0.f);

@@ -114,6 +114,44 @@ __global__ __launch_bounds__(256) void k_lr_post(int n, int h, const float* __re
   }
 }
 
+// k_lrt_post (fused_lowrank.hip: T = Xc^T Vc from the product Y = M (r o Vc), T_i = r_i (Y_i + r_i Vc_i) - mean_i (1^T Vc))
+// and k_lr_post on the same eight rows, in one launch: same operations in the same order (bit-identical)
+__global__ __launch_bounds__(256) void k_lrt_lr_post(int n, int h, YView Y, const float* __restrict__ Vs, int ldvs,
+                                                     const float* __restrict__ r, const float* __restrict__ mean,
+                                                     const double* __restrict__ colsum, float* __restrict__ T, int ldv,
+                                                     const double* __restrict__ stats, float* __restrict__ Rm,
+                                                     float* __restrict__ cvec, double* __restrict__ rowval) {
+  constexpr int RB = 256 / LR_HMAX;
+  __shared__ float tl[RB][2 * LR_HMAX];
+  const int row0 = blockIdx.x * RB;
+  for (int e = threadIdx.x; e < RB * 2 * h; e += 256) {
+    const int ri = e / (2 * h), k = e - ri * (2 * h), i = row0 + ri;
+    if (i < n) {
+      const float v = r[i] * (Y.at(i, k) + Vs[(size_t)i * ldvs + k]) - (float)((double)mean[i] * colsum[k]);
+      T[(size_t)i * ldv + k] = v;
+      tl[ri][k] = v;
+    }
+  }
+  __syncthreads();
+  const int l = threadIdx.x & (LR_HMAX - 1), jr = threadIdx.x >> 5, j = row0 + jr;
+  const bool on = j < n && l < h;
+  const float* w = tl[jr];
+  double m = 0.0, cz = 0.0;
+  if (on) {
+    for (int k = 0; k < h; ++k) m += (double)w[k] * stats[2 * h + (size_t)k * h + l];
+    cz = (double)w[l] * stats[h + l];
+    Rm[(size_t)j * 2 * h + l] = (float)(m - (double)w[h + l]);
+    Rm[(size_t)j * 2 * h + h + l] = w[l];
+  }
+  double quad = on ? m * (double)w[l] : 0.0;
+#pragma unroll
+  for (int o = LR_HMAX / 2; o > 0; o >>= 1) { quad += __shfl_xor(quad, o); cz += __shfl_xor(cz, o); }
+  if (l == 0 && j < n) {
+    cvec[j] = (float)((cz - (double)T[(size_t)j * ldv + 2 * h]) / (double)n);      // t3 (a column of zeros on a fused step)
+    rowval[j] = quad;
+  }
+}
+
 // N x N pass: G_ij += a2 (delta_i^2 Xc_ij + c_j) + a1 P1_ij ;  rowval_i = sum_j P1_ij Xc_ij  (linear_HSIC(Fadj, X))
 __global__ __launch_bounds__(256) void k_lr_elem(int n, int ld, const float* __restrict__ Xc,
                                                  const float* __restrict__ P1, const float* __restrict__ delta,
@@ -382,6 +420,11 @@ void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, d
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta, const float* rs, float* Vs, int ldvs) {
   LAUNCH(k_lr_prep, dim3((n + 255) / 256), dim3(256), st, n, h, Z, ldz, stats, Lf, V, ldv, delta, rs, Vs, ldvs);
+}
+void launch_lrt_lr_post(hipStream_t st, int n, int h, YView Y, const float* Vs, int ldvs, const float* r, const float* mean,
+                        const double* colsum, float* T, int ldv, const double* stats, float* Rm, float* cvec, double* rowval) {
+  LAUNCH(k_lrt_lr_post, dim3((n + 256 / LR_HMAX - 1) / (256 / LR_HMAX)), dim3(256), st, n, h, Y, Vs, ldvs, r, mean, colsum, T, ldv, stats,
+         Rm, cvec, rowval);
 }
 void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,
                     double* rowval) {
