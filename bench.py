@@ -9,10 +9,11 @@ timed region.  Prints ONE JSON line (rank 0).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synthetic-10k-hsic|cora-shape-hsic|...]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU) and runs ONE attack, row-block sharded over the
-ranks (DESIGN.md section 6: every N x N pass split by rows, collectives over RCCL inside the timed region);
-`value` is the steps of that attack per second ("scaling": "strong").  Independent replicas, one per GPU, are the
-side figure `replica_probe`.
+N > 1 runs ONE attack, row-block sharded over N ranks, one per GPU (every N x N pass split by
+rows, collectives over RCCL inside the timed region); `value` is the steps of that attack per second ("scaling":
+"strong").  Under torch.distributed.run (RANK / WORLD_SIZE set) this process is one of the ranks and --gpus must equal
+WORLD_SIZE; a plain `python bench.py --gpus N` starts the N ranks itself (launch_ranks) and prints rank 0's line.
+Independent replicas, one per GPU, are the side figure `replica_probe`.
 
 Workloads carry their own start and learning rate (WORKLOADS below): adj_changes starts at start_kappa / N x U[0, 1)
 -- row sums O(1), the scale of a sparse graph, near the balance of the loss's N x N terms (which shrink the adjacency)
@@ -319,9 +320,47 @@ def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode,
     return out
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, exactly as the driver's
+    own multi-GPU command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`) from this still-GPU-free process, forward rank 0's JSON line as the ONLY stdout line
+    and fail if any rank fails.  (MCGRA_BENCH_SHARED_GPU=1 in the environment puts every rank on cuda:0 over gloo: the
+    1-GPU test mode.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)          # the ranks' stderr passes through
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                cand = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(cand, dict) and "metric" in cand:
+                line = cand
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(r.stdout)
+        raise SystemExit(f"bench.py: the {n_ranks}-rank launch failed (exit code {r.returncode}"
+                         + ("" if line is not None else ", no result line from rank 0") + ")")
+    if line["n_gpus"] != n_ranks:
+        raise SystemExit(f"bench.py: asked for {n_ranks} ranks, the line says {line['n_gpus']}")
+    print(json.dumps(line), flush=True)
+    return line
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU) of ONE row-block sharded attack; default: WORLD_SIZE under a launcher, else 1.  "
+                         "Without a launcher and N > 1 this process starts the N ranks itself (torch.distributed.run)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="synthetic-10k-hsic", choices=sorted(WORKLOADS))
@@ -334,6 +373,13 @@ def main(argv=None):
                     help="skip the extra runs at N = 1 (other evaluation of the N x N x N product, Cora-shape workload)")
     a = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ:
+        if (a.gpus or 1) > 1:
+            # plain `python bench.py --gpus N`: this process (which has not touched the GPU) starts the N ranks itself
+            return launch_ranks(a.gpus, list(sys.argv[1:] if argv is None else argv))
+    elif a.gpus is not None and a.gpus != int(os.environ["WORLD_SIZE"]):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} under a launcher that set WORLD_SIZE={os.environ['WORLD_SIZE']}: "
+                         "the two must agree (one rank per GPU)")
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     # MCGRA_BENCH_SHARED_GPU=1 (tests on a 1-GPU box): every rank on cuda:0, the collectives over gloo with host-staged
@@ -384,11 +430,12 @@ def main(argv=None):
     for _ in range(a.warmup):
         one_step()
     eng.profile(True); eng.gemm_stats(reset=True)
+    ex0 = stepper.exchanges if stepper is not None else 0
     dt = timed_region(one_step, a.steps, 0, torch.cuda.synchronize, world, dist, red_dev, torch)
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
     eng_path = dict(eng.path_stats(), fused_steps=eng.fused_steps(), gram_split_steps=eng.gram_split_steps())
-    stepper_exchanges = (stepper.exchanges / (a.warmup + a.steps)) if stepper is not None else None
+    stepper_exchanges = ((stepper.exchanges - ex0) / a.steps) if stepper is not None else None      # of the timed steps
 
     # the same N x N x N product alone on the chip (no side-stream company), for the roofline's "alone" figure
     alone_ms = None
@@ -426,7 +473,15 @@ def main(argv=None):
         except Exception as e:
             split = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    # the split product by itself (no side-stream company): same engine with MCGRA_OVERLAP=0, for roofline.alone
+    # the split product by itself: the timed engine's own last product replayed back to back with nothing beside it
+    replay_ms = None
+    if world == 1 and measure == "HSIC" and pmode in (2, 3) and eng_path["fused_steps"] > 0 and wp[0] != 0:
+        try:
+            eng.product_replay(3)
+            replay_ms = eng.product_replay(20)
+        except Exception as e:
+            replay_ms = None
+    # ... and the step without the side stream (same engine configuration with MCGRA_OVERLAP=0): what the fork is worth
     alone = None
     side_stream = (os.environ.get("MCGRA_OVERLAP") or ("1" if pmode == 3 else "0")) == "1"
     if world == 1 and measure == "HSIC" and pmode in (2, 3) and side_stream and not a.no_split_probe:
@@ -486,7 +541,7 @@ def main(argv=None):
                        "forward_reuse": bool(monitor and os.environ.get("MCGRA_NO_FWD_REUSE") != "1"),
                        "parallelism": (f"row-block x{world}: one attack, rows of the learnable adjacency and of every N x N pass "
                                        f"split over the ranks ({plan.rows_per_rank} rows each); per step one all-to-all of "
-                                       "P1 tile blocks, all-gathers of n x c node arrays, all-reduces of scalars "
+                                       "P1 tile blocks and all-gathers of n x c node arrays with the partial scalars in their lane "
                                        + ("(gloo, host-staged: the ranks share ONE GPU -- a test mode, not a measurement)"
                                           if shared_gpu else "(RCCL)")
                                        if world > 1 else "single")},
@@ -536,13 +591,17 @@ def main(argv=None):
                                    "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
                                    "gemm_share_of_step": st["ms"] / (1e3 * dt),
                                    "side_stream": side_stream}
-                if alone is not None and "product_avg_launch_ms" in alone:
-                    # the same launch with nothing beside it (MCGRA_OVERLAP=0): faster product, slower step
-                    ams = alone["product_avg_launch_ms"]
+                if replay_ms or (alone is not None and "product_avg_launch_ms" in alone):
+                    # the same launch with nothing beside it: 20 back-to-back replays on this engine's planes
+                    # (mcgra_attack_product_replay), else the MCGRA_OVERLAP=0 run's launches: faster product, slower step
+                    ams = replay_ms or alone["product_avg_launch_ms"]
                     out["roofline"]["alone"] = {"avg_launch_ms": ams, "achieved": 2.0 * n ** 3 / (ams * 1e-3) / 1e12,
                                                 "frac": 2.0 * n ** 3 / (ams * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                                 "issued_frac": 2.0 * npp * n ** 3 / (ams * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                                                "steps_per_s_without_side_stream": alone["value"]}
+                                                "how": "20 back-to-back replays" if replay_ms else "MCGRA_OVERLAP=0 run"}
+                    if alone is not None and "value" in alone:
+                        out["roofline"]["alone"]["steps_per_s_without_side_stream"] = alone["value"]
+                        out["roofline"]["alone"]["launch_ms_without_side_stream"] = alone.get("product_avg_launch_ms")
             elif eng.gram_split_steps() > 0:
                 # Gram evaluation (MCGRA_NO_LOWRANK=1, masked or GAT / SAGE steps) on the same 2-plane fp16 kernel: four
                 # launches per step; each counted as the reference's dense n x n x n product (2 n^3 flop) although the two

@@ -331,6 +331,11 @@ int mcgra_attack_copy_buffer(mcgra_attack_t* h, void* stream, const char* name, 
  * mcgra_attack_gemm_stats synchronises, then returns launch count, total
  * milliseconds and total flops since the last reset. */
 int mcgra_attack_profile(mcgra_attack_t* h, int enable);
+/* Measurement aid: `reps` back-to-back launches of the last fused step's N x N x N product (split2_m16_kernel on the
+ * operand planes that step packed; results go to scratch) with nothing beside them, timed by HIP events on `stream`;
+ * returns the mean launch time.  bench.py's roofline.alone and scripts/power_trace.py's product_alone phase.  No engine
+ * state changes.  Needs a preceding fused low-rank step with w1 != 0. */
+int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, double* ms_per_launch);
 int mcgra_attack_gemm_stats(mcgra_attack_t* h, int reset, int64_t* launches,
                             double* ms, double* flops);
 

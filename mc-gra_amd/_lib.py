@@ -34,6 +34,7 @@ SYMBOLS = [
     "mcgra_attack_monitor", "mcgra_attack_finalize", "mcgra_attack_buffer", "mcgra_attack_copy_buffer",
     "mcgra_attack_profile",
     "mcgra_attack_gemm_stats",
+    "mcgra_attack_product_replay",
 ]
 
 
@@ -117,6 +118,7 @@ def _load():
         "mcgra_attack_copy_buffer": [vp, vp, C.c_char_p, fp, C.c_int],
         "mcgra_attack_profile": [vp, C.c_int],
         "mcgra_attack_gemm_stats": [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "mcgra_attack_product_replay": [vp, vp, C.c_int, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

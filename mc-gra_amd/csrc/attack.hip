@@ -390,7 +390,10 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         h->world = cfg->shard_world; h->rpr = cfg->shard_rows; h->rank = cfg->row_begin / cfg->shard_rows;
         h->npad = h->rpr * h->world;
         h->row0 = cfg->row_begin; h->row1 = cfg->row_end;
-        h->sgw = (he + 2 + 3) & ~3;
+        // exchanged node arrays (attack_fused.hip: wide_stage / narrow_stage): n-vector columns (decode backward | |xc_i|^2 as
+        // two words) + a two-column scalar lane; the wide one carries a product's fcols columns in front of them
+        h->sgw = ((he + 2 + 3) & ~3) + 2;
+        h->fyw = fc + h->sgw;
       }
     }
     if (h->fused_ok && !rc) {

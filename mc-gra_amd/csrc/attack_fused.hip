@@ -48,6 +48,16 @@ __global__ void k_stage_to_rows(int n, int w, const float* __restrict__ stage, i
   dst[(size_t)i * ldd + k] = stage[(size_t)i * sgw + c0 + k];
 }
 __global__ void k_u32_to_f64(const unsigned int* __restrict__ a, double* __restrict__ out) { out[0] = (double)a[0]; }
+// The scalar lane of an exchanged node array: two float columns that hold one double per row.  Rank k leaves its partial
+// sum q in row k * rpr + q of its own chunk; behind the all-gather every rank adds the `world` partials in rank order --
+// the same bits on every rank, and no all-reduce.
+__global__ void k_lane_sum(int world, int rpr, int ldw, const float* __restrict__ lane, int nq, double* __restrict__ out) {
+  const int q = threadIdx.x;
+  if (q >= nq) return;
+  double s = 0.0;
+  for (int k = 0; k < world; ++k) s += *reinterpret_cast<const double*>(lane + ((size_t)k * rpr + q) * ldw);
+  out[q] = s;
+}
 // late mean: from the pack's per-block row sums / sums of squares of adj_norm (uncentred): rowsum_i = sum_p psum[i][p],
 // mean_i = rowsum_i / n, |xc_i|^2 = sum_p psq[i][p] - rowsum_i^2 / n        (fp64)
 __global__ __launch_bounds__(256) void k_mean_fin(int n, int np, const float* __restrict__ psum, const float* __restrict__ psq,
@@ -78,12 +88,30 @@ __global__ __launch_bounds__(256) void k_rmax2(int n, const float* __restrict__ 
 }  // namespace mcgra
 
 static inline dim3 g1(size_t count) { return dim3((unsigned)((count + 255) / 256)); }
-static void rows_to_stage(mcgra_attack* h, hipStream_t st, int w, const float* src, int lds_, int c0) {
+// The two exchanged node arrays of a row-block rank (views into its arena): WIDE = [product columns (fcols) | n-vector
+// columns | scalar lane], the result of a skinny product on M together with whatever n-vectors and partial scalars are
+// ready at the same point of the step; NARROW = [n-vector columns | scalar lane] for the exchanges without a product.
+struct Stage { float* base; int ld, vec0, lane0; };
+static Stage wide_stage(const mcgra_attack* h) { return Stage{h->FY, h->fyw, h->fcols, h->fyw - 2}; }
+static Stage narrow_stage(const mcgra_attack* h) { return Stage{h->SG, h->sgw, 0, h->sgw - 2}; }
+static void rows_to_stage(mcgra_attack* h, hipStream_t st, const Stage& sg, int w, const float* src, int lds_, int c0) {
   if (h->row1 > h->row0)
-    hipLaunchKernelGGL(k_rows_to_stage, g1((size_t)(h->row1 - h->row0) * w), dim3(256), 0, st, h->row0, h->row1, w, src, lds_, h->SG, h->sgw, c0);
+    hipLaunchKernelGGL(k_rows_to_stage, g1((size_t)(h->row1 - h->row0) * w), dim3(256), 0, st, h->row0, h->row1, w, src, lds_, sg.base, sg.ld,
+                       sg.vec0 + c0);
 }
-static void stage_to_rows(mcgra_attack* h, hipStream_t st, int w, int c0, float* dst, int ldd) {
-  hipLaunchKernelGGL(k_stage_to_rows, g1((size_t)h->n * w), dim3(256), 0, st, h->n, w, h->SG, h->sgw, c0, dst, ldd);
+static void stage_to_rows(mcgra_attack* h, hipStream_t st, const Stage& sg, int w, int c0, float* dst, int ldd) {
+  hipLaunchKernelGGL(k_stage_to_rows, g1((size_t)h->n * w), dim3(256), 0, st, h->n, w, sg.base, sg.ld, sg.vec0 + c0, dst, ldd);
+}
+// slot q of this rank's scalar lane (a double)
+static double* lane_slot(const mcgra_attack* h, const Stage& sg, int q) {
+  return reinterpret_cast<double*>(sg.base + ((size_t)h->rank * h->rpr + q) * sg.ld + sg.lane0);
+}
+static int lane_zero(mcgra_attack* h, hipStream_t st, const Stage& sg, int nq) {
+  MCGRA_HIP(hipMemset2DAsync(lane_slot(h, sg, 0), (size_t)sg.ld * 4, 0, 8, nq, st));
+  return 0;
+}
+static void lane_sum(mcgra_attack* h, hipStream_t st, const Stage& sg, int nq, double* out) {
+  hipLaunchKernelGGL(k_lane_sum, dim3(1), dim3(64), 0, st, h->world, h->rpr, sg.ld, sg.base + sg.lane0, nq, out);
 }
 
 bool fused_step_possible(const mcgra_attack* h) { return h->fused_ok; }
@@ -98,14 +126,14 @@ static void x_allreduce(mcgra_exchange_t* ex, int64_t off, int count) {
 static void x_alltoall(mcgra_exchange_t* ex, int64_t off_send, int64_t off_recv, int64_t chunk_bytes) {
   ex->kind = MCGRA_XCHG_ALLTOALL; ex->count = 0; ex->offset = off_send; ex->offset2 = off_recv; ex->chunk_bytes = chunk_bytes;
 }
-#define X_FY(h) x_allgather(ex, (h)->off_fy, (int64_t)(h)->rpr * (h)->fcols * 4)
+#define X_FY(h) x_allgather(ex, (h)->off_fy, (int64_t)(h)->rpr * (h)->fyw * 4)
 #define X_SG(h) x_allgather(ex, (h)->off_sg, (int64_t)(h)->rpr * (h)->sgw * 4)
 
 int64_t fused_exchange_bytes(const mcgra_attack* h) {
   if (!h->sharded) return 0;
   const int64_t a = 256;
   auto up = [&](int64_t x) { return (x + a - 1) / a * a; };
-  return up((int64_t)h->npad * h->fcols * 4) + up((int64_t)h->npad * h->sgw * 4) + up(16 * 8) +
+  return up((int64_t)h->npad * h->fyw * 4) + up((int64_t)h->npad * h->sgw * 4) + up(16 * 8) +
          2 * up((int64_t)h->world * h->rpr * h->rpr * 4) + up((int64_t)h->npad * h->ld * 4);
 }
 
@@ -113,11 +141,11 @@ int64_t fused_exchange_bytes(const mcgra_attack* h) {
 // a monolithic engine leaves a split-K product as its slabs and hands its consumers a view of them (h->fy).
 static int mm_rows(mcgra_attack* h, hipStream_t st, int ncol) {
   const int rows = h->row1 - h->row0;
-  h->fy = YView{h->FY, h->fcols, 1, 0};
+  h->fy = YView{h->FY, h->sharded ? h->fyw : h->fcols, 1, 0};
   if (rows <= 0) return 0;
-  if (h->sharded)
+  if (h->sharded)      // into the product columns of the wide exchange stage
     return eg(h, st, false, false, rows, ncol, h->n, 1.f, h->M + (size_t)h->row0 * h->ld, h->ld, h->FV, h->fcols, 0.f,
-              h->FY + (size_t)h->row0 * h->fcols, h->fcols);
+              h->FY + (size_t)h->row0 * h->fyw, h->fyw);
   if (h->planes_valid && planes_mm_supported(h->n, ncol)) {      // beside the N x N x N product: from its own operand planes
     MCGRA_HIP(planes_mm(st, h->n, h->Bpack, split3_chunks(h->n, 2), h->amax + 1, h->FV, h->fcols, ncol, h->r, h->ws, h->ws_bytes, &h->fy,
                         h->pm_scratch));
@@ -150,21 +178,23 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
       if (!h->sharded) {
         launch_reduce_rows(st, h->rowsq, n, 2, h->scal + S_SQ);      // rowsq | rowsum are adjacent, and so are S_SQ | S_SUM
       } else {
-        MCGRA_HIP(hipMemsetAsync(h->SC, 0, 2 * sizeof(double), st));
+        // own rows of r and d, and this rank's share of |adj_changes|^2 and sum(modified_adj) in the scalar lane: ONE gather
+        const Stage sg = narrow_stage(h);
+        CHK(lane_zero(h, st, sg, 2));
         if (R1 > R0) {
-          launch_reduce_rows(st, h->rowsq + R0, R1 - R0, 1, h->SC + 0);
-          launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, h->SC + 1);
+          launch_reduce_rows(st, h->rowsq + R0, R1 - R0, 1, lane_slot(h, sg, 0));
+          launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, lane_slot(h, sg, 1));
         }
-        rows_to_stage(h, st, 1, h->r, 1, 0);
-        rows_to_stage(h, st, 1, h->d, 1, 1);
+        rows_to_stage(h, st, sg, 1, h->r, 1, 0);
+        rows_to_stage(h, st, sg, 1, h->d, 1, 1);
       }
       FS_XCHG(h->fw_state, 1, X_SG(h))
       if (h->sharded) {
-        stage_to_rows(h, st, 1, 0, h->r, 1);
-        stage_to_rows(h, st, 1, 1, h->d, 1);
+        const Stage sg = narrow_stage(h);
+        stage_to_rows(h, st, sg, 1, 0, h->r, 1);
+        stage_to_rows(h, st, sg, 1, 1, h->d, 1);
+        lane_sum(h, st, sg, 2, h->scal + S_SQ);          // S_SQ | S_SUM are adjacent
       }
-      FS_XCHG(h->fw_state, 2, x_allreduce(ex, h->off_sc, 2))
-      if (h->sharded) MCGRA_HIP(hipMemcpyAsync(h->scal + S_SQ, h->SC, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
       for (h->fs_l = 0; h->fs_l < L; ++h->fs_l) {
         {
           const int l = h->fs_l, w = h->wdt[l];
@@ -425,28 +455,17 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
                                  h->hmax, h->nmask);
-        MCGRA_HIP(hipMemsetAsync(h->SC + 2, 0, 2 * sizeof(double), st));
-        hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, h->SC + 2);
-        if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, h->SC + 3);
-        rows_to_stage(h, st, he, h->GZn, h->hmax, 0);
-        if (use2) rows_to_stage(h, st, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
+        // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair count and entropy partial: they ride in
+        // the gather of the first low-rank product below (or, without c2, in a gather of their own)
+        const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
+        CHK(lane_zero(h, st, sg, 2));
+        hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, lane_slot(h, sg, 0));
+        if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 1));
+        rows_to_stage(h, st, sg, he, h->GZn, h->hmax, 0);
+        if (use2) rows_to_stage(h, st, sg, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
       }
       MCGRA_KERNEL_CHECK();
-      FS_XCHG(h->fs_state, 2, X_SG(h))
-      if (h->sharded) {
-        stage_to_rows(h, st, he, 0, h->GZn, h->hmax);
-        if (use2) stage_to_rows(h, st, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
-      }
-      FS_XCHG(h->fs_state, 3, x_allreduce(ex, h->off_sc + 16, 2))
-      if (h->sharded) MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 3, sizeof(double), hipMemcpyDeviceToDevice, st));
-      // A relu-masked pair (S_ij <= 0) voids the low-rank algebra.  The count is posted to mapped host memory now and
-      // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
-      // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
-      // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
-      if (use2 && h->sharded) {
-        hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, nullptr, h->SC + 2, h->mask_seq_dev, h->mask_host_dev);
-        h->mask_want = ++h->mask_seq;
-      }
+      if (!use2) { FS_XCHG(h->fs_state, 2, X_SG(h)) }
 
       // ---- low-rank factors (section 1b) with the products on M (section 1c).  T = Xc^T Vc without the delta^2 column
       //      of V: on a low-rank step every row of Zn has unit norm (a dead row would have masked its pairs), so that
@@ -462,6 +481,21 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         CHK(mm_rows(h, st, 2 * he));
       }
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
+      if (h->sharded) {
+        const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
+        stage_to_rows(h, st, sg, he, 0, h->GZn, h->hmax);
+        if (use2) stage_to_rows(h, st, sg, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
+        lane_sum(h, st, sg, 2, h->SC + 2);                       // SC[2] masked pairs, SC[3] entropy term of modified_adj1
+        MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 3, sizeof(double), hipMemcpyDeviceToDevice, st));
+        // A relu-masked pair (S_ij <= 0) voids the low-rank algebra.  The count is posted to mapped host memory now and
+        // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
+        // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
+        // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
+        if (use2) {
+          hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, nullptr, h->SC + 2, h->mask_seq_dev, h->mask_host_dev);
+          h->mask_want = ++h->mask_seq;
+        }
+      }
       if (use2) {
         if (!h->t3_zero) {                                                                        // t3 = 0
           MCGRA_HIP(hipMemset2DAsync(h->lrT + 2 * he, (size_t)h->lr_ldv * 4, 0, 4, n, st));
@@ -585,20 +619,25 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         float* ps1 = h->KY;
         double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
         h->fs_nblk = tail_reduce_call(h, st, 2, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
-        if (h->sharded) MCGRA_HIP(hipMemsetAsync(h->SC + 4, 0, 3 * sizeof(double), st));
+        const Stage sgt = narrow_stage(h);
+        if (h->sharded) CHK(lane_zero(h, st, sgt, 2));
         if (h->fs_nblk > 0 && want_vals) {
-          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? h->SC + 4 : h->scal + S_H1);
-          launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? h->SC + 5 : h->scal + S_V6);
+          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 0) : h->scal + S_H1);
+          launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 1) : h->scal + S_V6);
         }
         {
           const bool cn_in_gd = h->fused_post && R1 > R0;
           fl_tail_gd(st, n, R0, R1, ps1, h->d, h->gd, cn_in_gd ? h->scal + S_SQ : nullptr, (float)(c.weight_sup * 0.001),
                      cn_in_gd ? h->mm + 2 : nullptr);
         }
-        if (h->sharded) rows_to_stage(h, st, 1, h->gd, 1, 0);
+        if (h->sharded) rows_to_stage(h, st, sgt, 1, h->gd, 1, 0);
       }
       FS_XCHG(h->fs_state, 10, X_SG(h))
-      if (h->sharded) stage_to_rows(h, st, 1, 0, h->gd, 1);
+      if (h->sharded) {
+        const Stage sgt = narrow_stage(h);
+        stage_to_rows(h, st, sgt, 1, 0, h->gd, 1);
+        lane_sum(h, st, sgt, 2, h->SC + 4);                      // SC[4] sum P1 o Xc, SC[5] entropy term of adj_norm
+      }
       // ---- the decision, on the host
       if (use2) {
         bool masked;        // (no initialiser: the resumable step jumps into the block below)
@@ -659,10 +698,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         const size_t cnt = (size_t)n * nt;
         prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
                            h->rowsum, R0, R1);
-        if (R1 > R0) launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, h->SC + 6);
+        const Stage sgc = narrow_stage(h);
+        CHK(lane_zero(h, st, sgc, 1));
+        if (R1 > R0) launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, lane_slot(h, sgc, 0));
       }
-      if (h->fs_want) { FS_XCHG(h->fs_state, 11, x_allreduce(ex, h->off_sc + 32, 3)) }
+      if (h->fs_want) { FS_XCHG(h->fs_state, 11, X_SG(h)) }
       if (h->sharded && h->fs_want) {
+        lane_sum(h, st, narrow_stage(h), 1, h->SC + 6);
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_H1, h->SC + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_V6, h->SC + 5, sizeof(double), hipMemcpyDeviceToDevice, st));
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_CLAMPSUM, h->SC + 6, sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -695,7 +737,7 @@ int mcgra_attack_bind_exchange(mcgra_attack_t* h, void* arena, int64_t bytes) {
   auto up = [&](int64_t x) { return (x + a - 1) / a * a; };
   h->arena = (char*)arena; h->arena_bytes = bytes;
   int64_t o = 0;
-  h->off_fy = o; o += up((int64_t)h->npad * h->fcols * 4);
+  h->off_fy = o; o += up((int64_t)h->npad * h->fyw * 4);
   h->off_sg = o; o += up((int64_t)h->npad * h->sgw * 4);
   h->off_sc = o; o += up(16 * 8);
   h->off_a2s = o; o += up((int64_t)h->world * h->rpr * h->rpr * 4);
@@ -760,6 +802,34 @@ int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out) {
   if (h->fs_want == 2) { for (int i = 0; i < 10; ++i) out[i] = h->fs_scalars[i]; return 0; }
   if (h->fs_want != 1) { set_error("the step was begun without want_scalars"); return MCGRA_EINVAL; }
   return collect_scalars(h, st, out, true);
+}
+
+int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, double* ms_per_launch) {
+  if (!h || reps < 1) { set_error("bad argument"); return MCGRA_EINVAL; }
+  if (!h->fused_ok || !h->fused_last || h->cfg.w[0] == 0.f) {
+    set_error("product_replay: the last step must have been a fused low-rank step with the c1 term (w1 != 0)");
+    return MCGRA_EINVAL;
+  }
+  // the operand planes of the last step's product are still in Apack / Bpack (Bpack no longer describes M, which does not
+  // matter here); KX and KY are scratch between steps
+  hipStream_t st = (hipStream_t)stream;
+  const int P = split3_panel(), p_off = h->row0 / P, p_cnt = h->row1 > h->row0 ? (h->row1 - h->row0 + P - 1) / P : 0;
+  if (p_cnt == 0) { if (ms_per_launch) *ms_per_launch = 0.0; return 0; }
+  hipEvent_t e0, e1;
+  MCGRA_HIP(hipEventCreate(&e0));
+  MCGRA_HIP(hipEventCreate(&e1));
+  MCGRA_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i)
+    MCGRA_HIP(split3_symm(st, h->n, h->Apack, h->Bpack, h->KX, h->ld, 0, -1, h->KY, sizeof(float) * (size_t)h->n * h->ld, h->split_planes,
+                          h->amax, p_off, p_cnt));
+  MCGRA_HIP(hipEventRecord(e1, st));
+  MCGRA_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MCGRA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_per_launch) *ms_per_launch = (double)ms / reps;
+  // (no engine state is touched: the next step packs its own planes)
+  return 0;
 }
 
 int mcgra_attack_get_rows(mcgra_attack_t* h, void* stream, float* out) {

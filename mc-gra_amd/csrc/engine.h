@@ -158,8 +158,8 @@ struct mcgra_attack {
   int64_t arena_bytes = 0;
   int64_t off_fy = 0, off_sg = 0, off_sc = 0, off_a2s = 0, off_a2r = 0, off_nxn = 0;
   float *SG = 0, *A2S = 0, *A2R = 0, *NXS = 0;   // views into the arena: n-vector stage [npad][sgw], all-to-all send / recv, N x N stage
-  double* SC = 0;                  // 16 exchanged scalars
-  int sgw = 0;
+  double* SC = 0;                  // 16 scalars summed over the ranks (from the stages' scalar lanes)
+  int sgw = 0, fyw = 0;            // row widths (floats, even) of the narrow / wide exchanged node arrays
   // resumable step (protothread state: the step runs to the next exchange point and returns)
   int fs_state = 0, fw_state = 0, fs_l = 0, fs_l2 = 0, fs_what = 0, fs_want = 0, fs_np = 0, fs_nblk = 0;
   bool fs_active = false, fs_adopted = false, fs_dec_forked = false;

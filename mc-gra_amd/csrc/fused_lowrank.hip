@@ -948,11 +948,24 @@ void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv
 
 // decode recomputed per pair for rows [row0, row1); returns the number of v7 partials (0 and GZn = 0 when kie7 == 0:
 // then only the mask count is produced, by the same kernel with kie7 = 0).  slabs: lr_decode_slabs(n) * n * h floats.
+// column slices of the decode of a ROW RANGE: a row-block rank has 1 / world of the row blocks, so it cuts the columns finer to
+// fill the chip (N = 10 000 on 8 ranks: 5 row blocks x 13 slices = 65 blocks took 0.49 ms per rank, as long as the whole
+// matrix on one GPU; 5 x 128: 0.05 ms).  The full range keeps lr_decode_slabs (the monolithic engine's bits do not move).
+// slabs: fl_decode_slabs * n * h floats (<= 128 slices: fits the 64 x n x 64 split-K workspace for h <= 32).
+int fl_decode_slabs(int n, int rows) {
+  if (rows >= n) return lr_decode_slabs(n);
+  const int nb = (rows + 255) / 256;
+  int js = (1024 + nb - 1) / nb;
+  if (js > 128) js = 128;
+  if (js > n / 64) js = n / 64;
+  const int js0 = lr_decode_slabs(n);
+  return js < js0 ? js0 : js;
+}
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
                   double* v7part, float* GZn, int ldg, unsigned int* nmask) {
   const int rows = row1 - row0;
   if (rows <= 0) return 0;
-  const int nb = (rows + 255) / 256, js = lr_decode_slabs(n), jper = (n + js - 1) / js;
+  const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows), jper = (n + js - 1) / js;
   if (h == 8) LAUNCH(k_decode_fly<8>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
   else if (h == 16) LAUNCH(k_decode_fly<16>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
   else LAUNCH(k_decode_fly<32>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);

@@ -379,6 +379,14 @@ class AttackEngine:
             torch.cuda.current_stream().synchronize()
         return out
 
+    def product_replay(self, reps=10):
+        """Mean launch time [ms] of `reps` back-to-back launches of the last fused step's N x N x N product, nothing beside
+        them (mcgra_attack_product_replay: a measurement aid, no engine state changes)."""
+        ms = C.c_double(0)
+        with torch.cuda.device(self.device):
+            check(lib.mcgra_attack_product_replay(self._h, _stream(), int(reps), C.byref(ms)))
+        return ms.value
+
     def profile(self, enable=True):
         check(lib.mcgra_attack_profile(self._h, int(enable)))
 

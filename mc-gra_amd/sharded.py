@@ -120,6 +120,9 @@ def run_lockstep(backends, what=SHARD_STEP, want_scalars=False):
     for b in backends:
         b.begin(what, want_scalars)
     n_ex = 0
+    joint = getattr(backends[0], "joint", None)
+    if joint is not None and not all(getattr(b, "joint", None) is joint for b in backends):
+        joint = None
     while True:
         exs = [b.next() for b in backends]
         kinds = {e[0] for e in exs}
@@ -130,6 +133,17 @@ def run_lockstep(backends, what=SHARD_STEP, want_scalars=False):
             break
         n_ex += 1
         arenas = [b.arena for b in backends]
+        if joint is not None and kind in (XCHG_ALLGATHER, XCHG_ALLTOALL):
+            # arenas are rows of ONE [world, bytes] tensor (lockstep_backends): a collective is one strided copy, so the
+            # emulation's own launches do not grow with world^2 (per-rank timing, scripts/shard_emulate.py)
+            if kind == XCHG_ALLGATHER:
+                full = joint[:, off:off + w * chunk].view(w, w, chunk)              # [holder, chunk owner, bytes]
+                own = torch.diagonal(full, dim1=0, dim2=1).t().clone()         # [owner, bytes]: every rank's own chunk
+                full.copy_(own.unsqueeze(0).expand(w, w, chunk))
+            else:
+                send = joint[:, off:off + w * chunk].view(w, w, chunk)              # [src, dst, bytes]
+                joint[:, off2:off2 + w * chunk].view(w, w, chunk).copy_(send.transpose(0, 1))
+            continue
         if kind == XCHG_ALLGATHER:
             for src in range(w):
                 piece = arenas[src][off + src * chunk: off + (src + 1) * chunk]
@@ -154,10 +168,14 @@ def run_lockstep(backends, what=SHARD_STEP, want_scalars=False):
 class HipShardBackend:
     """An AttackEngine created as a row-block rank, with its exchange arena owned by torch."""
 
-    def __init__(self, engine, plan):
+    def __init__(self, engine, plan, arena=None, joint=None):
+        """arena: a caller-owned uint8 device tensor of engine.exchange_bytes() bytes (default: allocated here); joint: the
+        [world, bytes] tensor the arena is a row of (lockstep_backends)."""
         self.eng, self.plan = engine, plan
         nbytes = engine.exchange_bytes()
-        self.arena = torch.zeros(nbytes, device=engine.device, dtype=torch.uint8)
+        self.arena = torch.zeros(nbytes, device=engine.device, dtype=torch.uint8) if arena is None else arena
+        assert self.arena.numel() >= nbytes and self.arena.is_contiguous()
+        self.joint = joint
         engine.bind_exchange(self.arena)
 
     def begin(self, what, want_scalars):
@@ -168,3 +186,12 @@ class HipShardBackend:
 
     def scalars(self):
         return self.eng.shard_scalars()
+
+
+def lockstep_backends(engines, plans):
+    """HipShardBackends of all ranks of one attack inside one process with their arenas as the rows of ONE tensor, so that
+    run_lockstep executes a collective as a single strided device copy."""
+    nbytes = max(e.exchange_bytes() for e in engines)
+    nbytes = (nbytes + 255) // 256 * 256
+    joint = torch.zeros(len(engines), nbytes, device=engines[0].device, dtype=torch.uint8)
+    return [HipShardBackend(e, p, arena=joint[k], joint=joint) for k, (e, p) in enumerate(zip(engines, plans))]

@@ -25,7 +25,7 @@ n = bench.WORKLOADS[a.workload][0]
 out = {"workload": a.workload, "what": __doc__.split("\n\n")[0], "rows": []}
 for world in [int(x) for x in a.worlds.split(",")]:
     plans = [S.RowBlockPlan(n, world, r) for r in range(world)]
-    bks = [S.HipShardBackend(bench.build_engine(pkg, torch, dev, a.workload, 0, plan=p)[0], p) for p in plans]
+    bks = S.lockstep_backends([bench.build_engine(pkg, torch, dev, a.workload, 0, plan=p)[0] for p in plans], plans)
     for _ in range(2):
         S.run_lockstep(bks, S.SHARD_STEP); S.run_lockstep(bks, S.SHARD_MONITOR)
     torch.cuda.synchronize()

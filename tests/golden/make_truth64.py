@@ -6,7 +6,7 @@ O(1) Gram entries in fp32), which bounds what "equal to the reference" can mean 
 
     python tests/golden/make_truth64.py          (~10 min and ~30 GB per start on 8 cores)
     python tests/golden/make_truth64.py mid      (the n = 1200 fixture, seconds)
-    python tests/golden/make_truth64.py readme   (the README-line fixtures, ~10 min)
+    python tests/golden/make_truth64.py readme   (the README-line fixtures, ~10 min; `readme+`: only the ones the file lacks)
 
 Writes tests/golden/bench10k_hsic_fp64.npz: for each start of the fixture (`run`, `one0`, ...) `<name>_g64` = the
 mirrored packed gradient of its first step at `packed_pos`, plus its largest magnitude over the whole vector."""
@@ -86,7 +86,7 @@ def mid(tag="mid_s1200_hsic_sparse"):
     np.savez_compressed(os.path.join(OUT, f"{tag}_fp64.npz"), packed_pos=z["packed_pos"], step0_g64=g64, step0_g64_absmax=gmax)
 
 
-def readme():
+def readme(only_missing=False):
     """The same for the README-line fixtures (make_golden.py --only readme): first-step gradient of the float64 oracle at each
     fixture's packed positions and the AUC of the float64 run to its end -> tests/golden/readme_fp64.npz (`<fixture>_g64` as
     float32, `<fixture>_gmax`, `<fixture>_auc64`); ~10 min."""
@@ -94,7 +94,13 @@ def readme():
     O.F32 = np.float64
     f8 = lambda x: np.asarray(x).astype(np.float64)
     out = {}
+    path = os.path.join(OUT, "readme_fp64.npz")
+    if only_missing and os.path.exists(path):      # `readme+`: keep what the file holds, add the fixtures it does not know yet
+        old = np.load(path)
+        out = {k: old[k] for k in old.files}
     for name in H.readme_cases():
+        if f"{name}_auc64" in out:
+            continue
         z = H.load_readme(name)
         n = len(z["labels"])
         w0 = H.weights_from(z)
@@ -133,7 +139,7 @@ def readme():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mid":
         mid()
-    elif len(sys.argv) > 1 and sys.argv[1] == "readme":
-        readme()
+    elif len(sys.argv) > 1 and sys.argv[1] in ("readme", "readme+"):
+        readme(only_missing=sys.argv[1] == "readme+")
     else:
         main()

@@ -46,9 +46,26 @@ def a0_of(z):
     return None
 
 
+def seeded_noise(seed, t, shape):
+    """Step t's noise of a seeded eps != 0 run (same generator as tests/golden/make_golden.py:seeded_noise: numpy's legacy
+    RandomState, bit-reproducible across platforms by its compatibility policy)."""
+    return np.random.RandomState(int(seed) + int(t)).standard_normal(shape).astype(np.float32)
+
+
 def noise_of(z, t):
-    """Noise the reference drew at step t (recorded torch.randn_like), or None when eps == 0."""
-    return z["noise"][t] if "noise" in z else None
+    """Noise the reference drew at step t, or None when eps == 0: the recorded torch.randn_like matrices (`noise`), or -- on
+    large graphs -- the seeded stream the reference was handed (`noise_seed`), checked against the digest the generating
+    run kept of it (sum, sum of squares, three entries: float64)."""
+    if "noise" in z:
+        return z["noise"][t]
+    if "noise_seed" in z:
+        n = len(z["labels"])
+        zn = seeded_noise(z["noise_seed"], t, (n, n))
+        z8 = zn.astype(np.float64)
+        dig = np.array([z8.sum(), (z8 ** 2).sum(), z8[0, 0], z8[-1, -1], z8[n // 2, n // 3]])
+        assert np.allclose(dig, z["noise_digest"][t], rtol=1e-12, atol=1e-9), "the seeded noise stream is not the fixture's"
+        return zn
+    return None
 
 
 def oracle_from(z):

@@ -106,3 +106,39 @@ def test_row_block_plan():
     q = RowBlockPlan(200, 4, 3)
     assert q.rows_per_rank == 256 and q.n_pad == 1024 and not q.has_rows and q.row_end == q.row_begin
     assert RowBlockPlan(2708, 1, 0).row_end == 2708
+
+
+# ---- bench.py --gpus N without a launcher: the ranks are started by bench.py itself ---------------------------------
+def test_bench_gpus_flag_starts_ranks_and_refuses_a_mismatch(monkeypatch, capsys):
+    """`python bench.py --gpus 4` with no RANK / WORLD_SIZE must start 4 ranks (the driver's own torch.distributed.run command
+    line on 127.0.0.1) and forward rank 0's JSON line as the only stdout line; under a launcher --gpus must equal
+    WORLD_SIZE.  (The launch itself runs on the GPU box: tests/test_gpu_multiproc.py::test_plain_bench_gpus2_...)"""
+    import json
+    import subprocess
+    import bench
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        rank0 = json.dumps({"metric": "attack-steps/sec", "value": 1.0, "n_gpus": 4})
+        return subprocess.CompletedProcess(cmd, 0, stdout="noise from a rank\n{not json\n" + rank0 + "\n", stderr=None)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    line = bench.main(["--gpus", "4", "--steps", "3", "--workload", "synthetic-4k-hsic"])
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1 and json.loads(out[0]) == line and line["n_gpus"] == 4
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "3", "--workload", "synthetic-4k-hsic"]
+    # a rank that fails, or a launch without a result line, is an error -- not a silent 1-GPU number
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 1, stdout="", stderr=None))
+    with pytest.raises(SystemExit):
+        bench.main(["--gpus", "2"])
+    # under a launcher: --gpus must agree with WORLD_SIZE
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.main(["--gpus", "4", "--no-cpu-baseline"])

@@ -73,7 +73,9 @@ def test_row_block_ranks_as_processes_match_the_monolithic_step(pkg, world, n, w
             assert np.array_equal(r[f"scal{t}"], ranks[0][f"scal{t}"]), "scalars are identical on every rank"
             assert np.allclose(r[f"scal{t}"], ref, rtol=3e-5, atol=1e-6 * max(1.0, abs(a["loss"]))), (t, r[f"scal{t}"], ref)
     assert all(int(r["fused_steps"]) == 3 and int(r["general_steps"]) == 0 for r in ranks) and mono.fused_steps() == 3
-    assert all(int(r["exchanges"]) >= 3 * 8 for r in ranks)
+    nl = len(spec["widths"])
+    # 8 per step + monitor at L = 2, + 1: loss terms asked for, + the first step's own forward (no monitor call in front of it)
+    assert all(int(r["exchanges"]) == 3 * (2 * nl + 4 + 1) + (nl + 1) for r in ranks)
 
 
 def test_row_block_processes_masked_steps_then_fused_again(pkg, tmp_path, monkeypatch):
@@ -106,9 +108,29 @@ def test_row_block_processes_masked_steps_then_fused_again(pkg, tmp_path, monkey
     assert mono.path_stats()["general_steps"] == 2 and mono.fused_steps() == 2
 
 
+def _one_rank_auc(workload, steps, seed=0):
+    """The same workload, start and step count on ONE rank (monolithic fused step), through bench.py's own helpers."""
+    import torch
+    import mcgra_loader
+    import bench
+    pkg = mcgra_loader.load()
+    dev = torch.device("cuda:0")
+    eng, inp, adj_dev = bench.build_engine(pkg, torch, dev, workload, seed)
+    for _ in range(steps):
+        eng.step(); eng.monitor()
+    lab = torch.as_tensor(inp["labels"], device=dev)
+    final = eng.finalize(0, eng.buffer("HA"), eng.buffer("YA"), (lab[:, None] == lab[None, :]).float())
+    auc = bench.gpu_auc(adj_dev, final, torch)
+    fused = eng.fused_steps()
+    del eng, final
+    torch.cuda.empty_cache()
+    return auc, fused
+
+
 def test_bench_world2_branch_on_a_shared_gpu(tmp_path):
     """bench.py's `world > 1` branch (RowBlockPlan + HipShardBackend + ShardedStepper inside the timing contract) driven
-    by two processes for 2 timed steps; MCGRA_BENCH_SHARED_GPU=1 selects gloo + host staging on cuda:0."""
+    by two processes for 2 timed steps; MCGRA_BENCH_SHARED_GPU=1 selects gloo + host staging on cuda:0.  The recovered-
+    adjacency AUC of the 2-rank attack equals the 1-rank attack's on the same workload, start and step count."""
     out = str(tmp_path / "bench2")
     argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "synthetic-4k-hsic", "--no-shard-probe"]
     _run_ranks(W.run_bench_rank, 2, (argv,), out, timeout=900)
@@ -116,5 +138,83 @@ def test_bench_world2_branch_on_a_shared_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong"
     assert line["value"] > 0 and abs(line["value"] * line["ms_per_step"] - 1e3) < 1e-6 * 1e3
     assert line["config"]["fused_steps"] == 3 and line["config"]["general_steps"] == 0
-    assert line["collectives_per_step"] >= 8
+    assert line["collectives_per_step"] == 8           # per timed step + monitor at L = 2 (round 3: 11)
+    auc1, fused1 = _one_rank_auc("synthetic-4k-hsic", 3)
+    assert fused1 == 3 and 0.5 < auc1 < 1.0
+    assert abs(line["auc"] - auc1) <= 1e-6, (line["auc"], auc1)
+
+
+def test_plain_bench_gpus2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher environment (--gpus was parsed and ignored,
+    so the command measured one GPU): bench.main starts the two ranks itself (torch.distributed.run from a process that has
+    not touched the GPU), prints rank 0's line as the only stdout line, and that line says n_gpus == 2.  The caller here is a
+    fork-server child (this pytest process has initialised the GPU and must not fork + exec)."""
+    out = str(tmp_path / "plain2")
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "synthetic-4k-hsic", "--no-shard-probe"]
+    ctx = mp.get_context("forkserver")
+    p = ctx.Process(target=W.run_bench_plain, args=(argv, out, {"MCGRA_BENCH_SHARED_GPU": "1", "OMP_NUM_THREADS": "2"}))
+    p.start()
+    p.join(900)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("timeout")
+    err = out + ".rank0.err"
+    assert p.exitcode == 0, open(err).read() if os.path.exists(err) else f"exit code {p.exitcode}"
+    lines = [ln for ln in open(out + ".stdout").read().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["fused_steps"] == 3 and line["config"]["general_steps"] == 0
+    assert "gloo" in line["config"]["parallelism"]          # the shared-GPU test mode says so in the line
     assert 0.5 < line["auc"] < 1.0
+
+
+def test_row_block_processes_at_the_headline_size(pkg, tmp_path):
+    """Two row-block ranks of `synthetic-10k-hsic` as separate processes (gloo, host-staged arena slices) against the
+    monolithic fused step and the float64 fixture -- the sizes at which the product's slab split-K tail, planes_mm
+    (n >= 8192) and 20-panel row blocks run, none of which had crossed a process boundary before.
+    Bars: those of test_sharded_ranks_match_monolithic_at_10k for the union of rows and the scalars; the first-step
+    gradient of the union within 3e-4 of the float64 evaluation (bench10k_hsic_fp64.npz: run_g64)."""
+    import torch
+    import bench
+    wl = "synthetic-10k-hsic"
+    n = bench.WORKLOADS[wl][0]
+    z64 = np.load(os.path.join(H.GOLDEN, "bench10k_hsic_fp64.npz"))
+    z = np.load(os.path.join(H.GOLDEN, "bench10k_hsic.npz"))
+    pi, pj = H.tril_pos(z64["packed_pos"])
+    spec = dict(workload=wl, seed=int(z["seed"]), steps=2, pos_i=pi.tolist(), pos_j=pj.tolist())
+    out = str(tmp_path / "mp10k")
+    _run_ranks(W.run_workload_rank, 2, (spec,), out, timeout=1500)
+    ranks = [np.load(f"{out}.rank{r}.npz") for r in range(2)]
+    assert all(int(r["fused_steps"]) == 2 and int(r["general_steps"]) == 0 for r in ranks)
+    # first-step gradient of the union at the fixture's sampled positions against the float64 evaluation
+    g = np.zeros(len(pi), np.float32)
+    seen = np.zeros(len(pi), bool)
+    for r in ranks:
+        g[r["own"]] = r["g0"]; seen |= r["own"]
+    assert seen.all()
+    gmax = float(z64["run_g64_absmax"])
+    err = float(np.abs(g - z64["run_g64"]).max()) / gmax
+    assert err <= 3e-4, err
+    dev = torch.device("cuda:0")
+    mono, _, _ = bench.build_engine(pkg, torch, dev, wl, int(z["seed"]))
+    lr = bench.workload_lr(wl, n)
+    for t in range(2):
+        a = mono.step(want_scalars=True); mono.monitor()
+        rows = torch.cat([torch.as_tensor(np.fromfile(f"{out}.rank{r}.rows{t}.f32", np.float32).reshape(-1, n), device=dev)
+                          for r in range(2)], 0)
+        ref = mono.buffer("M")
+        assert rows.shape == ref.shape
+        assert float(((rows - ref).abs() > 0.05 * lr).float().mean()) < 2e-3, f"step {t}"
+        assert float((rows - rows.T).abs().max()) == 0.0, "ranks must agree on mirrored entries bit for bit"
+        del rows, ref
+        names = ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "clamp_sum")
+        assert np.array_equal(ranks[0][f"scal{t}"], ranks[1][f"scal{t}"]), "scalars are identical on every rank"
+        for k in ("loss", "c1", "c2", "c9", "c10"):
+            assert ranks[0][f"scal{t}"][names.index(k)] == pytest.approx(a[k], rel=1e-4), (t, k)
+        if t == 0:      # ... and the monolithic engine's own first gradient at the same positions
+            gm = mono.buffer("G_sym")[torch.as_tensor(pi, device=dev), torch.as_tensor(pj, device=dev)].cpu().numpy()
+            assert float(np.abs(g - gm).max()) / gmax <= 1e-4
+    for r in range(2):
+        for t in range(2):
+            os.remove(f"{out}.rank{r}.rows{t}.f32")
