@@ -35,6 +35,7 @@ SYMBOLS = [
     "mcgra_attack_profile",
     "mcgra_attack_gemm_stats",
     "mcgra_attack_product_replay",
+    "mcgra_attack_test_mutate",
 ]
 
 
@@ -119,6 +120,7 @@ def _load():
         "mcgra_attack_profile": [vp, C.c_int],
         "mcgra_attack_gemm_stats": [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "mcgra_attack_product_replay": [vp, vp, C.c_int, C.POINTER(C.c_double)],
+        "mcgra_attack_test_mutate": [vp, C.c_int],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

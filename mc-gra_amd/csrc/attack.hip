@@ -218,6 +218,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   }
   h->n = cfg->n;
   h->ld = (cfg->n + 3) & ~3;
+  // (experiment, round 4) rows of the N x N buffers on 128-byte lines: MCGRA_LD_ALIGN=32 rounds ld up to 32 floats
+  { const char* e = getenv("MCGRA_LD_ALIGN"); if (e && atoi(e) >= 4 && (atoi(e) & (atoi(e) - 1)) == 0) h->ld = (cfg->n + atoi(e) - 1) & ~(atoi(e) - 1); }
   h->L = cfg->nlayer;
   h->Le = cfg->emb_nlayer;
   h->C = cfg->nclass;
@@ -238,7 +240,6 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn);
   { const char* e = getenv("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
-  { const char* e = getenv("MCGRA_TEST_MUTATE"); h->test_mutate = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'r' ? 2 : 0)); }
   if (h->keep_gsym) { A_(GSYM, nn); }
   if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
     A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn);
@@ -331,9 +332,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       (void)hipGetDevice(&dev);
       if (dev < 0 || dev >= 64) dev = 0;
       // the product's stream: normal priority (A/B at N = 10 000, same box: low 153.8, normal 154.8, high 154.4 steps/s;
-      // round 1's fp32 SYMM, which left no room beside itself, wanted the lowest).  MCGRA_P1_PRIO=low|normal|high.
-      int pr2 = (pr_least + pr_greatest) / 2;
-      if (const char* ep = getenv("MCGRA_P1_PRIO")) pr2 = ep[0] == 'h' ? pr_greatest : (ep[0] == 'l' ? pr_least : pr2);
+      // round 1's fp32 SYMM, which left no room beside itself, wanted the lowest)
+      const int pr2 = (pr_least + pr_greatest) / 2;
       if (!side2[dev] && hipStreamCreateWithPriority(&side2[dev], hipStreamNonBlocking, pr2) != hipSuccess) side2[dev] = nullptr;
       if (!side3[dev] && hipStreamCreateWithFlags(&side3[dev], hipStreamNonBlocking) != hipSuccess) side3[dev] = nullptr;
       if (!side4[dev] && hipStreamCreateWithFlags(&side4[dev], hipStreamNonBlocking) != hipSuccess) side4[dev] = nullptr;
@@ -471,12 +471,22 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
 #undef A1_
     if (rc) return rc;
     MCGRA_HIP(hipMemcpy2DAsync(h->ORI, (size_t)ld * 4, ori_adj, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
+    if (!h->has_ori) {             // what create decided, for a later set_graph without ori_adj
+      h->lr_ok0 = h->lr_ok; h->fused_ok0 = h->fused_ok; h->gram_split0 = h->gram_split; h->fwd_reuse0 = h->fwd_reuse;
+      h->late_mean0 = h->late_mean; h->planes_mm_on0 = h->planes_mm_on;
+    }
     h->has_ori = true;
     h->lr_ok = h->fused_ok = h->gram_split = false;
+    h->late_mean = h->planes_mm_on = false;
     h->fwd_reuse = false;          // the monitoring forward (:290-293) runs on the UNclamped M + ori: nothing to adopt
   } else {
+    if (h->has_ori) {              // back to a zero ori_adj on the same handle: the create-time paths again
+      h->lr_ok = h->lr_ok0; h->fused_ok = h->fused_ok0; h->gram_split = h->gram_split0; h->fwd_reuse = h->fwd_reuse0;
+      h->late_mean = h->late_mean0; h->planes_mm_on = h->planes_mm_on0;
+    }
     h->has_ori = false;
   }
+  h->fused_fwd_valid = h->fwd_cached = h->prep_valid = h->planes_valid = false;      // (a new graph: nothing of the old one to adopt)
   MCGRA_HIP(hipMemcpy2DAsync(h->FADJ, (size_t)ld * 4, feature_adj, (size_t)n * 4, (size_t)n * 4, n, hipMemcpyDeviceToDevice, st));
   MCGRA_HIP(hipMemcpyAsync(h->labels, labels, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
   MCGRA_HIP(hipMemcpyAsync(h->idx, idx_attack, sizeof(int) * h->na, hipMemcpyDeviceToDevice, st));
@@ -1181,8 +1191,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     launch_normbwd(st, n, ld, h->G_ADJN, A, h->r, h->d, h->rowpart, nb_colpart, nb_strips, h->gd, nullptr, normbwd_parts);
     // (its row sums of the new M go to G_A, which this path leaves unused; not with a projection still to come)
     const size_t cnt = (size_t)n * rankk_apply_adam_tiles(n);
-    static const bool no_partials = [] { const char* e = getenv("MCGRA_NO_PREP_PARTIALS"); return e && e[0] == '1'; }();
-    const bool emit = !may_project && !gen && !no_partials && 3 * cnt + 4 <= (size_t)n * ld;
+    const bool emit = !may_project && !gen && 3 * cnt + 4 <= (size_t)n * ld;
     MCGRA_HIP(rankk_apply_adam(st, n, ld, hs, h->GPu, hs, h->Tu, hs, h->G_ADJN, h->r, h->gd, gate, h->M, h->am, h->av, h->mm + 2,
                                (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(c.lr / bc1), (float)sqrt(bc2), 1e-8f,
                                h->keep_gsym ? h->GSYM : nullptr, may_project ? 0 : 1, emit ? h->G_A : nullptr,

@@ -17,6 +17,7 @@
 // (n x h) work is replicated on all ranks.
 // A step whose decode masks a pair (S_ij <= 0 off the diagonal) is handed back to the general path.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "engine.h"
@@ -322,8 +323,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   // reductions that only feed the returned loss terms are skipped when the caller did not ask for them (a row-block
   // rank keeps them: they ride in exchanges whose layout is fixed)
   const bool want_vals = h->sharded || h->fs_want;
-  static const bool no_st3 = [] { const char* e = getenv("MCGRA_NO_ST3"); return e && e[0] == '1'; }();      // A/B switch
-  hipStream_t s3 = no_st3 ? st : h->st3;
+  hipStream_t s3 = h->st3;
   auto join = [&]() -> int {
     if (h->p1_inflight) {
       if (ovl) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -594,9 +594,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // (the coefficient of the norm term comes out of k_tail_gd's launch; a rank without rows has no Adam pass to feed)
       if (!(h->fused_post && R1 > R0)) hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
       CHK(join());
-      // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py): MCGRA_TEST_MUTATE=p1 wipes the product's result, =rk drops
-      // the rank-k terms of the tail (both GCN chains' backward and the low-rank term of c2) from the gradient -- a parity
-      // test that stays green under either is blind to split2_m16_kernel / the fp16-split rank-k rounds of k_tail_reduce
+      // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py; armed by mcgra_attack_test_mutate, which says so on stderr): 1
+      // wipes the product's result, 2 drops the rank-k terms of the tail (both GCN chains' backward and the low-rank term of
+      // c2) from the gradient -- a parity test that stays green under either is blind to split2_m16_kernel / the fp16-split
+      // rank-k rounds of k_tail_reduce
       if (h->test_mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
       if (h->sharded && use1) {
         for (int s = 0; s < h->world; ++s) {
@@ -802,6 +803,15 @@ int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out) {
   if (h->fs_want == 2) { for (int i = 0; i < 10; ++i) out[i] = h->fs_scalars[i]; return 0; }
   if (h->fs_want != 1) { set_error("the step was begun without want_scalars"); return MCGRA_EINVAL; }
   return collect_scalars(h, st, out, true);
+}
+
+int mcgra_attack_test_mutate(mcgra_attack_t* h, int what) {
+  if (!h || what < 0 || what > 2) { set_error("test_mutate: what = %d", what); return MCGRA_EINVAL; }
+  h->test_mutate = what;
+  if (what)
+    fprintf(stderr, "[mcgra] TEST MUTATION ARMED on engine %p: the fused step now %s -- its gradients are WRONG on purpose\n", (void*)h,
+            what == 1 ? "wipes the N x N x N product's result" : "drops the rank-k terms of its tail");
+  return 0;
 }
 
 int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, double* ms_per_launch) {

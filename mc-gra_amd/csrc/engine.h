@@ -40,7 +40,7 @@ struct mcgra_attack {
   bool fwd_cached = false, fwd_reuse = true;
   bool fuse_tail = true;           // apply + rank-k + mirror + Adam in one kernel (MCGRA_NO_FUSED_TAIL=1: separate kernels)
   bool prep_valid = false;         // G_A holds the per-tile row sums of the current M (left by the fused tail kernel)
-  int test_mutate = 0;             // MCGRA_TEST_MUTATE (read at create; TEST-ONLY, see attack_fused.hip): 1 wipes P1, 2 drops the tail's rank-k terms
+  int test_mutate = 0;             // TEST-ONLY (mcgra_attack_test_mutate, see attack_fused.hip): 1 wipes P1, 2 drops the tail's rank-k terms
   bool keep_gsym = false;          // MCGRA_KEEP_GSYM=1: keep the mirrored packed gradient of each step readable as "G_sym" (parity tests)
   float* ADJN_next = 0;
   bool graph_set = false, model_set = false;
@@ -132,6 +132,8 @@ struct mcgra_attack {
   GemmTimer timer;
   // fused low-rank step (attack_fused.hip): everything N x N from M and n-vectors; MCGRA_NO_FUSED_LR=1 disables
   bool fused_ok = false;           // configuration allows it
+  // create-time values of the path switches a non-zero ori_adj turns off (set_graph restores them when ori_adj goes away)
+  bool lr_ok0 = false, fused_ok0 = false, gram_split0 = false, fwd_reuse0 = false, late_mean0 = false, planes_mm_on0 = false;
   bool fused_fwd_valid = false;    // both chains, heads, d / r / mean of the CURRENT M are in place (left by the monitor call)
   bool fused_last = false;         // the last step ran fused: adj_norm of that iteration was never stored (see em_last)
   int fcols = 0;                   // leading dimension of FV / FY

@@ -387,6 +387,10 @@ class AttackEngine:
             check(lib.mcgra_attack_product_replay(self._h, _stream(), int(reps), C.byref(ms)))
         return ms.value
 
+    def test_mutate(self, what):
+        """TEST ONLY (mcgra_attack_test_mutate): 'p1' wipes the product's result, 'rk' drops the tail's rank-k terms, None disarms."""
+        check(lib.mcgra_attack_test_mutate(self._h, {None: 0, "p1": 1, "rk": 2}[what]))
+
     def profile(self, enable=True):
         check(lib.mcgra_attack_profile(self._h, int(enable)))
 

@@ -174,12 +174,12 @@ def test_row_block_processes_at_the_headline_size(pkg, tmp_path):
     monolithic fused step and the float64 fixture -- the sizes at which the product's slab split-K tail, planes_mm
     (n >= 8192) and 20-panel row blocks run, none of which had crossed a process boundary before.
     Bars: those of test_sharded_ranks_match_monolithic_at_10k for the union of rows and the scalars; the first-step
-    gradient of the union within 3e-4 of the float64 evaluation (bench10k_hsic_fp64.npz: run_g64)."""
+    gradient of the union within 3e-4 of the reference's own code in float64 (bench10k_hsic_ref64.npz: run_g64ref)."""
     import torch
     import bench
     wl = "synthetic-10k-hsic"
     n = bench.WORKLOADS[wl][0]
-    z64 = np.load(os.path.join(H.GOLDEN, "bench10k_hsic_fp64.npz"))
+    z64 = np.load(os.path.join(H.GOLDEN, "bench10k_hsic_ref64.npz"))
     z = np.load(os.path.join(H.GOLDEN, "bench10k_hsic.npz"))
     pi, pj = H.tril_pos(z64["packed_pos"])
     spec = dict(workload=wl, seed=int(z["seed"]), steps=2, pos_i=pi.tolist(), pos_j=pj.tolist())
@@ -193,8 +193,8 @@ def test_row_block_processes_at_the_headline_size(pkg, tmp_path):
     for r in ranks:
         g[r["own"]] = r["g0"]; seen |= r["own"]
     assert seen.all()
-    gmax = float(z64["run_g64_absmax"])
-    err = float(np.abs(g - z64["run_g64"]).max()) / gmax
+    gmax = float(z64["run_g64ref_absmax"])
+    err = float(np.abs(g - z64["run_g64ref"]).max()) / gmax
     assert err <= 3e-4, err
     dev = torch.device("cuda:0")
     mono, _, _ = bench.build_engine(pkg, torch, dev, wl, int(z["seed"]))

@@ -1080,6 +1080,57 @@ def test_split_loop_variants_give_the_default_loops_bits(pkg):
     assert digests["3"] == digests["0"]
 
 
+_SPLIT_EDGE_PROBE = r"""
+import os, sys
+sys.path.insert(0, os.environ["MCGRA_TEST_ROOT"])
+import numpy as np
+import torch
+import mcgra_loader
+mcgra_loader.load()
+from mc_gra_amd import engine as E
+for n in (1300, 4100, 2564):
+    rng = np.random.RandomState(n)
+    F = rng.randn(n, 24).astype(np.float32)
+    S = (F @ F.T).astype(np.float32); S = (S + S.T) * 0.5
+    X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1
+    outs = [E.ssymm_split_f16(torch.tensor(S, device="cuda"), torch.tensor(X, device="cuda")).cpu().numpy() for _ in range(2)]
+    assert np.array_equal(outs[0], outs[1])
+    np.save(os.path.join(os.environ["MCGRA_PROBE_OUT"], f"p{n}.npy"), outs[0])
+"""
+
+
+def test_thin_edge_tiles_last_gives_the_split_k_schemes_product(pkg, tmp_path):
+    """n not a multiple of the 256-row panel with a thin last panel (1300: 20 rows, 4100: 4, 2564: 4): the 2-plane kernel puts
+    that panel's tiles last in every XCD's list and multiplies only their valid 16 x 16 sub-tiles, one grid, no split-K
+    tail (split3_symm: SPLIT_EDGE).  Against the round-3 scheme (MCGRA_SPLIT_EDGE=0: every tile in full, ragged round cut
+    along K; one child per value, the switch is read once per process): tiles whose K loop is whole in both schemes carry
+    the same bits (same MFMA order per accumulator), the others differ by the summation order of the K slabs only; both
+    within 1e-6 of |S||X| of float64."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("1", "0"):
+        d = tmp_path / f"edge{mode}"
+        d.mkdir()
+        env = dict(os.environ, MCGRA_SPLIT_EDGE=mode, MCGRA_TEST_ROOT=root, MCGRA_PROBE_OUT=str(d))
+        r = subprocess.run([sys.executable, "-c", _SPLIT_EDGE_PROBE], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = {n: np.load(d / f"p{n}.npy") for n in (1300, 4100, 2564)}
+    for n in (1300, 4100, 2564):
+        rng = np.random.RandomState(n)
+        F = rng.randn(n, 24).astype(np.float32)
+        S = (F @ F.T).astype(np.float32); S = (S + S.T) * 0.5
+        X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1
+        ref = S.astype(np.float64) @ X.astype(np.float64).T
+        den = np.abs(S).astype(np.float64) @ np.abs(X).astype(np.float64).T
+        a, b = outs["1"][n], outs["0"][n]
+        assert (np.abs(a - ref) / den).max() <= 1e-6 and (np.abs(b - ref) / den).max() <= 1e-6
+        assert (np.abs(a.astype(np.float64) - b) / den).max() <= 2e-7
+        same = float((a == b).mean())
+        assert same > 0.5, (n, same)          # (everything outside the round-3 scheme's split-K tail)
+
+
 @pytest.mark.parametrize("scale", [1.0, 3.0e-12, 7.0e11])
 def test_split_f16_product_operand_scales(pkg, torch_, scale):
     """The fp16 planes live in [2^-24, 2^16): the kernel's exact power-of-two operand scales must make the result
@@ -1367,3 +1418,27 @@ def test_fused_lowrank_hands_masked_steps_to_the_general_path(pkg, monkeypatch):
     assert engs[0].path_stats() == engs[1].path_stats() == {"lowrank_steps": 0, "general_steps": 2}
     assert engs[0].fused_steps() == 0
     assert torch.equal(engs[0].get_adj_changes(), engs[1].get_adj_changes())
+
+
+def test_set_graph_without_ori_restores_the_fused_path(pkg):
+    """set_graph with a non-zero ori_adj sends the handle to the general step (the low-rank / fused forms assume modified_adj ==
+    M); a later set_graph WITHOUT ori_adj on the same handle must get the create-time paths back (it stayed on
+    the general step for good, 3x slower at N = 10 000, with no indication) -- and give the gradient bits of a fresh engine."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5)
+    fresh = H.engine_from(pkg, z)
+    eng = H.engine_from(pkg, z)
+    ori = np.triu((np.random.RandomState(1).rand(1100, 1100) < 0.01).astype(np.float32), 1)
+    ori = ori + ori.T
+    eng.set_graph(z["features"], z["adj"], ori, z["feature_adj"], z["labels"], z["idx_attack"])
+    eng.set_adj_changes(H.a0_of(z))
+    eng.step()
+    assert eng.fused_steps() == 0 and eng.path_stats()["general_steps"] == 1
+    eng.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
+    eng.set_adj_changes(H.a0_of(z))
+    eng.step(); fresh.step()
+    assert eng.fused_steps() == 1 and fresh.fused_steps() == 1 and eng.path_stats()["general_steps"] == 1
+    # (the Adam moments of the handle have seen the ori step, so only the gradient -- which does not -- is compared)
+    assert torch.equal(eng.buffer("G_sym"), fresh.buffer("G_sym"))
+    eng.monitor(); eng.step()
+    assert eng.fused_steps() == 2
