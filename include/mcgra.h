@@ -252,8 +252,12 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
  *   - the N x N x N product as a COLUMN block P1[:, rows] = (H Kf H) Xc[:, rows] from planes packed from the rank's
  *     own rows (Xc^T rows = adj_norm rows by symmetry), then one all-to-all of tile blocks that hands every rank its
  *     ROW block P1[rows, :] as well (the mirrored gradient needs P1_ij and P1_ji);
- *   - decode, tail reductions and Adam on the rank's rows; n-vectors (r, d, gd, ...) are all-gathered, the few
- *     scalars all-reduced.
+ *   - decode, tail reductions and Adam on the rank's rows; n-vectors (r, d, gd, the decode backward) ride in the same
+ *     all-gathers as the products where both are ready at the same point, and every scalar that is summed over the ranks
+ *     (|adj_changes|^2, the masked-pair count, the loss terms) rides in a two-column "lane" of the gathered array: rank k
+ *     leaves its partial in row k * rows_per_rank + q, and behind the gather every rank adds the `world` partials in rank
+ *     order -- the same bits on every rank, and no all-reduce.  Per step + monitoring forward at L GCN layers: 2 L + 3
+ *     all-gathers and the one all-to-all (8 collectives at L = 2; one more gather when want_scalars is set).
  * The engine runs until the next exchange point and describes the collective; the host layer (mc-gra_amd/sharded.py)
  * executes it with torch.distributed (backend "nccl" = RCCL) on views of ONE caller-owned device arena:
  *     mcgra_attack_bind_exchange(h, arena, mcgra_attack_exchange_bytes(h));
@@ -265,7 +269,8 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
  * (mcgra_attack_fused_steps); anything else returns MCGRA_ENOSUP from mcgra_attack_create with shard_world > 0. */
 #define MCGRA_XCHG_DONE 0
 #define MCGRA_XCHG_ALLGATHER 1      /* `world` chunks of chunk_bytes at offset; this rank's chunk (index rank) is filled */
-#define MCGRA_XCHG_ALLREDUCE_F64 2  /* sum over ranks of `count` doubles at offset */
+#define MCGRA_XCHG_ALLREDUCE_F64 2  /* sum over ranks of `count` doubles at offset (kept in the protocol; the fused step no longer
+                                       asks for it: its scalars ride in the gathers' lane) */
 #define MCGRA_XCHG_ALLTOALL 3       /* `world` chunks of chunk_bytes: send from offset, receive into offset2 */
 typedef struct mcgra_exchange {
   int32_t kind, count;

@@ -3,7 +3,7 @@
 // stream, with a hand-derived backward (no autograd).  Host code only enqueues;
 // nothing here reads device memory back unless the caller asks for scalars.
 //
-// State layout in HBM (all fp32, leading dimension ld = round_up(n, 4)):
+// State layout in HBM (all fp32, leading dimension ld = round_up(n, 32)):
 //   M            learnable adjacency, dense symmetric, zero diagonal
 //                (adj_changes of the reference is its strict lower triangle)
 //   am, av       Adam moments, same layout (mirrored halves stay identical
@@ -217,8 +217,10 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     delete h; set_error("bad act / fin_layers"); return MCGRA_EINVAL;
   }
   h->n = cfg->n;
-  h->ld = (cfg->n + 3) & ~3;
-  // (experiment, round 4) rows of the N x N buffers on 128-byte lines: MCGRA_LD_ALIGN=32 rounds ld up to 32 floats
+  // rows of the N x N buffers start on 128-byte lines (ld a multiple of 32 floats; round 3: of 4): the 64- and 128-column
+  // tile rows of the tail, the pack and the skinny products are then whole lines (+1 ... 2 % steps/s at N = 10 000, where
+  // ld = 10 016).  MCGRA_LD_ALIGN=4: round 3's rule (A/B measurements).
+  h->ld = (cfg->n + 31) & ~31;
   { const char* e = getenv("MCGRA_LD_ALIGN"); if (e && atoi(e) >= 4 && (atoi(e) & (atoi(e) - 1)) == 0) h->ld = (cfg->n + atoi(e) - 1) & ~(atoi(e) - 1); }
   h->L = cfg->nlayer;
   h->Le = cfg->emb_nlayer;
@@ -343,6 +345,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
           hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_r, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork3, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess ||
           hipHostMalloc((void**)&h->mask_host, 8, hipHostMallocMapped) != hipSuccess ||
@@ -367,6 +371,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                   (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
     h->row0 = 0; h->row1 = (int)n;
     { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
+    { const char* ee = getenv("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
     { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
     {
       const char* ep = getenv("MCGRA_PLANES_MM");
@@ -428,6 +433,8 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (h->st4) (void)hipStreamSynchronize(h->st4);
   if (h->ev_fork4) (void)hipEventDestroy(h->ev_fork4);
   if (h->ev_join4) (void)hipEventDestroy(h->ev_join4);
+  if (h->ev_r) (void)hipEventDestroy(h->ev_r);
+  if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
   if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
   if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
   if (h->mask_host) (void)hipHostFree((void*)h->mask_host);
@@ -459,6 +466,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   if (!h || !features || !adj || !feature_adj || !labels || !idx_attack) { set_error("null argument"); return MCGRA_EINVAL; }
   if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
+  if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }
   const int n = h->n, ld = h->ld, hs = h->hsum;
   if (ori_adj) {
     // general path only: the fused / low-rank forms assume modified_adj == M and modified_adj1 == offdiag relu(Zn Zn^T)
@@ -553,6 +561,10 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
 int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* packed) {
   if (h) h->fwd_cached = h->prep_valid = h->fused_fwd_valid = h->skip_fused = false;      // whatever the last step / monitor call left is stale now
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
+  if (h->early_pack) {      // a pack of the old M may still be reading it on the side stream
+    MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_pack, 0));
+    h->early_pack = false;
+  }
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
   return 0;
@@ -791,6 +803,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
   h->fused_last = false;
   h->fused_fwd_valid = false;
+  if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }      // (the general step packs its own operands)
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C;
   const double sg = sign_of(h);
@@ -1312,6 +1325,8 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   if (decode_mode < 0 || decode_mode > 6) { set_error("decode_mode %d", decode_mode); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
+  // (a pack a monitor call forked for a step that never came: it reads M, which is overwritten below, and writes scratch)
+  if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }
   if (!h->have_step) {               // epochs == 0: adj_norm of :142
     if (h->has_ori) CHK(forward_ori_unclamped(h, st, h->ADJN));
     else CHK(forward_common(h, st, h->ADJN, nullptr));
@@ -1385,6 +1400,7 @@ int mcgra_attack_copy_buffer(mcgra_attack_t* h, void* stream, const char* name, 
   int r = 0, c = 0, l = 0;
   CHK(mcgra_attack_buffer(h, name, &p, &r, &c, &l));
   if (!dst || dst_ld < c) { set_error("bad destination"); return MCGRA_EINVAL; }
+  if (h->early_pack) MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_pack, 0));      // (scratch buffers under a forked pack)
   MCGRA_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 4, p, (size_t)l * 4, (size_t)c * 4, r, hipMemcpyDeviceToDevice,
                              (hipStream_t)stream));
   return 0;

@@ -48,6 +48,25 @@ __global__ void k_stage_to_rows(int n, int w, const float* __restrict__ stage, i
   const int i = e / w, k = e % w;
   dst[(size_t)i * ldd + k] = stage[(size_t)i * sgw + c0 + k];
 }
+// all-to-all of P1 tile blocks: block s of the send buffer = P1[rows of rank s][own columns] (a rank computed the column
+// block P1[:, own rows]); block s of the receive buffer = P1[own rows][columns of rank s].  One launch each instead of
+// `world` strided copies.  A2[s][q][c], q, c < rpr.
+__global__ void k_a2a_pack(int n, int ld, int rpr, int R0, int R1, const float* __restrict__ KX, float* __restrict__ A2) {
+  const int s = blockIdx.z, q = blockIdx.y, row = s * rpr + q;
+  if (row >= n) return;
+  const float* src = KX + (size_t)row * ld + R0;
+  float* dst = A2 + ((size_t)s * rpr + q) * rpr;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < R1 - R0; c += gridDim.x * blockDim.x) dst[c] = src[c];
+}
+__global__ void k_a2a_unpack(int n, int ld, int rpr, int R0, int R1, int self, const float* __restrict__ A2, float* __restrict__ KX) {
+  const int s = blockIdx.z, q = blockIdx.y;
+  if (s == self || R0 + q >= R1) return;                 // (the own block is already in place)
+  const int c0 = s * rpr, cw = min(rpr, n - c0);
+  if (cw <= 0) return;
+  const float* src = A2 + ((size_t)s * rpr + q) * rpr;      // peer s packed its KX[my rows, its columns]
+  float* dst = KX + (size_t)(R0 + q) * ld + c0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cw; c += gridDim.x * blockDim.x) dst[c] = src[c];
+}
 __global__ void k_u32_to_f64(const unsigned int* __restrict__ a, double* __restrict__ out) { out[0] = (double)a[0]; }
 // The scalar lane of an exchanged node array: two float columns that hold one double per row.  Rank k leaves its partial
 // sum q in row k * rpr + q of its own chunk; behind the all-gather every rank adds the `world` partials in rank order --
@@ -177,6 +196,22 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         launch_prep(st, false, n, ld, h->M, nullptr, nullptr, 0.f, nullptr, nullptr, h->d, h->r, h->rowsq, h->rowsum, R0, R1);
       }
       if (!h->sharded) {
+        // Early pack: the planes of the N x N x N product's operand need r only, and the pack is a pure streaming pass
+        // (read M, write planes) while the forward's two skinny products keep the fp32 matrix pipe busy at 3 - 4 TB/s: the
+        // pack runs on the product's stream beside them instead of behind them (0.16 ms off the path in front of the product).
+        // The product still waits for the forward (ev_fork): a forward beside the product itself was measured a wash.
+        h->early_pack = false;
+        if (h->late_mean && h->overlap && h->st2 && h->early_pack_on) {
+          const int np = split3_pack_rsq_parts(n, h->split_planes);
+          float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
+          MCGRA_HIP(hipEventRecord(h->ev_r, st));
+          MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_r, 0));
+          if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, h->st2, n, h->r, h->amax + 1);
+          split3_pack_from_m(h->st2, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
+                             h->cfg.w[1] != 0 ? h->A1 : nullptr, psum);
+          MCGRA_HIP(hipEventRecord(h->ev_pack, h->st2));
+          h->early_pack = true;
+        }
         launch_reduce_rows(st, h->rowsq, n, 2, h->scal + S_SQ);      // rowsq | rowsum are adjacent, and so are S_SQ | S_SUM
       } else {
         // own rows of r and d, and this rank's share of |adj_changes|^2 and sum(modified_adj) in the scalar lane: ONE gather
@@ -237,7 +272,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
         CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
       }
-      if (h->late_mean) { if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, st, n, h->r, h->amax + 1); }
+      if (h->late_mean) { if (h->amax && !h->early_pack) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, st, n, h->r, h->amax + 1); }
       else fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
       MCGRA_KERNEL_CHECK();
   }
@@ -279,6 +314,7 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   MCGRA_HIP(hipMemcpy(&seq, h->mask_seq_dev, sizeof(seq), hipMemcpyDeviceToHost));
   h->mask_seq = h->mask_want = seq;
   h->p1_inflight = h->fs_dec_forked = false;
+  h->early_pack = false;
   h->nmask_zero = h->t3_zero = false;
   h->fused_fwd_valid = h->fwd_cached = h->prep_valid = false;
   h->fs_open = false;
@@ -354,10 +390,17 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->late_mean) {
         // uncentred planes ((H Kf H) 1 = 0: the product does not see the centring vector), row sums and sums of squares of
         // adj_norm from the same pass -> the column means (adj_norm is symmetric) and |xc_i|^2
-        const int np = split3_pack_rsq_parts(n, h->split_planes);
-        float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
-        split3_pack_from_m(st, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
-                           use2 ? h->A1 : nullptr, psum);
+        if (h->early_pack) {
+          // packed on the product's stream beside this M's forward (fused_forward_pt): everything on the caller's stream that
+          // reads the planes or the pack's row partials (k_mean_fin, planes_mm) waits for it here
+          MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));
+          h->early_pack = false;
+        } else {
+          const int np = split3_pack_rsq_parts(n, h->split_planes);
+          float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
+          split3_pack_from_m(st, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
+                             use2 ? h->A1 : nullptr, psum);
+        }
         h->planes_valid = h->planes_mm_on;          // (the means themselves: behind the fork, below)
       } else
       if (p_cnt > 0) {
@@ -599,23 +642,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // c2) from the gradient -- a parity test that stays green under either is blind to split2_m16_kernel / the fp16-split
       // rank-k rounds of k_tail_reduce
       if (h->test_mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
-      if (h->sharded && use1) {
-        for (int s = 0; s < h->world; ++s) {
-          const int sr0 = s * h->rpr, sr1 = sr0 + h->rpr < n ? sr0 + h->rpr : n;
-          if (sr1 > sr0 && R1 > R0)
-            MCGRA_HIP(hipMemcpy2DAsync(h->A2S + (size_t)s * h->rpr * h->rpr, (size_t)h->rpr * 4, h->KX + (size_t)sr0 * ld + R0,
-                                       (size_t)ld * 4, (size_t)(R1 - R0) * 4, sr1 - sr0, hipMemcpyDeviceToDevice, st));
-        }
-      }
+      if (h->sharded && use1 && R1 > R0)
+        hipLaunchKernelGGL(k_a2a_pack, dim3(2, h->rpr, h->world), dim3(256), 0, st, n, ld, h->rpr, R0, R1, h->KX, h->A2S);
       if (use1) { FS_XCHG(h->fs_state, 9, x_alltoall(ex, h->off_a2s, h->off_a2r, (int64_t)h->rpr * h->rpr * 4)) }
-      if (h->sharded && use1) {
-        for (int s = 0; s < h->world; ++s) {
-          const int sr0 = s * h->rpr, sr1 = sr0 + h->rpr < n ? sr0 + h->rpr : n;
-          if (s != h->rank && sr1 > sr0 && R1 > R0)       // peer s packed its KX[my rows, its columns]
-            MCGRA_HIP(hipMemcpy2DAsync(h->KX + (size_t)R0 * ld + sr0, (size_t)ld * 4, h->A2R + (size_t)s * h->rpr * h->rpr,
-                                       (size_t)h->rpr * 4, (size_t)(sr1 - sr0) * 4, R1 - R0, hipMemcpyDeviceToDevice, st));
-        }
-      }
+      if (h->sharded && use1 && R1 > R0)
+        hipLaunchKernelGGL(k_a2a_unpack, dim3(2, h->rpr, h->world), dim3(256), 0, st, n, ld, h->rpr, R0, R1, h->rank, h->A2R, h->KX);
       {
         float* ps1 = h->KY;
         double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
@@ -825,6 +856,7 @@ int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, doubl
   hipStream_t st = (hipStream_t)stream;
   const int P = split3_panel(), p_off = h->row0 / P, p_cnt = h->row1 > h->row0 ? (h->row1 - h->row0 + P - 1) / P : 0;
   if (p_cnt == 0) { if (ms_per_launch) *ms_per_launch = 0.0; return 0; }
+  if (h->early_pack) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));      // (planes a monitor call is still packing: equally valid operands)
   hipEvent_t e0, e1;
   MCGRA_HIP(hipEventCreate(&e0));
   MCGRA_HIP(hipEventCreate(&e1));

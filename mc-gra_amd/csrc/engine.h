@@ -93,6 +93,11 @@ struct mcgra_attack {
   // right after the normalisation and runs (MFMA-bound) under the HBM-bound rest of the step
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // early pack (attack_fused.hip): the planes of the product's operand are packed on the product's stream as soon as r is
+  // known, beside the forward's two products on the caller's stream (ev_r: r ready; ev_pack: planes and row partials ready)
+  hipEvent_t ev_r = nullptr, ev_pack = nullptr;
+  bool early_pack_on = true;       // MCGRA_EARLY_PACK=0 disables (A/B)
+  bool early_pack = false;         // Bpack / the pack's row partials describe the CURRENT M (packed by the forward of this M)
   // third stream of the fused step: the small-operand terms c9 / c10 (a chain of ~16 tiny launches that needs only the
   // forward) run beside the low-rank factor chain; its products use their own split-K workspace
   hipStream_t st3 = nullptr;

@@ -950,13 +950,13 @@ void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv
 // then only the mask count is produced, by the same kernel with kie7 = 0).  slabs: lr_decode_slabs(n) * n * h floats.
 // column slices of the decode of a ROW RANGE: a row-block rank has 1 / world of the row blocks, so it cuts the columns finer to
 // fill the chip (N = 10 000 on 8 ranks: 5 row blocks x 13 slices = 65 blocks took 0.49 ms per rank, as long as the whole
-// matrix on one GPU; 5 x 128: 0.05 ms).  The full range keeps lr_decode_slabs (the monolithic engine's bits do not move).
-// slabs: fl_decode_slabs * n * h floats (<= 128 slices: fits the 64 x n x 64 split-K workspace for h <= 32).
+// matrix on one GPU; 5 x 64 slices: 0.14 ms beside the product).  The full range keeps lr_decode_slabs (the monolithic engine's bits do not move).
+// slabs: fl_decode_slabs * n * h floats (<= 64 slices: fits the 64 x n x 64 split-K workspace for h <= 32; more slices make the sum of the slabs the longer kernel).
 int fl_decode_slabs(int n, int rows) {
   if (rows >= n) return lr_decode_slabs(n);
   const int nb = (rows + 255) / 256;
-  int js = (1024 + nb - 1) / nb;
-  if (js > 128) js = 128;
+  int js = (768 + nb - 1) / nb;
+  if (js > 64) js = 64;
   if (js > n / 64) js = n / 64;
   const int js0 = lr_decode_slabs(n);
   return js < js0 ? js0 : js;

@@ -189,9 +189,6 @@ __device__ __forceinline__ f32x16 plane_mma(u32x4 a, u32x4 b, f32x16 c) {
 
 // launch flags of the split kernels
 constexpr int SPLIT_BETA = 1;      // C += product (instead of C = product)
-constexpr int SPLIT_EDGE = 4;      // (set by split3_symm itself) n is not a multiple of the 256-row panel and its last panel is thin:
-                                   // the tiles of that panel come LAST in every XCD's list and multiply only their valid 16 x 16
-                                   // sub-tiles (split2_m16_kernel), so the ragged end of the launch is filled with cheap tiles
 constexpr int SPLIT_TRI = 2;       // A == B (Gram product): only tiles on or below the diagonal are computed; tiles below it
                                    // are stored twice, as computed and mirrored, so that C is the full, bitwise symmetric matrix
 // linear tile index -> (tile_m, tile_n): 4-panel groups over the tile grid (gemm_f32.hip), or the lower triangle row by row
@@ -427,36 +424,14 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
   constexpr int COPY = 512 * 16, AOPS = 2 * OPB / COPY;   // 4 copies per operand and step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tile_m, tile_n, lin, part;
-  const int last_panel = (n - 1) / TB, vlast = n - last_panel * TB;      // valid rows / columns of the last 256-panel
   {
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    if (beta & SPLIT_EDGE) {
-      // (ksplit == 1, tile_base == 0: the whole launch is one grid.)  Every XCD gets a contiguous chunk of the interior
-      // tiles (4-panel groups over the interior grid) followed by its share of the edge tiles: the hardware hands out
-      // blocks in order, so the thin tiles fill the ragged end of each XCD's list.
-      const int me = (panel_off + tiles_m - 1 == last_panel) ? 1 : 0, ne = (npanel_off + tiles_n - 1 == last_panel) ? 1 : 0;
-      const int tmi = tiles_m - me, tni = tiles_n - ne, n_int = tmi * tni;
-      const int qi = n_int >> 3, ri = n_int & 7;
-      const int int_x = qi + (xcd < ri ? 1 : 0), int_off = xcd * qi + min(xcd, ri);
-      const int before = xcd * q + min(xcd, r), sidx = bid >> 3;
-      part = 0;
-      if (sidx < int_x) {
-        lin = int_off + sidx;
-        split_tile_of(lin, tmi, tni, panel_off, npanel_off, 0, tile_m, tile_n);
-      } else {
-        int le = (before - int_off) + (sidx - int_x);
-        lin = n_int + le;
-        if (me && le < tiles_n) { tile_m = panel_off + tiles_m - 1; tile_n = npanel_off + le; }
-        else { le -= me ? tiles_n : 0; tile_m = panel_off + le; tile_n = npanel_off + tiles_n - 1; }
-      }
-    } else {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     part = bid % ksplit;
     lin = tile_base + bid / ksplit;
     split_tile_of(lin, tiles_m, tiles_n, panel_off, npanel_off, beta, tile_m, tile_n);
-    }
   }
   const int kper = (nks + ksplit - 1) / ksplit;
   const int kc_begin = part * kper;
@@ -524,37 +499,6 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc[i][j], 0, 0, 0);
       a0 = n0; a1 = n1;
     }
-  };
-
-  // A tile of the thin last panel: only the 16 x 16 sub-tiles that hold valid rows / columns are multiplied (the rest of the
-  // packed panel is zero padding).  Same MFMA order per accumulator as `multiply`: the valid elements get the same bits.
-  // mi / nj are wave-uniform (SGPRs): the guards are scalar branches around statically indexed accumulators.
-  int mi = 8, nj = 4;
-  if constexpr (MODE == 0) {
-    const int vr = tile_m == last_panel ? vlast : TB, vc = tile_n == last_panel ? vlast : TB;
-    mi = __builtin_amdgcn_readfirstlane(max(0, min(8, (vr - wm * 128 + 15) >> 4)));
-    nj = __builtin_amdgcn_readfirstlane(max(0, min(4, (vc - wn * 64 + 15) >> 4)));
-  }
-  auto multiply_edge = [&](int stage, auto&& before_reads) {
-    const char* s = smem + stage * STAGE;
-    before_reads();
-    if (mi == 0 || nj == 0) return;
-    f16x8 b0[4], b1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nj) { b0[j] = frag(s, b_off + j * 256); b1[j] = frag(s, b_off + j * 256 + PLANE); }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < mi) {
-        const f16x8 a0 = frag(s, a_off + i * 256), a1 = frag(s, a_off + i * 256 + PLANE);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < nj) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc[i][j], 0, 0, 0);
-          }
-      }
   };
 
   if constexpr (MODE == 3) {
@@ -655,12 +599,6 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     stage_tile(0, 0);
     __syncthreads();                      // (waits for the copies of this wave, then for everybody's)
     if constexpr (MODE == 0) {
-      if ((beta & SPLIT_EDGE) && (tile_m == last_panel || tile_n == last_panel)) {      // block-uniform
-        for (int kc = 0; kc < nk; ++kc) {
-          multiply_edge(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
-          __syncthreads();
-        }
-      } else
       for (int kc = 0; kc < nk; ++kc) {
         multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
         __syncthreads();
@@ -827,21 +765,6 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     while (ksplit > 1 && (size_t)ksplit * rem * TB * TB * sizeof(float) > slab_bytes) --ksplit;
   }
   if (ksplit <= 1) { full = total; rem = 0; }
-  // Thin last panel (n = 10 000: 16 valid rows of 256, 79 of the 1600 tiles): those tiles multiply only their valid 16 x 16
-  // sub-tiles and come last in every XCD's list, the whole launch is ONE grid (no split-K tail): 1521 interior tiles fill
-  // 5.94 rounds and the 79 thin ones the rest, instead of 6.25 rounds of full tiles.  Taken when the interior tiles leave at
-  // most half a round ragged; the default loop of the 2-plane kernel only.  MCGRA_SPLIT_EDGE=0 disables (A/B, tests).
-  if (planes == 2 && !(beta & SPLIT_TRI)) {
-    static const bool edge_on = [] { const char* e = getenv("MCGRA_SPLIT_EDGE"); return !(e && e[0] == '0'); }();
-    static const int loop_mode = [] { const char* e = getenv("MCGRA_SPLIT_LOOP"); return e && (e[0] == '2' || e[0] == '3') ? 1 : 0; }();
-    const int last = (n - 1) / TB, vlast = n - last * TB;
-    const int me = (panel_off + tm - 1 == last) ? 1 : 0, ne = (npanel_off + tiles - 1 == last) ? 1 : 0;
-    const int n_int = (tm - me) * (tiles - ne), rag = n_int % slots;
-    if (edge_on && !loop_mode && vlast <= TB / 2 && (me || ne) && (total <= slots || rag == 0 || 2 * rag >= slots)) {
-      beta |= SPLIT_EDGE;
-      full = total; rem = 0; ksplit = 1;
-    }
-  }
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2) {      // 2-plane fp16 split: split2_m16_kernel (v_mfma_f32_16x16x32_f16, global_load_lds staging)
       constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;

@@ -1080,57 +1080,6 @@ def test_split_loop_variants_give_the_default_loops_bits(pkg):
     assert digests["3"] == digests["0"]
 
 
-_SPLIT_EDGE_PROBE = r"""
-import os, sys
-sys.path.insert(0, os.environ["MCGRA_TEST_ROOT"])
-import numpy as np
-import torch
-import mcgra_loader
-mcgra_loader.load()
-from mc_gra_amd import engine as E
-for n in (1300, 4100, 2564):
-    rng = np.random.RandomState(n)
-    F = rng.randn(n, 24).astype(np.float32)
-    S = (F @ F.T).astype(np.float32); S = (S + S.T) * 0.5
-    X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1
-    outs = [E.ssymm_split_f16(torch.tensor(S, device="cuda"), torch.tensor(X, device="cuda")).cpu().numpy() for _ in range(2)]
-    assert np.array_equal(outs[0], outs[1])
-    np.save(os.path.join(os.environ["MCGRA_PROBE_OUT"], f"p{n}.npy"), outs[0])
-"""
-
-
-def test_thin_edge_tiles_last_gives_the_split_k_schemes_product(pkg, tmp_path):
-    """n not a multiple of the 256-row panel with a thin last panel (1300: 20 rows, 4100: 4, 2564: 4): the 2-plane kernel puts
-    that panel's tiles last in every XCD's list and multiplies only their valid 16 x 16 sub-tiles, one grid, no split-K
-    tail (split3_symm: SPLIT_EDGE).  Against the round-3 scheme (MCGRA_SPLIT_EDGE=0: every tile in full, ragged round cut
-    along K; one child per value, the switch is read once per process): tiles whose K loop is whole in both schemes carry
-    the same bits (same MFMA order per accumulator), the others differ by the summation order of the K slabs only; both
-    within 1e-6 of |S||X| of float64."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for mode in ("1", "0"):
-        d = tmp_path / f"edge{mode}"
-        d.mkdir()
-        env = dict(os.environ, MCGRA_SPLIT_EDGE=mode, MCGRA_TEST_ROOT=root, MCGRA_PROBE_OUT=str(d))
-        r = subprocess.run([sys.executable, "-c", _SPLIT_EDGE_PROBE], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[mode] = {n: np.load(d / f"p{n}.npy") for n in (1300, 4100, 2564)}
-    for n in (1300, 4100, 2564):
-        rng = np.random.RandomState(n)
-        F = rng.randn(n, 24).astype(np.float32)
-        S = (F @ F.T).astype(np.float32); S = (S + S.T) * 0.5
-        X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1
-        ref = S.astype(np.float64) @ X.astype(np.float64).T
-        den = np.abs(S).astype(np.float64) @ np.abs(X).astype(np.float64).T
-        a, b = outs["1"][n], outs["0"][n]
-        assert (np.abs(a - ref) / den).max() <= 1e-6 and (np.abs(b - ref) / den).max() <= 1e-6
-        assert (np.abs(a.astype(np.float64) - b) / den).max() <= 2e-7
-        same = float((a == b).mean())
-        assert same > 0.5, (n, same)          # (everything outside the round-3 scheme's split-K tail)
-
-
 @pytest.mark.parametrize("scale", [1.0, 3.0e-12, 7.0e11])
 def test_split_f16_product_operand_scales(pkg, torch_, scale):
     """The fp16 planes live in [2^-24, 2^16): the kernel's exact power-of-two operand scales must make the result
@@ -1442,3 +1391,30 @@ def test_set_graph_without_ori_restores_the_fused_path(pkg):
     assert torch.equal(eng.buffer("G_sym"), fresh.buffer("G_sym"))
     eng.monitor(); eng.step()
     assert eng.fused_steps() == 2
+
+
+def test_early_pack_beside_the_forward_is_bit_identical(pkg, monkeypatch):
+    """The planes of the N x N x N product's operand are packed on the product's stream as soon as r is known, beside the
+    forward's two skinny products (attack_fused.hip: early pack), instead of behind them on the caller's stream
+    (MCGRA_EARLY_PACK=0): same kernels on the same data, so the same bits -- also when the adjacency is replaced while a
+    monitor call's pack is still in flight (the stale planes must be dropped, not multiplied), and through finalize."""
+    import torch
+    z = _synthetic_case(1283, 11, (16, 16), 4, seed=21)
+    early = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_EARLY_PACK", "0")
+    late = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_EARLY_PACK")
+    a1 = H.init_adj_changes(1283, 99, 0.03)
+    for t in range(4):
+        for e in (early, late):
+            e.step(); e.monitor()
+            if t == 1:
+                e.set_adj_changes(a1)          # the monitor call above has forked a pack of the OLD adjacency
+        assert torch.equal(early.get_adj_changes(), late.get_adj_changes()), t
+        assert torch.equal(early.buffer("G_sym"), late.buffer("G_sym")), t
+    assert early.fused_steps() == 4 and late.fused_steps() == 4
+    lab = z["labels"]
+    la = (lab[:, None] == lab[None, :]).astype(np.float32)
+    fa = early.finalize(0, early.buffer("HA"), early.buffer("YA"), la)
+    fb = late.finalize(0, late.buffer("HA"), late.buffer("YA"), la)
+    assert torch.equal(fa, fb)
