@@ -1273,6 +1273,7 @@ int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, doubl
       MCGRA_HIP(hipMemcpyAsync(out_logp, h->logp, sizeof(float) * (size_t)h->n * h->C, hipMemcpyDeviceToDevice, st));
     if (sparsity) {
       double s;
+      if (h->early_pack) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));      // (the sum rides on the pack's stream)
       MCGRA_HIP(hipMemcpyAsync(&s, h->scal + S_SUM, sizeof(double), hipMemcpyDeviceToHost, st));
       MCGRA_HIP(hipStreamSynchronize(st));
       *sparsity = s / ((double)h->n * h->n);

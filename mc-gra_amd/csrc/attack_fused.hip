@@ -209,10 +209,12 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
           if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, h->st2, n, h->r, h->amax + 1);
           split3_pack_from_m(h->st2, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
                              h->cfg.w[1] != 0 ? h->A1 : nullptr, psum);
+          // (|adj_changes|^2 and sum(modified_adj): nothing of the forward needs them -- off the caller's stream too)
+          launch_reduce_rows(h->st2, h->rowsq, n, 2, h->scal + S_SQ);
           MCGRA_HIP(hipEventRecord(h->ev_pack, h->st2));
           h->early_pack = true;
         }
-        launch_reduce_rows(st, h->rowsq, n, 2, h->scal + S_SQ);      // rowsq | rowsum are adjacent, and so are S_SQ | S_SUM
+        if (!h->early_pack) launch_reduce_rows(st, h->rowsq, n, 2, h->scal + S_SQ);      // rowsq | rowsum are adjacent, and so are S_SQ | S_SUM
       } else {
         // own rows of r and d, and this rank's share of |adj_changes|^2 and sum(modified_adj) in the scalar lane: ONE gather
         const Stage sg = narrow_stage(h);
