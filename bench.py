@@ -41,6 +41,9 @@ WORKLOADS = {
     "cora-shape-hsic": (2708, 1433, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "cora-shape-mse": (2708, 1433, 7, 16, 2, "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-4k-hsic": (4096, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    # the headline workload with ~100 relu-masked decode pairs (10 x 10 nodes whose embeddings have disjoint supports: see
+    # masked_variant): rounds 1 - 3 sent every such step to the Gram evaluation (3x slower), now it stays fused
+    "synthetic-10k-hsic-masked": (10000, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     # BASELINE.json configs[4] shape on ONE GPU (54 GB of N x N buffers; ~0.5 s per step)
     "synthetic-20k-hsic-3layer": (20000, 256, 7, 16, 3, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-30k-hsic-3layer": (30000, 256, 7, 16, 3, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
@@ -104,6 +107,34 @@ def make_a0(n, seed, scale):
     return (np.random.RandomState(seed + 1000).rand(n * (n - 1) // 2) * scale).astype(np.float32)
 
 
+MASKED_VARIANTS = {"synthetic-10k-hsic-masked": (10, 10)}      # (nodes alive on the first half of em only, on the second half only)
+
+
+def masked_variant(workload, inp, a0, seed):
+    """Weights and start of a `*-masked` workload (tests/test_gpu_parity.py:_few_masked_pairs_case at the bench's scale).  The
+    second GCN layer's input is almost rank one, T_1 = 1 u^T + 1e-3 noise, so em_i = relu(s_i u + b), s_i = rowsum_i of the
+    learnable adjacency (~ 0.5 at the bench's start): the first half of the coordinates is alive for s_i < 1 (u = -1,
+    b = 1), the second half for s_i > 0.3 (u = +1, b = -0.3).  `lo` rows are scaled down (s ~ 0.1) and `hi` rows up (s ~ 1.5):
+    their lo x hi cross pairs have embeddings with disjoint supports, S_ij == 0 exactly -- relu-masked pairs, no dead row."""
+    if workload not in MASKED_VARIANTS:
+        return inp, a0
+    n_lo, n_hi = MASKED_VARIANTS[workload]
+    n, hid = inp["adj"].shape[0], inp["dims"][-1]
+    rng = np.random.RandomState(seed + 77)
+    W = [w.copy() for w in inp["W"]]; b = [x.copy() for x in inp["b"]]
+    W[0][:, 0] = 0.0; b[0][0] = 1.0                                   # H_0[:, 0] == 1 on every node
+    u = np.concatenate([-np.ones(hid // 2), np.ones(hid - hid // 2)]).astype(np.float32)
+    W[1] = (rng.randn(*W[1].shape) * 1e-3).astype(np.float32); W[1][0] += u
+    b[1] = np.concatenate([1.0 * np.ones(hid // 2), -0.3 * np.ones(hid - hid // 2)]).astype(np.float32)
+    f = np.ones(n, np.float32)
+    lo = 5 + 7 * np.arange(n_lo); hi = 9 + 11 * np.arange(n_hi)
+    f[lo] = 0.2; f[hi] = 3.0
+    # scale rows and columns of the packed start: entry (i, j), i > j, at i (i - 1) / 2 + j
+    ii = np.repeat(np.arange(1, n), np.arange(1, n)); jj = np.concatenate([np.arange(k) for k in range(1, n)])
+    a0 = (a0 * f[ii] * f[jj]).astype(np.float32)
+    return dict(inp, W=W, b=b), a0
+
+
 def feature_adj_cora(feats_dev, torch):
     """main.dot_product_decode for cora (main.py:44-48), on device (setup, untimed)."""
     from mc_gra_amd import engine as E
@@ -142,7 +173,7 @@ def _oracle_for(workload, seed, ns):
     cfg = O.AttackConfig(measure=measure, weight_sup=1.0, weight_param=wp, lr=workload_lr(workload, ns), num_edges=float("inf"))
     orc = O.PGDAttackOracle(w, X, inp["adj"], np.zeros((ns, ns), np.float32), fadj, inp["labels"], inp["idx_attack"], cfg)
     orc.set_adj_changes(make_a0(ns, seed, start_scale(workload, ns)))
-    return orc
+    return orc          # (the `*-masked` variants differ in weights and start only: the same work per step)
 
 
 def _cpu_child(workload, seed, ns, budget_s, q):
@@ -240,6 +271,8 @@ def build_engine(pkg, torch, dev, workload, seed, weight_param=None, **kw):
     n, f, c, hid, nl, measure, wp = WORKLOADS[workload]
     wp = wp if weight_param is None else weight_param
     inp = make_inputs(n, f, c, hid, nl, seed)
+    a0 = make_a0(n, seed, start_scale(workload, n))
+    inp, a0 = masked_variant(workload, inp, a0, seed)
     X = torch.as_tensor(inp["features"], device=dev)
     fadj = feature_adj_cora(X, torch)
     eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, 1.0, wp, workload_lr(workload, n), 1e30, n, device=dev, **kw)
@@ -248,7 +281,7 @@ def build_engine(pkg, torch, dev, workload, seed, weight_param=None, **kw):
     eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
     # seeded non-zero start: with measure=HSIC the origin is a fixed point of the exact dynamics
     # (DESIGN.md section 5, fact 2), so a zero start would time a run that optimises nothing
-    eng.set_adj_changes(torch.as_tensor(make_a0(n, seed, start_scale(workload, n)), device=dev))
+    eng.set_adj_changes(torch.as_tensor(a0, device=dev))
     return eng, inp, adj_dev
 
 
@@ -276,13 +309,14 @@ PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
 PLANE_PRODUCTS = {0: 1, 2: 6, 3: 3}
 
 
-def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode, overlap=None):
+def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode, overlap=None, extra_env=None):
     """The same workload with another evaluation of the one N x N x N product (MCGRA_SPLIT_BF16=mode): the pure fp32
     MFMA path beside a split headline, or the other way round; overlap=0: the product alone on the chip instead of
     beside the step's HBM-bound kernels.  Never the reported `value`."""
     env = {"MCGRA_SPLIT_BF16": str(mode)}
     if overlap is not None:
         env["MCGRA_OVERLAP"] = str(overlap)
+    env.update(extra_env or {})
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -434,7 +468,8 @@ def main(argv=None):
     dt = timed_region(one_step, a.steps, 0, torch.cuda.synchronize, world, dist, red_dev, torch)
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
-    eng_path = dict(eng.path_stats(), fused_steps=eng.fused_steps(), gram_split_steps=eng.gram_split_steps())
+    eng_path = dict(eng.path_stats(), fused_steps=eng.fused_steps(), gram_split_steps=eng.gram_split_steps(),
+                    masked_fused_steps=eng.masked_fused_steps())
     stepper_exchanges = ((stepper.exchanges - ex0) / a.steps) if stepper is not None else None      # of the timed steps
 
     # the same N x N x N product alone on the chip (no side-stream company), for the roofline's "alone" figure
@@ -490,6 +525,19 @@ def main(argv=None):
         except Exception as e:
             alone = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # the same workload when the fused low-rank step does not apply (a dead embedding row, a GAT / GraphSAGE victim, CKA, a
+    # hidden width > 32): the reference's own formulation, four N x N x N products per step on the same split kernel
+    gram = None
+    if world == 1 and measure == "HSIC" and pmode in (2, 3) and not a.no_split_probe:
+        try:
+            g = product_probe(pkg, torch, dev, a.workload, a.seed, min(a.steps, 5), 1, monitor, pmode, extra_env={"MCGRA_NO_LOWRANK": "1"})
+            gram = {"value": g["value"], "unit": "attack-steps/s", "ms_per_step": g["ms_per_step"], "steps": g["steps"], "auc": g["auc"],
+                    "headline_over_this": (a.steps / dt) / g["value"],
+                    "what": "Gram evaluation of linear_HSIC (MCGRA_NO_LOWRANK=1): what a step costs when the fused low-rank step "
+                            "does not apply"}
+        except Exception as e:
+            gram = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # BASELINE.json configs[1] (Cora-sized dense GCN + HSIC, fp32) beside the 10k headline: same engine, same timing
     extra = None
     if world == 1 and a.workload == "synthetic-10k-hsic" and not a.no_split_probe:
@@ -537,6 +585,8 @@ def main(argv=None):
                        # without relu-masked pairs; a masked step is redone by the Gram evaluation, 2.8x slower)
                        "fused_steps": eng_path["fused_steps"], "lowrank_steps": eng_path["lowrank_steps"],
                        "general_steps": eng_path["general_steps"], "gram_split_steps": eng_path["gram_split_steps"],
+                       # fused steps whose decode relu-masked pairs of live embedding rows (they stand; only a dead row falls back)
+                       "masked_fused_steps": eng_path["masked_fused_steps"],
                        "monitor_forward": monitor,
                        "forward_reuse": bool(monitor and os.environ.get("MCGRA_NO_FWD_REUSE") != "1"),
                        "parallelism": (f"row-block x{world}: one attack, rows of the learnable adjacency and of every N x N pass "
@@ -555,6 +605,8 @@ def main(argv=None):
             out["fp32_mfma_probe" if pmode else "split_bf16_probe"] = split
         if extra is not None:
             out["other_workloads"] = extra
+        if gram is not None:
+            out["gram_path_probe"] = gram
         if st["launches"]:
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12

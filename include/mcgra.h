@@ -298,6 +298,14 @@ int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long lo
  * never stored).  Conditions: measure HSIC, ReLU GCN victim, eps == 0, the split product (n >= 1024 or
  * MCGRA_SPLIT_BF16=2/3), n >= 256, widths <= 32; MCGRA_NO_FUSED_LR=1 disables it. */
 long long mcgra_attack_fused_steps(mcgra_attack_t* h);
+/* Fused steps whose decode relu-masked pairs (S_ij <= 0 off the diagonal) while every embedding row was alive: they stand.
+ * With a ReLU embedding zn >= 0, so a masked pair has S_ij == 0 exactly: the value of modified_adj1 is still Z Z^T - D, and
+ * what relu'(0) = 0 takes out of the decode backward is a multiple of zn_j on row i -- coordinates on which em_i is zero,
+ * i.e. which the embedding layer's own ReLU backward masks anyway (measured: bit-identical
+ * gradients with and without an explicit correction).  Only a DEAD row (em_i == 0: zn_i == 0, the algebra takes
+ * |zn_i| = 1) sends a step to the Gram evaluation.  Rounds 1 - 3 sent every step with a masked pair there (3x slower at
+ * N = 10 000). */
+long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h);
 /* Gram-evaluation steps (masked decode, GAT / SAGE chains, MCGRA_NO_LOWRANK) whose four N x N x N products ran on the
  * 2-plane fp16 kernel instead of fp32 SYMM (n >= 1024, HSIC, eps == 0; MCGRA_GRAM_SPLIT=0 turns it off). */
 long long mcgra_attack_gram_split_steps(mcgra_attack_t* h);

@@ -36,6 +36,7 @@ SYMBOLS = [
     "mcgra_attack_gemm_stats",
     "mcgra_attack_product_replay",
     "mcgra_attack_test_mutate",
+    "mcgra_attack_masked_fused_steps",
 ]
 
 
@@ -128,6 +129,8 @@ def _load():
         fn.restype = C.c_int
     lib.mcgra_attack_fused_steps.argtypes = [vp]
     lib.mcgra_attack_fused_steps.restype = C.c_longlong
+    lib.mcgra_attack_masked_fused_steps.argtypes = [vp]
+    lib.mcgra_attack_masked_fused_steps.restype = C.c_longlong
     lib.mcgra_attack_gram_split_steps.argtypes = [vp]
     lib.mcgra_attack_gram_split_steps.restype = C.c_longlong
     lib.mcgra_attack_exchange_bytes.argtypes = [vp]

@@ -671,11 +671,20 @@ __global__ void k_cn(const double* __restrict__ scal, float coef, float* __restr
   out[0] = sq > 0.0 ? (float)(coef / sqrt(sq)) : 0.f;
 }
 
-// {sequence number, masked?} of the decode into mapped host memory (the host polls the sequence number)
+// {sequence number, code} of the decode into mapped host memory (the host polls the sequence number).  code: 0 = no
+// relu-masked pair; 1 = masked pairs, every embedding row alive: the fused low-rank step stands (with a
+// ReLU embedding a masked pair has S_ij == 0 exactly, the forward is unchanged, and what relu'(0) = 0 removes from the decode
+// backward lies on coordinates the embedding's own ReLU masks anyway); 2 = a dead embedding row (count[1]): the step is
+// redone by the Gram evaluation.
 __global__ void k_post_mask(unsigned int* __restrict__ count_u32, const double* __restrict__ count_f64,
                             unsigned int* __restrict__ seq_dev, unsigned int* __restrict__ host_slot) {
-  const unsigned int masked = count_u32 ? (*count_u32 != 0u) : (*count_f64 != 0.0);
-  if (count_u32) *count_u32 = 0u;          // re-armed for the next decode
+  unsigned int masked;
+  if (count_u32) {
+    masked = count_u32[1] != 0u ? 2u : (count_u32[0] != 0u ? 1u : 0u);
+    count_u32[0] = 0u; count_u32[1] = 0u;          // re-armed for the next decode
+  } else {
+    masked = count_f64[1] != 0.0 ? 2u : (count_f64[0] != 0.0 ? 1u : 0u);      // (row-block rank: sums over the ranks)
+  }
   const unsigned int seq = ++*seq_dev;
   __hip_atomic_store(host_slot + 1, masked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
@@ -1246,6 +1255,7 @@ int step_general(mcgra_attack_t* h, void* stream, const float* noise, double* sc
   return step_impl(h, stream, noise, scalars_out, 0xF);
 }
 
+long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h) { return h ? (long long)h->masked_fused_steps : 0; }
 int mcgra_attack_product_mode(mcgra_attack_t* h) {
   return h ? (h->split_mode == 2 && h->split_planes == 2 ? 3 : h->split_mode) : 0;
 }

@@ -484,7 +484,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           MCGRA_HIP(hipStreamWaitEvent(s4, h->ev_fork4, 0));
         }
         // (with c2, k_post_mask leaves the counter at zero for the next fused step; the general path does not)
-        if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), s4));
+        if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask);
         if (want_vals) launch_reduce_rows(s4, h->rowvals, h->fs_np, 1, h->scal + S_V7);
@@ -496,16 +496,17 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (s4 != st) MCGRA_HIP(hipEventRecord(h->ev_join4, s4));
         h->fs_dec_forked = s4 != st;
       } else {
-        MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+        MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), st));
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
                                  h->hmax, h->nmask);
-        // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair count and entropy partial: they ride in
-        // the gather of the first low-rank product below (or, without c2, in a gather of their own)
+        // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair and dead-row counts and its entropy partial:
+        // they ride in the gather of the first low-rank product below (or, without c2, in a gather of their own)
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
-        CHK(lane_zero(h, st, sg, 2));
+        CHK(lane_zero(h, st, sg, 3));
         hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, lane_slot(h, sg, 0));
-        if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 1));
+        hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask + 1, lane_slot(h, sg, 1));
+        if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 2));
         rows_to_stage(h, st, sg, he, h->GZn, h->hmax, 0);
         if (use2) rows_to_stage(h, st, sg, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
       }
@@ -530,14 +531,14 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
         stage_to_rows(h, st, sg, he, 0, h->GZn, h->hmax);
         if (use2) stage_to_rows(h, st, sg, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
-        lane_sum(h, st, sg, 2, h->SC + 2);                       // SC[2] masked pairs, SC[3] entropy term of modified_adj1
-        MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 3, sizeof(double), hipMemcpyDeviceToDevice, st));
-        // A relu-masked pair (S_ij <= 0) voids the low-rank algebra.  The count is posted to mapped host memory now and
+        lane_sum(h, st, sg, 3, h->SC + 8);                       // SC[8] masked pairs, SC[9] dead rows, SC[10] entropy term of modified_adj1
+        MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 10, sizeof(double), hipMemcpyDeviceToDevice, st));
+        // A dead embedding row voids the low-rank algebra (k_post_mask).  The counts are posted to mapped host memory now and
         // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
         // long landed, so the host never waits with an empty queue behind it (a readback + sync here cost 0.14 of the
-        // 0.87 ms Cora-size step).  Everything in between writes scratch only; on a masked step it is thrown away.
+        // 0.87 ms Cora-size step).  Everything in between writes scratch only; on such a step it is thrown away.
         if (use2) {
-          hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, nullptr, h->SC + 2, h->mask_seq_dev, h->mask_host_dev);
+          hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, st, nullptr, h->SC + 8, h->mask_seq_dev, h->mask_host_dev);
           h->mask_want = ++h->mask_seq;
         }
       }
@@ -687,7 +688,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
               }
             }
           }
-          masked = h->mask_host[1] != 0u;
+          const unsigned int code = h->mask_host[1];      // 0: no masked pair, 1: masked pairs of live rows (the step stands), 2: a dead row
+          masked = code >= 2u;
+          if (code == 1u) ++h->masked_fused_steps;
         }
         if (masked) {
           // relu'(0) = 0 masks a pair in the reference's backward: the low-rank algebra does not apply.  A row-block

@@ -118,6 +118,7 @@ struct mcgra_attack {
   unsigned int mask_want = 0;                    // sequence number of the post the step in flight will poll for
   bool p1_inflight = false;
   bool skip_fused = false;         // the last step's decode masked a pair: the general path goes first (it re-checks)
+  int64_t masked_fused_steps = 0;  // fused steps whose decode relu-masked pairs of live rows (they stand: DESIGN.md section 1b)
   bool nmask_zero = false;         // the decode's masked-pair counter holds 0 (left so by k_post_mask)
   bool t3_zero = false;            // column 2 he of lrT (t3 of the low-rank factors) holds zeros (fused step; the general path writes it)
   bool overlap = false;            // MCGRA_OVERLAP=1 forks the N x N x N product onto the engine's own stream

@@ -350,7 +350,7 @@ __global__ void k_lrq_post(int n, int w, YView Y, const float* __restrict__ Vs, 
 
 // ---------------------------------------------------------------------------------- decode, recomputed per pair
 // For rows i in [row0, row1), all j:  S_ij = zn_i . zn_j (the fmaf chain of rankk_nt: same bits as the stored form),
-// A1_ij = [i != j] relu(S_ij);  nmask += #{i != j : S_ij <= 0};  v7 partials of sum ie_value(A1) (diagonal included, as
+// A1_ij = [i != j] relu(S_ij);  nmask[0] += #{i != j : S_ij <= 0}, nmask[1] += #{i : zn_i == 0};  v7 partials of sum ie_value(A1) (diagonal included, as
 // Info_entropy runs over the whole matrix, :44-52);  slabs: G_Zn_i = sum_{j != i, S_ij > 0} 2 ie'(A1_ij) zn_j.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int H>
@@ -370,6 +370,14 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
   f32x2 acc[H];
 #pragma unroll
   for (int k = 0; k < H; ++k) { zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f; acc[k] = f32x2{0.f, 0.f}; }
+  // a dead embedding row (em_i == 0, so zn_i == 0 and S_ii == 0): nmask[1].  It is the ONLY thing that voids the fused
+  // low-rank step (its algebra takes |zn_i| = 1); relu-masked pairs of live rows do not.
+  if (valid && blockIdx.y == 0) {
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < H; ++k) nz |= zi[k] != 0.f;
+    if (!nz) atomicAdd(nmask + 1, 1u);
+  }
   double v7 = 0.0;
   int masked = 0;
   for (int jc = j0; jc < j1; jc += JC) {

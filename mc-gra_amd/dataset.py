@@ -51,7 +51,8 @@ class Dataset():
         return adj, features, labels
 
     # lines of <name>_A.txt the reference reads (dataset.py:255, :295): usair's file holds 13 599, the last 17 are never seen
-    EDGE_LINES = {'usair': 13582, 'brazil': 1074}
+    # (europe: dataset.py:276; its data files are not part of the reference checkout).  Any other edge-list dataset: every line
+    EDGE_LINES = {'usair': 13582, 'brazil': 1074, 'europe': 5995}
 
     def _load_edge_list(self, name):
         f = np.loadtxt(osp.join(self.root, name, f'{name}_lable.txt'))
@@ -60,8 +61,11 @@ class Dataset():
         n = len(ids)
         g = np.zeros((n, n))
         with open(osp.join(self.root, name, f'{name}_A.txt')) as fh:
-            for _ in range(self.EDGE_LINES[name]):
-                row = fh.readline().strip().split()
+            lines = fh.readlines()
+            for ln in lines[:self.EDGE_LINES.get(name, len(lines))]:
+                row = ln.strip().split()
+                if len(row) < 2:
+                    continue
                 i, j = int(row[0]), int(row[1])
                 g[pos[i], pos[j]] = 1
                 g[pos[j], pos[i]] = 1

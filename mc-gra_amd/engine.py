@@ -379,6 +379,10 @@ class AttackEngine:
             torch.cuda.current_stream().synchronize()
         return out
 
+    def masked_fused_steps(self):
+        """Fused steps whose decode relu-masked pairs of live embedding rows (they stand; only a dead row falls back)."""
+        return int(lib.mcgra_attack_masked_fused_steps(self._h))
+
     def product_replay(self, reps=10):
         """Mean launch time [ms] of `reps` back-to-back launches of the last fused step's N x N x N product, nothing beside
         them (mcgra_attack_product_replay: a measurement aid, no engine state changes)."""

@@ -1418,3 +1418,69 @@ def test_early_pack_beside_the_forward_is_bit_identical(pkg, monkeypatch):
     fa = early.finalize(0, early.buffer("HA"), early.buffer("YA"), la)
     fb = late.finalize(0, late.buffer("HA"), late.buffer("YA"), la)
     assert torch.equal(fa, fb)
+
+
+def _few_masked_pairs_case(n=1100, seed=31, n_high=2, weight_param=None):
+    """A synthetic case whose decode relu-masks a FEW pairs exactly and has no dead embedding row.  The second GCN layer's
+    input is (almost) rank one, T_1 = 1 u^T + 1e-3 noise, so em_i = relu(s_i u + b) with s_i = rowsum_i(modified_adj): the
+    first eight coordinates are alive for s_i < 50 (u = -1, b = 50), the last eight for s_i > 15 (u = +1, b = -15).  The
+    seeded start has row sums ~ 27 (all sixteen alive); three rows are scaled down (s ~ 6: first eight only) and two up
+    (s ~ 80: last eight only): their 3 x 2 cross pairs have embeddings with disjoint supports, S_ij == 0 exactly."""
+    z = _synthetic_case(n, 11, (16, 16), 4, seed=seed, **({"weight_param": weight_param} if weight_param else {}))
+    z["lr"] = np.array(1e-4)                                   # (Adam moves every row sum by <= n lr = 0.11 per step: the supports stay)
+    rng = np.random.RandomState(seed)
+    z["W0"][:, 0] = 0.0
+    z["b0"][0] = 1.0                                           # H_0[:, 0] == 1 on every node
+    u = np.concatenate([-np.ones(8), np.ones(8)]).astype(np.float32)
+    W1 = (rng.randn(16, 16) * 1e-3).astype(np.float32)
+    W1[0] += u
+    z["W1"] = W1
+    z["b1"] = np.concatenate([50.0 * np.ones(8), -15.0 * np.ones(8)]).astype(np.float32)
+    A = O.unpack_sym(H.a0_of(z), n)
+    f = np.ones(n, np.float32)
+    low = [5, 400, 901]
+    high = [9, 777] if n_high == 2 else [9 + 10 * k for k in range(n_high)]
+    f[low] = 0.2; f[high] = 3.0
+    A = (A * f[:, None] * f[None, :]).astype(np.float32)
+    return z, O.pack_tril(A), low, high
+
+
+@pytest.mark.parametrize("n_high,wp", [(2, None), (100, None), (100, NXN_ONLY), (100, (0.0, 1.0, 0, 0, 0, 0, 0, 0, 0, 0))])
+def test_relu_masked_pairs_of_live_rows_keep_the_fused_step(pkg, monkeypatch, n_high, wp):
+    """the fused path was a cliff -- ONE relu-masked decode pair sent the step to the Gram evaluation,
+    3x slower at N = 10 000.  It need not: with a ReLU embedding zn >= 0, so a masked pair has S_ij == 0 EXACTLY -- the value
+    of modified_adj1 = offdiag relu(S) is still Z Z^T - D, every forward quantity of the low-rank step stands -- and what
+    relu'(0) = 0 removes from the decode backward, g_ij zn_j on row i, lies on coordinates where em_i is zero (disjoint
+    supports), which the embedding layer's own ReLU backward masks anyway; its component along zn_i is zn_i . zn_j = 0.
+    So only a DEAD row (em_i == 0) voids the algebra (it takes |zn_i| = 1).  Here the decode masks 12 or 600 pairs on every
+    step, no row is dead: the step stays fused, and its gradient equals the Gram evaluation's (MCGRA_NO_LOWRANK=1: the
+    reference's formulation, which masks per pair) to 3e-5 and the oracle's to 3e-4 of the gradient's largest magnitude --
+    with the README weights, with the N x N terms alone and with c2 alone (where the decode backward IS the gradient)."""
+    import torch
+    z, a0, low, high = _few_masked_pairs_case(n_high=n_high, weight_param=wp)
+    orc = H.oracle_from(z)
+    orc.set_adj_changes(a0)
+    fused = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    gram = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    for e in (fused, gram):
+        e.set_adj_changes(a0)
+    for t in range(3):
+        orc.step()
+        S = orc.last["S"]
+        off = ~np.eye(S.shape[0], dtype=bool)
+        assert int(((S <= 0) & off).sum()) == 2 * len(low) * len(high) and float(np.diag(S).min()) > 0.5, "the case must mask pairs, no dead row"
+        a = fused.step(want_scalars=True); fused.monitor()
+        b = gram.step(want_scalars=True); gram.monitor()
+        gf, gg = fused.buffer("G_sym"), gram.buffer("G_sym")
+        gmax = float(gg.abs().max())
+        assert float((gf - gg).abs().max()) <= 3e-5 * gmax, t
+        go = torch.as_tensor(orc.last["G_sym"], device=gf.device)
+        assert float((gf - go).abs().max()) <= 3e-4 * float(go.abs().max()), t
+        for k in ("loss", "c1", "c2", "c7", "c9"):
+            assert a[k] == pytest.approx(b[k], rel=3e-4, abs=1e-6), (t, k)
+        gram.set_adj_changes(fused.get_adj_changes())           # teacher forcing: one state, two evaluations
+        orc.set_adj_changes(fused.get_adj_changes().cpu().numpy())
+    assert fused.fused_steps() == 3 and fused.masked_fused_steps() == 3 and fused.path_stats()["general_steps"] == 0
+    assert gram.path_stats()["general_steps"] == 3 and gram.masked_fused_steps() == 0
