@@ -324,3 +324,25 @@ def test_config4_shape_30k_3layer_properties(ctx, monkeypatch):
     assert err < 1e-4, err
     for k in ("loss", "c1", "c2", "c6", "c7"):
         assert a[k] == pytest.approx(b[k], rel=1e-3, abs=1e-6), k
+
+
+def test_masked_bench_workload_stays_fused_at_10k(ctx, monkeypatch):
+    """`synthetic-10k-hsic-masked`: the headline shape with 10 x 10 nodes whose embeddings have disjoint supports -- 200
+    relu-masked decode pairs, no dead row.  Rounds 1 - 3 redid every such step with the Gram evaluation (3x slower); the
+    fused step stands and its gradient equals the Gram evaluation's."""
+    pkg, torch, bench, dev = ctx
+    wl = "synthetic-10k-hsic-masked"
+    fast, _, _ = bench.build_engine(pkg, torch, dev, wl, 0)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    gram, _, _ = bench.build_engine(pkg, torch, dev, wl, 0)
+    monkeypatch.delenv("MCGRA_NO_LOWRANK")
+    for t in range(2):
+        a = fast.step(want_scalars=True); fast.monitor()
+        b = gram.step(want_scalars=True)
+        gf, gg = fast.buffer("G_sym"), gram.buffer("G_sym")
+        assert float((gf - gg).abs().max()) <= 5e-5 * float(gg.abs().max()), t
+        for k in ("loss", "c1", "c2", "c9"):
+            assert a[k] == pytest.approx(b[k], rel=3e-4, abs=1e-6), (t, k)
+        gram.set_adj_changes(fast.get_adj_changes())
+    assert fast.fused_steps() == 2 and fast.masked_fused_steps() == 2 and fast.path_stats()["general_steps"] == 0
+    assert gram.path_stats()["general_steps"] == 2
