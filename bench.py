@@ -395,8 +395,11 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks (one per GPU) of ONE row-block sharded attack; default: WORLD_SIZE under a launcher, else 1.  "
                          "Without a launcher and N > 1 this process starts the N ranks itself (torch.distributed.run)")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (defaults: 200 timed steps behind 20 untimed ones, 1.3 s in all.  The chip's clock settles over the first ~30 steps of
+    # a run -- the product takes 4.80 ms per launch over steps 4 - 23 and 4.66 over steps 21 - 220 on the same box -- so a
+    # 20-step window behind 3 warm-up steps, rounds 1 - 3's default, times the transient: 172 - 173 against 175 - 178 steps/s)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="synthetic-10k-hsic", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-monitor", action="store_true", help="skip the per-step monitoring forward (:290-296)")
@@ -502,7 +505,7 @@ def main(argv=None):
     split = None
     if world == 1 and measure == "HSIC" and not a.no_split_probe:
         try:
-            split = product_probe(pkg, torch, dev, a.workload, a.seed + rank, a.steps, a.warmup, monitor, 0 if pmode else 2)
+            split = product_probe(pkg, torch, dev, a.workload, a.seed + rank, min(a.steps, 20), min(a.warmup, 3), monitor, 0 if pmode else 2)
             split["headline_auc"] = auc
             split["headline_over_this"] = aggregate_value(world, a.steps, dt) / split["value"]
         except Exception as e:
@@ -521,7 +524,7 @@ def main(argv=None):
     side_stream = (os.environ.get("MCGRA_OVERLAP") or ("1" if pmode == 3 else "0")) == "1"
     if world == 1 and measure == "HSIC" and pmode in (2, 3) and side_stream and not a.no_split_probe:
         try:
-            alone = product_probe(pkg, torch, dev, a.workload, a.seed + rank, min(a.steps, 10), a.warmup, monitor, pmode, overlap=0)
+            alone = product_probe(pkg, torch, dev, a.workload, a.seed + rank, min(a.steps, 40), min(a.warmup, 10), monitor, pmode, overlap=0)
         except Exception as e:
             alone = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -611,12 +614,12 @@ def main(argv=None):
             avg_ms = st["ms"] / st["launches"]
             ach = st["flops"] / st["launches"] / (avg_ms * 1e-3) / 1e12
             # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
-            # (profiles/r03_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
+            # (profiles/r04_gemm_traffic.json, FETCH_SIZE doubled per the gfx950 correction); PMC counters
             # cannot be read from inside the timed process, so the committed profile value is reported.
             traffic = None
             ps = eng_path
             lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
-            tp = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+            tp = os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")
             role = {2: "split", 3: "split_f16"}.get(pmode, "symm") if lowrank else "symm"
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
                 ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == role or not lowrank]
@@ -686,7 +689,7 @@ def main(argv=None):
             out["roofline"] = None
         # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed
         # profile) over the step time that is not the product (step without the side stream - product alone)
-        sp = os.path.join(ROOT, "profiles", "r03_step_traffic.json")
+        sp = os.path.join(ROOT, "profiles", "r04_step_traffic.json")
         if world == 1 and a.workload == "synthetic-10k-hsic" and os.path.exists(sp) and alone is not None and "value" in alone:
             bytes_out = json.load(open(sp))["outside_product_bytes_per_step"]
             ms_out = 1e3 / alone["value"] - alone.get("product_avg_launch_ms", 0.0)
