@@ -513,7 +513,8 @@ def main(argv=None):
 
     # the split product by itself: the timed engine's own last product replayed back to back with nothing beside it
     replay_ms = None
-    if world == 1 and measure == "HSIC" and pmode in (2, 3) and eng_path["fused_steps"] > 0 and wp[0] != 0:
+    # (not under --no-split-probe: the rocprofv3 passes of profiles/ then hold the step's own launches only)
+    if world == 1 and measure == "HSIC" and pmode in (2, 3) and eng_path["fused_steps"] > 0 and wp[0] != 0 and not a.no_split_probe:
         try:
             eng.product_replay(3)
             replay_ms = eng.product_replay(20)
