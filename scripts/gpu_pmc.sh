@@ -6,7 +6,7 @@ R="$GRAFT_REPO_ROOT"
 cd /tmp
 B="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_stats" -- python3 $B > "$R/gpurun_out/${TAG}_stats.log" 2>&1
-B2="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split-probe"
+B2="$R/bench.py --steps ${PMC_STEPS:-2} --warmup 1 --no-cpu-baseline --no-split-probe"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${TAG}_fetch" -- python3 $B2 > "$R/gpurun_out/${TAG}_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${TAG}_write" -- python3 $B2 > "$R/gpurun_out/${TAG}_write.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$R/gpurun_out/${TAG}_sq" -- python3 $B2 > "$R/gpurun_out/${TAG}_sq.log" 2>&1
