@@ -239,8 +239,8 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
  *   [0] loss  [1] origin_loss  [2] c1 [3] c2 [4] c6 [5] c7 [6] c9 [7] c10
  *   [8] sum(clamp(adj_changes,0,1)) after the update  [9] nll
  * Passing NULL keeps the call asynchronous, except for one 4-byte device-to-host readback per step on HSIC
- * configurations with w2 != 0 (the count of relu-masked decode pairs that selects the low-rank or the Gram
- * evaluation).  When the preceding call on this handle was mcgra_attack_monitor (and eps == 0) the
+ * configurations with w2 != 0 (whether the decode found a dead embedding row, which selects the low-rank or the Gram
+ * evaluation; the fused step reads it from mapped host memory without emptying the queue).
  * step adopts that call's forward instead of recomputing it (same bits). */
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
                       double* scalars_out);
@@ -254,7 +254,7 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
  *     ROW block P1[rows, :] as well (the mirrored gradient needs P1_ij and P1_ji);
  *   - decode, tail reductions and Adam on the rank's rows; n-vectors (r, d, gd, the decode backward) ride in the same
  *     all-gathers as the products where both are ready at the same point, and every scalar that is summed over the ranks
- *     (|adj_changes|^2, the masked-pair count, the loss terms) rides in a two-column "lane" of the gathered array: rank k
+ *     (|adj_changes|^2, the masked-pair and dead-row counts, the loss terms) rides in a two-column "lane" of the gathered array: rank k
  *     leaves its partial in row k * rows_per_rank + q, and behind the gather every rank adds the `world` partials in rank
  *     order -- the same bits on every rank, and no all-reduce.  Per step + monitoring forward at L GCN layers: 2 L + 3
  *     all-gathers and the one all-to-all (8 collectives at L = 2; one more gather when want_scalars is set).
@@ -306,7 +306,7 @@ long long mcgra_attack_fused_steps(mcgra_attack_t* h);
  * |zn_i| = 1) sends a step to the Gram evaluation.  Rounds 1 - 3 sent every step with a masked pair there (3x slower at
  * N = 10 000). */
 long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h);
-/* Gram-evaluation steps (masked decode, GAT / SAGE chains, MCGRA_NO_LOWRANK) whose four N x N x N products ran on the
+/* Gram-evaluation steps (a dead embedding row, GAT / SAGE chains, CKA, MCGRA_NO_LOWRANK) whose four N x N x N products ran on the
  * 2-plane fp16 kernel instead of fp32 SYMM (n >= 1024, HSIC, eps == 0; MCGRA_GRAM_SPLIT=0 turns it off). */
 long long mcgra_attack_gram_split_steps(mcgra_attack_t* h);
 
