@@ -240,8 +240,9 @@ int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed)
  *   [8] sum(clamp(adj_changes,0,1)) after the update  [9] nll
  * Passing NULL keeps the call asynchronous, except for one 4-byte device-to-host readback per step on HSIC
  * configurations with w2 != 0 (whether the decode found a dead embedding row, which selects the low-rank or the Gram
- * evaluation; the fused step reads it from mapped host memory without emptying the queue).
- * step adopts that call's forward instead of recomputing it (same bits). */
+ * evaluation; the fused step reads it from mapped host memory without emptying the queue).  When the
+ * preceding call on this handle was mcgra_attack_monitor (and eps == 0) the step adopts that call's forward instead of
+ * recomputing it (same bits). */
 int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
                       double* scalars_out);
 
