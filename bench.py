@@ -236,6 +236,69 @@ def cpu_baseline(workload, seed, timeout_s=210.0):
     return dict(value=None, unit="attack-steps/s", cores=os.cpu_count(), kind="port", sample=f"oracle did not finish a step ({err})")
 
 
+_NOT_IN_STEP = ("fillBufferAligned grid=65536", "k_dd2_accum", "k_axpby2d", "rankk_nt_kernel<16>", "k_decode_post", "k_unpack_sym",
+                "k_split_absmax", "k_center_cols", "k_rowsum", "copyBuffer")
+
+
+def live_traffic(workload, seed, steps=6, timeout_s=120.0):
+    """Memory-side bytes of THIS build on THIS box, measured inside the bench invocation: two child runs of this script
+    under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, `--kernel-trace` only beside them: the form
+    MI355X_MICROARCH.md prescribes), started -- like the CPU baseline -- before this process touches the GPU.  Bytes =
+    2 x FETCH_SIZE + WRITE_SIZE (the gfx950 correction; counted at the L2's memory side, Infinity-Cache hits included).
+    Returns {"product_bytes_per_launch", "outside_product_bytes_per_step", ...} or None (no rocprofv3, a failed pass): the
+    bench line then falls back to the committed passes of profiles/ and says so.  The accounting is the one of
+    scripts/profile_summary.py (kernels a step launches, by launch count; the one-off launches of set_graph / finalize
+    excluded by name)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    per = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(steps), "--warmup", "1", "--workload", workload, "--seed", str(seed), "--no-cpu-baseline",
+                   "--no-split-probe", "--no-live-traffic"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except Exception:
+                return None
+            fs = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None
+            for row in csv.DictReader(open(fs[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
+                k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + f" grid={row['Grid_Size']}"
+                e = per.setdefault(k, {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+                e[ctr] += float(row["Counter_Value"])
+                if ctr == "FETCH_SIZE":
+                    e["n"] += 1
+    nsteps = steps + 1
+    prod_main, outside = None, 0.0
+    for k, v in per.items():
+        n = max(v["n"], 1)
+        b = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) / n * 1024.0
+        if "split2_m16_kernel" in k or "split3_symm_kernel" in k:
+            if prod_main is None or b > prod_main:
+                prod_main = b                      # the main grid (the split-K tail of the ragged round is a second, smaller launch)
+            continue
+        if ("mcgra::" in k or "rocclr" in k) and n >= nsteps and "gemm_f32_kernel<128, 128" not in k and "k_split3_reduce" not in k \
+                and not any(x in k for x in _NOT_IN_STEP):
+            outside += b * (n // nsteps)
+    if prod_main is None:
+        return None
+    return {"product_bytes_per_launch": prod_main, "outside_product_bytes_per_step": outside, "steps_in_pass": nsteps,
+            "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace over {nsteps} steps of this workload, run by this invocation "
+                   "before its timed region; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}
+
+
 def timed_region(step_fn, steps, warmup, sync, world, dist=None, device=None, torch=None):
     """The driver's timing contract: W untimed steps, then exactly K steps bracketed by barrier + device sync on
     both sides; returns the MAX over ranks of the elapsed seconds.  `sync()` is torch.cuda.synchronize on GPU
@@ -406,6 +469,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-shard-probe", action="store_true",
                     help="N > 1: skip the extra (untimed-for-value) run of independent replicas, one attack per rank")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure the memory-side traffic of this build on this box "
+                         "(N = 1; implied by --no-split-probe)")
     ap.add_argument("--no-split-probe", action="store_true",
                     help="skip the extra runs at N = 1 (other evaluation of the N x N x N product, Cora-shape workload)")
     a = ap.parse_args(argv)
@@ -425,6 +491,13 @@ def main(argv=None):
     # CPU baseline first (N = 1 only): its child process is forked before anything here touches the GPU, and it is over
     # before the timed region starts, so the host cores are idle while the GPU is timed
     cpu = cpu_baseline(a.workload, a.seed) if (world == 1 and not a.no_cpu_baseline) else None
+    # ... and so are the two PMC passes that measure this build's memory-side traffic on this box (children under rocprofv3)
+    live = None
+    if world == 1 and not a.no_live_traffic and not a.no_split_probe and WORKLOADS[a.workload][5] == "HSIC":
+        try:
+            live = live_traffic(a.workload, a.seed)
+        except Exception:
+            live = None
     import torch
     import torch.distributed as dist
     if shared_gpu:
@@ -622,9 +695,13 @@ def main(argv=None):
             lowrank = ps["lowrank_steps"] > 0 and ps["general_steps"] == 0
             tp = os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")
             role = {2: "split", 3: "split_f16"}.get(pmode, "symm") if lowrank else "symm"
+            traffic_source = None
             if a.workload == "synthetic-10k-hsic" and os.path.exists(tp):
                 ks = [k for k in json.load(open(tp))["kernels"] if k.get("role") == role or not lowrank]
                 traffic = sum(k["hbm_bytes_corrected"] * k["launches"] for k in ks) / max(1, sum(k["launches"] for k in ks)) if ks else None
+                traffic_source = "committed PMC passes (profiles/r04_gemm_traffic.json)"
+            if live is not None and lowrank and pmode:
+                traffic, traffic_source = live["product_bytes_per_launch"], live["how"]
             if lowrank and pmode:
                 # the 16-bit matrix cores issue 6 (bf16 x 3) or 3 (fp16 x 2) plane products per fp32-equivalent product
                 npp = PLANE_PRODUCTS[pmode]
@@ -643,7 +720,7 @@ def main(argv=None):
                                    "issued_flop_per_launch": npp * st["flops"] / st["launches"], "issued_achieved": issued,
                                    "issued_frac": issued / PEAK_BF16_MFMA_TFLOPS,
                                    "fp32_mfma_peak_multiple": ach / PEAK_F32_MFMA_TFLOPS,
-                                   "traffic": traffic, "traffic_unit": "bytes/launch",
+                                   "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_source,
                                    "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
                                    "gemm_share_of_step": st["ms"] / (1e3 * dt),
                                    "side_stream": side_stream}
@@ -691,13 +768,14 @@ def main(argv=None):
         # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed
         # profile) over the step time that is not the product (step without the side stream - product alone)
         sp = os.path.join(ROOT, "profiles", "r04_step_traffic.json")
-        if world == 1 and a.workload == "synthetic-10k-hsic" and os.path.exists(sp) and alone is not None and "value" in alone:
-            bytes_out = json.load(open(sp))["outside_product_bytes_per_step"]
+        if world == 1 and alone is not None and "value" in alone and (live is not None or (a.workload == "synthetic-10k-hsic" and os.path.exists(sp))):
+            bytes_out = live["outside_product_bytes_per_step"] if live is not None else json.load(open(sp))["outside_product_bytes_per_step"]
             ms_out = 1e3 / alone["value"] - alone.get("product_avg_launch_ms", 0.0)
             if ms_out > 0:
                 out["step_outside_product"] = {"bound": "hbm", "bytes_per_step": bytes_out, "ms_per_step": ms_out,
                                                "achieved": bytes_out / (ms_out * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                                "frac": bytes_out / (ms_out * 1e-3) / 1e9 / 8000.0,
+                                               "bytes_source": live["how"] if live is not None else "committed PMC passes (profiles/r04_step_traffic.json)",
                                                "note": "launch- and VALU-bound kernels included: ~75 node-level launches per step"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
