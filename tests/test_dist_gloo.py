@@ -142,3 +142,51 @@ def test_bench_gpus_flag_starts_ranks_and_refuses_a_mismatch(monkeypatch, capsys
     monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0")
     with pytest.raises(SystemExit, match="must agree"):
         bench.main(["--gpus", "4", "--no-cpu-baseline"])
+
+
+def test_live_traffic_accounting(monkeypatch):
+    """bench.live_traffic: the two `rocprofv3 --pmc` child passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only beside them) and
+    the accounting of their CSVs -- 2 x FETCH_SIZE + WRITE_SIZE per kernel, the product's main grid per launch, everything
+    else a step launches per step, one-off launches excluded -- on a faked profiler output."""
+    import csv
+    import shutil
+    import subprocess
+    import bench
+    steps = 3
+    nl = steps + 1                     # warm-up step + timed steps
+    rows = {   # kernel -> (grid, launches, FETCH KB per launch, WRITE KB per launch)
+        "void mcgra::(anonymous namespace)::split2_m16_kernel<0>(char const*)": (786432, nl, 3000.0, 400.0),
+        "void mcgra::(anonymous namespace)::split2_m16_kernel<0>(char const*, int)": (131072, nl, 200.0, 60.0),      # split-K tail
+        "mcgra::k_tail_adam(int)": (6310144, nl, 400.0, 900.0),
+        "mcgra::k_planes_mm<2>(int)": (266240, 3 * nl, 200.0, 16.0),
+        "mcgra::k_dd2_accum(int)": (2560000, nl, 999.0, 999.0),                      # finalize: not part of a step
+        "mcgra::k_center_cols(int)": (2560000, 1, 999.0, 999.0),                     # set_graph: once
+        "void at::native::vectorized_elementwise_kernel<4>(int)": (1000, 50, 5.0, 5.0),
+    }
+    seen = []
+
+    def fake_run(cmd, **kw):
+        seen.append(cmd)
+        ctr = cmd[cmd.index("--pmc") + 1]
+        assert "--kernel-trace" in cmd and not any(x in cmd for x in ("-s", "--sys-trace", "-r", "--runtime-trace", "--hip-trace"))
+        assert cmd[cmd.index("--") + 1] == sys.executable and "--no-live-traffic" in cmd and "--no-split-probe" in cmd
+        d = os.path.join(cmd[cmd.index("-d") + 1], "host")
+        os.makedirs(d)
+        with open(os.path.join(d, "1_counter_collection.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+            i = 0
+            for k, (g, n, fe, wr) in rows.items():
+                for _ in range(n):
+                    i += 1
+                    w.writerow([i, g, k, ctr, fe if ctr == "FETCH_SIZE" else wr, 0, 1])
+        return subprocess.CompletedProcess(cmd, 0)
+
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3" if name == "rocprofv3" else None)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    out = bench.live_traffic("synthetic-10k-hsic", 0, steps=steps)
+    assert [c[c.index("--pmc") + 1] for c in seen] == ["FETCH_SIZE", "WRITE_SIZE"]
+    assert out["product_bytes_per_launch"] == (2 * 3000.0 + 400.0) * 1024
+    assert out["outside_product_bytes_per_step"] == ((2 * 400.0 + 900.0) + 3 * (2 * 200.0 + 16.0)) * 1024
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert bench.live_traffic("synthetic-10k-hsic", 0) is None
