@@ -67,7 +67,27 @@ __global__ void k_a2a_unpack(int n, int ld, int rpr, int R0, int R1, int self, c
   float* dst = KX + (size_t)(R0 + q) * ld + c0;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cw; c += gridDim.x * blockDim.x) dst[c] = src[c];
 }
+// two n-vector blocks in one launch each way (r | d; decode backward | |xc_i|^2): a row-block rank's step is a chain of
+// launches of a few microseconds, every one of them on its critical path
+__global__ void k_rows_to_stage2(int row0, int row1, int w0, const float* __restrict__ s0, int l0, int c0, int w1,
+                                 const float* __restrict__ s1, int l1, int c1, float* __restrict__ stage, int sgw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, wt = w0 + w1;
+  if (e >= (row1 - row0) * wt) return;
+  const int i = row0 + e / wt, k = e % wt;
+  stage[(size_t)i * sgw + (k < w0 ? c0 + k : c1 + k - w0)] = k < w0 ? s0[(size_t)i * l0 + k] : s1[(size_t)i * l1 + k - w0];
+}
+__global__ void k_stage_to_rows2(int n, const float* __restrict__ stage, int sgw, int w0, int c0, float* __restrict__ d0, int l0,
+                                 int w1, int c1, float* __restrict__ d1, int l1) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, wt = w0 + w1;
+  if (e >= n * wt) return;
+  const int i = e / wt, k = e % wt;
+  if (k < w0) d0[(size_t)i * l0 + k] = stage[(size_t)i * sgw + c0 + k];
+  else d1[(size_t)i * l1 + k - w0] = stage[(size_t)i * sgw + c1 + k - w0];
+}
 __global__ void k_u32_to_f64(const unsigned int* __restrict__ a, double* __restrict__ out) { out[0] = (double)a[0]; }
+__global__ void k_u32x2_to_f64(const unsigned int* __restrict__ a, double* __restrict__ o0, double* __restrict__ o1) {
+  o0[0] = (double)a[0]; o1[0] = (double)a[1];
+}
 // The scalar lane of an exchanged node array: two float columns that hold one double per row.  Rank k leaves its partial
 // sum q in row k * rpr + q of its own chunk; behind the all-gather every rank adds the `world` partials in rank order --
 // the same bits on every rank, and no all-reduce.
@@ -118,6 +138,17 @@ static void rows_to_stage(mcgra_attack* h, hipStream_t st, const Stage& sg, int 
   if (h->row1 > h->row0)
     hipLaunchKernelGGL(k_rows_to_stage, g1((size_t)(h->row1 - h->row0) * w), dim3(256), 0, st, h->row0, h->row1, w, src, lds_, sg.base, sg.ld,
                        sg.vec0 + c0);
+}
+static void rows_to_stage2(mcgra_attack* h, hipStream_t st, const Stage& sg, int w0, const float* s0, int l0, int c0, int w1,
+                           const float* s1, int l1, int c1) {
+  if (h->row1 > h->row0)
+    hipLaunchKernelGGL(k_rows_to_stage2, g1((size_t)(h->row1 - h->row0) * (w0 + w1)), dim3(256), 0, st, h->row0, h->row1, w0, s0, l0,
+                       sg.vec0 + c0, w1, s1, l1, sg.vec0 + c1, sg.base, sg.ld);
+}
+static void stage_to_rows2(mcgra_attack* h, hipStream_t st, const Stage& sg, int w0, int c0, float* d0, int l0, int w1, int c1,
+                           float* d1, int l1) {
+  hipLaunchKernelGGL(k_stage_to_rows2, g1((size_t)h->n * (w0 + w1)), dim3(256), 0, st, h->n, sg.base, sg.ld, w0, sg.vec0 + c0, d0, l0, w1,
+                     sg.vec0 + c1, d1, l1);
 }
 static void stage_to_rows(mcgra_attack* h, hipStream_t st, const Stage& sg, int w, int c0, float* dst, int ldd) {
   hipLaunchKernelGGL(k_stage_to_rows, g1((size_t)h->n * w), dim3(256), 0, st, h->n, w, sg.base, sg.ld, sg.vec0 + c0, dst, ldd);
@@ -218,19 +249,16 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
       } else {
         // own rows of r and d, and this rank's share of |adj_changes|^2 and sum(modified_adj) in the scalar lane: ONE gather
         const Stage sg = narrow_stage(h);
-        CHK(lane_zero(h, st, sg, 2));
-        if (R1 > R0) {
+        if (R1 > R0) {      // (the slots are written in full; only a rank without rows has to clear them)
           launch_reduce_rows(st, h->rowsq + R0, R1 - R0, 1, lane_slot(h, sg, 0));
           launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, lane_slot(h, sg, 1));
-        }
-        rows_to_stage(h, st, sg, 1, h->r, 1, 0);
-        rows_to_stage(h, st, sg, 1, h->d, 1, 1);
+        } else CHK(lane_zero(h, st, sg, 2));
+        rows_to_stage2(h, st, sg, 1, h->r, 1, 0, 1, h->d, 1, 1);
       }
       FS_XCHG(h->fw_state, 1, X_SG(h))
       if (h->sharded) {
         const Stage sg = narrow_stage(h);
-        stage_to_rows(h, st, sg, 1, 0, h->r, 1);
-        stage_to_rows(h, st, sg, 1, 1, h->d, 1);
+        stage_to_rows2(h, st, sg, 1, 0, h->r, 1, 1, 1, h->d, 1);
         lane_sum(h, st, sg, 2, h->scal + S_SQ);          // S_SQ | S_SUM are adjacent
       }
       for (h->fs_l = 0; h->fs_l < L; ++h->fs_l) {
@@ -503,12 +531,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair and dead-row counts and its entropy partial:
         // they ride in the gather of the first low-rank product below (or, without c2, in a gather of their own)
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
-        CHK(lane_zero(h, st, sg, 3));
-        hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask, lane_slot(h, sg, 0));
-        hipLaunchKernelGGL(k_u32_to_f64, dim3(1), dim3(1), 0, st, h->nmask + 1, lane_slot(h, sg, 1));
+        hipLaunchKernelGGL(k_u32x2_to_f64, dim3(1), dim3(1), 0, st, h->nmask, lane_slot(h, sg, 0), lane_slot(h, sg, 1));
         if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 2));
-        rows_to_stage(h, st, sg, he, h->GZn, h->hmax, 0);
-        if (use2) rows_to_stage(h, st, sg, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
+        else MCGRA_HIP(hipMemsetAsync(lane_slot(h, sg, 2), 0, sizeof(double), st));
+        if (use2) rows_to_stage2(h, st, sg, he, h->GZn, h->hmax, 0, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
+        else rows_to_stage(h, st, sg, he, h->GZn, h->hmax, 0);
       }
       MCGRA_KERNEL_CHECK();
       if (!use2) { FS_XCHG(h->fs_state, 2, X_SG(h)) }
@@ -529,8 +556,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
       if (h->sharded) {
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
-        stage_to_rows(h, st, sg, he, 0, h->GZn, h->hmax);
-        if (use2) stage_to_rows(h, st, sg, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
+        if (use2) stage_to_rows2(h, st, sg, he, 0, h->GZn, h->hmax, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
+        else stage_to_rows(h, st, sg, he, 0, h->GZn, h->hmax);
         lane_sum(h, st, sg, 3, h->SC + 8);                       // SC[8] masked pairs, SC[9] dead rows, SC[10] entropy term of modified_adj1
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 10, sizeof(double), hipMemcpyDeviceToDevice, st));
         // A dead embedding row voids the low-rank algebra (k_post_mask).  The counts are posted to mapped host memory now and
@@ -655,7 +682,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
         h->fs_nblk = tail_reduce_call(h, st, 2, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
         const Stage sgt = narrow_stage(h);
-        if (h->sharded) CHK(lane_zero(h, st, sgt, 2));
+        if (h->sharded && !(h->fs_nblk > 0 && want_vals)) CHK(lane_zero(h, st, sgt, 2));
         if (h->fs_nblk > 0 && want_vals) {
           launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 0) : h->scal + S_H1);
           launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 1) : h->scal + S_V6);
@@ -736,8 +763,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         prep_from_partials(st, n, h->G_A, reinterpret_cast<const double*>(h->G_A + ((cnt + 1) & ~(size_t)1)), h->d, h->r, h->rowsq,
                            h->rowsum, R0, R1);
         const Stage sgc = narrow_stage(h);
-        CHK(lane_zero(h, st, sgc, 1));
         if (R1 > R0) launch_reduce_rows(st, h->rowsum + R0, R1 - R0, 1, lane_slot(h, sgc, 0));
+        else CHK(lane_zero(h, st, sgc, 1));
       }
       if (h->fs_want) { FS_XCHG(h->fs_state, 11, X_SG(h)) }
       if (h->sharded && h->fs_want) {

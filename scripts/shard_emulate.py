@@ -35,8 +35,35 @@ for world in [int(x) for x in a.worlds.split(",")]:
         nex += S.run_lockstep(bks, S.SHARD_STEP); nex += S.run_lockstep(bks, S.SHARD_MONITOR)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    # the emulation's own copies (what a real run replaces by RCCL collectives): the same exchanges replayed on the joint
+    # arena without any engine work, timed alone
+    joint = bks[0].joint
+    recorded = []
+    orig_next = [b.next for b in bks]
+    bks[0].next = lambda: (recorded.append(orig_next[0]()) or recorded[-1])
+    S.run_lockstep(bks, S.SHARD_STEP); S.run_lockstep(bks, S.SHARD_MONITOR)
+    bks[0].next = orig_next[0]
+    exs = [e for e in recorded if e[0] in (S.XCHG_ALLGATHER, S.XCHG_ALLTOALL)]
+    def replay():
+        w = world
+        for kind, count, off, off2, chunk in exs:
+            if kind == S.XCHG_ALLGATHER:
+                full = joint[:, off:off + w * chunk].view(w, w, chunk)
+                own = torch.diagonal(full, dim1=0, dim2=1).t().clone()
+                full.copy_(own.unsqueeze(0).expand(w, w, chunk))
+            else:
+                send = joint[:, off:off + w * chunk].view(w, w, chunk)
+                joint[:, off2:off2 + w * chunk].view(w, w, chunk).copy_(send.transpose(0, 1))
+    replay(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        replay()
+    torch.cuda.synchronize()
+    copies_ms = 1e3 * (time.perf_counter() - t1) / 20
     row = {"world": world, "rows_per_rank": plans[0].rows_per_rank, "sum_over_ranks_ms": 1e3 * dt,
            "per_rank_compute_ms": 1e3 * dt / world, "collectives_per_step": nex / a.steps,
+           "emulation_copies_ms_per_step": copies_ms,
+           "per_rank_compute_ms_without_emulation_copies": (1e3 * dt - copies_ms) / world,
            "alltoall_bytes_per_rank": 4 * world * plans[0].rows_per_rank ** 2 if world > 1 else 0,
            "allgather_node_bytes_per_rank": plans[0].n_pad * 64 * 4}
     out["rows"].append(row)
