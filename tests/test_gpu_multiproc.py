@@ -218,3 +218,34 @@ def test_row_block_processes_at_the_headline_size(pkg, tmp_path):
     for r in range(2):
         for t in range(2):
             os.remove(f"{out}.rank{r}.rows{t}.f32")
+
+
+def test_plain_bench_measures_its_traffic_live(tmp_path):
+    """`python bench.py` as the driver runs it at N = 1 (here: the 4k workload, 5 steps): before it touches the GPU the process
+    runs two children of itself under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` and reports the product's memory-side
+    bytes per launch and the rest of the step's per step from THEM (the line quoted committed profiles) --
+    `traffic_source` says so.  The caller is a fork-server child: this pytest process has initialised the GPU."""
+    import shutil
+    out = str(tmp_path / "live")
+    argv = ["--steps", "5", "--warmup", "1", "--workload", "synthetic-4k-hsic", "--no-cpu-baseline"]
+    ctx = mp.get_context("forkserver")
+    p = ctx.Process(target=W.run_bench_plain, args=(argv, out, {"OMP_NUM_THREADS": "2"}))
+    p.start()
+    p.join(900)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("timeout")
+    err = out + ".rank0.err"
+    assert p.exitcode == 0, open(err).read() if os.path.exists(err) else f"exit code {p.exitcode}"
+    lines = [ln for ln in open(out + ".stdout").read().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    r = line["roofline"]
+    assert line["n_gpus"] == 1 and line["config"]["fused_steps"] == 6 and r["bound"] == "mfma"
+    if shutil.which("rocprofv3"):
+        assert r["traffic_source"].startswith("rocprofv3 --pmc"), r["traffic_source"]
+        n = 4096
+        compulsory = 2 * n * n * 4 + n * n * 4           # both operands' planes once + the result
+        assert compulsory <= r["traffic"] <= 12 * compulsory, (r["traffic"], compulsory)
+        so = line["step_outside_product"]
+        assert so["bytes_source"].startswith("rocprofv3 --pmc") and 8 * n * n * 4 <= so["bytes_per_step"] <= 40 * n * n * 4
