@@ -15,6 +15,12 @@ rows, collectives over RCCL inside the timed region); `value` is the steps of th
 WORLD_SIZE; a plain `python bench.py --gpus N` starts the N ranks itself (launch_ranks) and prints rank 0's line.
 Independent replicas, one per GPU, are the side figure `replica_probe`.
 
+At N = 1 two things happen BEFORE this process touches the GPU (child processes): the CPU baseline (whole oracle steps of the
+same workload on the host cores, `cpu_baseline`) and two runs of this script under `rocprofv3 --pmc FETCH_SIZE` /
+`--pmc WRITE_SIZE` that measure the build's memory-side traffic on this box (`live_traffic` -> `roofline.traffic`,
+`step_outside_product.bytes_per_step`; without rocprofv3 the committed passes of profiles/ stand in, and the line says which).
+Defaults: 200 timed steps behind 20 untimed ones (the clock settles over the first ~30 steps of a run).
+
 Workloads carry their own start and learning rate (WORKLOADS below): adj_changes starts at start_kappa / N x U[0, 1)
 -- row sums O(1), the scale of a sparse graph, near the balance of the loss's N x N terms (which shrink the adjacency)
 and its small-operand terms (which grow it) -- and lr is a fraction of that scale, so that the timed steps stay in the
