@@ -41,7 +41,7 @@ def _final_checks(z, final, name):
     assert np.mean(np.abs(got - ref) > 2e-2 * max(1.0, scale)) < 0.01
     assert abs(final.astype(np.float64).sum() - float(z["final_sum"])) <= 1e-4 * abs(float(z["final_sum"]))
     auc = O.metric_pool(z["adj"], final, z["idx_attack"])
-    # north_star's bar, 1e-4 -- on 35 of the 37 lines.  On AIDS lines 158 and 174 (MSELoss with Y_A: entries of the ensemble
+    # north_star's bar, 1e-4 -- on 38 of the 40 lines.  On AIDS lines 158 and 174 (MSELoss with Y_A: entries of the ensemble
     # sit within 1e-6 of each other) the reference's own AUC is 3.0e-3 / 2.7e-3 away from the float64 run of the same
     # algorithm (tests/golden/make_truth64.py readme): there the bar is the reference's own distance from it
     bar = max(1e-4, abs(float(z["auc"]) - float(TRUTH[f"{name}_auc64"])))
@@ -86,7 +86,7 @@ def test_readme_line_engine_against_reference(pkg, name):
 @pytest.mark.parametrize("name", [c for c in CASES if "_eps" not in c])
 def test_readme_line_through_the_class(pkg, name):
     """The same lines through PGDAttack.attack as main.py drives it (host layer: the constant-feature_adj rule of :212, the
-    dataset -> decode branch mapping, label_adj); eps != 0 lines draw their noise on the device and have no counterpart."""
+    dataset -> decode branch mapping, label_adj); the eps != 0 lines: test_readme_eps_line_through_the_class."""
     import torch
     from mc_gra_amd import engine as E
     z = H.load_readme(name)
@@ -122,3 +122,39 @@ def test_main_entry_runs_readme_lines_on_the_committed_datasets(pkg, dataset, li
     ref = float(H.load_readme(fixture)["auc"])
     assert abs(res["auc_attack"] - ref) < 0.03, (res, ref)
     assert os.path.exists(tmp_path / "results" / "result.txt")
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if "_eps" in c])
+def test_readme_eps_line_through_the_class(pkg, name, monkeypatch):
+    """The `eps != 0` README lines (brazil 149; usair 104 / 112 and cora 120 -- a negative eps -- at n > 1000) through
+    PGDAttack.attack: the class draws adding_noise's torch.randn on the device (topology_attack.py:474-478); here that draw is
+    handed the noise the reference's run was handed (recorded matrices, or the seeded stream of the large graphs), as
+    make_golden.py did to the reference's torch.randn_like -- the host layer then has to reproduce the reference's AUC."""
+    import torch
+    from mc_gra_amd import engine as E
+    from mc_gra_amd import topology_attack as TA
+    z = H.load_readme(name)
+    n = len(z["labels"])
+    w = H.weights_from(z)
+    victim, emb = H.FakeGCN(w), H.FakeGCN(w)
+    dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")
+    Y_A, H_A2 = E.gcn_forward(dev(z["features"]), dev(z["adj"]), [dev(x) for x in w.W], [dev(x) for x in w.b], dev(w.Wlin),
+                              dev(w.blin), emb_nlayer=2)
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=H_A2, Y_A=Y_A, nnodes=n, loss_type="CE", device="cuda:0")
+    draws = []
+    real_randn = torch.randn
+
+    def seeded_randn(*shape, **kw):
+        if tuple(shape) == (n, n):
+            t = len(draws)
+            draws.append(t)
+            return torch.as_tensor(H.noise_of(z, t), device=kw.get("device", "cpu"))
+        return real_randn(*shape, **kw)
+
+    monkeypatch.setattr(TA.torch, "randn", seeded_randn)
+    lab = z["labels"]
+    model.attack(_args(z), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]), z["feature_adj"], 0, 0, 0,
+                 None, None, z["idx_test"], z["adj"], z["features"], np.zeros_like(z["adj"]), lab, z["idx_attack"],
+                 float(z["num_edges"]), 0, epochs=int(z["epochs"]), label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    assert len(draws) == int(z["epochs"]), "one draw of adding_noise per step"
+    _final_checks(z, model.modified_adj.cpu().numpy(), name)
