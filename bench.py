@@ -551,7 +551,7 @@ def main(argv=None):
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
     eng_path = dict(eng.path_stats(), fused_steps=eng.fused_steps(), gram_split_steps=eng.gram_split_steps(),
-                    masked_fused_steps=eng.masked_fused_steps())
+                    masked_fused_steps=eng.masked_fused_steps(), cut_product_steps=eng.cut_product_steps())
     stepper_exchanges = ((stepper.exchanges - ex0) / a.steps) if stepper is not None else None      # of the timed steps
 
     # the same N x N x N product alone on the chip (no side-stream company), for the roofline's "alone" figure
@@ -684,6 +684,9 @@ def main(argv=None):
             out["replica_probe"] = replicas
         if stepper_exchanges is not None:
             out["collectives_per_step"] = stepper_exchanges
+            # steps (warm-up + timed) whose product ran the peers' row panels first and handed them to the all-to-all while the
+            # own panels were still running (rank 0's count; default for 2 <= N <= 4)
+            out["config"]["all_to_all_beside_product_steps"] = eng_path["cut_product_steps"]
         if split is not None:
             out["fp32_mfma_probe" if pmode else "split_bf16_probe"] = split
         if extra is not None:

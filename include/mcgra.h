@@ -307,6 +307,12 @@ long long mcgra_attack_fused_steps(mcgra_attack_t* h);
  * |zn_i| = 1) sends a step to the Gram evaluation.  Rounds 1 - 3 sent every step with a masked pair there (3x slower at
  * N = 10 000). */
 long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h);
+/* Row-block steps whose N x N x N product was cut for the all-to-all of P1: the rank computes the row
+ * panels of its peers first and its own last, in one linear tile order cut behind the peers' tiles; the MCGRA_XCHG_ALLTOALL
+ * exchange point is reached when the first part is done, so the collective runs beside the second part (the engine joins it
+ * behind the exchange).  Default: wherever a whole round of the chip ends behind the peers' tiles (the cut is then free), and
+ * for 2 <= shard_world <= 4 in any case (a second ragged round); MCGRA_A2A_OVERLAP=0 / 1 forces it off / on. */
+long long mcgra_attack_cut_product_steps(mcgra_attack_t* h);
 /* Gram-evaluation steps (a dead embedding row, GAT / SAGE chains, CKA, MCGRA_NO_LOWRANK) whose four N x N x N products ran on the
  * 2-plane fp16 kernel instead of fp32 SYMM (n >= 1024, HSIC, eps == 0; MCGRA_GRAM_SPLIT=0 turns it off). */
 long long mcgra_attack_gram_split_steps(mcgra_attack_t* h);

@@ -37,6 +37,7 @@ SYMBOLS = [
     "mcgra_attack_product_replay",
     "mcgra_attack_test_mutate",
     "mcgra_attack_masked_fused_steps",
+    "mcgra_attack_cut_product_steps",
 ]
 
 
@@ -131,6 +132,8 @@ def _load():
     lib.mcgra_attack_fused_steps.restype = C.c_longlong
     lib.mcgra_attack_masked_fused_steps.argtypes = [vp]
     lib.mcgra_attack_masked_fused_steps.restype = C.c_longlong
+    lib.mcgra_attack_cut_product_steps.argtypes = [vp]
+    lib.mcgra_attack_cut_product_steps.restype = C.c_longlong
     lib.mcgra_attack_gram_split_steps.argtypes = [vp]
     lib.mcgra_attack_gram_split_steps.restype = C.c_longlong
     lib.mcgra_attack_exchange_bytes.argtypes = [vp]

@@ -345,6 +345,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
           hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_r, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork3, hipEventDisableTiming) != hipSuccess ||
@@ -399,6 +400,10 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         // two words) + a two-column scalar lane; the wide one carries a product's fcols columns in front of them
         h->sgw = ((he + 2 + 3) & ~3) + 2;
         h->fyw = fc + h->sgw;
+        // the all-to-all of P1 beside the own row panels of the product (attack_fused.hip): free when a whole round of the chip
+        // ends behind the peers' tiles, worth a second ragged round while world <= 4 (world 8 at N = 10 000: 200 tiles on 256
+        // CUs, nothing to run beside)
+        { const char* ee = getenv("MCGRA_A2A_OVERLAP"); h->a2a_overlap = ee ? (ee[0] == '1' ? 2 : 0) : (h->world >= 2 ? 1 : 0); }
       }
     }
     if (h->fused_ok && !rc) {
@@ -429,6 +434,7 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (h->st2) (void)hipStreamSynchronize(h->st2);      // (shared side streams: drained, not destroyed)
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_first) (void)hipEventDestroy(h->ev_first);
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
   if (h->ev_fork4) (void)hipEventDestroy(h->ev_fork4);
@@ -1256,6 +1262,7 @@ int step_general(mcgra_attack_t* h, void* stream, const float* noise, double* sc
 }
 
 long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h) { return h ? (long long)h->masked_fused_steps : 0; }
+long long mcgra_attack_cut_product_steps(mcgra_attack_t* h) { return h ? (long long)h->cut_product_steps : 0; }
 int mcgra_attack_product_mode(mcgra_attack_t* h) {
   return h ? (h->split_mode == 2 && h->split_planes == 2 ? 3 : h->split_mode) : 0;
 }

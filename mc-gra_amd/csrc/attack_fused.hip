@@ -51,9 +51,9 @@ __global__ void k_stage_to_rows(int n, int w, const float* __restrict__ stage, i
 // all-to-all of P1 tile blocks: block s of the send buffer = P1[rows of rank s][own columns] (a rank computed the column
 // block P1[:, own rows]); block s of the receive buffer = P1[own rows][columns of rank s].  One launch each instead of
 // `world` strided copies.  A2[s][q][c], q, c < rpr.
-__global__ void k_a2a_pack(int n, int ld, int rpr, int R0, int R1, const float* __restrict__ KX, float* __restrict__ A2) {
+__global__ void k_a2a_pack(int n, int ld, int rpr, int R0, int R1, int self, const float* __restrict__ KX, float* __restrict__ A2) {
   const int s = blockIdx.z, q = blockIdx.y, row = s * rpr + q;
-  if (row >= n) return;
+  if (row >= n || s == self) return;                     // (the own block stays where it is -- and may still be in the making)
   const float* src = KX + (size_t)row * ld + R0;
   float* dst = A2 + ((size_t)s * rpr + q) * rpr;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < R1 - R0; c += gridDim.x * blockDim.x) dst[c] = src[c];
@@ -344,6 +344,7 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   MCGRA_HIP(hipMemcpy(&seq, h->mask_seq_dev, sizeof(seq), hipMemcpyDeviceToHost));
   h->mask_seq = h->mask_want = seq;
   h->p1_inflight = h->fs_dec_forked = false;
+  h->p1_first = false;
   h->early_pack = false;
   h->nmask_zero = h->t3_zero = false;
   h->fused_fwd_valid = h->fwd_cached = h->prep_valid = false;
@@ -449,6 +450,25 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         }
         CHK(timer_begin(h, sp, h->profile));
+        h->p1_first = false;
+        if (h->sharded && h->a2a_overlap && ovl && h->world > 1 && h->test_mutate != 1) {
+          // Row panels of the peers first (rotated start: the panel behind the own ones, wrapping), own panels last, the launch
+          // cut behind the peers' tiles: the all-to-all that hands them over waits for ev_first only and runs beside the rest.
+          // The cut sits on a whole round of the chip when that still leaves own tiles behind it (a cut costs a ragged round).
+          const int tiles_all = (n + P - 1) / P, rot = (p_off + p_cnt) % tiles_all;
+          const int span = min(tiles_all, (tiles_all - p_cnt + 3) & ~3) * p_cnt, total = tiles_all * p_cnt;
+          int first = (span + 255) / 256 * 256;
+          // (no whole round left behind the peers' tiles: a cut there costs a second ragged round -- taken while the own
+          // panels are at least a quarter of the product, world <= 4, or when forced)
+          if (first >= total) first = (h->world <= 4 || h->a2a_overlap == 2) ? span : 0;
+          if (first > 0 && first < total) {
+            MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, rot, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
+                                  h->amax, p_off, p_cnt, 4, first, h->ev_first));
+            h->p1_first = true;
+            ++h->cut_product_steps;
+          }
+        }
+        if (!h->p1_first)
         MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
                               h->amax, p_off, p_cnt));
         CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
@@ -545,7 +565,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       //      column is constant, its centred copy is rounding noise and t3 = Xc^T (delta^2 - mean) is taken as 0 --
       //      which keeps the product at 32 columns (one column tile of the skinny kernel)
       if (use2) {
-        launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats);
+        launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats, h->sharded && h->world > 1);
         // (the right-hand side r o V of the product below comes out of the same launch: fl_cat_scaled's values)
         launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta, h->fused_post ? h->r : nullptr,
                        h->fused_post ? h->FV : nullptr, fc);
@@ -666,15 +686,19 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       (void)tail_reduce_call(h, st, 1, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
       // (the coefficient of the norm term comes out of k_tail_gd's launch; a rank without rows has no Adam pass to feed)
       if (!(h->fused_post && R1 > R0)) hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
-      CHK(join());
+      // (a cut product: the peers' row panels are done at ev_first; the own ones are joined behind the all-to-all)
+      if (h->p1_first && h->p1_inflight) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_first, 0));
+      else CHK(join());
       // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py; armed by mcgra_attack_test_mutate, which says so on stderr): 1
       // wipes the product's result, 2 drops the rank-k terms of the tail (both GCN chains' backward and the low-rank term of
       // c2) from the gradient -- a parity test that stays green under either is blind to split2_m16_kernel / the fp16-split
       // rank-k rounds of k_tail_reduce
       if (h->test_mutate == 1 && use1) MCGRA_HIP(hipMemsetAsync(h->KX, 0, sizeof(float) * (size_t)n * ld, st));
       if (h->sharded && use1 && R1 > R0)
-        hipLaunchKernelGGL(k_a2a_pack, dim3(2, h->rpr, h->world), dim3(256), 0, st, n, ld, h->rpr, R0, R1, h->KX, h->A2S);
+        hipLaunchKernelGGL(k_a2a_pack, dim3(2, h->rpr, h->world), dim3(256), 0, st, n, ld, h->rpr, R0, R1, h->rank, h->KX, h->A2S);
       if (use1) { FS_XCHG(h->fs_state, 9, x_alltoall(ex, h->off_a2s, h->off_a2r, (int64_t)h->rpr * h->rpr * 4)) }
+      CHK(join());
+      h->p1_first = false;
       if (h->sharded && use1 && R1 > R0)
         hipLaunchKernelGGL(k_a2a_unpack, dim3(2, h->rpr, h->world), dim3(256), 0, st, n, ld, h->rpr, R0, R1, h->rank, h->A2R, h->KX);
       {

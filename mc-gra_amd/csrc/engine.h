@@ -93,6 +93,11 @@ struct mcgra_attack {
   // right after the normalisation and runs (MFMA-bound) under the HBM-bound rest of the step
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // row-block ranks: the product computes the row panels of the peers first and the own ones last; ev_first is recorded behind
+  // the first part, the P1 all-to-all then runs beside the second (attack_fused.hip; MCGRA_A2A_OVERLAP=0 / 1 forces off / on)
+  hipEvent_t ev_first = nullptr;
+  int a2a_overlap = 0;             // 0: the product in one piece; 1: cut where it is free or cheap (default); 2: always (MCGRA_A2A_OVERLAP=1)
+  bool p1_first = false;           // the forked product of this step was cut: the all-to-all waits for ev_first only
   // early pack (attack_fused.hip): the planes of the product's operand are packed on the product's stream as soon as r is
   // known, beside the forward's two products on the caller's stream (ev_r: r ready; ev_pack: planes and row partials ready)
   hipEvent_t ev_r = nullptr, ev_pack = nullptr;
@@ -118,6 +123,7 @@ struct mcgra_attack {
   unsigned int mask_want = 0;                    // sequence number of the post the step in flight will poll for
   bool p1_inflight = false;
   bool skip_fused = false;         // the last step's decode masked a pair: the general path goes first (it re-checks)
+  int64_t cut_product_steps = 0;   // row-block steps whose product was cut for the all-to-all (a2a_overlap)
   int64_t masked_fused_steps = 0;  // fused steps whose decode relu-masked pairs of live rows (they stand: DESIGN.md section 1b)
   bool nmask_zero = false;         // the decode's masked-pair counter holds 0 (left so by k_post_mask)
   bool t3_zero = false;            // column 2 he of lrT (t3 of the low-rank factors) holds zeros (fused step; the general path writes it)

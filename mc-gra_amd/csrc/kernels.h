@@ -98,7 +98,7 @@ bool lr_decode_supported(int h);
 size_t lr_qtz_doubles(int h);
 int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, const float* Z, int ldz, const float* QQ,
                          float kie7, float* slabs, double* v7part, float* GZn, int ldg, double* qtz);
-void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats);
+void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats, bool dense = false);   // dense: the row-block ranks' form (same bits)
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta, const float* rs = nullptr, float* Vs = nullptr, int ldvs = 0);
 void launch_lr_post(hipStream_t st, int n, int h, const float* T, int ldv, const double* stats, float* Rm, float* cvec,

@@ -47,6 +47,45 @@ __global__ __launch_bounds__(64) void k_lr_colstats_part(int n, int h, const flo
   for (int o = hp; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
   if (r == 0 && k < h) part[((size_t)b * LR_PARTS + pz) * h + k] = acc;
 }
+// The same sums for a row-block rank, whose side chain -- not its eighth of the N x N x N product -- is the critical path: ONE
+// load per lane and row (z_ik); z_ib and |z_i|^2 come from the row's other lanes by shuffles, four rows per lane in flight
+// (above, every lane loads z_ib and, for the two delta statistics, the whole row: a chain of dependent loads, 54 us alone and
+// 170 us beside the product).  Same operations in the same order per accumulator: same bits (three workloads hashed after three
+// steps).  NOT used by the monolithic engine: there the chain above ends long before the product does, and the denser kernel
+// made the product slower by more than its own duration (4.74 - 4.79 against 4.67 - 4.70 ms per launch, three alternating runs on
+// one box) -- per-rank compute at world 8 by emulation: 1.25 against 1.30 ms.
+__global__ __launch_bounds__(64) void k_lr_colstats_part_dense(int n, int h, const float* __restrict__ Z, int ldz,
+                                                               double* __restrict__ part) {
+  const int b = blockIdx.x, pz = blockIdx.y;
+  const int per = (n + LR_PARTS - 1) / LR_PARTS, i0 = pz * per, i1 = min(n, i0 + per);
+  int hp = 8;
+  while (hp < h) hp <<= 1;
+  const int lane = threadIdx.x, k = lane & (hp - 1), r = lane / hp, rpi = 64 / hp, g0 = lane & ~(hp - 1);
+  double acc = 0.0;
+  for (int i = i0 + r; i < i1; i += 4 * rpi) {
+    float zk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ii = i + u * rpi;
+      zk[u] = (ii < i1 && k < h) ? Z[(size_t)ii * ldz + k] : 0.f;      // (rows past the end: zeros, which add nothing)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double wgt;
+      if (b < h) wgt = (double)__shfl(zk[u], g0 + b);
+      else if (b == h) wgt = 1.0;
+      else {
+        float d = 0.f;
+        for (int q = 0; q < h; ++q) { const float zq = __shfl(zk[u], g0 + q); d += zq * zq; }
+        wgt = (double)d;
+      }
+      if (b == h + 2) { if (k == 0) acc += wgt * wgt; }
+      else if (k < h) acc += wgt * (double)zk[u];
+    }
+  }
+  for (int o = hp; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+  if (r == 0 && k < h) part[((size_t)b * LR_PARTS + pz) * h + k] = acc;
+}
 __global__ void k_lr_colstats_fin(int n, int h, const double* __restrict__ part, double* __restrict__ stats) {
   const int b = blockIdx.x, k = threadIdx.x;
   if (k >= h) return;
@@ -412,9 +451,10 @@ int launch_lr_decode_bwd(hipStream_t st, int n, int ld, int h, const float* A1, 
   return nb * js;
 }
 
-void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats) {
+void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, double* stats, bool dense) {
   double* part = stats + (size_t)2 * h + (size_t)h * h + 2;
-  LAUNCH(k_lr_colstats_part, dim3(h + 3, LR_PARTS), dim3(64), st, n, h, Z, ldz, part);
+  if (dense) LAUNCH(k_lr_colstats_part_dense, dim3(h + 3, LR_PARTS), dim3(64), st, n, h, Z, ldz, part);
+  else LAUNCH(k_lr_colstats_part, dim3(h + 3, LR_PARTS), dim3(64), st, n, h, Z, ldz, part);
   LAUNCH(k_lr_colstats_fin, dim3(h + 3), dim3(64), st, n, h, part, stats);
 }
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,

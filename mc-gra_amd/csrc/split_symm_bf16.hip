@@ -191,6 +191,8 @@ __device__ __forceinline__ f32x16 plane_mma(u32x4 a, u32x4 b, f32x16 c) {
 constexpr int SPLIT_BETA = 1;      // C += product (instead of C = product)
 constexpr int SPLIT_TRI = 2;       // A == B (Gram product): only tiles on or below the diagonal are computed; tiles below it
                                    // are stored twice, as computed and mirrored, so that C is the full, bitwise symmetric matrix
+constexpr int SPLIT_WRAP = 4;      // the launch covers ALL row panels starting at panel_off and wrapping around: a row-block rank
+                                   // computes the row panels of its peers first and its own last (split3_symm: first_tiles)
 // linear tile index -> (tile_m, tile_n): 4-panel groups over the tile grid (gemm_f32.hip), or the lower triangle row by row
 __device__ __forceinline__ void split_tile_of(int lin, int tiles_m, int tiles_n, int panel_off, int npanel_off, int flags,
                                               int& tile_m, int& tile_n) {
@@ -207,6 +209,7 @@ __device__ __forceinline__ void split_tile_of(int lin, int tiles_m, int tiles_n,
   const int first_m = group_id * GROUP_M;
   const int gm = min(tiles_m - first_m, GROUP_M);
   tile_m = first_m + (lin % group_sz) % gm + panel_off;     // row-block sharding: this launch starts at panel_off
+  if ((flags & SPLIT_WRAP) && tile_m >= tiles_m) tile_m -= tiles_m;
   tile_n = (lin % group_sz) / gm + npanel_off;              // column-block ranks: this launch starts at column panel npanel_off
 }
 
@@ -738,7 +741,7 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
 // planes == 2: amax[0], amax[1] = the magnitudes the operands were packed with.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax, int npanel_off,
-                       int npanel_cols, int beta) {
+                       int npanel_cols, int beta, int first_tiles, hipEvent_t ev_first) {
   const int nkc = chunks_of(n, planes), tiles_all = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles_all;
   const int tiles = npanel_cols >= 0 ? npanel_cols : tiles_all;      // column panels of this launch
@@ -753,18 +756,10 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
       if (cus_of[dev]) slots = cus_of[dev];
     }
   }
-  // Whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs idle is cut along K so
-  // that it fills the chip too (tiles are 256 x 256 x n: 1600 of them on 256 CUs would otherwise take 7 rounds for 6.25).
-  // (SPLIT_TRI: whole square launches only; tiles on or below the diagonal)
-  if ((beta & 2) && (tm != tiles_all || tiles != tiles_all || panel_off || npanel_off)) return hipErrorInvalidValue;
-  const int total = (beta & 2) ? tiles_all * (tiles_all + 1) / 2 : tm * tiles;
-  int full = (total / slots) * slots, rem = total - full, ksplit = 1;
-  if (rem > 0 && rem * 2 <= slots && slab) {
-    ksplit = slots / rem;
-    if (ksplit > 8) ksplit = 8;
-    while (ksplit > 1 && (size_t)ksplit * rem * TB * TB * sizeof(float) > slab_bytes) --ksplit;
-  }
-  if (ksplit <= 1) { full = total; rem = 0; }
+  // (SPLIT_TRI: whole square launches only; tiles on or below the diagonal.  SPLIT_WRAP: all row panels, any start)
+  if ((beta & SPLIT_TRI) && (tm != tiles_all || tiles != tiles_all || panel_off || npanel_off || first_tiles > 0)) return hipErrorInvalidValue;
+  if ((beta & SPLIT_WRAP) && (tm != tiles_all || panel_off < 0 || panel_off >= tiles_all || (beta & SPLIT_TRI))) return hipErrorInvalidValue;
+  const int total = (beta & SPLIT_TRI) ? tiles_all * (tiles_all + 1) / 2 : tm * tiles;
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2) {      // 2-plane fp16 split: split2_m16_kernel (v_mfma_f32_16x16x32_f16, global_load_lds staging)
       constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;
@@ -789,15 +784,43 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     }
     return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
   };
-  if (full > 0) {
-    hipError_t e = launch(full, 0, 1, nullptr);
+  // The linear tiles [lo, hi): whole rounds of `slots` tiles run as they are; a ragged last round that would leave most CUs
+  // idle is cut along K so that it fills the chip too (tiles are 256 x 256 x n: 1600 of them on 256 CUs would otherwise take
+  // 7 rounds for 6.25).
+  auto run = [&](int lo, int hi) -> hipError_t {
+    const int cnt = hi - lo;
+    if (cnt <= 0) return hipSuccess;
+    int full = (cnt / slots) * slots, rem = cnt - full, ksplit = 1;
+    if (rem > 0 && rem * 2 <= slots && slab) {
+      ksplit = slots / rem;
+      if (ksplit > 8) ksplit = 8;
+      while (ksplit > 1 && (size_t)ksplit * rem * TB * TB * sizeof(float) > slab_bytes) --ksplit;
+    }
+    if (ksplit <= 1) { full = cnt; rem = 0; }
+    if (full > 0) {
+      hipError_t e = launch(full, lo, 1, nullptr);
+      if (e != hipSuccess) return e;
+    }
+    if (rem > 0) {
+      hipError_t e = launch(rem * ksplit, lo + full, ksplit, slab);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, lo + full,
+                         npanel_off, beta);
+    }
+    return hipSuccess;
+  };
+  // first_tiles > 0: the launch is cut at that linear tile, and ev_first is recorded behind the first part (what a
+  // row-block rank's peers wait for: its all-to-all then runs beside the second part)
+  const int cut = (first_tiles > 0 && first_tiles < total) ? first_tiles : 0;
+  hipError_t e = run(0, cut ? cut : total);
+  if (e != hipSuccess) return e;
+  if (ev_first) {
+    e = hipEventRecord(ev_first, st);
     if (e != hipSuccess) return e;
   }
-  if (rem > 0) {
-    hipError_t e = launch(rem * ksplit, full, ksplit, slab);
+  if (cut) {
+    e = run(cut, total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_split3_reduce, dim3(rem, 8), dim3(256), 0, st, slab, rem, ksplit, C, n, ldc, tm, tiles, panel_off, full,
-                       npanel_off, beta);
   }
   return hipGetLastError();
 }

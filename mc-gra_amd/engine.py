@@ -383,6 +383,10 @@ class AttackEngine:
         """Fused steps whose decode relu-masked pairs of live embedding rows (they stand; only a dead row falls back)."""
         return int(lib.mcgra_attack_masked_fused_steps(self._h))
 
+    def cut_product_steps(self):
+        """Row-block steps whose product was cut so that the P1 all-to-all runs beside its own row panels."""
+        return int(lib.mcgra_attack_cut_product_steps(self._h))
+
     def product_replay(self, reps=10):
         """Mean launch time [ms] of `reps` back-to-back launches of the last fused step's N x N x N product, nothing beside
         them (mcgra_attack_product_replay: a measurement aid, no engine state changes)."""

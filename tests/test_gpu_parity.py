@@ -746,6 +746,40 @@ def test_sharded_ranks_match_monolithic_step(pkg, n, widths, world, wp, monkeypa
                 assert b[k] == pytest.approx(a[k], rel=3e-5, abs=1e-6 * max(1.0, abs(a["loss"]))), (t, k, b[k], a[k])
             assert all(b[k] == sc[0][k] for b in sc), "scalars are identical on every rank"
     assert all(b.eng.fused_steps() == 3 for b in bks) and mono.fused_steps() == 3
+    # 2 <= world <= 4: every rank with rows computed its peers' row panels first and handed them to the all-to-all while its
+    # own panels were still running; a larger world cuts only where a whole round of the chip ends
+    # behind the peers' tiles (never at these sizes)
+    cut = 3 if 2 <= world <= 4 else 0
+    assert [b.eng.cut_product_steps() for b in bks] == [cut if p.has_rows else 0 for p in plans]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_cut_product_for_the_all_to_all_matches_the_uncut_step(pkg, world, monkeypatch):
+    """The product of a row-block rank cut for the all-to-all (peers' row panels first, rotated and wrapping around the own
+    ones; the exchange point reached behind the first part, the own panels joined behind the exchange) against the same ranks
+    with the product in one piece (MCGRA_A2A_OVERLAP=0): the same tiles by the same arithmetic -- only which of them fall
+    into a ragged round's split-K differs -- so rows, mirrored bits and loss terms agree as the sharded and the monolithic
+    step do.  world 5 (forced on; two ranks without rows) covers a rotation that wraps in the middle of the row panels."""
+    import torch
+    from mc_gra_amd import sharded as S
+    z = _synthetic_case(1283, 11, (16, 16), 4, seed=1283)
+    monkeypatch.setenv("MCGRA_A2A_OVERLAP", "1")
+    plans, cut = _shard_engines(pkg, z, world, joint=world == 3)
+    monkeypatch.setenv("MCGRA_A2A_OVERLAP", "0")
+    _, whole = _shard_engines(pkg, z, world)
+    lr = float(z["lr"])
+    for t in range(3):
+        sa = S.run_lockstep(cut, S.SHARD_STEP, want_scalars=True)
+        sb = S.run_lockstep(whole, S.SHARD_STEP, want_scalars=True)
+        S.run_lockstep(cut, S.SHARD_MONITOR); S.run_lockstep(whole, S.SHARD_MONITOR)
+        ra, rb = _gather_rows(cut), _gather_rows(whole)
+        assert float(((ra - rb).abs() > 0.05 * lr).float().mean()) < 2e-3, t
+        assert float((ra - ra.T).abs().max()) == 0.0
+        for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "clamp_sum"):
+            assert sa[0][k] == pytest.approx(sb[0][k], rel=3e-5, abs=1e-6 * max(1.0, abs(sb[0]["loss"]))), (t, k)
+            assert all(b[k] == sa[0][k] for b in sa)
+    assert [b.eng.cut_product_steps() for b in cut] == [3 if p.has_rows else 0 for p in plans]
+    assert all(b.eng.cut_product_steps() == 0 for b in whole)
 
 
 def test_sharded_ranks_hand_masked_steps_to_the_general_path(pkg, monkeypatch):
