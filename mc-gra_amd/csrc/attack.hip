@@ -411,6 +411,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(FV, n * (size_t)fc); A_(em_last, nm); A_(fstat, 256 + fl_wcolsum_scratch_doubles());
       if (!h->sharded) { A_(FY, n * (size_t)fc); }      // a row-block rank keeps FY in the exchange arena
       A_(rkbuf, fl_tail_pack_bytes((int)n));           // packed fp16 planes of the tail's rank-k panels
+      A_(Zpair, (n + 2) * (size_t)h->hmax);
       if (!h->sharded) { A_(ws_dec, (size_t)lr_decode_slabs((int)n) * n * he); }
       h->fused_ok = (rc == 0);
     }

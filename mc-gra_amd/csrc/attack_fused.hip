@@ -519,7 +519,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
-      launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
+      launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f, h->Zpair);
       if (!h->sharded) {
         // monolithic, small graphs (where the step is bound by its chain of dependent node-level kernels): the decode -- the
         // longest of them, and it needs only Zn -- on a fourth stream with its own slabs, beside the low-rank factor chain;
@@ -534,7 +534,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         // (with c2, k_post_mask leaves the counter at zero for the next fused step; the general path does not)
         if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
-        h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask);
+        h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask, h->Zpair, want_vals);
         if (want_vals) launch_reduce_rows(s4, h->rowvals, h->fs_np, 1, h->scal + S_V7);
         if (use2) {
           hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, s4, h->nmask, nullptr, h->mask_seq_dev, h->mask_host_dev);
@@ -547,7 +547,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), st));
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
-                                 h->hmax, h->nmask);
+                                 h->hmax, h->nmask, h->Zpair, true);
         // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair and dead-row counts and its entropy partial:
         // they ride in the gather of the first low-rank product below (or, without c2, in a gather of their own)
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
@@ -565,7 +565,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       //      column is constant, its centred copy is rounding noise and t3 = Xc^T (delta^2 - mean) is taken as 0 --
       //      which keeps the product at 32 columns (one column tile of the skinny kernel)
       if (use2) {
-        launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats, h->sharded && h->world > 1);
+        // (the dense form where this chain is the critical path -- a row-block rank, a graph whose product is short -- and the
+        // slow one beside the long product of a large monolithic graph, which the dense one holds up: lowrank_kernels.hip)
+        launch_lr_colstats(st, n, he, h->Zn, h->hmax, h->lrStats, (h->sharded && h->world > 1) || n < 8192);
         // (the right-hand side r o V of the product below comes out of the same launch: fl_cat_scaled's values)
         launch_lr_prep(st, n, he, h->Zn, h->hmax, h->lrStats, h->lrL, h->lrV, h->lr_ldv, h->lrDelta, h->fused_post ? h->r : nullptr,
                        h->fused_post ? h->FV : nullptr, fc);

@@ -164,6 +164,7 @@ struct mcgra_attack {
   bool planes_mm_on = false, planes_valid = false;
   bool fused_post = true;          // forward: post pass + next layer's T / heads in one launch (MCGRA_NO_FUSED_POST=1: separate kernels)
   char* pm_scratch = nullptr;
+  float* Zpair = nullptr;          // pair-interleaved copy of Zn for the decode's scalar loads (fused_lowrank.hip: k_decode_fly_s)
   int64_t fused_steps = 0;
   // row-block sharding (mcgra_attack_shard_*): this rank owns rows [row0, row1) of M / am / av
   bool sharded = false;

@@ -353,15 +353,18 @@ __global__ void k_lrq_post(int n, int w, YView Y, const float* __restrict__ Vs, 
 // A1_ij = [i != j] relu(S_ij);  nmask[0] += #{i != j : S_ij <= 0}, nmask[1] += #{i : zn_i == 0};  v7 partials of sum ie_value(A1) (diagonal included, as
 // Info_entropy runs over the whole matrix, :44-52);  slabs: G_Zn_i = sum_{j != i, S_ij > 0} 2 ie'(A1_ij) zn_j.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int H>
+// The columns' vectors come out of SCALAR registers: zn_j is the same for every lane, so the pairs (zn_2P[k], zn_2P+1[k]) are read
+// from a pair-interleaved copy of Zn through the scalar cache (wave-uniform address: s_load_dwordx16) and feed the packed FMAs
+// (v_pk_fma_f32: two fused multiply-adds per lane and instruction) as SGPR pairs -- no LDS, no barrier.  Each S_ij is its own
+// k-ordered fmaf chain, i.e. the bits of the stored form.  (Rounds 2 - 4 staged the columns in LDS and read them by broadcast,
+// 2 x H / 2 ds_read_b128 per pair of columns and wave: bit-identical, 1.5 % slower per step at n = 2708 / 4096, no different at
+// N = 10 000 -- there the pass is paid for in the clock of the product it runs beside, LDS or not: DESIGN.md section 8.)
+// V7 = false: the entropy VALUE (a returned loss term only) is not summed.
+template <int H, bool V7>
 __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
-                                                    float kie7, int jper, float* __restrict__ slabs,
-                                                    double* __restrict__ v7part, unsigned int* __restrict__ nmask) {
-  // Two columns j per iteration: zs[jp][k] holds (z_{2jp}[k], z_{2jp+1}[k]) so that both dot products and both
-  // accumulations are packed FMAs (v_pk_fma_f32: two fused multiply-adds per lane and instruction; each S_ij is still
-  // its own k-ordered fmaf chain, i.e. the bits of the stored form).
-  constexpr int JC = 128;
-  __shared__ __attribute__((aligned(16))) f32x2 zs[JC / 2][H];
+                                                      const f32x2* __restrict__ Zp, float kie7, int jper,
+                                                      float* __restrict__ slabs, double* __restrict__ v7part,
+                                                      unsigned int* __restrict__ nmask) {
   __shared__ double sh[16];
   const int i = row0 + blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < row1;
@@ -370,8 +373,6 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
   f32x2 acc[H];
 #pragma unroll
   for (int k = 0; k < H; ++k) { zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f; acc[k] = f32x2{0.f, 0.f}; }
-  // a dead embedding row (em_i == 0, so zn_i == 0 and S_ii == 0): nmask[1].  It is the ONLY thing that voids the fused
-  // low-rank step (its algebra takes |zn_i| = 1); relu-masked pairs of live rows do not.
   if (valid && blockIdx.y == 0) {
     bool nz = false;
 #pragma unroll
@@ -380,50 +381,39 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
   }
   double v7 = 0.0;
   int masked = 0;
-  for (int jc = j0; jc < j1; jc += JC) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < JC * H; e += 256) {
-      const int jj = e / H, c = e - jj * H, j = jc + jj;
-      zs[jj >> 1][c][jj & 1] = j < j1 ? Z[(size_t)j * ldz + c] : 0.f;
+  for (int P = j0 >> 1; 2 * P < j1; ++P) {
+    const f32x2* __restrict__ zp = Zp + (size_t)P * H;      // wave-uniform
+    f32x2 t[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) t[k] = zp[k];
+    f32x2 s = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < H; ++k) s = __builtin_elementwise_fma(f32x2{zi[k], zi[k]}, t[k], s);
+    f32x2 w;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 2 * P + u;
+      const bool in = j >= j0 && j < j1;
+      const bool off = valid && in && i != j;
+      if (off && !(s[u] > 0.f)) ++masked;
+      const float a1 = off ? fmaxf(s[u], 0.f) : 0.f;
+      float val, g;
+      ie_term(a1, kie7, val, g);
+      if (V7 && valid && in) v7 += (double)val;
+      w[u] = (off && a1 > 0.f) ? 2.f * g : 0.f;
     }
-    __syncthreads();
-    const int jn = min(JC, j1 - jc);
-    for (int jp = 0; 2 * jp < jn; ++jp) {
-      f32x2 s = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < H; k += 2) {
-        const float4 t = *reinterpret_cast<const float4*>(&zs[jp][k]);     // (z_j0[k], z_j1[k], z_j0[k+1], z_j1[k+1])
-        s = __builtin_elementwise_fma(f32x2{zi[k], zi[k]}, f32x2{t.x, t.y}, s);
-        s = __builtin_elementwise_fma(f32x2{zi[k + 1], zi[k + 1]}, f32x2{t.z, t.w}, s);
-      }
-      f32x2 w;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = jc + 2 * jp + u;
-        const bool in = 2 * jp + u < jn;
-        const bool off = valid && in && i != j;
-        if (off && !(s[u] > 0.f)) ++masked;
-        const float a1 = off ? fmaxf(s[u], 0.f) : 0.f;
-        float val, g;
-        ie_term(a1, kie7, val, g);
-        if (valid && in) v7 += (double)val;
-        w[u] = (off && a1 > 0.f) ? 2.f * g : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < H; k += 2) {
-        const float4 t = *reinterpret_cast<const float4*>(&zs[jp][k]);
-        acc[k] = __builtin_elementwise_fma(w, f32x2{t.x, t.y}, acc[k]);
-        acc[k + 1] = __builtin_elementwise_fma(w, f32x2{t.z, t.w}, acc[k + 1]);
-      }
-    }
+    for (int k = 0; k < H; ++k) acc[k] = __builtin_elementwise_fma(w, t[k], acc[k]);
   }
   if (valid) {
     float* o = slabs + ((size_t)blockIdx.y * n + i) * H;
 #pragma unroll
     for (int k = 0; k < H; ++k) o[k] = acc[k][0] + acc[k][1];
   }
-  const double t = block_sum_d(v7, sh);
-  if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if (V7) {
+    const double tt = block_sum_d(v7, sh);
+    if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tt;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o, 64);
   if ((threadIdx.x & 63) == 0 && masked) atomicAdd(nmask, (unsigned int)masked);
@@ -963,20 +953,25 @@ void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv
 int fl_decode_slabs(int n, int rows) {
   if (rows >= n) return lr_decode_slabs(n);
   const int nb = (rows + 255) / 256;
-  int js = (768 + nb - 1) / nb;
+  int js = 256 / nb;                 // (one block per CU: lr_decode_slabs)
   if (js > 64) js = 64;
   if (js > n / 64) js = n / 64;
   const int js0 = lr_decode_slabs(n);
   return js < js0 ? js0 : js;
 }
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
-                  double* v7part, float* GZn, int ldg, unsigned int* nmask) {
+                  double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7) {
   const int rows = row1 - row0;
   if (rows <= 0) return 0;
   const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows), jper = (n + js - 1) / js;
-  if (h == 8) LAUNCH(k_decode_fly<8>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
-  else if (h == 16) LAUNCH(k_decode_fly<16>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
-  else LAUNCH(k_decode_fly<32>, dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, kie7, jper, slabs, v7part, nmask);
+  const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);
+#define MCGRA_DECODE(H_)                                                                                                          \
+  do {                                                                                                                            \
+    if (want_v7) LAUNCH((k_decode_fly<H_, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask); \
+    else LAUNCH((k_decode_fly<H_, false>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask);       \
+  } while (0)
+  if (h == 8) MCGRA_DECODE(8); else if (h == 16) MCGRA_DECODE(16); else MCGRA_DECODE(32);
+#undef MCGRA_DECODE
   LAUNCH(k_sum_slabs_rows, g1((size_t)rows * h), dim3(256), st, n, row0, row1, h, js, slabs, GZn, ldg);
   return nb * js;
 }

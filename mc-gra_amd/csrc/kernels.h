@@ -69,7 +69,7 @@ void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, f
                         int elu_in);
 void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,
                      const float* cnt, float scale, float* GZ, double* rownll);
-void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p);
+void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p, float* zpair = nullptr);
 void launch_row_normalize_bwd(hipStream_t st, int n, int h, const float* GZn, const float* Zn, int ld,
                               const float* nrm, float* GZ, int ldg);
 void launch_softmax_bwd(hipStream_t st, int n, int c, const float* sm, const float* Gsm, int ld, float* GZ);
@@ -149,7 +149,7 @@ void fl_lrq_pre(hipStream_t st, int n, int w, const float* W, int ldw, const flo
 void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, const float* r, const float* mean,
                  const double* colsum, const double* mw, const double* msum, float* Q, int ldq);
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
-                  double* v7part, float* GZn, int ldg, unsigned int* nmask);
+                  double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7 = true);   // zpair: Zn pair-interleaved, (n + 1) / 2 * 2 * h floats (launch_row_normalize writes it)
 int fl_tail_tiles(int n);
 bool fl_tail_supported(int n, int ld, int kmax);
 int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,

@@ -47,13 +47,15 @@ __global__ __launch_bounds__(64) void k_lr_colstats_part(int n, int h, const flo
   for (int o = hp; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
   if (r == 0 && k < h) part[((size_t)b * LR_PARTS + pz) * h + k] = acc;
 }
-// The same sums for a row-block rank, whose side chain -- not its eighth of the N x N x N product -- is the critical path: ONE
-// load per lane and row (z_ik); z_ib and |z_i|^2 come from the row's other lanes by shuffles, four rows per lane in flight
-// (above, every lane loads z_ib and, for the two delta statistics, the whole row: a chain of dependent loads, 54 us alone and
-// 170 us beside the product).  Same operations in the same order per accumulator: same bits (three workloads hashed after three
-// steps).  NOT used by the monolithic engine: there the chain above ends long before the product does, and the denser kernel
-// made the product slower by more than its own duration (4.74 - 4.79 against 4.67 - 4.70 ms per launch, three alternating runs on
-// one box) -- per-rank compute at world 8 by emulation: 1.25 against 1.30 ms.
+// The same sums where this chain of node-level kernels IS the critical path (a row-block rank, whose share of the N x N x N
+// product is short; a monolithic graph below n = 8192): ONE load per lane and row (z_ik); z_ib and |z_i|^2 come from the row's
+// other lanes by shuffles, four rows per lane in flight (above, every lane loads z_ib and, for the two delta statistics, the
+// whole row: a chain of dependent loads, 54 us alone and 170 us beside the product).  Same operations in the same order per
+// accumulator: same bits (three workloads hashed after three steps).  Per step, three alternating runs on one box
+// (profiles/r04_ab_colstats_dense.txt): n = 4096 0.670 against 0.700 ms, n = 2708 0.411 against 0.421 ms, per rank at world 8
+// (emulation) 1.25 against 1.30 ms -- and N = 10 000 on one GPU 5.62 against 5.51 ms: there the chain ends long before the
+// product does, and the denser kernel holds the product up by more than its own duration, so the large
+// monolithic graph keeps the slow form.
 __global__ __launch_bounds__(64) void k_lr_colstats_part_dense(int n, int h, const float* __restrict__ Z, int ldz,
                                                                double* __restrict__ part) {
   const int b = blockIdx.x, pz = blockIdx.y;
@@ -421,9 +423,13 @@ __global__ void k_lr_sum_slabs(int n, int h, int nslab, const float* __restrict_
 }
 // returns the number of v7 partials written; slabs must hold nslab * n * h floats (nslab = lr_decode_slabs(n))
 bool lr_decode_supported(int h) { return h == 8 || h == 16 || h == 32; }
+// At most ONE block per CU (nb * js <= 256).  The decode runs beside the N x N x N product, whose rounds end with their slowest
+// tile: with more blocks than CUs (round 1 - 4: >= 512, "two per CU") some CUs carry two decode blocks next to their product
+// tile, and every round waits for those -- N = 10 000, one box: 240 blocks 5.50 ms per step (product 4.46 ms per launch, what it
+// takes alone), 280 blocks 5.73, 320 blocks 5.82, 520 blocks (the old rule) 5.65 (profiles/r04_ab_decode_blocks.txt).
 int lr_decode_slabs(int n) {
   const int nb = (n + 255) / 256;
-  int js = (512 + nb - 1) / nb;
+  int js = 256 / nb;
   if (js > 64) js = 64;
   if (js > n / 64) js = n / 64;        // keeps nb * js partials <= n and the j slices >= 64 long
   return js < 1 ? 1 : js;

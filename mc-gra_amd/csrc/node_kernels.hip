@@ -103,8 +103,10 @@ __global__ void k_nll_grad(int n, int c, const float* __restrict__ logp, const f
 }
 
 // F.normalize(Z, p=2, dim=1) (:415): nrm_i = |Z_i|, Zn = Z / max(nrm, 1e-12)
+// zpair (nullable): a pair-interleaved copy of Zn, zpair[i / 2][k][i & 1] (zeros past row n - 1): what the decode of the fused
+// step reads through the scalar cache (fused_lowrank.hip: k_decode_fly)
 __global__ void k_row_normalize(int n, int h, const float* __restrict__ Z, int ldz, float* __restrict__ Zn,
-                                int ldo, float* __restrict__ nrm, float pnorm) {
+                                int ldo, float* __restrict__ nrm, float pnorm, float* __restrict__ zpair) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
@@ -117,7 +119,14 @@ __global__ void k_row_normalize(int n, int h, const float* __restrict__ Z, int l
   }
   if (nrm) nrm[i] = s;
   const float den = fmaxf(s, 1e-12f);
-  for (int k = 0; k < h; ++k) Zn[(size_t)i * ldo + k] = Z[(size_t)i * ldz + k] / den;
+  for (int k = 0; k < h; ++k) {
+    const float v = Z[(size_t)i * ldz + k] / den;
+    Zn[(size_t)i * ldo + k] = v;
+    if (zpair) {
+      zpair[((size_t)(i >> 1) * h + k) * 2 + (i & 1)] = v;
+      if (i == n - 1 && !(i & 1)) zpair[((size_t)(i >> 1) * h + k) * 2 + 1] = 0.f;
+    }
+  }
 }
 
 // backward of F.normalize: G_Z += (G_Zn - Zn <Zn, G_Zn>) / nrm   (nrm >= eps)
@@ -309,8 +318,8 @@ void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const floa
                      const float* cnt, float scale, float* GZ, double* rownll) {
   LAUNCH(k_nll_grad, g1(n), dim3(256), st, n, c, logp, sm, ld, labels, cnt, scale, GZ, rownll);
 }
-void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p) {
-  LAUNCH(k_row_normalize, g1(n), dim3(256), st, n, h, Z, ldz, Zn, ldo, nrm, p);
+void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p, float* zpair) {
+  LAUNCH(k_row_normalize, g1(n), dim3(256), st, n, h, Z, ldz, Zn, ldo, nrm, p, zpair);
 }
 void launch_row_normalize_bwd(hipStream_t st, int n, int h, const float* GZn, const float* Zn, int ld,
                               const float* nrm, float* GZ, int ldg) {
