@@ -307,7 +307,10 @@ long long mcgra_attack_fused_steps(mcgra_attack_t* h);
  * |zn_i| = 1) sends a step to the Gram evaluation.  Rounds 1 - 3 sent every step with a masked pair there (3x slower at
  * N = 10 000). */
 long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h);
-/* Row-block steps whose N x N x N product was cut for the all-to-all of P1: the rank computes the row
+/* Steps whose N x N x N product was cut in two behind whole rounds of the chip.  Monolithic engine, n >= 8192 (DESIGN.md section
+ * 1c): behind ~0.8 of the tiles the first rows of P1 are complete in both orientations, and the tail's first pass over them runs
+ * beside the product's last rounds (bit-identical to the uncut step; MCGRA_EARLY_TAIL=0 disables; not when the loss terms are
+ * asked for).  Row-block ranks: cut for the all-to-all of P1: the rank computes the row
  * panels of its peers first and its own last, in one linear tile order cut behind the peers' tiles; the MCGRA_XCHG_ALLTOALL
  * exchange point is reached when the first part is done, so the collective runs beside the second part (the engine joins it
  * behind the exchange).  Default: wherever a whole round of the chip ends behind the peers' tiles (the cut is then free), and

@@ -346,6 +346,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_second, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_r, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_fork3, hipEventDisableTiming) != hipSuccess ||
@@ -373,6 +374,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     h->row0 = 0; h->row1 = (int)n;
     { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
     { const char* ee = getenv("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
+    { const char* ee = getenv("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
     { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
     {
       const char* ep = getenv("MCGRA_PLANES_MM");
@@ -436,6 +438,7 @@ int mcgra_attack_destroy(mcgra_attack_t* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_first) (void)hipEventDestroy(h->ev_first);
+  if (h->ev_second) (void)hipEventDestroy(h->ev_second);
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
   if (h->ev_fork4) (void)hipEventDestroy(h->ev_fork4);

@@ -345,6 +345,7 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   h->mask_seq = h->mask_want = seq;
   h->p1_inflight = h->fs_dec_forked = false;
   h->p1_first = false;
+  h->tail_rows = 0;
   h->early_pack = false;
   h->nmask_zero = h->t3_zero = false;
   h->fused_fwd_valid = h->fwd_cached = h->prep_valid = false;
@@ -352,13 +353,21 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   return 0;
 }
 
+// Row partials [n][nt] and value partials of the tail's first pass: the END of KY.  (Its start holds the split-K slabs of the
+// product's ragged rounds, and the second part of a cut product writes them while the early pass over the finished rows runs.)
+static size_t tail_ps_floats(const mcgra_attack* h) {
+  const size_t nt = fl_tail_tiles(h->n);
+  return ((((size_t)h->n * nt + 1) & ~(size_t)1) + 4 * nt * nt + 3) & ~(size_t)3;
+}
+static float* tail_ps(const mcgra_attack* h) { return h->KY + (size_t)h->n * h->ld - tail_ps_floats(h); }
+
 // k_tail_reduce of the step (phase 1: only its rank-k panels are packed -- their inputs are ready before the N x N x N
 // product is joined; 2: the pass itself).  Returns the number of blocks (partials of the loss-term values).
 static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pair, int R0, int R1, bool use1, bool use2, float a1,
                             float a2, float kie6, bool want_vals) {
   const int n = h->n, hs = h->hsum, he = h->wdt[h->Le - 1], nt = fl_tail_tiles(n);
-  float* ps1 = h->KY;                                            // [n][nt]: idle (the product's split-K slabs are done)
-  double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
+  float* ps1 = tail_ps(h);                                       // [n][nt]
+  double* vpart = reinterpret_cast<double*>(ps1 + (((size_t)n * nt + 1) & ~(size_t)1));
   const float* Ls[2] = {h->GPv, h->lrL};
   const float* Rs[2] = {h->Tv, h->lrR};
   const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
@@ -468,7 +477,27 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
             ++h->cut_product_steps;
           }
         }
-        if (!h->p1_first)
+        h->tail_rows = h->tail_rows2 = 0;
+        if (!h->p1_first && !h->sharded && ovl && h->early_tail_on && n >= 8192 && !want_vals && h->test_mutate != 1) {
+          // The tail's first pass needs P1_ij and P1_ji: the rows the product has finished in BOTH orientations.  Its tiles run
+          // in groups of four row panels, so behind a cut on whole rounds of the chip at ~0.8 of the launch the first
+          // `tail_rows` rows are complete, and the pass over them runs beside the product's last rounds (N = 10 000: the cut
+          // at 1 280 of 1 600 tiles = five rounds = eight groups = 8 192 rows, two thirds of the pass).
+          const int tiles_all = (n + P - 1) / P, total = tiles_all * tiles_all, group = 4 * tiles_all;
+          const int cut = (int)(0.8 * total) / 256 * 256;
+          const int rows = min(n, cut / group * 4 * P);
+          // ... and a second cut behind the last whole round: the rows that one completes, beside the ragged rest
+          int cut2 = total / 256 * 256, rows2 = min(n, cut2 / group * 4 * P);
+          if (cut2 <= cut || cut2 >= total || rows2 <= rows) { cut2 = 0; rows2 = 0; }
+          if (cut >= 256 && cut < total && rows >= n / 2) {
+            MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * ((size_t)n * ld - tail_ps_floats(h)),
+                                  h->split_planes, h->amax, p_off, p_cnt, 0, cut, h->ev_first, cut2, cut2 ? h->ev_second : nullptr));
+            h->tail_rows = rows;
+            h->tail_rows2 = rows2;
+            ++h->cut_product_steps;
+          }
+        }
+        if (!h->p1_first && h->tail_rows == 0)
         MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
                               h->amax, p_off, p_cnt));
         CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
@@ -690,7 +719,18 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (!(h->fused_post && R1 > R0)) hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
       // (a cut product: the peers' row panels are done at ev_first; the own ones are joined behind the all-to-all)
       if (h->p1_first && h->p1_inflight) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_first, 0));
-      else CHK(join());
+      else {
+        if (h->tail_rows > 0 && h->p1_inflight) {      // the pass over the rows that are complete, beside the product's last rounds
+          MCGRA_HIP(hipStreamWaitEvent(st, h->ev_first, 0));
+          (void)tail_reduce_call(h, st, 2, pair, 0, h->tail_rows, use1, use2, a1, a2, (float)(k6 / n2), false);
+          if (h->tail_rows2 > h->tail_rows) {
+            MCGRA_HIP(hipStreamWaitEvent(st, h->ev_second, 0));
+            (void)tail_reduce_call(h, st, 2, pair, h->tail_rows, h->tail_rows2, use1, use2, a1, a2, (float)(k6 / n2), false);
+            h->tail_rows = h->tail_rows2;
+          }
+        } else h->tail_rows = 0;
+        CHK(join());
+      }
       // TEST-ONLY mutation guard (tests/test_gpu_fullsize.py; armed by mcgra_attack_test_mutate, which says so on stderr): 1
       // wipes the product's result, 2 drops the rank-k terms of the tail (both GCN chains' backward and the low-rank term of
       // c2) from the gradient -- a parity test that stays green under either is blind to split2_m16_kernel / the fp16-split
@@ -704,9 +744,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->sharded && use1 && R1 > R0)
         hipLaunchKernelGGL(k_a2a_unpack, dim3(2, h->rpr, h->world), dim3(256), 0, st, n, ld, h->rpr, R0, R1, h->rank, h->A2R, h->KX);
       {
-        float* ps1 = h->KY;
-        double* vpart = reinterpret_cast<double*>(h->KY + (((size_t)n * nt + 1) & ~(size_t)1));
-        h->fs_nblk = tail_reduce_call(h, st, 2, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
+        float* ps1 = tail_ps(h);
+        double* vpart = reinterpret_cast<double*>(ps1 + (((size_t)n * nt + 1) & ~(size_t)1));
+        h->fs_nblk = tail_reduce_call(h, st, 2, pair, h->sharded ? R0 : h->tail_rows, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
+        h->tail_rows = 0;
         const Stage sgt = narrow_stage(h);
         if (h->sharded && !(h->fs_nblk > 0 && want_vals)) CHK(lane_zero(h, st, sgt, 2));
         if (h->fs_nblk > 0 && want_vals) {

@@ -95,9 +95,13 @@ struct mcgra_attack {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // row-block ranks: the product computes the row panels of the peers first and the own ones last; ev_first is recorded behind
   // the first part, the P1 all-to-all then runs beside the second (attack_fused.hip; MCGRA_A2A_OVERLAP=0 / 1 forces off / on)
-  hipEvent_t ev_first = nullptr;
+  hipEvent_t ev_first = nullptr, ev_second = nullptr;
   int a2a_overlap = 0;             // 0: the product in one piece; 1: cut where it is free or cheap (default); 2: always (MCGRA_A2A_OVERLAP=1)
   bool p1_first = false;           // the forked product of this step was cut: the all-to-all waits for ev_first only
+  // monolithic, n >= 8192: the product is cut behind whole rounds of the chip that cover the first `tail_rows` rows of P1 (both
+  // orientations); the tail's first pass over those rows runs beside the product's last rounds (MCGRA_EARLY_TAIL=0 disables)
+  bool early_tail_on = true;
+  int tail_rows = 0, tail_rows2 = 0;   // rows behind the first / second cut of this step's product (0: no early tail pass)
   // early pack (attack_fused.hip): the planes of the product's operand are packed on the product's stream as soon as r is
   // known, beside the forward's two products on the caller's stream (ev_r: r ready; ev_pack: planes and row partials ready)
   hipEvent_t ev_r = nullptr, ev_pack = nullptr;

@@ -741,7 +741,7 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
 // planes == 2: amax[0], amax[1] = the magnitudes the operands were packed with.
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax, int npanel_off,
-                       int npanel_cols, int beta, int first_tiles, hipEvent_t ev_first) {
+                       int npanel_cols, int beta, int first_tiles, hipEvent_t ev_first, int second_tiles, hipEvent_t ev_second) {
   const int nkc = chunks_of(n, planes), tiles_all = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles_all;
   const int tiles = npanel_cols >= 0 ? npanel_cols : tiles_all;      // column panels of this launch
@@ -811,7 +811,9 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   };
   // first_tiles > 0: the launch is cut at that linear tile, and ev_first is recorded behind the first part (what a
   // row-block rank's peers wait for: its all-to-all then runs beside the second part)
+  // (second_tiles / ev_second: a second cut behind the first, same rules)
   const int cut = (first_tiles > 0 && first_tiles < total) ? first_tiles : 0;
+  const int cut2 = (cut && second_tiles > cut && second_tiles < total) ? second_tiles : 0;
   hipError_t e = run(0, cut ? cut : total);
   if (e != hipSuccess) return e;
   if (ev_first) {
@@ -819,7 +821,15 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
     if (e != hipSuccess) return e;
   }
   if (cut) {
-    e = run(cut, total);
+    e = run(cut, cut2 ? cut2 : total);
+    if (e != hipSuccess) return e;
+  }
+  if (ev_second) {
+    e = hipEventRecord(ev_second, st);
+    if (e != hipSuccess) return e;
+  }
+  if (cut2) {
+    e = run(cut2, total);
     if (e != hipSuccess) return e;
   }
   return hipGetLastError();

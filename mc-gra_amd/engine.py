@@ -384,7 +384,8 @@ class AttackEngine:
         return int(lib.mcgra_attack_masked_fused_steps(self._h))
 
     def cut_product_steps(self):
-        """Row-block steps whose product was cut so that the P1 all-to-all runs beside its own row panels."""
+        """Steps whose product was cut in two: a row-block rank's so that the P1 all-to-all runs beside its own row panels, a
+        large monolithic graph's so that the tail's first pass runs beside the product's last rounds."""
         return int(lib.mcgra_attack_cut_product_steps(self._h))
 
     def product_replay(self, reps=10):

@@ -208,6 +208,35 @@ def test_state_invariants_and_determinism_at_10k(ctx):
     assert outs[0][1] == outs[1][1]
 
 
+def test_early_tail_pass_beside_the_product_is_bit_identical_at_10k(ctx, monkeypatch):
+    """n >= 8192: the product is cut behind five of its 6.25 rounds (1 280 of 1 600 tiles = eight groups of four row panels), and
+    the tail's first pass over the rows those tiles complete in both orientations (8 192 of 10 000) runs beside the last rounds;
+    the rest of the pass follows the join.  Same tiles through the same ragged round, same tile pairs by the same arithmetic:
+    the state after three bench steps (step + monitoring forward) is bit-identical to MCGRA_EARLY_TAIL=0, and the step that
+    returns its loss terms (value partials in one launch) keeps the product in one piece."""
+    pkg, torch, bench, dev = ctx
+    outs = []
+    for env in (None, "0"):
+        if env is not None:
+            monkeypatch.setenv("MCGRA_EARLY_TAIL", env)
+        eng, inp, _ = _engine(ctx)
+        for _ in range(3):
+            eng.step(); eng.monitor()
+        assert eng.cut_product_steps() == (3 if env is None else 0)
+        if env is None:
+            eng.step(want_scalars=True)
+            assert eng.cut_product_steps() == 3
+            eng.step()
+            assert eng.cut_product_steps() == 4
+        else:
+            eng.step(want_scalars=True); eng.step()
+        outs.append(eng.buffer("M").clone())
+        assert eng.fused_steps() == 5
+        del eng
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_lowrank_and_gram_evaluations_agree_at_10k(ctx, monkeypatch):
     pkg, torch, bench, dev = ctx
     fast, _, _ = _engine(ctx)
