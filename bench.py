@@ -291,11 +291,12 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
     for k, v in per.items():
         n = max(v["n"], 1)
         b = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) / n * 1024.0
-        if "split2_m16_kernel" in k or "split3_symm_kernel" in k:
-            if prod_main is None or b > prod_main:
-                prod_main = b                      # the main grid (the split-K tail of the ragged round is a second, smaller launch)
+        if "split2_m16_kernel" in k or "split3_symm_kernel" in k or "k_split3_reduce" in k:
+            # ONE product per step, in several launches: the parts of a cut launch (whole rounds of the chip, DESIGN.md section
+            # 1c), the split-K launch of the ragged last round and the sum of its slabs -- all of them, per step
+            prod_main = (prod_main or 0.0) + b * n / nsteps
             continue
-        if ("mcgra::" in k or "rocclr" in k) and n >= nsteps and "gemm_f32_kernel<128, 128" not in k and "k_split3_reduce" not in k \
+        if ("mcgra::" in k or "rocclr" in k) and n >= nsteps and "gemm_f32_kernel<128, 128" not in k \
                 and not any(x in k for x in _NOT_IN_STEP):
             outside += b * (n // nsteps)
     if prod_main is None:
@@ -722,7 +723,9 @@ def main(argv=None):
                 out["roofline"] = {"bound": "mfma",
                                    "kernel": "split2_m16_kernel (P1 = (H Kf H) Xc, the one N x N x N product of a low-rank "
                                              "linear_HSIC step, as a " + arith + ", fp32 accumulate, fp32-level error; one "
-                                             "launch per step)",
+                                             "product per step -- `launch` below = that product: the kernel's grid cut behind whole "
+                                             "rounds of the chip for the tail pass that runs beside its last rounds, + the split-K "
+                                             "launch of the ragged round and the sum of its slabs; timed from the first to the last)",
                                    "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                                    "algorithmic_flop_per_launch": st["flops"] / st["launches"],      # 2 n^2 x the rank's rows

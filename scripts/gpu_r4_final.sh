@@ -18,3 +18,10 @@ python scripts/shard_emulate.py > $O/shard_emulate.json.log 2>&1; grep '^{"world
 python scripts/diag_10k.py > $O/diag_10k.txt 2>&1; tail -12 $O/diag_10k.txt | cut -c1-330
 python scripts/diag_readme.py > $O/readme_lines.txt 2>&1; tail -5 $O/readme_lines.txt | cut -c1-200
 python scripts/power_trace.py --out $O/power_trace.json > $O/power_trace.log 2>&1; tail -3 $O/power_trace.log
+# the driver's own window, and the early tail pass at the largest single-GPU shape
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-probe > $O/bench_20_5.json 2>/dev/null
+python -c "
+import json; l=json.loads(open('$O/bench_20_5.json').read().strip().splitlines()[-1]); print('20/5', l['value'], l['ms_per_step'])"
+for i in 1 2 3; do for v in 1 0; do
+MCGRA_EARLY_TAIL=$v python bench.py --steps 10 --warmup 3 --workload synthetic-30k-hsic-3layer --no-cpu-baseline --no-split-probe | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('30k early_tail $v', round(d['value'],3), round(d['ms_per_step'],2))"
+done; done 2>/dev/null | tee $O/early_tail_30k.txt

@@ -85,6 +85,16 @@ json.dump({"note": "HBM-side bytes per attack step (2 x FETCH_SIZE + WRITE_SIZE 
                        sorted(step_rows, key=lambda r: -r[1] * r[2])[:40]]},
           open(os.path.join(P, f"{tag}_step_traffic.json"), "w"), indent=1)
 print("per step: product", prod / 1e9, "GB; outside", rest / 1e9, "GB in", rest_ms, "ms")
+# the split product is ONE product per step in several launches (parts of a cut grid, the ragged round's split-K launch, the sum
+# of its slabs): one entry for all of them, per product
+sp = [(k, c, hbm, ms) for k, c, hbm, ms in step_rows if "split2_m16_kernel" in k or "split3_symm_kernel" in k or "k_split3_reduce" in k]
+if sp:
+    out["kernels"] = [k for k in out["kernels"] if k["role"] not in ("split_f16", "split")]
+    out["kernels"].insert(0, {"kernel": "split2_m16_kernel: one product = " + " + ".join(f"{int(c)} x {k}" for k, c, hbm, ms in sp),
+                              "role": "split_f16" if any("split2_m16" in k for k, *_ in sp) else "split", "launches": steps_in_pass,
+                              "fetch_size_kb": None, "write_size_kb": None,
+                              "hbm_bytes_corrected": sum(hbm * c for k, c, hbm, ms in sp),
+                              "avg_ms": sum(ms * c for k, c, hbm, ms in sp)})
 # entries of other evaluations of the product (earlier passes with MCGRA_SPLIT_BF16=0 / 2) stay in the file
 old_path = os.path.join(P, f"{tag}_gemm_traffic.json")
 if os.path.exists(old_path):

@@ -157,6 +157,8 @@ def test_live_traffic_accounting(monkeypatch):
     rows = {   # kernel -> (grid, launches, FETCH KB per launch, WRITE KB per launch)
         "void mcgra::(anonymous namespace)::split2_m16_kernel<0>(char const*)": (786432, nl, 3000.0, 400.0),
         "void mcgra::(anonymous namespace)::split2_m16_kernel<0>(char const*, int)": (131072, nl, 200.0, 60.0),      # split-K tail
+        "void mcgra::(anonymous namespace)::split2_m16_kernel<0>(char const*, long)": (655360, nl, 500.0, 80.0),    # second part of a cut launch
+        "mcgra::(anonymous namespace)::k_split3_reduce(float const*)": (131072, nl, 30.0, 20.0),                     # sum of the tail's slabs
         "mcgra::k_tail_adam(int)": (6310144, nl, 400.0, 900.0),
         "mcgra::k_planes_mm<2>(int)": (266240, 3 * nl, 200.0, 16.0),
         "mcgra::k_dd2_accum(int)": (2560000, nl, 999.0, 999.0),                      # finalize: not part of a step
@@ -186,7 +188,8 @@ def test_live_traffic_accounting(monkeypatch):
     monkeypatch.setattr(subprocess, "run", fake_run)
     out = bench.live_traffic("synthetic-10k-hsic", 0, steps=steps)
     assert [c[c.index("--pmc") + 1] for c in seen] == ["FETCH_SIZE", "WRITE_SIZE"]
-    assert out["product_bytes_per_launch"] == (2 * 3000.0 + 400.0) * 1024
+    # one product per step = every launch of the split kernel (parts of a cut launch, split-K tail) + the sum of its slabs
+    assert out["product_bytes_per_launch"] == pytest.approx(((2 * 3000.0 + 400.0) + (2 * 200.0 + 60.0) + (2 * 500.0 + 80.0) + (2 * 30.0 + 20.0)) * 1024)
     assert out["outside_product_bytes_per_step"] == ((2 * 400.0 + 900.0) + 3 * (2 * 200.0 + 16.0)) * 1024
     monkeypatch.setattr(shutil, "which", lambda name: None)
     assert bench.live_traffic("synthetic-10k-hsic", 0) is None
