@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"
 cd /tmp
-B="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-probe"
+B="$R/bench.py --steps ${STATS_STEPS:-60} --warmup ${STATS_WARMUP:-20} --no-cpu-baseline --no-split-probe"      # (long enough to be out of the clock's settling: the first ~30 steps of a run are 5 - 10 % slower)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_stats" -- python3 $B > "$R/gpurun_out/${TAG}_stats.log" 2>&1
 B2="$R/bench.py --steps ${PMC_STEPS:-2} --warmup 1 --no-cpu-baseline --no-split-probe"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${TAG}_fetch" -- python3 $B2 > "$R/gpurun_out/${TAG}_fetch.log" 2>&1
