@@ -115,15 +115,27 @@ __global__ __launch_bounds__(256) void k_mean_fin(int n, int np, const float* __
   }
 }
 // operand-scale bound of the uncentred adj_norm: |r_i (M_ij + [i == j]) r_j| <= max r^2   (M in [0, 1], zero diagonal)
-__global__ __launch_bounds__(256) void k_rmax2(int n, const float* __restrict__ r, float* __restrict__ out) {
-  __shared__ float shm[4];
+// (one block of 1024 threads, 16-byte loads: two or three loads per thread.  As 256 threads with one float per iteration it was
+//  forty dependent round trips -- 80 us beside the forward's first product, in front of the pack on the product's stream.)
+__global__ __launch_bounds__(1024) void k_rmax2(int n, const float* __restrict__ r, float* __restrict__ out) {
+  __shared__ float shm[16];
   float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, r[i] * r[i]);
+  const int n4 = n >> 2;
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(r)[i];
+    m = fmaxf(fmaxf(m, fmaxf(v.x * v.x, v.y * v.y)), fmaxf(v.z * v.z, v.w * v.w));
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 1024) m = fmaxf(m, r[i] * r[i]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  if (threadIdx.x == 0) {
+    float t = shm[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t = fmaxf(t, shm[w]);
+    out[0] = t;
+  }
 }
 }  // namespace mcgra
 
@@ -237,7 +249,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
           float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
           MCGRA_HIP(hipEventRecord(h->ev_r, st));
           MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_r, 0));
-          if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, h->st2, n, h->r, h->amax + 1);
+          if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(1024), 0, h->st2, n, h->r, h->amax + 1);
           split3_pack_from_m(h->st2, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, 0, -1,
                              h->cfg.w[1] != 0 ? h->A1 : nullptr, psum);
           // (|adj_changes|^2 and sum(modified_adj): nothing of the forward needs them -- off the caller's stream too)
@@ -302,7 +314,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->sm));
         CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
       }
-      if (h->late_mean) { if (h->amax && !h->early_pack) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(256), 0, st, n, h->r, h->amax + 1); }
+      if (h->late_mean) { if (h->amax && !h->early_pack) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(1024), 0, st, n, h->r, h->amax + 1); }
       else fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
       MCGRA_KERNEL_CHECK();
   }
