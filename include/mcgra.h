@@ -361,7 +361,8 @@ int mcgra_attack_profile(mcgra_attack_t* h, int enable);
 int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, double* ms_per_launch);
 /* TEST ONLY -- never call it in a real run.  Arms a deliberate defect in the fused step so that a parity test can prove it
  * would notice one (tests/test_gpu_fullsize.py::test_mutations_turn_the_10k_reference_test_red): what = 1 wipes the result
- * of the N x N x N product before the tail reads it, 2 drops the rank-k terms of the tail, 0 disarms.  Says so on stderr. */
+ * of the N x N x N product before the tail reads it, 2 drops the rank-k terms of the tail, 0 disarms.  Says so on stderr.
+ * Arming is refused (MCGRA_EINVAL) unless the engine was created with MCGRA_TESTING=1 in the environment. */
 int mcgra_attack_test_mutate(mcgra_attack_t* h, int what);
 int mcgra_attack_gemm_stats(mcgra_attack_t* h, int reset, int64_t* launches,
                             double* ms, double* flops);

@@ -209,7 +209,6 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   }
   mcgra_attack* h = new mcgra_attack();
   h->cfg = *cfg;
-  { const char* e = getenv("MCGRA_NO_SYM"); h->use_sym = !(e && e[0] == '1'); }
   h->act = cfg->act; h->head_act = cfg->head_act; h->has_self = cfg->has_self;
   h->fin0 = cfg->fin_layers[0] > 0 ? cfg->fin_layers[0] : 1;
   h->fin1 = cfg->fin_layers[1] > 0 ? cfg->fin_layers[1] : 2;
@@ -219,9 +218,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   h->n = cfg->n;
   // rows of the N x N buffers start on 128-byte lines (ld a multiple of 32 floats; round 3: of 4): the 64- and 128-column
   // tile rows of the tail, the pack and the skinny products are then whole lines (+1 ... 2 % steps/s at N = 10 000, where
-  // ld = 10 016).  MCGRA_LD_ALIGN=4: round 3's rule (A/B measurements).
+  // ld = 10 016; profiles/r04_ab_edge_tiles_ld_align.txt).
   h->ld = (cfg->n + 31) & ~31;
-  { const char* e = getenv("MCGRA_LD_ALIGN"); if (e && atoi(e) >= 4 && (atoi(e) & (atoi(e) - 1)) == 0) h->ld = (cfg->n + atoi(e) - 1) & ~(atoi(e) - 1); }
   h->L = cfg->nlayer;
   h->Le = cfg->emb_nlayer;
   h->C = cfg->nclass;
@@ -242,6 +240,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn);
   { const char* e = getenv("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
+  { const char* e = getenv("MCGRA_TESTING"); h->testing = e && e[0] == '1'; }
   if (h->keep_gsym) { A_(GSYM, nn); }
   if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
     A_(KY, nn); A_(KFC, nn); A_(XC, nn); A_(YC, nn);
@@ -277,7 +276,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   {
     const char* e = getenv("MCGRA_NO_LOWRANK");
     const int he = h->wdt[h->Le - 1];
-    h->lr_ok = cfg->measure == MCGRA_MEASURE_HSIC && h->act == 0 && he <= 32 && !(e && e[0] == '1') && h->use_sym;
+    h->lr_ok = cfg->measure == MCGRA_MEASURE_HSIC && h->act == 0 && he <= 32 && !(e && e[0] == '1');
     if (h->lr_ok) {
       h->lr_ldv = (2 * he + 1 + 3) & ~3;
       A_(lrL, n * 2 * he); A_(lrR, n * 2 * he); A_(lrQ, n * 2 * he); A_(lrV, n * (size_t)h->lr_ldv);
@@ -310,7 +309,6 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         const size_t pb = split3_pack_bytes((int)n, 2);
         A_(Gp0, pb); A_(Gp1, pb); A_(Gp2, pb);
         h->gram_split = (rc == 0);
-        { const char* et = getenv("MCGRA_GRAM_TRI"); h->gram_tri = !(et && et[0] == '0'); }
       }
     }
     // The product on the engine's own stream, beside the HBM-bound kernels of the step that do not need it.  On by
@@ -375,7 +373,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
     { const char* ee = getenv("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
     { const char* ee = getenv("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
-    { const char* el = getenv("MCGRA_LATE_MEAN"); h->late_mean = h->fused_ok && cfg->shard_world == 0 && !(el && el[0] == '0'); }
+    h->late_mean = h->fused_ok && cfg->shard_world == 0;
     {
       const char* ep = getenv("MCGRA_PLANES_MM");
       // default from n = 8192: on smaller graphs the step is bound by its chain of launches, and the two extra launches per
@@ -577,11 +575,12 @@ int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* p
   }
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
+  h->m_is_full = true;
   return 0;
 }
 int mcgra_attack_get_adj_changes(mcgra_attack_t* h, void* stream, float* packed) {
   if (!h || !packed) { set_error("null argument"); return MCGRA_EINVAL; }
-  if (h->sharded && h->have_step) { set_error("row-block rank: only rows [row_begin, row_end) are kept (mcgra_attack_get_rows)"); return MCGRA_EINVAL; }
+  if (h->sharded && !h->m_is_full) { set_error("row-block rank: only rows [row_begin, row_end) are kept between a step and mcgra_attack_finalize (mcgra_attack_get_rows)"); return MCGRA_EINVAL; }
   launch_pack_tril((hipStream_t)stream, h->n, h->ld, h->M, packed, false);
   MCGRA_KERNEL_CHECK();
   return 0;
@@ -838,7 +837,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const float* em = (h->has_ori ? h->He : h->Hu) + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
   const bool use1 = (w1 != 0), use2 = (w2 != 0);
-  const bool sym = h->use_sym;
+  const bool sym = true;      // SYRK / SYMM on lower tile storage for the linear_HSIC Grams
   // tile rows of this rank (single GPU: all of them)
   const int t_all = (n + SYM_TILE - 1) / SYM_TILE;
   // (a trailing rank of a padded plan may own no tile rows at all: t0 == t1 == t_all)
@@ -1033,8 +1032,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         return MCGRA_OK;
       };
       CHK(pair(0, 1, 1));
-      // Kx and Ky are symmetric: tiles on or below the diagonal, mirrored by the epilogue (MCGRA_GRAM_TRI=0: all tiles)
-      const int gram_flags = h->gram_tri ? 2 : 0;
+      // Kx and Ky are symmetric: tiles on or below the diagonal, mirrored by the epilogue
+      const int gram_flags = 2;
       split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
       CHK(timer_begin(h, st, big));
       MCGRA_HIP(split3_symm(st, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->G_A, slab, 2, h->amax + 8, 0, -1, gram_flags));
@@ -1367,6 +1366,7 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   }
   CHK(eg(h, st, false, true, n, n, h->wdt[Le - 1], 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->M, ld));
   launch_decode_post(st, n, ld, h->M, nullptr);            // adj_changes <- the decode (:301); M stays the state
+  h->m_is_full = true;                                     // (every rank of a row-block attack now holds the same, whole M)
   const float* mod = h->M;                                 // modified_adj = get_modified_adj(ori_adj) (:302)
   if (h->has_ori) {
     launch_axpby2d(st, n, h->M, ld, 1.f, h->ORI, ld, 1.f, h->Bbuf, ld);

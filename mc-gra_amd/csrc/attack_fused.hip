@@ -358,6 +358,9 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   h->p1_inflight = h->fs_dec_forked = false;
   h->p1_first = false;
   h->tail_rows = 0;
+  // (the streams were drained above, but st2 is non-blocking and shared with other engines: a pack forked for the abandoned
+  // step is ordered in front of this stream's next launches explicitly, as at every other site that drops the flag)
+  if (h->early_pack) (void)hipStreamWaitEvent(st, h->ev_pack, 0);
   h->early_pack = false;
   h->nmask_zero = h->t3_zero = false;
   h->fused_fwd_valid = h->fwd_cached = h->prep_valid = false;
@@ -478,7 +481,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           // The cut sits on a whole round of the chip when that still leaves own tiles behind it (a cut costs a ragged round).
           const int tiles_all = (n + P - 1) / P, rot = (p_off + p_cnt) % tiles_all;
           const int span = min(tiles_all, (tiles_all - p_cnt + 3) & ~3) * p_cnt, total = tiles_all * p_cnt;
-          int first = (span + 255) / 256 * 256;
+          const int slots = split3_slots();
+          int first = (span + slots - 1) / slots * slots;
           // (no whole round left behind the peers' tiles: a cut there costs a second ragged round -- taken while the own
           // panels are at least a quarter of the product, world <= 4, or when forced)
           if (first >= total) first = (h->world <= 4 || h->a2a_overlap == 2) ? span : 0;
@@ -496,12 +500,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
           // `tail_rows` rows are complete, and the pass over them runs beside the product's last rounds (N = 10 000: the cut
           // at 1 280 of 1 600 tiles = five rounds = eight groups = 8 192 rows, two thirds of the pass).
           const int tiles_all = (n + P - 1) / P, total = tiles_all * tiles_all, group = 4 * tiles_all;
-          const int cut = (int)(0.8 * total) / 256 * 256;
+          const int slots = split3_slots();
+          const int cut = (int)(0.8 * total) / slots * slots;
           const int rows = min(n, cut / group * 4 * P);
           // ... and a second cut behind the last whole round: the rows that one completes, beside the ragged rest
-          int cut2 = total / 256 * 256, rows2 = min(n, cut2 / group * 4 * P);
+          int cut2 = total / slots * slots, rows2 = min(n, cut2 / group * 4 * P);
           if (cut2 <= cut || cut2 >= total || rows2 <= rows) { cut2 = 0; rows2 = 0; }
-          if (cut >= 256 && cut < total && rows >= n / 2) {
+          if (cut >= slots && cut < total && rows >= n / 2) {
             MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * ((size_t)n * ld - tail_ps_floats(h)),
                                   h->split_planes, h->amax, p_off, p_cnt, 0, cut, h->ev_first, cut2, cut2 ? h->ev_second : nullptr));
             h->tail_rows = rows;
@@ -903,6 +908,7 @@ int mcgra_attack_shard_begin(mcgra_attack_t* h, void* stream, int what, int want
   h->fs_what = what; h->fs_want = want_scalars ? 1 : 0;
   h->fs_state = 0; h->fw_state = 0;
   h->fs_active = true;
+  if (what == MCGRA_SHARD_STEP && h->world > 1) h->m_is_full = false;      // from here on only the own rows of M are kept current
   return 0;
 }
 
@@ -949,6 +955,11 @@ int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out) {
 
 int mcgra_attack_test_mutate(mcgra_attack_t* h, int what) {
   if (!h || what < 0 || what > 2) { set_error("test_mutate: what = %d", what); return MCGRA_EINVAL; }
+  if (what && !h->testing) {
+    set_error("mcgra_attack_test_mutate: refused -- this engine was not created under MCGRA_TESTING=1 (a defect injector for the "
+              "parity suite's mutation guards, never part of a real run)");
+    return MCGRA_EINVAL;
+  }
   h->test_mutate = what;
   if (what)
     fprintf(stderr, "[mcgra] TEST MUTATION ARMED on engine %p: the fused step now %s -- its gradients are WRONG on purpose\n", (void*)h,

@@ -92,6 +92,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
                        int first_tiles = 0, hipEvent_t ev_first = nullptr,             // 4 = all row panels from panel_off, wrapping; first_tiles: cut of the linear tile range, ev_first recorded behind the first part
                        int second_tiles = 0, hipEvent_t ev_second = nullptr);          // a second cut behind the first
 int split3_panel();
+int split3_slots();      // tiles per round of the chip (= CUs of the current device): cuts of a launch are multiples of it
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

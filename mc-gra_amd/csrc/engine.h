@@ -33,6 +33,8 @@ struct mcgra_attack {
   int wdt[MCGRA_MAX_LAYERS + 1];   // width of layer l output (dims[l+1])
   int64_t t = 0;                   // Adam step count
   bool have_step = false;
+  bool m_is_full = true;           // every row of M is current (a row-block rank after its first step holds its own rows only, until finalize)
+  bool testing = false;            // MCGRA_TESTING=1 at create: mcgra_attack_test_mutate is accepted (refused otherwise)
   // The monitoring forward of :290-296 (victim on the updated adjacency) is exactly the first forward of the next
   // iteration (:164-167) when eps == 0: mcgra_attack_monitor leaves its adj_norm, degree vectors, chain and
   // log-probs in place and the next step adopts them instead of recomputing (bit-identical, one N x N pass and two
@@ -80,7 +82,6 @@ struct mcgra_attack {
   size_t ws_bytes = 0;
   int nstrips = 32;
   bool profile = false;
-  bool use_sym = true;             // SYRK / SYMM on lower tile storage for the linear_HSIC Grams (MCGRA_NO_SYM=1 disables)
   // low-rank linear_HSIC(adj_norm, modified_adj1) (lowrank_kernels.hip); MCGRA_NO_LOWRANK=1 disables
   bool lr_ok = false;              // configuration allows it (HSIC, ReLU embedding, width <= 32)
   bool lr_step = false;            // the step in flight takes it (no relu-masked pair in the decode)
@@ -142,7 +143,7 @@ struct mcgra_attack {
   // Gram evaluation (masked / GAT / MCGRA_NO_LOWRANK steps) through the same kernel: planes of Xc, Yc, the combined
   // Grams and Yc^T; amax[2] = max |Yc|, [3] = max |2 (s1 Kfc + s2 Kyc)|, [4] = max |2 s2 Kxc|, [8..15] = the
   // (A, B) scale pairs of the four products
-  bool gram_split = false, gram_tri = true;
+  bool gram_split = false;
   unsigned char *Gp0 = 0, *Gp1 = 0, *Gp2 = 0;
   int64_t gram_split_steps = 0;
   GemmTimer timer;
@@ -161,7 +162,6 @@ struct mcgra_attack {
   // Monolithic fused step: the column means of adj_norm come out of the PACK of the product's operand (row sums of the
   // packed values) instead of out of a 33rd column (M r) of the first forward product; the product's operand is then
   // packed uncentred -- (H Kf H) 1 = 0, so P1 is the same up to 1e-7 -- and the means are only needed behind the pack.
-  // MCGRA_LATE_MEAN=0 disables (A/B).
   bool late_mean = false;
   // ... and with uncentred planes of the CURRENT M in Bpack (between the pack of a step and its Adam pass) the skinny
   // products on M that run beside the N x N x N product read those planes (planes_mm.hip).  MCGRA_PLANES_MM=0 disables.

@@ -416,7 +416,6 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
 // step, one barrier per 32 k.  On a power-limited chip the 16 x 16 shape holds a higher clock than 32 x 32
 // (MI355X_MICROARCH.md: 1.12-1.15 x the FLOP/s at equal cycles on random operands).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int MODE>
 __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
                                                             float* __restrict__ C, int n, int ldc, int nks,
                                                             int tiles_m, int tiles_n, int panel_off, int tile_base,
@@ -475,9 +474,6 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
   auto frag = [&](const char* s, int off) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(s + off)); };
   auto multiply = [&](int stage, auto&& before_reads) {
     const char* s = smem + stage * STAGE;
-    // MODE 2: the copies of the next tile go out first (with them between the head reads and the first MFMAs the compiler
-    // waits for all ten reads, lgkmcnt(0): it does not count past an LDS-DMA; with the reads last it waits for six)
-    if constexpr (MODE == 2) before_reads();
     f16x8 b0[4], b1[4];
     f16x8 a1 = frag(s, a_off + PLANE);
 #pragma unroll
@@ -485,7 +481,7 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     f16x8 a0 = frag(s, a_off);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1[j] = frag(s, b_off + j * 256 + PLANE);
-    if constexpr (MODE != 2) before_reads();
+    before_reads();      // (the copies of the next tile, behind the head reads)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f16x8 n0 = a0, n1 = a1;
@@ -504,121 +500,12 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     }
   };
 
-  if constexpr (MODE == 3) {
-    // ---- staggered wave groups (MCGRA_SPLIT_LOOP=3).  A step is cut into four phases of two row tiles (24 MFMAs per wave)
-    // with a raw s_barrier behind each; the waves of row group wm = 1 run ONE PHASE behind those of wm = 0 (they take one
-    // barrier more in front of the loop, the others one more behind it).  Each SIMD holds one wave of either group, so the
-    // head of a step -- ten fragment reads with nothing to multiply yet -- of one wave sits under the last / second phase
-    // of the other wave's MFMAs instead of idling the matrix pipe.  Staging by region, counted waits, never vmcnt(0) in
-    // the steady state:
-    //   A rows of the own group (16 KB, read all step long by the own group only): stage s+1 issued in phase 0 of step s
-    //     (the barrier just passed ended the own group's reads of that buffer), awaited in front of the barrier that ends
-    //     phase 3 (vmcnt(4): the copies of B issued behind it may stay in flight), read from phase 0 of step s+1;
-    //   B (32 KB, read by both groups in their phase 0 only -- the eight B fragments stay in registers): stage s+2 issued in
-    //     phase 2 of step s (both groups read stage s at least one barrier ago), awaited in front of the barrier that ends
-    //     phase 2 of step s+1 (vmcnt(8)), i.e. two barriers ahead of the other group's read: a wait retires copies for
-    //     the waiting wave only, the barrier behind it publishes them.
-    const int gw = wave & 3;
-    auto load_a = [&](int kc, int stage) {
-      const char* src = Ap + ((size_t)tile_m * nks + kc_begin + kc) * (2 * OPB);
-      char* dst = smem + stage * STAGE;
-#pragma unroll
-      for (int p4 = 0; p4 < 4; ++p4) {
-        const int piece = gw * 4 + p4, seg = piece >> 1;       // segment (chunk, plane, k half): 128 rows x 16 B of this group
-        const int off = (seg >> 2) * OPB + ((seg >> 1) & 1) * PLANE + (seg & 1) * (PLANE / 2) + wm * 2048 + (piece & 1) * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + off + lane * 16), (lptr_t)(dst + off), 16, 0, 0);
-      }
-    };
-    auto load_b = [&](int kc, int stage) {
-      const char* src = Bp + ((size_t)tile_n * nks + kc_begin + kc) * (2 * OPB) + wave * 4096;
-      char* dst = smem + stage * STAGE + 2 * OPB + wave * 4096;
-#pragma unroll
-      for (int p4 = 0; p4 < 4; ++p4)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + p4 * 1024 + lane * 16), (lptr_t)(dst + p4 * 1024), 16, 0, 0);
-    };
-    auto bar = [&]() {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    if (nk > 0) {
-      load_a(0, 0);
-      load_b(0, 0);
-      if (nk > 1) load_b(1, 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      bar();
-      const bool late = __builtin_amdgcn_readfirstlane(wm) != 0;
-      if (late) bar();
-      f16x8 b0[4], b1[4], a0, a1;
-      for (int kc = 0; kc < nk; ++kc) {
-        const char* s = smem + (kc & 1) * STAGE;
-        auto rows2 = [&](int i0) {
-#pragma unroll
-          for (int ii = 0; ii < 2; ++ii) {
-            const int i = i0 + ii;
-            f16x8 n0 = a0, n1 = a1;
-            if (i + 1 < 8) {
-              n0 = frag(s, a_off + (i + 1) * 256);
-              n1 = frag(s, a_off + (i + 1) * 256 + PLANE);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc[i][j], 0, 0, 0);
-            a0 = n0; a1 = n1;
-          }
-        };
-        // phase 0
-        if (kc + 1 < nk) load_a(kc + 1, (kc + 1) & 1);
-        a1 = frag(s, a_off + PLANE);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b0[j] = frag(s, b_off + j * 256);
-        a0 = frag(s, a_off);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = frag(s, b_off + j * 256 + PLANE);
-        rows2(0);
-        bar();
-        // phase 1
-        rows2(2);
-        bar();
-        // phase 2
-        if (kc + 2 < nk) load_b(kc + 2, kc & 1);
-        rows2(4);
-        if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        bar();
-        // phase 3
-        rows2(6);
-        if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bar();
-      }
-      if (!late) bar();
-    }
-  } else
   if (nk > 0) {
     stage_tile(0, 0);
     __syncthreads();                      // (waits for the copies of this wave, then for everybody's)
-    if constexpr (MODE == 0) {
-      for (int kc = 0; kc < nk; ++kc) {
-        multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
-        __syncthreads();
-      }
-    } else if constexpr (MODE == 3) {
-      // (unreachable: MODE 3 has its own loop below)
-    } else {
-    int kc = 0;
-    // steady state without a condition around the staging: the head reads, the copies and the first MFMAs then sit in
-    // ONE basic block and the compiler waits for the fragments it needs (counted lgkmcnt) instead of for all ten reads at
-    // a block entry
-    for (; kc + 1 < nk; ++kc) {
-      multiply(kc & 1, [&]() { stage_tile(kc + 1, (kc + 1) & 1); });
+    for (int kc = 0; kc < nk; ++kc) {
+      multiply(kc & 1, [&]() { if (kc + 1 < nk) stage_tile(kc + 1, (kc + 1) & 1); });
       __syncthreads();
-    }
-    multiply(kc & 1, [&]() {});
-    __syncthreads();
     }
   }
   const float inv = ldexpf(1.f, amax_exp(amax[0]) + amax_exp(amax[1]) - 30);      // undo the operand scales: exact
@@ -739,6 +626,19 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
 // (panel_rows < 0: all panels).  Tiles are independent; a row range gives the same bits as the full launch except for
 // the tiles of the ragged last round, whose split along K depends on how many tiles the launch has.
 // planes == 2: amax[0], amax[1] = the magnitudes the operands were packed with.
+// Tiles per round of the chip: one block per CU of the current device (256 on MI355X).  Callers that cut a launch
+// (first_tiles / second_tiles) snap their cuts to multiples of it.
+int split3_slots() {
+  static int cus_of[64] = {0};            // per device: written once with the same value by whoever gets there first
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (!cus_of[dev] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      cus_of[dev] = cus;
+    if (cus_of[dev]) return cus_of[dev];
+  }
+  return 256;
+}
+
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax, int npanel_off,
                        int npanel_cols, int beta, int first_tiles, hipEvent_t ev_first, int second_tiles, hipEvent_t ev_second) {
@@ -746,16 +646,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   const int tm = panel_rows >= 0 ? panel_rows : tiles_all;
   const int tiles = npanel_cols >= 0 ? npanel_cols : tiles_all;      // column panels of this launch
   if (tm <= 0 || tiles <= 0) return hipSuccess;
-  int slots = 256;               // one block per CU of the device this launch goes to
-  {
-    static int cus_of[64] = {0};            // per device: written once with the same value by whoever gets there first
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-      if (!cus_of[dev] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-        cus_of[dev] = cus;
-      if (cus_of[dev]) slots = cus_of[dev];
-    }
-  }
+  const int slots = split3_slots();      // one block per CU of the device this launch goes to
   // (SPLIT_TRI: whole square launches only; tiles on or below the diagonal.  SPLIT_WRAP: all row panels, any start)
   if ((beta & SPLIT_TRI) && (tm != tiles_all || tiles != tiles_all || panel_off || npanel_off || first_tiles > 0)) return hipErrorInvalidValue;
   if ((beta & SPLIT_WRAP) && (tm != tiles_all || panel_off < 0 || panel_off >= tiles_all || (beta & SPLIT_TRI))) return hipErrorInvalidValue;
@@ -763,24 +654,11 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2) {      // 2-plane fp16 split: split2_m16_kernel (v_mfma_f32_16x16x32_f16, global_load_lds staging)
       constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;
-      // MCGRA_SPLIT_LOOP=2: the K loop with its last step peeled and the copies of the next tile issued ahead of the head
-      // reads (one basic block: counted lgkmcnt waits).  Measured on one box, three alternating runs each: the product ALONE
-      // 4.48-4.51 ms against 4.58-4.60 ms of the default, but 5.14-5.21 against 4.99-5.04 ms beside the step's other
-      // kernels (153-154 against 157-158 steps/s): the default loop stays.
-      static const int mode = [] { const char* e = getenv("MCGRA_SPLIT_LOOP"); return e && e[0] == '2' ? 2 : (e && e[0] == '3' ? 3 : 0); }();
-      constexpr int smem_ = smem;
-#define MCGRA_LAUNCH_M16(MODE_)                                                                                              \
-      {                                                                                                                       \
-        hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel<MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
-        if (e != hipSuccess) return e;                                                                                        \
-        hipLaunchKernelGGL(split2_m16_kernel<MODE_>, dim3(grid), dim3(512), smem_, st, (const char*)Apack, (const char*)Bpack, C, n, \
-                           ldc, nkc / 2, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);                     \
-        return hipSuccess;                                                                                                    \
-      }
-      if (mode == 0) MCGRA_LAUNCH_M16(0)
-      if (mode == 3) MCGRA_LAUNCH_M16(3)
-      MCGRA_LAUNCH_M16(2)
-#undef MCGRA_LAUNCH_M16
+      hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(split2_m16_kernel, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc, nkc / 2, tm,
+                         tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
+      return hipSuccess;
     }
     return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
   };

@@ -8,6 +8,13 @@ H_A / Y_A, run PGDAttack on the MI355X hot path, report the recovered-adjacency 
 
 --arch gcn | sage | gat select the victim family as main.py:175-231 does.  Not provided (each exits with a message
 naming the reference line): --mode search/baseline/gaussian/gcn_attack, --measure KDE.
+
+Several GPUs of one node -- one process per GPU, RCCL over xGMI:
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 mc-gra_amd/main.py --dataset ... --measure HSIC ...
+Every rank loads the graph and trains the victim on the same seed (rank 0's weights are then broadcast), and
+PGDAttack.attack (main.py:298-307) runs ONE attack row-block sharded over the ranks when the configuration allows it
+(mc-gra_amd/topology_attack.py); rank 0 prints and logs the result.  MCGRA_SHARED_GPU=1 puts every rank on cuda:0 over
+gloo with host-staged exchanges: the test mode of a 1-GPU box.
 """
 import argparse
 import os
@@ -104,7 +111,41 @@ def label_adjacency(labels):
     return (lab[:, None] == lab[None, :]).astype(np.float32)
 
 
+def victim_tensors(m):
+    """Every parameter of a victim: the registered ones and those of the layers it keeps in plain lists (models/gcn.py:44,
+    graphsage.py:50, gat.py:47 -- as the reference's classes do)."""
+    mods = [m] + list(getattr(m, "gc", [])) + [a for heads in getattr(m, "attentions", []) for a in heads]
+    seen, out = set(), []
+    for mod in mods:
+        for p_ in mod.parameters():
+            if id(p_) not in seen:
+                seen.add(id(p_))
+                out.append(p_)
+    return out
+
+
+def init_distributed(args):
+    """Under a launcher that set WORLD_SIZE > 1 (torchrun): join the process group BEFORE anything touches the GPU and take
+    this rank's device.  Returns (rank, world); (0, 1) for a plain single-process run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world < 2:
+        return 0, 1
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("MCGRA_SHARED_GPU") == "1":
+            dist.init_process_group("gloo")
+            args.device = "cuda:0"
+        else:
+            local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+            args.device = f"cuda:{local}"
+            dist.init_process_group("nccl", device_id=torch.device(args.device))
+    torch.cuda.set_device(torch.device(args.device))
+    return dist.get_rank(), dist.get_world_size()
+
+
 def run(args):
+    rank, world = init_distributed(args)
     device = torch.device(args.device)
     np.random.seed(args.seed); random.seed(args.seed); torch.manual_seed(args.seed)       # main.py:142-146
     if args.measure == "KDE":
@@ -115,8 +156,9 @@ def run(args):
     random.sample(range(adj.shape[0]), int(adj.shape[0] * args.nlabel))                    # main.py:155 (consumes the RNG)
     adj, features, labels = utils.preprocess(adj, features, labels, preprocess_adj=False, onehot_feature=False)
     if args.mode == "prepare":
-        os.makedirs(args.saved_data, exist_ok=True)
-        np.save(os.path.join(args.saved_data, args.dataset + ".npy"), label_adjacency(labels))
+        if rank == 0:
+            os.makedirs(args.saved_data, exist_ok=True)
+            np.save(os.path.join(args.saved_data, args.dataset + ".npy"), label_adjacency(labels))
         return None
     feature_adj = dot_product_decode(features, args.dataset)
     if args.nofeature:
@@ -145,6 +187,19 @@ def run(args):
         embedding = embedding_gat(nfeat=nfeat, nclass=nclass, nhid=16, nlayer=args.nlayers, dropout=0.5, alpha=0.1,
                                   nheads=5, device=device)
         embedding.attentions = victim_model.attentions
+    if world > 1:
+        # one victim for all ranks: rank 0's parameters (training on the same seed is not guaranteed to be bit-reproducible
+        # across processes); the embedding shares / copies them as main.py:190 / :210 / :231 do
+        import torch.distributed as dist
+        staged = str(dist.get_backend()).lower() != "nccl"
+        with torch.no_grad():
+            for p_ in victim_tensors(victim_model):
+                t_ = p_.data.cpu() if staged else p_.data
+                dist.broadcast(t_, 0)
+                if staged:
+                    p_.data.copy_(t_)
+        if args.arch != "gat":
+            embedding.gc = deepcopy(victim_model.gc)
     # main.py:233-241, call for call: the victim is in eval mode (fit() leaves it there), the freshly built embedding is
     # NOT -- embedding_gat.forward therefore applies F.dropout(0.5) and the reference's H_A priors of --arch gat carry
     # dropout noise (embedding_GCN / embedding_graphsage have no dropout); each call consumes the RNG as the reference's does
@@ -168,6 +223,8 @@ def run(args):
     label_adj = np.load(lab_path) if os.path.exists(lab_path) else label_adjacency(labels)
     model = PGDAttack(model=victim_model, embedding=embedding, H_A=H_A2, Y_A=Y_A, nnodes=adj.shape[0],
                       loss_type='CE', device=device)
+    if getattr(args, "adj_changes_init", None) is not None:      # (tests: a seeded start; adj_changes is a public attribute, :77)
+        model.adj_changes = args.adj_changes_init
     model.attack(args, None, lr, 0, args.weight_sup, weight_param, feature_adj, 0, 0, 0, idx_train, idx_val,
                  idx_test, adj, features, init_adj, labels, idx_attack, num_edges, 0, epochs=args.epochs,
                  label_adj=label_adj)
@@ -176,6 +233,9 @@ def run(args):
            "auc_train": float(metric_pool(adj, inference_adj, idx_train)),
            "auc_all": float(metric_pool(adj, inference_adj, np.arange(adj.shape[0]))),
            "density": float(inference_adj.mean())}
+    res["path"] = dict(model.history.get("path", {}), world=world)
+    if rank != 0:           # every rank holds the same modified_adj; rank 0 reports
+        return res
     print(f"current auc={res['auc_all']}")
     os.makedirs("./results/", exist_ok=True)
     with open(os.path.join("./results", args.log_name), "a") as f:                         # main.py:314-323

@@ -11,8 +11,15 @@ without libmcgra_hip.so it raises.
 Arguments the reference accepts but this path does not cover yet raise
 NotImplementedError naming the reference line (measure KDE,
 an embedding whose weights differ from victim_model.gc).
+
+Several GPUs: when ``torch.distributed`` is initialised with more than one rank (``torchrun ... main.py``: one process
+per GPU, backend "nccl" = RCCL), ``attack`` runs ONE attack row-block sharded over the ranks (mc-gra_amd/sharded.py,
+DESIGN.md section 6) whenever the configuration is one the fused low-rank step covers (measure HSIC, ReLU GCN victim,
+eps == 0, ori_adj == 0, n >= 1024, hidden widths <= 32, w1 or w2 non-zero, a projection budget that cannot bind); every
+rank returns the same ``modified_adj``.  Any other configuration says on stderr that it runs replicated.
 """
 import os
+import sys
 
 import numpy as np
 import scipy.sparse as sp
@@ -42,6 +49,27 @@ def _decode_mode(args):
             return 6            # p=5
         return 3
     raise ValueError(f"dot_product_decode2 has no branch for dataset {ds!r} (topology_attack.py:421-467)")
+
+
+def _dist_group():
+    """(torch.distributed, world, rank, host_staged) of an initialised default process group with more than one rank, else
+    (None, 1, 0, False).  host_staged: the group is a host one (gloo) -- ranks that SHARE a GPU (RCCL refuses two ranks on one
+    device): the exchanged arena slices are copied through the host (sharded.run_exchange), a test mode, never the fast path."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None, 1, 0, False
+    return dist, dist.get_world_size(), dist.get_rank(), str(dist.get_backend()).lower() != "nccl"
+
+
+def _bcast(dist, t, host_staged):
+    """rank 0's copy of a float / int tensor on every rank (in place on a contiguous tensor; returns it)."""
+    if host_staged:
+        c = t.detach().cpu().contiguous()
+        dist.broadcast(c, 0)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, 0)
+    return t
 
 
 def _dense_np(x, dtype=np.float32):
@@ -142,6 +170,30 @@ class PGDAttack(BaseAttack):
                         "modified_adj)")
         return W, b, Wlin, blin, Ws, "relu", "none", False
 
+    @staticmethod
+    def _replicated_reason(measure, eps, ori_np, Ws, act, head_act, loss_type, n, dims, w1, w2, num_edges):
+        """None when the row-block sharded fused step covers this configuration (include/mcgra.h: mcgra_attack_shard_*;
+        csrc/attack.hip: the create-time rule), else why it does not."""
+        if measure != "HSIC":
+            return f"measure {measure} (only the fused low-rank HSIC step is sharded)"
+        if loss_type != "CE":
+            return "loss_type 'CW' takes no step"
+        if eps != 0:
+            return "eps != 0 (adding_noise makes modified_adj asymmetric: general step)"
+        if ori_np is not None:
+            return "a non-zero ori_adj (general step)"
+        if Ws is not None or act != "relu" or head_act != "none":
+            return "a GAT / GraphSAGE victim (Gram evaluation of linear_HSIC)"
+        if n < 1024 and os.environ.get("MCGRA_SPLIT_BF16", "") not in ("2", "3"):
+            return f"n = {n} < 1024 (the product runs on the fp32 kernel: nothing to shard)"
+        if max(dims[1:]) > 32:
+            return f"hidden width {max(dims[1:])} > 32"
+        if w1 == 0 and w2 == 0:
+            return "w1 == w2 == 0 (no N x N HSIC term)"
+        if num_edges < 0.5 * float(n) * float(n):
+            return "a projection budget that can bind (host-driven bisection)"
+        return None
+
     def test(self, idx_attack, idx_val, idx_test, adj, features, labels, victim_model):
         """topology_attack.py:83-93 through mcgra_gcn_forward / mcgra_normalize_adj."""
         from . import engine as E
@@ -219,14 +271,39 @@ class PGDAttack(BaseAttack):
 
         if self.engine is not None:
             self.engine.close()
+        # ---- several ranks (torchrun main.py: main.py:298-307 is called by every rank): one attack, row-block sharded
+        dist, world, rank, host_staged = _dist_group()
+        plan = stepper = None
+        if world > 1:
+            why = self._replicated_reason(measure, eps, ori_np, Ws, act, head_act, self.loss_type, n, dims, w1, w2, num_edges)
+            if why is None:
+                from .sharded import HipShardBackend, RowBlockPlan, ShardedStepper
+                plan = RowBlockPlan(n, world, rank)
+            elif rank == 0:
+                print(f"[mc-gra_amd] PGDAttack.attack under {world} ranks runs REPLICATED (every rank the whole attack): {why}",
+                      file=sys.stderr, flush=True)
+        to_dev = lambda t: torch.as_tensor(np.asarray(t.detach().cpu() if isinstance(t, torch.Tensor) else t),
+                                           dtype=torch.float32).to(dev).contiguous()
+        if plan is not None:
+            # every rank must hold rank 0's victim bit for bit (the node-level part of the step is replicated and the ranks
+            # must agree on it): a victim trained per rank on the same seed is not guaranteed to be
+            W = [_bcast(dist, to_dev(w), host_staged) for w in W]
+            b = [_bcast(dist, to_dev(x), host_staged) for x in b]
+            Wlin, blin = _bcast(dist, to_dev(Wlin), host_staged), _bcast(dist, to_dev(blin), host_staged)
+            idx_t = _bcast(dist, torch.as_tensor(idx, device=dev), host_staged)
+            idx = idx_t.cpu().numpy()
         eng = AttackEngine(n, dims, int(Wlin.shape[0]), emb_nlayer, measure, weight_supervised,
                            (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev,
-                           act=act, head_act=head_act, has_self=Ws is not None, fin_layers=fin_layers)
+                           act=act, head_act=head_act, has_self=Ws is not None, fin_layers=fin_layers, plan=plan)
         eng.set_model(W, b, Wlin, blin, Ws)
         eng.set_graph(_dense_np(ori_features), adj_np, ori_np, fadj, lab, idx)
         if self._adj_changes_init is not None:
-            eng.set_adj_changes(self._adj_changes_init)
+            a0 = torch.as_tensor(self._adj_changes_init, dtype=torch.float32).to(dev).contiguous()
+            eng.set_adj_changes(_bcast(dist, a0, host_staged) if plan is not None else a0)
         self.engine = eng
+        if plan is not None:
+            stepper = ShardedStepper(HipShardBackend(eng, plan), plan, dist=dist, host_staged=host_staged)
+        self.sharded_world = world if plan is not None else 1
 
         idx_test_t = None
         if monitor and idx_test is not None:
@@ -236,13 +313,22 @@ class PGDAttack(BaseAttack):
         for t in range(epochs):
             # adding_noise (:474-478): torch.randn_like on the attack device, as the reference draws it
             if self.loss_type == 'CE':
-                eng.step(noise=torch.randn(n, n, device=dev) if eps != 0 else None)
+                if stepper is not None:
+                    stepper.step()
+                else:
+                    eng.step(noise=torch.randn(n, n, device=dev) if eps != 0 else None)
             if monitor:
-                out2, spars = eng.monitor(want_sparsity=False)       # (:290-296)
+                if stepper is not None:
+                    stepper.monitor()                                    # (:290-296), the next step adopts it
+                    out2 = eng.buffer("logp") if idx_test_t is not None else None
+                else:
+                    out2, spars = eng.monitor(want_sparsity=False)       # (:290-296)
                 if idx_test_t is not None:
                     acc_test_list.append((out2[idx_test_t].max(1)[1] == lab_t[idx_test_t]).double().mean())
         if acc_test_list:
             self.history["acc_test"] = [float(a) for a in torch.stack(acc_test_list).cpu()]
+        self.history["path"] = dict(eng.path_stats(), fused_steps=eng.fused_steps(), sharded_world=self.sharded_world,
+                                    collectives=stepper.exchanges if stepper is not None else 0)
 
         use_HA, use_YA, use_Y = bool(args.useH_A), bool(args.useY_A), bool(args.useY)
         H_A = self.H_A.detach() if (use_HA and self.H_A is not None) else None
@@ -256,5 +342,10 @@ class PGDAttack(BaseAttack):
                              f"({n}, {dims[emb_nlayer]}) (main.py:238-241)")
         if Y_A is not None and tuple(Y_A.shape) != (n, int(Wlin.shape[0])):
             raise ValueError(f"Y_A has shape {tuple(Y_A.shape)}, expected ({n}, {int(Wlin.shape[0])})")
+        if plan is not None:
+            # the post-loop ensemble (:300-324) needs only what every rank holds (the last iteration's embedding and the
+            # priors): it runs replicated, on rank 0's priors, and every rank returns the same modified_adj
+            H_A = _bcast(dist, to_dev(H_A), host_staged) if H_A is not None else None
+            Y_A = _bcast(dist, to_dev(Y_A), host_staged) if Y_A is not None else None
         self.modified_adj = eng.finalize(_decode_mode(args), H_A, Y_A, label_adj if use_Y else None).detach()
         return 0, 0, 0, 0

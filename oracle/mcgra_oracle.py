@@ -32,7 +32,9 @@ ALIGN_PARAMETER_CORA = {
     "c6": 10, "c7": 10, "c8": 0.01, "c9": 1, "c10": 1,
 }
 
-MEASURES = ("HSIC", "MSELoss", "KL", "CKA", "DP")  # "KDE" needs cuda:0 in the reference (utils.py:991)
+# "KDE": utils.MutualInformation (utils.py:980-1049) asks for device='cuda:0' in ONE torch.linspace call (utils.py:990-991);
+# tests/golden/make_golden.py drops that keyword (no arithmetic changes) to run the reference's CPU path with it
+MEASURES = ("HSIC", "MSELoss", "KL", "CKA", "DP", "KDE")
 
 
 # --------------------------------------------------------------------------
@@ -313,9 +315,77 @@ def dp_grads(X, Y, need_x=True, need_y=True):
     return val, gX, gY
 
 
+KDE_SIGMA = 2 * 0.4 ** 2      # MutualInformation(sigma=0.4): self.sigma = 2 * sigma ** 2 (utils.py:985)
+KDE_EPS = 1e-10               # self.epsilon (utils.py:988)
+
+
+def kde_bins(num_bins: int) -> np.ndarray:
+    """torch.linspace(0, num_bins, num_bins).float() (utils.py:990-991): b_j = j * num_bins / (num_bins - 1)."""
+    if num_bins == 1:
+        return np.zeros(1, F32)
+    return (np.arange(num_bins, dtype=np.float64) * (num_bins / (num_bins - 1.0))).astype(F32)
+
+
+def kde_kernel_values(V: np.ndarray) -> np.ndarray:
+    """marginalPdf's kernel_values (utils.py:995-996) for a 2-D input [m, c] with num_bins == c, as every call site has it
+    (topology_attack.py:199-201: num_bins = feature_adj.shape[0] on N x N operands; :244-246, :261-263: the operand's
+    width): `values - bins.unsqueeze(0).unsqueeze(0)` broadcasts the bins over the LAST axis, so entry (i, j) is
+    compared with bin j only: k_ij = exp(-0.5 ((V_ij - b_j) / sigma)^2)."""
+    b = kde_bins(V.shape[1])
+    res = (V.astype(F32) - b[None, :]).astype(F32)
+    t = (res / F32(KDE_SIGMA)).astype(F32)
+    with np.errstate(under="ignore"):
+        return np.exp(F32(-0.5) * t * t).astype(F32)
+
+
+def kde_mi_grads(X, Y, need_x=True, need_y=True):
+    """MutualInformation(sigma=0.4, num_bins=X.shape[1], normalize=True)(X, Y)[0] (utils.py:1014-1049) and its gradients.
+    pdf = mean_i k / (sum + eps) (utils.py:998-1000); joint = k1^T k2 / (sum + eps) (:1004-1010); entropies with log2(p + eps)
+    (:1033-1036); 2 (H1 + H2 - H12) / (H1 + H2) (:1038-1041).  Columns whose kernel values are all exactly zero in float32
+    (bins far from every value: all but the first ~6 on N x N operands with values in [0, 1]) add nothing to any sum and are
+    skipped in the joint -- the same numbers, not an approximation."""
+    k1, k2 = kde_kernel_values(X), kde_kernel_values(Y)
+    m = X.shape[0]
+    ln2 = math.log(2.0)
+
+    def marginal(k):
+        q = k.mean(0, dtype=np.float64)
+        nrm = q.sum() + KDE_EPS
+        p = q / nrm
+        H = -(p * np.log2(p + KDE_EPS)).sum()
+        return p, nrm, H
+
+    p1, n1, H1 = marginal(k1)
+    p2, n2, H2 = marginal(k2)
+    c1, c2 = np.flatnonzero(k1.any(0)), np.flatnonzero(k2.any(0))
+    J = k1[:, c1].astype(np.float64).T @ k2[:, c2].astype(np.float64)
+    nJ = J.sum() + KDE_EPS
+    P = J / nJ
+    H12 = -(P * np.log2(P + KDE_EPS)).sum()
+    S = H1 + H2
+    val = F32(2.0 * (S - H12) / S)
+    # out = 2 - 2 H12 / S
+    g_H12, g_H = -2.0 / S, 2.0 * H12 / (S * S)
+    dH = lambda p: -(np.log2(p + KDE_EPS) + p / ((p + KDE_EPS) * ln2))
+    gP = g_H12 * dH(P)
+    gJ = (gP - (gP * P).sum()) / nJ
+
+    def back(k, V, p, nrm, cols, gk_joint):
+        gp = g_H * dH(p)
+        gq = (gp - (gp * p).sum()) / nrm
+        gk = np.repeat((gq / m)[None, :], m, 0)
+        gk[:, cols] += gk_joint
+        b = kde_bins(V.shape[1]).astype(np.float64)
+        return (gk * k * (-(V.astype(np.float64) - b[None, :]) / (KDE_SIGMA * KDE_SIGMA))).astype(F32)
+
+    gX = back(k1, X, p1, n1, c1, k2[:, c2].astype(np.float64) @ gJ.T) if need_x else None
+    gY = back(k2, Y, p2, n2, c2, k1[:, c1].astype(np.float64) @ gJ) if need_y else None
+    return val, gX, gY
+
+
 _CALC = {
     "HSIC": linear_hsic_grads, "MSELoss": mse_grads, "KL": kl_grads,
-    "CKA": linear_cka_grads, "DP": dp_grads,
+    "CKA": linear_cka_grads, "DP": dp_grads, "KDE": kde_mi_grads,
 }
 
 

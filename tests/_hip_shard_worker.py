@@ -158,3 +158,107 @@ def run_workload_rank(rank, world, port, spec, out):
         with open(f"{out}.rank{rank}.err", "w") as fh:
             fh.write(traceback.format_exc())
         raise
+
+
+def run_cora_class(name, epochs=None):
+    """PGDAttack.attack on a Cora fixture with the reference-trained weights it carries (tests/test_gpu_parity.py:_run_cora):
+    returns (fixture, modified_adj, AUC, model).  Under an initialised process group the class shards the attack itself."""
+    import argparse
+    import numpy as np
+    import torch
+    import mcgra_loader
+    pkg = mcgra_loader.load()
+    from mc_gra_amd import engine as E
+    from oracle import mcgra_oracle as O
+    from tests import helpers as H
+    z = H.load_cora(name)
+    if epochs is not None:
+        z["epochs"] = np.array(epochs)
+    w = O.GCNWeights([z["W0"], z["W1"]], [z["b0"], z["b1"]], z["Wlin"], z["blin"])
+    victim, emb = H.FakeGCN(w), H.FakeGCN(w)
+    X, adj, lab = z["features"], z["adj"], z["labels"]
+    fadj = H.cora_feature_adj(X)
+    d = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")
+    Y_A, H_A2 = E.gcn_forward(d(X), d(adj), [d(x) for x in w.W], [d(x) for x in w.b], d(w.Wlin), d(w.blin), emb_nlayer=2)
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=H_A2, Y_A=Y_A, nnodes=adj.shape[0], loss_type="CE", device="cuda:0")
+    if H.a0_of(z) is not None:
+        model.adj_changes = H.a0_of(z)
+    args = argparse.Namespace(max_eval=100, lr=0, dataset="cora", eps=0, measure=str(z["measure"]), useH_A=True, useY_A=True,
+                              useY=True, w1=0, w2=0, w6=0, w7=0, w8=0, w9=0, w10=0)
+    model.attack(args, None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]), fadj, 0, 0, 0, None, None,
+                 z["idx_test"], adj, X, np.zeros_like(adj), lab, z["idx_attack"], float(z["num_edges"]), 0,
+                 epochs=int(z["epochs"]), label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    final = model.modified_adj.cpu().numpy()
+    return z, final, O.metric_pool(adj, final, z["idx_attack"]), model
+
+
+def run_class_rank(rank, world, port, spec, out):
+    """One rank of PGDAttack.attack under a process group (gloo: the ranks share the GPU): the class finds the group, shards
+    the attack over the ranks (mc-gra_amd/topology_attack.py) and returns the same modified_adj on every rank."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+        os.environ.pop("MCGRA_KEEP_GSYM", None)
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        z, final, auc, model = run_cora_class(spec["name"], spec.get("epochs"))
+        sp = z["sample_pos"]
+        np.savez(f"{out}.rank{rank}.npz", auc=auc, final_sample=final[sp[:, 0], sp[:, 1]], final_sum=final.astype(np.float64).sum(),
+                 acc_test=np.array(model.history.get("acc_test", [])), sharded_world=model.history["path"]["sharded_world"],
+                 fused_steps=model.history["path"]["fused_steps"], general_steps=model.history["path"]["general_steps"],
+                 collectives=model.history["path"]["collectives"],
+                 adj_changes_sum=float(model.adj_changes.double().sum()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        with open(f"{out}.rank{rank}.err", "w") as fh:
+            fh.write(traceback.format_exc())
+        raise
+
+
+def main_args(root, extra=()):
+    """Command line of the main.py runs below: cora, HSIC with the README's weights, 6 epochs, from a seeded sparse start."""
+    return ["--dataset", "cora", "--dataset_root", str(root), "--w1", "0.01", "--w2", "0.01", "--w6", "10", "--w7", "10",
+            "--w9", "10", "--w10", "1000", "--lr", "-4.5", "--useH_A", "--useY_A", "--useY", "--measure", "HSIC",
+            "--epochs", "6"] + list(extra)
+
+
+def run_main(argv, n):
+    """mc_gra_amd.main.run from a seeded sparse start (adj_changes = U[0,1) / n: the origin is a fixed point of the HSIC loss)."""
+    import numpy as np
+    import mcgra_loader
+    mcgra_loader.load()
+    from mc_gra_amd import main as M
+    args = M.build_parser().parse_args(argv)
+    args.adj_changes_init = (np.random.RandomState(123).rand(n * (n - 1) // 2) / n).astype(np.float32)
+    return M.run(args)
+
+
+def run_main_rank(rank, world, port, argv, n, cwd, out):
+    """One rank of `torchrun ... main.py` on a shared GPU (MCGRA_SHARED_GPU=1: gloo, host-staged): main.py joins the group
+    itself, before it touches the GPU."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), OMP_NUM_THREADS="2", MCGRA_SHARED_GPU="1")
+        os.environ.pop("MCGRA_KEEP_GSYM", None)
+        os.chdir(cwd)
+        import json
+        res = run_main(argv, n)
+        with open(f"{out}.rank{rank}.json", "w") as fh:
+            json.dump(res, fh)
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        with open(f"{out}.rank{rank}.err", "w") as fh:
+            fh.write(traceback.format_exc())
+        raise

@@ -193,3 +193,46 @@ def test_live_traffic_accounting(monkeypatch):
     assert out["outside_product_bytes_per_step"] == ((2 * 400.0 + 900.0) + 3 * (2 * 200.0 + 16.0)) * 1024
     monkeypatch.setattr(shutil, "which", lambda name: None)
     assert bench.live_traffic("synthetic-10k-hsic", 0) is None
+
+
+def _class_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mcgra_loader
+    mcgra_loader.load()
+    from mc_gra_amd import topology_attack as TA
+    d, w, r, staged = TA._dist_group()
+    t = torch.full((3,), float(rank + 1))
+    TA._bcast(d, t, staged)
+    q.put((rank, w, r, staged, t.tolist()))
+    dist.destroy_process_group()
+
+
+def test_class_finds_the_process_group_and_knows_what_it_can_shard():
+    """PGDAttack.attack's view of torch.distributed (no GPU): no group -> one rank; a gloo group -> world, rank, host-staged
+    exchanges, rank 0's tensors on every rank; and which configurations the row-block sharded fused step covers (the rest
+    run replicated and say so)."""
+    import mcgra_loader
+    mcgra_loader.load()
+    from mc_gra_amd import topology_attack as TA
+    assert TA._dist_group() == (None, 1, 0, False)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_class_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out == [(0, 2, 0, True, [1.0, 1.0, 1.0]), (1, 2, 1, True, [1.0, 1.0, 1.0])]
+    why = TA.PGDAttack._replicated_reason
+    ok = dict(measure="HSIC", eps=0.0, ori_np=None, Ws=None, act="relu", head_act="none", loss_type="CE", n=2708,
+              dims=[1433, 16, 16], w1=0.01, w2=0.01, num_edges=1e30)
+    assert why(**ok) is None
+    for change, word in ((dict(measure="MSELoss"), "MSELoss"), (dict(eps=0.1), "eps"), (dict(ori_np=object()), "ori_adj"),
+                         (dict(Ws=[1]), "GraphSAGE"), (dict(act="elu"), "GAT"), (dict(n=300), "1024"),
+                         (dict(dims=[10, 64, 64]), "width"), (dict(w1=0, w2=0), "w1"), (dict(num_edges=5.0), "projection"),
+                         (dict(loss_type="CW"), "CW")):
+        assert word in why(**dict(ok, **change)), change

@@ -58,7 +58,12 @@ def _reference_run_errors(ctx, z, z64, name, steps=None, check=True, mutate=None
     pi, pj = _tril_pos(z["packed_pos"])
     ti, tj = torch.as_tensor(pi, device=dev), torch.as_tensor(pj, device=dev)
     sd, sc = int(z[f"{name}_a0_seed"]), float(z[f"{name}_a0_scale"])
-    eng, inp, adj_dev = bench.build_engine(pkg, torch, dev, WL, seed)
+    if mutate:          # the defect injector is accepted only by an engine created under MCGRA_TESTING=1
+        os.environ["MCGRA_TESTING"] = "1"
+    try:
+        eng, inp, adj_dev = bench.build_engine(pkg, torch, dev, WL, seed)
+    finally:
+        os.environ.pop("MCGRA_TESTING", None)
     assert eng.product_mode() == 3, "the default product of this size is the 2-plane fp16 split"
     if mutate:
         eng.test_mutate(mutate)
@@ -206,6 +211,47 @@ def test_state_invariants_and_determinism_at_10k(ctx):
         torch.cuda.empty_cache()
     assert torch.equal(outs[0][0], outs[1][0]), "two runs must give identical bits"
     assert outs[0][1] == outs[1][1]
+
+
+def test_the_build_bench_times_gives_the_parity_builds_bits_at_10k(ctx, monkeypatch):
+    """Every in-process parity test creates its engines under MCGRA_KEEP_GSYM=1 (k_tail_adam / k_adam_sym then also store the
+    mirrored packed gradient, "G_sym"); bench.py and a user's run do not.  The two forms of the Adam pass must be the same
+    arithmetic: three bench steps (step + monitoring forward) of the headline workload WITHOUT the switch give the state of the
+    engine WITH it, bit for bit -- and the engine without it refuses to hand out G_sym."""
+    pkg, torch, bench, dev = ctx
+    outs = []
+    for keep in (True, False):
+        if keep:
+            monkeypatch.setenv("MCGRA_KEEP_GSYM", "1")
+        else:
+            monkeypatch.delenv("MCGRA_KEEP_GSYM", raising=False)
+        eng, inp, _ = _engine(ctx)
+        for _ in range(3):
+            eng.step(); eng.monitor()
+        outs.append(eng.buffer("M").clone())
+        assert eng.fused_steps() == 3
+        if keep:
+            assert float(eng.buffer("G_sym").abs().max()) > 0
+        else:
+            with pytest.raises(Exception, match="MCGRA_KEEP_GSYM"):
+                eng.buffer("G_sym")
+        del eng
+        torch.cuda.empty_cache()
+    monkeypatch.setenv("MCGRA_KEEP_GSYM", "1")
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_defect_injector_is_refused_outside_a_testing_engine(ctx, monkeypatch):
+    """mcgra_attack_test_mutate (the mutation guards' defect injector) is accepted only by an engine created under
+    MCGRA_TESTING=1; a production engine refuses to arm it (disarming is always allowed)."""
+    pkg, torch, bench, dev = ctx
+    monkeypatch.delenv("MCGRA_TESTING", raising=False)
+    eng, _, _ = bench.build_engine(pkg, torch, dev, "cora-shape-hsic", 0)
+    with pytest.raises(Exception, match="MCGRA_TESTING"):
+        eng.test_mutate("p1")
+    eng.test_mutate(None)
+    del eng
+    torch.cuda.empty_cache()
 
 
 def test_early_tail_pass_beside_the_product_is_bit_identical_at_10k(ctx, monkeypatch):

@@ -252,3 +252,68 @@ def test_plain_bench_measures_its_traffic_live(tmp_path):
         assert compulsory <= r["traffic"] <= 12 * compulsory, (r["traffic"], compulsory)
         so = line["step_outside_product"]
         assert so["bytes_source"].startswith("rocprofv3 --pmc") and 8 * n * n * 4 <= so["bytes_per_step"] <= 40 * n * n * 4
+
+
+# ---- the sharded step behind the class surface and main.py (north_star: "keep the PGDAttack / BaseAttack class surface and
+# main.py entry" AND "partition ... row-block across up to 8 MI355X") ------------------------------------------------------
+def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path):
+    """Two processes call PGDAttack.attack on Cora (reference-trained weights of cora_hsic_sparse.npz, HSIC, sparse start)
+    under a process group: the class builds RowBlockPlan + HipShardBackend + ShardedStepper itself, every step is a fused
+    row-block step, both ranks return the SAME modified_adj, its AUC equals the 1-process run's to 1e-6 and the REFERENCE's
+    (the fixture's) to 1e-4."""
+    out = str(tmp_path / "cls")
+    _run_ranks(W.run_class_rank, 2, (dict(name="cora_hsic_sparse"),), out)
+    z, final1, auc1, model1 = W.run_cora_class("cora_hsic_sparse")
+    assert model1.history["path"]["sharded_world"] == 1
+    ranks = [np.load(f"{out}.rank{r}.npz") for r in range(2)]
+    epochs = int(z["epochs"])
+    for r in ranks:
+        assert int(r["sharded_world"]) == 2 and int(r["fused_steps"]) == epochs and int(r["general_steps"]) == 0
+        assert int(r["collectives"]) > 8 * epochs
+        assert abs(float(r["auc"]) - auc1) <= 1e-6, (float(r["auc"]), auc1)
+        assert abs(float(r["auc"]) - float(z["auc"])) <= 1e-4, (float(r["auc"]), float(z["auc"]))
+        assert len(r["acc_test"]) == epochs and np.allclose(r["acc_test"], model1.history["acc_test"])
+    assert np.array_equal(ranks[0]["final_sample"], ranks[1]["final_sample"]), "every rank returns the same modified_adj"
+    assert float(ranks[0]["final_sum"]) == float(ranks[1]["final_sum"])
+    assert float(ranks[0]["adj_changes_sum"]) == float(ranks[1]["adj_changes_sum"]) > 0      # adj_changes readable after the run
+    sp = z["sample_pos"]
+    assert np.mean(np.abs(ranks[0]["final_sample"] - final1[sp[:, 0], sp[:, 1]]) > 1e-3) < 1e-3
+
+
+def test_main_entry_under_a_launcher_shards_the_attack(pkg, tmp_path, monkeypatch):
+    """`torchrun --nproc-per-node 2 main.py --dataset cora --measure HSIC ...` (two fork-server processes with the launcher's
+    environment on the box's one GPU, MCGRA_SHARED_GPU=1): main.py joins the group before it touches the GPU, trains the
+    victim, rank 0's weights go to every rank, PGDAttack.attack runs ONE row-block sharded attack; the AUC of both ranks
+    equals the plain 1-process `main.py` run's to 1e-6 and only rank 0 writes the log."""
+    import scipy.sparse as sp
+    z = H.load_cora("cora_hsic_sparse")
+    A = sp.csr_matrix(np.triu(z["adj"], 1)); X = sp.csr_matrix(z["features"])
+    root = tmp_path / "dataset"; root.mkdir()
+    np.savez(root / "cora.npz", adj_data=A.data, adj_indices=A.indices, adj_indptr=A.indptr, adj_shape=A.shape,
+             attr_data=X.data, attr_indices=X.indices, attr_indptr=X.indptr, attr_shape=X.shape, labels=z["labels"])
+    n = z["adj"].shape[0]
+    argv = W.main_args(root)
+    cwd2 = tmp_path / "w2"; cwd2.mkdir()
+    out = str(tmp_path / "main2")
+    ctx = mp.get_context("forkserver")
+    port = _free_port()
+    ps = [ctx.Process(target=W.run_main_rank, args=(r, 2, port, argv, n, str(cwd2), out)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(900)
+    errs = [open(f"{out}.rank{r}.err").read() for r in range(2) if os.path.exists(f"{out}.rank{r}.err")]
+    assert not errs and all(p.exitcode == 0 for p in ps), "\n".join(errs)
+    res2 = [json.load(open(f"{out}.rank{r}.json")) for r in range(2)]
+    cwd1 = tmp_path / "w1"; cwd1.mkdir()
+    monkeypatch.chdir(cwd1)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    res1 = W.run_main(argv, n)
+    assert res1["path"]["sharded_world"] == 1 and res1["path"]["fused_steps"] == 6
+    for r in res2:
+        assert r["path"]["sharded_world"] == 2 and r["path"]["fused_steps"] == 6 and r["path"]["general_steps"] == 0
+        assert abs(r["auc_all"] - res1["auc_all"]) <= 1e-6, (r["auc_all"], res1["auc_all"])
+    assert res2[0]["auc_all"] == res2[1]["auc_all"]
+    assert 0.8 < res1["auc_all"] < 0.95
+    assert os.path.exists(cwd2 / "results" / "result.txt") and len(open(cwd2 / "results" / "result.txt").read().split("current parameter")) == 2

@@ -119,21 +119,6 @@ def test_syrk_symm_lower_tile_storage(pkg, torch_, n, k):
     assert np.abs(got - refp).max() <= 1e-5 * np.abs(refp).max()
 
 
-def test_engine_sym_equals_full(pkg, torch_, monkeypatch):
-    """The symmetric GEMM path gives the same step as full Gram GEMMs (MCGRA_NO_SYM=1)."""
-    z = H.load_case("s200_hsic_init")
-    outs = []
-    for nosym in ("0", "1"):
-        monkeypatch.setenv("MCGRA_NO_SYM", nosym)
-        eng = H.engine_from(pkg, z)
-        for _ in range(2):
-            eng.step()
-        outs.append((eng.buffer("G_sym").cpu().numpy(), eng.buffer("M").cpu().numpy()))
-        eng.close()
-    assert np.abs(outs[0][0] - outs[1][0]).max() <= 2e-5 * np.abs(outs[1][0]).max()
-    assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-6
-
-
 # ------------------------------------------------------------------ standalone ops
 def test_ops_against_reference_goldens(pkg, torch_):
     from mc_gra_amd import engine as E
@@ -1075,45 +1060,6 @@ def test_split_bf16_product_against_fp64(pkg, torch_, n, arith):
     assert err.max() <= 4 * (np.abs(f32 - ref) / scale).max() + 2e-7
 
 
-_SPLIT_LOOP_PROBE = r"""
-import hashlib, os, sys
-sys.path.insert(0, os.environ["MCGRA_TEST_ROOT"])
-import numpy as np
-import torch
-import mcgra_loader
-mcgra_loader.load()
-from mc_gra_amd import engine as E
-for n in (1000, 2708, 4100):
-    rng = np.random.RandomState(n)
-    F = rng.randn(n, 24).astype(np.float32)
-    S = (F @ F.T).astype(np.float32); S = (S + S.T) * 0.5
-    X = (rng.rand(n, n).astype(np.float32) - 0.3) * 0.1
-    sub = rng.rand(n).astype(np.float32) * 0.05
-    outs = [E.ssymm_split_f16(torch.tensor(S, device="cuda"), torch.tensor(X, device="cuda"), torch.tensor(sub, device="cuda")).cpu().numpy()
-            for _ in range(3)]
-    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
-    print("DIGEST", n, hashlib.sha1(outs[0].tobytes()).hexdigest())
-"""
-
-
-def test_split_loop_variants_give_the_default_loops_bits(pkg):
-    """MCGRA_SPLIT_LOOP=2 (peeled loop, copies first) and =3 (two wave groups one phase apart, four raw barriers per
-    step, counted vmcnt waits) keep the MFMA order of every accumulator: their results are the default loop's, bit for
-    bit, at sizes with a split-K tail and with padded chunks -- a lost copy or an early fragment read would show here
-    (the switch is read once per process: one child per value)."""
-    import subprocess
-    import sys
-    digests = {}
-    for mode in ("0", "2", "3"):
-        env = dict(os.environ, MCGRA_SPLIT_LOOP=mode, MCGRA_TEST_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        r = subprocess.run([sys.executable, "-c", _SPLIT_LOOP_PROBE], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests[mode] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
-        assert len(digests[mode]) == 3
-    assert digests["2"] == digests["0"]
-    assert digests["3"] == digests["0"]
-
-
 @pytest.mark.parametrize("scale", [1.0, 3.0e-12, 7.0e11])
 def test_split_f16_product_operand_scales(pkg, torch_, scale):
     """The fp16 planes live in [2^-24, 2^16): the kernel's exact power-of-two operand scales must make the result
@@ -1296,15 +1242,9 @@ def test_gram_evaluation_on_the_split_kernel_matches_fp32_symm(pkg, monkeypatch,
     z = _synthetic_case(1100, 11, (16, 16), 4, seed=21, weight_param=wp)
     monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
     split = H.engine_from(pkg, z)
-    monkeypatch.setenv("MCGRA_GRAM_TRI", "0")           # all tiles of the two Grams instead of the mirrored lower triangle
-    full = H.engine_from(pkg, z)
-    monkeypatch.delenv("MCGRA_GRAM_TRI")
     monkeypatch.setenv("MCGRA_GRAM_SPLIT", "0")
     f32 = H.engine_from(pkg, z)
     monkeypatch.delenv("MCGRA_GRAM_SPLIT"); monkeypatch.delenv("MCGRA_NO_LOWRANK")
-    full.step()
-    full_g = full.buffer("G_sym").clone()
-    del full
     o = H.oracle_from(z)
     for t in range(3):
         a, b = split.step(want_scalars=True), f32.step(want_scalars=True)
@@ -1312,8 +1252,6 @@ def test_gram_evaluation_on_the_split_kernel_matches_fp32_symm(pkg, monkeypatch,
         ga, gb = split.buffer("G_sym"), f32.buffer("G_sym")
         scale = float(gb.abs().max())
         assert float((ga - gb).abs().max()) / scale < 2e-5, t
-        if t == 0:      # a mirrored tile equals the one the full launch computes up to the order of its two cross terms
-            assert float((ga - full_g).abs().max()) / scale < 2e-6
         # (not for c2 alone: that gradient is a small difference of large Gram sums, any fp32 evaluation of it carries
         # 1e-3 .. 1e-2 of noise -- the two HIP evaluations above agree 100 x closer than either does with numpy's)
         if wp[0] != 0:
