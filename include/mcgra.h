@@ -46,7 +46,9 @@ enum mcgra_measure {
   MCGRA_MEASURE_MSE = 1,  /* torch.nn.MSELoss  topology_attack.py:194 */
   MCGRA_MEASURE_KL = 2,   /* PGDAttack.calc_kl topology_attack.py:483 */
   MCGRA_MEASURE_CKA = 3,  /* CudaCKA.linear_CKA utils.py:1091 */
-  MCGRA_MEASURE_DP = 4    /* PGDAttack.dot_product topology_attack.py:480 */
+  MCGRA_MEASURE_DP = 4,   /* PGDAttack.dot_product topology_attack.py:480 */
+  MCGRA_MEASURE_KDE = 5   /* utils.MutualInformation(sigma=0.4, num_bins=<operand width>, normalize=True) utils.py:980,
+                             topology_attack.py:199-201, :244-246, :261-263 */
   /* "KDE" (utils.MutualInformation, utils.py:980) hard-codes cuda:0 and cannot
      run on the reference CPU path; not provided. */
 };

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCGRA_LIB_PATH") or os.path.join(_HERE, "libmcgra_hip.so")   # override: A/B builds
 
 MAX_LAYERS = 8
-MEASURES = {"HSIC": 0, "MSELoss": 1, "KL": 2, "CKA": 3, "DP": 4}
+MEASURES = {"HSIC": 0, "MSELoss": 1, "KL": 2, "CKA": 3, "DP": 4, "KDE": 5}
 
 # every symbol include/mcgra.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [

@@ -188,9 +188,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
               cfg->nclass, cfg->n_attack);
     return MCGRA_EINVAL;
   }
-  if (cfg->measure < MCGRA_MEASURE_HSIC || cfg->measure > MCGRA_MEASURE_DP) {
-    set_error("measure %d: only HSIC, MSELoss, KL, CKA, DP exist on this path (KDE needs cuda:0-only utils.py:991)",
-              cfg->measure);
+  if (cfg->measure < MCGRA_MEASURE_HSIC || cfg->measure > MCGRA_MEASURE_KDE) {
+    set_error("measure %d: HSIC, MSELoss, KL, CKA, DP, KDE (topology_attack.py:194-208)", cfg->measure);
+    return MCGRA_ENOSUP;
+  }
+  if (cfg->measure == MCGRA_MEASURE_KDE && (cfg->dims[cfg->emb_nlayer] > KDE_MAXC || cfg->nclass > KDE_MAXC)) {
+    set_error("measure KDE: embedding width %d / %d classes; the c x c joint of utils.MutualInformation is built for widths <= %d",
+              cfg->dims[cfg->emb_nlayer], cfg->nclass, KDE_MAXC);
     return MCGRA_ENOSUP;
   }
   if (cfg->shard_world < 0 || (cfg->shard_world == 0 && (cfg->row_begin != 0 || (cfg->row_end != 0 && cfg->row_end < cfg->n)))) {
@@ -247,6 +251,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   }
   if (cfg->measure == MCGRA_MEASURE_KL) { A_(XC, nn); }      // XC holds softmax(feature_adj) rows
   if (cfg->measure == MCGRA_MEASURE_DP) { A_(KY, nn); A_(XC, nn); }
+  if (cfg->measure == MCGRA_MEASURE_KDE) { A_(kde, kde_scratch_doubles((int)n)); }
   A_(cmean, ld); A_(d, ld); A_(r, ld); A_(rowpart, ld); A_(colpart, (size_t)h->nstrips * ld); A_(gd, ld); A_(nrm, ld); A_(cnt, ld);
   A_(rowmin, ld); A_(rowmax, ld); A_(mm, 4);
   A_(mask_seq_dev, 1);
@@ -623,6 +628,10 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
     launch_sumsq(st, (size_t)width * hm, h->Q, h->scal + slot);
     CHK(eg(h, st, false, true, na, width, width, 1.f, Xg, hm, h->Q, hm, 0.f, h->Gg, hm));
     launch_scatter_add_rows_invnorm(st, na, width, h->Gg, hm, h->idx, h->scal + slot, (float)k_signed, G, ldg);
+  } else if (h->cfg.measure == MCGRA_MEASURE_KDE) {
+    // MutualInformation(num_bins = width)(X[idx], Y[idx])[0] (:244-249, :261-265): k_signed d / dY, rows scattered back
+    launch_kde_term(st, na, width, width, Xg, hm, h->Yg, hm, k_signed, nullptr, 0, false, h->Gg, hm, false, h->scal + slot, h->kde);
+    launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, 1.f, G, ldg);
   } else if (h->cfg.measure == MCGRA_MEASURE_KL) {   // calc_kl(X[idx], Y[idx]) (:483-487), X constant
     launch_kl_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->rowvals + 7 * (size_t)h->ld);
     launch_reduce_rows(st, h->rowvals + 7 * (size_t)h->ld, na, 1, h->scal + slot);
@@ -769,7 +778,7 @@ int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out, bool h
     const double norm_a = sqrt(0.5 * s[S_SQ]);
     const double origin = nll + norm_a * 0.001;
     double c1v = 0, c2v = 0;
-    const bool kl = c.measure == MCGRA_MEASURE_KL, dp = c.measure == MCGRA_MEASURE_DP;
+    const bool kl = c.measure == MCGRA_MEASURE_KL || c.measure == MCGRA_MEASURE_KDE, dp = c.measure == MCGRA_MEASURE_DP;      // (KDE: the slot holds the value, as for KL)
     if (cka) {
       double cst[8];
       MCGRA_HIP(hipMemcpy(cst, h->cst, sizeof(cst), hipMemcpyDeviceToHost));
@@ -953,6 +962,16 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       CHK(eg(h, st, false, true, n, n, n, 1.f, h->ADJN, ld, h->KY, ld, 0.f, h->XC, ld));         // d/dY = X P^T
       launch_axpy_invnorm(st, n, ld, h->XC, h->scal + S_H2, (float)k2, h->G_A1);
     }
+  } else if (c.measure == MCGRA_MEASURE_KDE) {
+    // calc = MutualInformation(sigma=0.4, num_bins=N) (:199-201): c1 = k1 calc(feature_adj, adj_norm)[0] (:213-216),
+    // c2 = k2 calc(adj_norm, modified_adj1)[0] (:222-225).  Entry (i, j) of an operand meets bin j only and bins j >= 7 are
+    // out of reach of values <= 2 in float32 (kde_kernels.hip): the terms live on the first KDE_NXN_COLS columns.
+    launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
+                     h->G_A1, h->rowvals);
+    launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);      // only the entropy slots are non-zero
+    const int kc = n < KDE_NXN_COLS ? n : KDE_NXN_COLS;
+    if (use1) launch_kde_term(st, n, kc, n, h->FADJ, ld, h->ADJN, ld, k1, nullptr, 0, false, h->G_ADJN, ld, true, h->scal + S_H1, h->kde);
+    if (use2) launch_kde_term(st, n, kc, n, h->ADJN, ld, h->A1, ld, k2, h->G_ADJN, ld, true, h->G_A1, ld, true, h->scal + S_H2, h->kde);
   } else if (c.measure == MCGRA_MEASURE_KL) {
     launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
                      h->G_A1, h->rowvals);

@@ -91,6 +91,14 @@ void launch_scale(hipStream_t st, size_t count, float* p, float v);
 void launch_count_idx(hipStream_t st, int m, const int* idx, float* cnt);
 void launch_argmax_eq(hipStream_t st, int m, int c, const float* logp, int ld, const int* idx, const int* labels, int* correct);
 
+// ---- kde_kernels.hip (measure KDE: utils.MutualInformation as `calc`, utils.py:980-1049)
+constexpr int KDE_MAXC = 32;        // widest operand (hidden width, classes)
+constexpr int KDE_NXN_COLS = 8;     // columns of an N x N operand whose kernel values can be non-zero in float32 (values <= 2)
+size_t kde_table_doubles();
+size_t kde_scratch_doubles(int m);
+void launch_kde_term(hipStream_t st, int m, int c, int nb, const float* X, int ldx, const float* Y, int ldy, double coef,
+                     float* GX, int ldgx, bool accx, float* GY, int ldgy, bool accy, double* val_out, double* scratch);
+
 // ---- lowrank_kernels.hip (low-rank linear_HSIC(adj_norm, modified_adj1))
 size_t lr_stats_doubles(int h);
 int lr_decode_slabs(int n);

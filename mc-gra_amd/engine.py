@@ -206,7 +206,7 @@ class AttackEngine:
         for i, d in enumerate(self.dims):
             cfg.dims[i] = d
         if measure not in _lib.MEASURES:
-            raise ValueError(f"measure {measure!r}: KDE needs cuda:0-only utils.MutualInformation and is not provided")
+            raise ValueError(f"measure {measure!r}: topology_attack.py:194-208 knows {sorted(_lib.MEASURES)}")
         cfg.measure = _lib.MEASURES[measure]
         cfg.n_attack = int(n_attack)
         cfg.weight_sup = float(weight_sup)

@@ -7,7 +7,7 @@ H_A / Y_A, run PGDAttack on the MI355X hot path, report the recovered-adjacency 
     python mc-gra_amd/main.py ...                             (stand-alone; bootstraps the loader itself)
 
 --arch gcn | sage | gat select the victim family as main.py:175-231 does.  Not provided (each exits with a message
-naming the reference line): --mode search/baseline/gaussian/gcn_attack, --measure KDE.
+naming the reference line): --mode search/baseline/gaussian/gcn_attack.
 
 Several GPUs of one node -- one process per GPU, RCCL over xGMI:
     torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 mc-gra_amd/main.py --dataset ... --measure HSIC ...
@@ -148,8 +148,6 @@ def run(args):
     rank, world = init_distributed(args)
     device = torch.device(args.device)
     np.random.seed(args.seed); random.seed(args.seed); torch.manual_seed(args.seed)       # main.py:142-146
-    if args.measure == "KDE":
-        sys.exit("measure=KDE needs utils.MutualInformation (utils.py:980), which is cuda:0-only and not provided")
     data = Dataset(root=args.dataset_root, name=args.dataset, setting='GCN')
     adj, features, labels, init_adj = data.adj, data.features, data.labels, data.init_adj
     idx_train, idx_val, idx_test = data.idx_train, data.idx_val, data.idx_test

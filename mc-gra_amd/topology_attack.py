@@ -8,9 +8,9 @@ C ABI of include/mcgra.h; this file only validates arguments, moves the inputs
 to HBM and drives the engine.  There is no CPU path: without a HIP device or
 without libmcgra_hip.so it raises.
 
-Arguments the reference accepts but this path does not cover yet raise
-NotImplementedError naming the reference line (measure KDE,
-an embedding whose weights differ from victim_model.gc).
+Arguments the reference accepts but this path does not cover raise
+NotImplementedError naming the reference line (an embedding whose weights differ
+from victim_model.gc).
 
 Several GPUs: when ``torch.distributed`` is initialised with more than one rank (``torchrun ... main.py``: one process
 per GPU, backend "nccl" = RCCL), ``attack`` runs ONE attack row-block sharded over the ranks (mc-gra_amd/sharded.py,
@@ -241,8 +241,8 @@ class PGDAttack(BaseAttack):
             w7 = args.w8
             w9, w10 = args.w9, args.w10
         measure = args.measure
-        if measure not in ("HSIC", "MSELoss", "KL", "DP", "CKA"):
-            raise NotImplementedError(f"measure {measure!r} (topology_attack.py:197-208) is not on the HIP path yet")
+        if measure not in ("HSIC", "MSELoss", "KL", "DP", "CKA", "KDE"):
+            raise ValueError(f"measure {measure!r}: topology_attack.py:194-208 knows HSIC, MSELoss, KL, KDE, CKA, DP")
         eps = float(getattr(args, "eps", 0) or 0)
 
         n = self.nnodes

@@ -320,10 +320,16 @@ KDE_EPS = 1e-10               # self.epsilon (utils.py:988)
 
 
 def kde_bins(num_bins: int) -> np.ndarray:
-    """torch.linspace(0, num_bins, num_bins).float() (utils.py:990-991): b_j = j * num_bins / (num_bins - 1)."""
+    """torch.linspace(0, num_bins, num_bins).float() (utils.py:990-991) as torch evaluates it in float32: step =
+    num_bins / (num_bins - 1), b_j = step * j in the lower half and fma(-step, num_bins - 1 - j, num_bins) in the upper."""
+    f4 = np.float32        # the bins are `.float()` whatever dtype the operands have (also in a float64 evaluation)
     if num_bins == 1:
-        return np.zeros(1, F32)
-    return (np.arange(num_bins, dtype=np.float64) * (num_bins / (num_bins - 1.0))).astype(F32)
+        return np.zeros(1, f4)
+    step = np.float64(f4(f4(num_bins) / f4(num_bins - 1)))
+    j = np.arange(num_bins)
+    lo = (step * j).astype(f4)
+    hi = (np.float64(num_bins) - step * (num_bins - 1 - j)).astype(f4)      # one rounding: torch's kernel uses a fused multiply-add
+    return np.where(j < num_bins // 2, lo, hi).astype(f4)
 
 
 def kde_kernel_values(V: np.ndarray) -> np.ndarray:

@@ -13,6 +13,10 @@ the computed path):
                               the package is not installed here, so an empty
                               module object satisfies the import.
   * matplotlib Agg backend  - plt.cla() at topology_attack.py:122.
+  * ``torch.linspace(..., device='cuda:0')`` - utils.MutualInformation (measure KDE) asks for its bins on 'cuda:0'
+                              (utils.py:990-991) although every other tensor of the run follows ``self.device``; on this
+                              CPU-only torch the keyword is dropped (the bins are then where the operands are).  No
+                              arithmetic changes: the same linspace values, the same float32 ops.
 The attack needs ./saved_data/<dataset>.npy (label adjacency, main.prepare()
 main.py:440-450; the zip that ships it is a missing large blob), so the script
 works in a temp cwd and writes label_adj[i,j] = (labels[i] == labels[j]) there.
@@ -41,6 +45,13 @@ def _import_reference():
     matplotlib.use("Agg")
     sys.path.insert(0, REF)
     import torch  # noqa
+    _linspace = torch.linspace
+
+    def linspace_where_the_operands_are(*a, **k):
+        k.pop("device", None)
+        return _linspace(*a, **k)
+
+    torch.linspace = linspace_where_the_operands_are
     import utils  # noqa  (reference utils.py)
     import topology_attack  # noqa
     from models.gcn import GCN, embedding_GCN  # noqa
@@ -309,6 +320,13 @@ def gen_small(tmp, only=None):
         # modified_adj1 / the post-loop adjacency carry + ori_adj (:188, :302)
         ("s48_hsic_ori", 48, 24, 4, 16, 2, "HSIC", base_wp, 1.0, 0.01, 3, 1e12),
         ("s48_mse_ori", 48, 24, 4, 16, 2, "MSELoss", base_wp, 1.0, 0.01, 3, 1e12),
+        # measure KDE (utils.MutualInformation as `calc`, topology_attack.py:199-201 and its four call sites): from the
+        # origin, from seeded starts (every term with a generic gradient), with noise; + the first gradient of the reference's
+        # own code in float64 (`step0_g64`)
+        ("s48_kde", 48, 24, 4, 16, 2, "KDE", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_kde_init", 48, 24, 4, 16, 2, "KDE", base_wp, 1.0, 0.01, 4, 1e12),
+        ("s200_kde_init", 200, 64, 6, 16, 2, "KDE", base_wp, 1.0, 0.01, 3, 1e12),
+        ("s48_kde_eps", 48, 24, 4, 16, 2, "KDE", base_wp, 1.0, 0.01, 3, 1e12),
     ]
     if only is not None:
         spec = [c for c in spec if c[0] in only]
@@ -342,6 +360,12 @@ def gen_small(tmp, only=None):
                                    epochs, "cora", (True, True, True), ne, a0=a0, eps=eps, ori_adj=ori)
         if eps != 0:
             extra.update(eps=eps, noise=np.stack(res["noises"]))
+        if measure == "KDE" and eps == 0:
+            r64 = run_reference_attack(adj, feats, labels, victim, idx_attack, measure, wp, wsup, lr, 1, "cora", (True, True, True),
+                                       ne, a0=a0, ori_adj=ori, f64=True)
+            extra.update(step0_g64=r64["steps_g"][0])
+            print(name, "reference fp32 vs its own float64 run, first gradient:",
+                  np.abs(res["steps_g"][0] - r64["steps_g"][0]).max() / np.abs(r64["steps_g"][0]).max())
         out = dict(adj=adj.numpy(), **extra, features=feats.numpy(), labels=lab, idx_attack=idx_attack,
                    measure=measure, weight_param=np.array(wp, dtype=np.float64), weight_sup=wsup,
                    lr=lr, epochs=epochs, num_edges=ne, nlayer=nl, final=res["final"],
@@ -569,8 +593,8 @@ def gen_mid(tmp):
 # README.md command lines of the reference, every one its CPU path can run: (tag, README line number, measure, use flags
 # (H_A, Y_A, Y), weight_sup, lr exponent, eps, w1..w10 by position, start).  `start` None = the README's own start
 # (adj_changes = 0); (seed, kappa) = a seeded start U[0, 1) * kappa / n with lr = kappa / (50 n) (scripts/nxn_share.py: where
-# the N x N terms carry the gradient).  Not here: the three --measure=KDE lines (13, 133 and brazil's: utils.py:990
-# hard-codes cuda:0); line 29 (tests/golden/cora_mse_*.npz).  The eps != 0 lines at n > 1000 (104, 112, 120: 5.6 - 29 MB of
+# the N x N terms carry the gradient).  Not here: line 29 (tests/golden/cora_mse_*.npz).  The two --measure=KDE lines (13, 133)
+# run with the `device='cuda:0'` keyword of utils.py:990-991 dropped (see the shims at the top).  The eps != 0 lines at n > 1000 (104, 112, 120: 5.6 - 29 MB of
 # noise per step) run on SEEDED noise (NOISE_SEEDS) instead of recorded matrices; brazil's line 149 and the n <= 300 cases
 # keep theirs.  Lines 116 and 120 sit in the README's usair section but name no dataset: they run on cora, as written.
 # eps != 0 lines whose noise is a seeded platform-independent stream instead of recorded matrices (run_reference_attack)
@@ -584,6 +608,7 @@ README_RUNS = {
         ("kl_hY", 141, "KL", (1, 0, 1), 1.0, -2.0, 0.0, {1: 0.001, 2: 100, 7: 0.01, 9: 0.001}, None),
         ("dp_yy", 145, "DP", (0, 1, 1), 1.0, -1.0, 0.0, {6: 10000, 10: 1}, None),
         ("kl_all_eps", 149, "KL", (1, 1, 1), 1.0, 0.0, 0.077458886396933, {1: 10, 2: 0.001, 6: 0.1, 9: 0.1, 10: 100}, None),
+        ("kde_Y", 133, "KDE", (0, 0, 1), 1.0, -2.5, 0.0, {1: 0.0001, 6: 0.001}, None),
     ],
     "usair": [
         ("mse_h", 96, "MSELoss", (1, 0, 0), 0.0, -3.0, 0.0, {2: 100, 6: 100, 7: 10000, 9: 100}, None),
@@ -629,6 +654,7 @@ README_RUNS = {
         ("mse_hy", 17, "MSELoss", (1, 1, 0), 0.0, -2.0, 0.0, {1: 1000, 2: 0.001, 6: 0.1, 7: 0.1, 9: 100, 10: 100}, None),
         ("mse_hY", 21, "MSELoss", (1, 0, 1), 1.0, -2.0, 0.0, {1: 100, 2: 0.0001, 6: 0.0001, 7: 1, 9: 10}, None),
         ("mse_yY", 25, "MSELoss", (0, 1, 1), 1.0, -3.0, 0.0, {1: 0.1, 6: 10, 10: 0.01}, None),
+        ("kde_Y", 13, "KDE", (0, 0, 1), 1.0, -3.0, 0.0, {1: 1000, 6: 0.01}, None),
         ("cka_yY", 116, "CKA", (0, 1, 1), 1.0, -2.0, 0.0, {1: 1000, 6: 1000, 10: 0.01}, None),
         # line 120: a NEGATIVE eps (seeded noise)
         ("dp_all_eps_neg", 120, "DP", (1, 1, 1), 1.0, 0.0, -0.010192774962135321, {1: 10000, 2: 1, 6: 10, 7: 0.1, 9: 0.01, 10: 0.01}, None),
@@ -959,6 +985,8 @@ if __name__ == "__main__":
             gen_cora(tmp)
         if a.only in ("ori",):
             gen_small(tmp, only=("s48_hsic_ori", "s48_mse_ori"))
+        if a.only in ("kde",):
+            gen_small(tmp, only=("s48_kde", "s48_kde_init", "s200_kde_init", "s48_kde_eps"))
         if a.only in ("cora_sparse",):
             gen_cora(tmp, only=("cora_hsic_sparse",))
         if a.only in ("all", "mid"):

@@ -232,7 +232,7 @@ def test_gcn_forward_matches_oracle(pkg, torch_):
 # by 2 lr: the fixture holds entries whose reference gradient is 1e-16 ... 1e-9 of the gradient's largest magnitude, and
 # Adam's first step is lr * sign(g))
 STRICT_OUTLIERS = {"s300_hsic_eps": 2}
-ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss", "KL", "DP", "CKA")]
+ENGINE_CASES = [c for c in H.attack_cases() if str(H.load_case(c)["measure"]) in ("HSIC", "MSELoss", "KL", "DP", "CKA", "KDE")]
 
 
 @pytest.mark.parametrize("name", ENGINE_CASES)
@@ -256,6 +256,8 @@ def test_step_gradients_match_reference(pkg, torch_, name):
         scale = np.abs(g_ref).max()
         tol = 6e-4 if "cka" in name else 3e-4
         assert np.abs(g - g_ref).max() <= tol * scale, (name, t, np.abs(g - g_ref).max(), scale)
+        if t == 0 and "step0_g64" in z:      # measure KDE: also against the reference's OWN code run in float64 (make_golden.py)
+            assert np.abs(g - z["step0_g64"]).max() <= 3e-5 * np.abs(z["step0_g64"]).max(), (name, np.abs(g - z["step0_g64"]).max())
         # intermediates against the oracle
         last = orc.last
         # the bisection case cannot be teacher-forced (state is not recoverable from the hook), so engine
@@ -273,11 +275,14 @@ def test_free_run_final_matches_reference(pkg, torch_, name):
     """Free-running loop + post-loop ensemble: final modified_adj and its AUC."""
     z = H.load_case(name)
     eng = H.engine_from(pkg, z)
+    # entries whose first gradient has the other SIGN in the reference's fp32 run than in the reference's own float64 run
+    # (s200_kde_init: 3 of 19 900, |g| = 5e-7 of the largest): Adam's first step is lr * sign(g), the engine follows the exact sign
+    ref_flip = (np.sign(z["steps_g"][0]) != np.sign(z["step0_g64"])) if "step0_g64" in z else False
     for t in range(int(z["epochs"])):
         nz = H.noise_of(z, t)
         eng.step(noise=None if nz is None else dev(torch_, nz))
         a = eng.get_adj_changes().cpu().numpy()
-        off = np.abs(a - np.clip(z["steps_a"][t], 0, 1)) >= 0.05 * float(z["lr"]) + 1e-6
+        off = (np.abs(a - np.clip(z["steps_a"][t], 0, 1)) >= 0.05 * float(z["lr"]) + 1e-6) & ~ref_flip
         # (n >= 256: a few of the 10^4..10^5 entries carry gradients at rounding-noise level, whose sign decides a whole
         # +-lr Adam move in the first steps -- DESIGN.md section 5; the small cases match entry for entry)
         assert off.mean() <= (0.0 if z["adj"].shape[0] < 256 else 1e-3) or float(z["num_edges"]) < 1e9, (t, off.sum())
