@@ -128,6 +128,12 @@ int mcgra_dot_product_decode(void* stream, int n, int d, const float* Z, float* 
  * useY_A / useY to the mode; mcgra_attack_finalize takes the same number.) */
 int mcgra_dot_product_decode2(void* stream, int n, int d, const float* Z, int mode, float* out);
 
+/* utils.MutualInformation(sigma=0.4, num_bins=c, normalize=True)(X, Y)[0] (utils.py:980-1049) for X, Y [m x c]: the
+ * operand's width is the number of bins (topology_attack.py:199-201, :244-246, :261-263), entry (i, j) meets bin j
+ * (utils.py:995).  *out = the value; gX, gY (optional, [m x c]) = d value / dX, d value / dY.  c > 32: square operands
+ * (m == c) whose values keep at most 32 bins within reach of a float32 kernel value; MCGRA_ENOSUP otherwise. */
+int mcgra_mutual_information(void* stream, int m, int c, const float* X, const float* Y, float* out, float* gX, float* gY);
+
 /* CudaCKA.linear_HSIC (utils.py:1085-1089) for X [m x dx], Y [m x dy]:
  * *out = sum(center(X X^T) * center(Y Y^T)).  Evaluated as |Xc^T Yc|_F^2. */
 int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X,

@@ -25,7 +25,7 @@ SYMBOLS = [
     "mcgra_ssyrk_lower", "mcgra_ssymm_lower",
     "mcgra_get_modified_adj", "mcgra_pack_tril", "mcgra_normalize_adj", "mcgra_info_entropy",
     "mcgra_dot_product_decode", "mcgra_dot_product_decode2", "mcgra_linear_hsic", "mcgra_hsic_regular", "mcgra_hsic_normalized", "mcgra_hsic_regular2", "mcgra_hsic_normalized_cca", "mcgra_distmat", "mcgra_mmd",
-    "mcgra_mmd_pxpy_pxy", "mcgra_mse",
+    "mcgra_mmd_pxpy_pxy", "mcgra_mse", "mcgra_mutual_information",
     "mcgra_gcn_forward",
     "mcgra_attack_create", "mcgra_attack_destroy", "mcgra_attack_set_model", "mcgra_attack_set_graph",
     "mcgra_attack_set_adj_changes", "mcgra_attack_get_adj_changes", "mcgra_attack_step",
@@ -96,6 +96,7 @@ def _load():
         "mcgra_mmd": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp],
         "mcgra_mmd_pxpy_pxy": [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, fp],
         "mcgra_mse": [vp, C.c_int64, fp, fp, fp],
+        "mcgra_mutual_information": [vp, C.c_int, C.c_int, fp, fp, fp, fp, fp],
         "mcgra_gcn_forward": [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), fp, fp, C.POINTER(C.c_void_p),
                               C.POINTER(C.c_void_p), fp, fp, C.c_int, C.c_int, fp, fp],
         "mcgra_attack_create": [C.POINTER(C.c_void_p), C.POINTER(AttackConfig)],

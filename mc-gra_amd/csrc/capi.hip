@@ -278,6 +278,44 @@ int mcgra_dot_product_decode2(void* stream, int n, int d, const float* Z, int mo
   return 0;
 }
 
+// utils.MutualInformation(sigma=0.4, num_bins=c, normalize=True)(X, Y) (utils.py:980-1049) for 2-D operands [m x c] whose
+// width is the number of bins (the shape every call site of topology_attack.py has): *out = the value; gX / gY (optional,
+// [m x c], leading dimension c) = its gradients.  Wider than 32 columns: square operands only (the attack's N x N terms) whose
+// values leave at most 32 bins within reach of a float32 kernel value (max |V| + 4.7 < 32) -- the active columns are computed
+// exactly, the others are exactly zero in the reference too (kde_kernels.hip).
+int mcgra_mutual_information(void* stream, int m, int c, const float* X, const float* Y, float* out, float* gX, float* gY) {
+  if (m < 1 || c < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  int act = c;
+  if (c > KDE_MAXC) {
+    if (m != c) { set_error("mutual_information: operands wider than %d columns must be square (the N x N terms)", KDE_MAXC); return MCGRA_ENOSUP; }
+    float* am = s.get<float>(2); NEED(am);
+    split_absmax(st, m, c, X, nullptr, false, am);
+    split_absmax(st, m, c, Y, nullptr, false, am + 1);
+    float h2[2];
+    MCGRA_HIP(hipMemcpyAsync(h2, am, sizeof(h2), hipMemcpyDeviceToHost, st));
+    MCGRA_HIP(hipStreamSynchronize(st));
+    const float vmax = h2[0] > h2[1] ? h2[0] : h2[1];
+    // bin j sits at j c / (c - 1) >= j; exp(-0.5 ((v - b) / 0.32)^2) == 0 in float32 once b - v > 4.62
+    act = (int)floorf(vmax + 4.7f) + 1;
+    if (act > c) act = c;
+    if (act > KDE_MAXC) { set_error("mutual_information: values up to %g reach %d bins (> %d)", vmax, act, KDE_MAXC); return MCGRA_ENOSUP; }
+  }
+  double* scratch = s.get<double>(kde_scratch_doubles(m)); NEED(scratch);
+  double* v = s.get<double>(1); NEED(v);
+  if (gX) MCGRA_HIP(hipMemsetAsync(gX, 0, sizeof(float) * (size_t)m * c, st));
+  if (gY) MCGRA_HIP(hipMemsetAsync(gY, 0, sizeof(float) * (size_t)m * c, st));
+  launch_kde_term(st, m, act, c, X, c, Y, c, 1.0, gX, c, false, gY, c, false, v, scratch);
+  MCGRA_KERNEL_CHECK();
+  double t;
+  MCGRA_HIP(hipMemcpyAsync(&t, v, sizeof(double), hipMemcpyDeviceToHost, st));
+  MCGRA_HIP(hipStreamSynchronize(st));
+  const float f = (float)t;
+  MCGRA_HIP(hipMemcpy(out, &f, sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
 int mcgra_linear_hsic(void* stream, int m, int dx, int dy, const float* X, const float* Y, float* out) {
   if (m < 1 || dx < 1 || dy < 1 || !X || !Y || !out) { set_error("bad argument"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;

@@ -151,6 +151,20 @@ def linear_hsic(X, Y):
 
 
 @_on_operand_device
+def mutual_information(X, Y, want_grad=False):
+    """utils.MutualInformation(sigma=0.4, num_bins=X.shape[1], normalize=True)(X, Y)[0] (utils.py:980-1049); want_grad: also
+    its gradients w.r.t. X and Y (mcgra_mutual_information)."""
+    m, c = X.shape
+    assert Y.shape == X.shape
+    X, Y = X.contiguous(), Y.contiguous()
+    out = torch.zeros(1, device=X.device, dtype=torch.float32)
+    gX = torch.empty_like(X) if want_grad else None
+    gY = torch.empty_like(Y) if want_grad else None
+    check(lib.mcgra_mutual_information(_stream(), m, c, _p(X), _p(Y), _p(out), _p(gX), _p(gY)))
+    return (out[0], gX, gY) if want_grad else out[0]
+
+
+@_on_operand_device
 def hsic_regular(x, y, sigma):
     """hsic.hsic_regular (hsic.py:117-124) with a given sigma."""
     out = torch.zeros(1, device=x.device, dtype=torch.float32)

@@ -67,3 +67,24 @@ def get_train_val_test_gcn(labels, seed=None):
         idx_unlabeled = np.hstack((idx_unlabeled, li[20:])).astype(int)
     idx_unlabeled = np.random.permutation(idx_unlabeled)
     return idx_train, idx_unlabeled[:len(idx_unlabeled) // 2], idx_unlabeled[len(idx_unlabeled) // 2:]
+
+
+class MutualInformation(torch.nn.Module):
+    """utils.MutualInformation (utils.py:980-1049) as topology_attack.py:199-201 / :244-246 / :261-263 construct it:
+    sigma = 0.4, normalize = True, num_bins = the operands' width.  forward(input1, input2) on 2-D CUDA tensors returns a
+    tensor of shape [1] like the reference's (callers index it with [0]); the bins live where the operands are (the
+    reference asks for device='cuda:0', utils.py:991).  Evaluated by mcgra_mutual_information (csrc/kde_kernels.hip)."""
+
+    def __init__(self, sigma=0.4, num_bins=256, normalize=True):
+        super().__init__()
+        if sigma != 0.4 or not normalize:
+            raise NotImplementedError("MutualInformation(sigma=0.4, normalize=True) is the form topology_attack.py uses")
+        self.sigma, self.num_bins, self.normalize, self.epsilon = 2 * sigma ** 2, num_bins, normalize, 1e-10
+
+    def forward(self, input1, input2):
+        from . import engine as E
+        if input1.dim() != 2 or input1.shape != input2.shape or input1.shape[1] != self.num_bins:
+            raise ValueError("2-D operands of width num_bins (utils.py:995 broadcasts the bins over the last axis)")
+        return E.mutual_information(input1.float(), input2.float()).reshape(1)
+
+    getMutualInformation = forward

@@ -476,6 +476,36 @@ def gen_ops(tmp):
     print("ops.npz", len(out), "arrays")
 
 
+def gen_ops_kde(tmp):
+    """utils.MutualInformation (utils.py:980-1049) as topology_attack.py constructs it (sigma=0.4, normalize=True, num_bins =
+    the operands' width) on 2-D operands of the shapes its call sites have: value and autograd gradients in float32 and --
+    the same module on double tensors -- in float64 -> ops_kde.npz."""
+    rng = np.random.RandomState(11)
+    out = {}
+    cases = [("nxn48", 48, 48, 0.0, 1.0), ("nxn160", 160, 160, 0.0, 1.0), ("nxn160_ori", 160, 160, 0.0, 2.0),
+             ("em16", 60, 16, 0.0, 4.0), ("sm7", 60, 7, None, None), ("wide20", 40, 20, -1.0, 21.0)]
+    for tag, m, c, lo, hi in cases:
+        if lo is None:      # Y_A (log-probs) against softmax(output2): the operands of c10 (:261-265)
+            X = torch.log_softmax(torch.tensor(rng.randn(m, c).astype(np.float32)) * 2, 1).numpy()
+            Y = torch.softmax(torch.tensor(rng.randn(m, c).astype(np.float32)) * 2, 1).numpy()
+        else:
+            X = (rng.rand(m, c) * (hi - lo) + lo).astype(np.float32)
+            Y = (rng.rand(m, c) * (hi - lo) + lo).astype(np.float32)
+        mi = rutils.MutualInformation(sigma=0.4, num_bins=c, normalize=True)
+        for dt, sfx in ((torch.float32, ""), (torch.float64, "64")):
+            tx, ty = torch.tensor(X, dtype=dt, requires_grad=True), torch.tensor(Y, dtype=dt, requires_grad=True)
+            v = mi(tx, ty)
+            assert tuple(v.shape) == (1,)
+            v[0].backward()
+            out.update({f"{tag}_val{sfx}": v.detach().numpy().copy(), f"{tag}_gx{sfx}": tx.grad.numpy().astype(np.float32),
+                        f"{tag}_gy{sfx}": ty.grad.numpy().astype(np.float32)})
+        out.update({f"{tag}_x": X, f"{tag}_y": Y})
+        print(tag, float(out[f"{tag}_val"][0]), float(out[f"{tag}_val64"][0]),
+              np.abs(out[f"{tag}_gx"] - out[f"{tag}_gx64"]).max() / np.abs(out[f"{tag}_gx64"]).max())
+    out["cases"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(OUT, "ops_kde.npz"), **out)
+
+
 def gen_cora(tmp, only=None):
     """Cora through the reference's own data path and victim training
     (main.py:148-190), README headline MSELoss config + an HSIC config."""
@@ -985,6 +1015,8 @@ if __name__ == "__main__":
             gen_cora(tmp)
         if a.only in ("ori",):
             gen_small(tmp, only=("s48_hsic_ori", "s48_mse_ori"))
+        if a.only in ("ops_kde", "kde"):
+            gen_ops_kde(tmp)
         if a.only in ("kde",):
             gen_small(tmp, only=("s48_kde", "s48_kde_init", "s200_kde_init", "s48_kde_eps"))
         if a.only in ("cora_sparse",):

@@ -285,7 +285,10 @@ def test_free_run_final_matches_reference(pkg, torch_, name):
         off = (np.abs(a - np.clip(z["steps_a"][t], 0, 1)) >= 0.05 * float(z["lr"]) + 1e-6) & ~ref_flip
         # (n >= 256: a few of the 10^4..10^5 entries carry gradients at rounding-noise level, whose sign decides a whole
         # +-lr Adam move in the first steps -- DESIGN.md section 5; the small cases match entry for entry)
-        assert off.mean() <= (0.0 if z["adj"].shape[0] < 256 else 1e-3) or float(z["num_edges"]) < 1e9, (t, off.sum())
+        # (... and where the reference's own first step went the other way on some entries, their 2 lr reach their neighbours'
+        # gradients from the second step on: s200_kde_init, 3 more entries at step 1, 10 at step 2 -- in the float64 oracle alike)
+        strict = z["adj"].shape[0] < 256 and not np.any(ref_flip)
+        assert off.mean() <= (0.0 if strict else 1e-3) or float(z["num_edges"]) < 1e9, (t, off.sum())
         # ... and an entry that does differ differs by Adam moves of opposite sign, not by anything larger
         if float(z["num_edges"]) >= 1e9:
             worst = float(np.abs(a - np.clip(z["steps_a"][t], 0, 1)).max())
@@ -1461,3 +1464,55 @@ def test_relu_masked_pairs_of_live_rows_keep_the_fused_step(pkg, monkeypatch, n_
         orc.set_adj_changes(fused.get_adj_changes().cpu().numpy())
     assert fused.fused_steps() == 3 and fused.masked_fused_steps() == 3 and fused.path_stats()["general_steps"] == 0
     assert gram.path_stats()["general_steps"] == 3 and gram.masked_fused_steps() == 0
+
+
+KDE_OPS = np.load(os.path.join(H.GOLDEN, "ops_kde.npz"))
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in KDE_OPS["cases"]])
+def test_mutual_information_op_against_the_reference(pkg, torch_, tag):
+    """mcgra_mutual_information (measure KDE's `calc`, utils.py:980-1049) on the operand shapes of its call sites -- N x N with
+    num_bins = N (values in [0, 1], and up to 2 as with a non-zero ori_adj), embeddings, log-probs against a softmax, a wide
+    value range -- against the reference module's value and autograd gradients: within 3e-6 of its float64 run, and of its
+    float32 run within that run's own distance from float64.  Also through the reference's class surface (utils.MutualInformation)."""
+    from mc_gra_amd import engine as E
+    from mc_gra_amd import utils as U
+    z = KDE_OPS
+    X, Y = dev(torch_, z[f"{tag}_x"]), dev(torch_, z[f"{tag}_y"])
+    val, gx, gy = E.mutual_information(X, Y, want_grad=True)
+    for g, nm in ((gx, "gx"), (gy, "gy")):
+        g = g.cpu().numpy()
+        g64 = z[f"{tag}_{nm}64"].astype(np.float64)
+        ref_true = np.abs(z[f"{tag}_{nm}"] - g64).max() / np.abs(g64).max()
+        assert np.abs(g - g64).max() / np.abs(g64).max() <= 3e-6, (tag, nm)
+        assert np.abs(g - z[f"{tag}_{nm}"]).max() / np.abs(g64).max() <= ref_true + 3e-6, (tag, nm, ref_true)
+    v64 = float(z[f"{tag}_val64"][0])
+    assert abs(float(val) - v64) <= 3e-6 * max(1.0, abs(v64))
+    mi = U.MutualInformation(sigma=0.4, num_bins=X.shape[1], normalize=True)
+    out = mi(X, Y)
+    assert tuple(out.shape) == (1,) and float(out[0]) == float(val)
+
+
+@pytest.mark.parametrize("n,widths,nclass", [(1100, (16, 16), 4), (1030, (24, 32, 8), 9)])
+def test_kde_steps_of_a_large_graph_match_the_oracle(pkg, torch_, n, widths, nclass):
+    """measure KDE at n >= 1024 (the launch shapes of large graphs; a 3-layer victim with a 32-wide embedding and 9 classes:
+    the 32-column form of the joint) with all four terms: per-step gradient against the oracle (which the reference fixtures
+    pin: attack_*_kde*.npz, README lines 13 / 133), scalars, free-run state."""
+    z = H.synthetic_case(n, 11, widths, nclass, seed=n, measure="KDE")
+    eng, o = H.engine_from(pkg, z), H.oracle_from(z)
+    for t in range(3):
+        sc = eng.step(want_scalars=True)
+        o.step()
+        g, g_or = eng.buffer("G_sym").cpu().numpy(), o.last["G_sym"]
+        assert np.abs(g - g_or).max() <= 1e-4 * np.abs(g_or).max(), (t, np.abs(g - g_or).max(), np.abs(g_or).max())
+        # the N x N terms reach the first KDE_NXN_COLS columns of adj_norm / modified_adj1 only
+        assert abs(sc["loss"] - o.last["loss"]) <= 2e-4 * abs(o.last["loss"]) + 1e-5
+        # (the normalised mutual information 2 (H1 + H2 - H12) / (H1 + H2) of the N x N operands is ~ 5e-6: a difference of
+        # entropies that agree to six digits -- its float32 kernel values bound the VALUE to ~ 2e-8 absolute, times the weight)
+        wp = z["weight_param"]
+        K = {"c1": wp[0] * 1e5, "c2": wp[1] * 1e5, "c9": wp[8], "c10": wp[9]}
+        for k in ("c1", "c2", "c9", "c10"):
+            assert sc[k] == pytest.approx(o.last["terms"][k], rel=1e-4, abs=2e-8 * K[k]), (t, k)
+        o.set_adj_changes(eng.get_adj_changes().cpu().numpy())
+    assert eng.path_stats() == {"lowrank_steps": 0, "general_steps": 0} and eng.fused_steps() == 0
+    eng.close()

@@ -251,3 +251,22 @@ def test_oracle_on_the_reference_readme_lines(name):
         ref = z["final_sample"].astype(np.float64)
         assert np.abs(final[sp[:, 0], sp[:, 1]] - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
         assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) <= 1e-4
+
+
+KDE_OPS = np.load(os.path.join(H.GOLDEN, "ops_kde.npz"))
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in KDE_OPS["cases"]])
+def test_oracle_mutual_information_against_the_reference(tag):
+    """utils.MutualInformation (measure KDE) on the operand shapes of its four call sites: the oracle's value and hand-derived
+    gradients against the reference module's own (autograd), in float32 and against the same module run on double tensors."""
+    z = KDE_OPS
+    X, Y = z[f"{tag}_x"], z[f"{tag}_y"]
+    assert np.array_equal(O.kde_bins(X.shape[1]), __import__("torch").linspace(0, X.shape[1], X.shape[1]).float().numpy())
+    val, gx, gy = O.kde_mi_grads(X, Y)
+    for g, nm in ((gx, "gx"), (gy, "gy")):
+        g64 = z[f"{tag}_{nm}64"].astype(np.float64)
+        ref_true = np.abs(z[f"{tag}_{nm}"] - g64).max() / np.abs(g64).max()
+        assert np.abs(g - g64).max() / np.abs(g64).max() <= 2e-6, (tag, nm)
+        assert np.abs(g - z[f"{tag}_{nm}"]).max() / np.abs(g64).max() <= ref_true + 2e-6, (tag, nm, ref_true)
+    assert abs(float(val) - float(z[f"{tag}_val64"][0])) <= 2e-6 * max(1.0, abs(float(z[f"{tag}_val64"][0])))
