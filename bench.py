@@ -262,30 +262,40 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
     import tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
-        return None
+        return {"error": "rocprofv3 not on PATH"}
+    # the profiler's preloaded library initialises the GPU before the program behind `--` starts: that program must be the
+    # interpreter ITSELF (an ELF binary), not a shim that would exec it (a pyenv / conda wrapper, a `#!/usr/bin/env` script)
+    py = os.path.realpath(sys.executable)
+    try:
+        with open(py, "rb") as fh:
+            if fh.read(4) != b"\x7fELF":
+                return {"error": f"{py} is not an ELF binary (a launcher that re-execs is refused under the profiler)"}
+    except OSError as e:
+        return {"error": f"cannot read {py}: {e}"}
     per = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
-            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__),
                    "--steps", str(steps), "--warmup", "1", "--workload", workload, "--seed", str(seed), "--no-cpu-baseline",
                    "--no-split-probe", "--no-live-traffic"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL, timeout=timeout_s)
-            except Exception:
-                return None
+            except Exception as e:
+                return {"error": f"{ctr} pass: {type(e).__name__}: {e}"[:200]}
             fs = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not fs:
-                return None
-            for row in csv.DictReader(open(fs[0])):
-                if row["Counter_Name"] != ctr:
-                    continue
-                k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + f" grid={row['Grid_Size']}"
-                e = per.setdefault(k, {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
-                e[ctr] += float(row["Counter_Value"])
-                if ctr == "FETCH_SIZE":
-                    e["n"] += 1
+                return {"error": f"{ctr} pass: exit code {r.returncode}, {len(fs)} counter file(s)"}
+            with open(fs[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + f" grid={row['Grid_Size']}"
+                    e = per.setdefault(k, {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+                    e[ctr] += float(row["Counter_Value"])
+                    if ctr == "FETCH_SIZE":
+                        e["n"] += 1
     nsteps = steps + 1
     prod_main, outside = None, 0.0
     for k, v in per.items():
@@ -300,7 +310,7 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
                 and not any(x in k for x in _NOT_IN_STEP):
             outside += b * (n // nsteps)
     if prod_main is None:
-        return None
+        return {"error": "no launch of the product kernel in the counter pass"}
     return {"product_bytes_per_launch": prod_main, "outside_product_bytes_per_step": outside, "steps_in_pass": nsteps,
             "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace over {nsteps} steps of this workload, run by this invocation "
                    "before its timed region; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}
@@ -424,6 +434,89 @@ def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode,
     return out
 
 
+def multi_rank_diagnostics(pkg, torch, dist, dev, rank, world, a, eng, stepper, plan, comm, st, auc, dt, monitor, shared_gpu):
+    """Fields of the N > 1 line beside `value` (never part of it; everything here runs behind the timed region):
+      comm_ms_per_step / allgather_ms / alltoall_ms   HIP events around every collective of the timed steps, on the stream it is
+                                issued on: what the compute stream loses to it, per step -- mean and max over the ranks
+      product_ms_per_rank       every rank's N x N x N product per step (its own HIP events)
+      compute_only_ms_per_step  the same steps with every collective answered by the rank's own data (sharded.run_echo): the
+                                launches of a real step, nothing exchanged -- max over the ranks
+      exposed_comm_ms_per_step  ms_per_step - compute_only_ms_per_step: what the exchange costs the step after overlap
+      state_check               recovered-adjacency AUC of the sharded attack against ONE rank running the same attack
+                                (same workload, start, warm-up + timed steps) -- rank 0 replays it when its HBM holds a second
+                                engine; |difference| <= 1e-4 is `ok`"""
+    from mc_gra_amd import sharded as S
+    n = WORKLOADS[a.workload][0]
+    steps = a.steps
+    prod_ms = st["ms"] / steps if st["launches"] else None
+    # compute only: from the workload's own start again (the echo leaves a state that is not the attack's)
+    eng.set_adj_changes(torch.as_tensor(masked_variant(a.workload, make_inputs(*WORKLOADS[a.workload][:5], a.seed),
+                                                       make_a0(n, a.seed, start_scale(a.workload, n)), a.seed)[1], device=dev))
+    k = max(2, min(steps, 20))
+    f0 = eng.fused_steps()
+    for _ in range(2):
+        S.run_echo(stepper.b, S.SHARD_STEP)
+        if monitor:
+            S.run_echo(stepper.b, S.SHARD_MONITOR)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        S.run_echo(stepper.b, S.SHARD_STEP)
+        if monitor:
+            S.run_echo(stepper.b, S.SHARD_MONITOR)
+    torch.cuda.synchronize()
+    echo_ms = 1e3 * (time.perf_counter() - t0) / k
+    echo_fused = eng.fused_steps() - f0
+    mine = {"rank": rank, "product_ms": prod_ms, "echo_ms": echo_ms, "echo_fused": echo_fused == k + 2,
+            "comm": {kk: (v / steps if kk != "count" else v / steps) for kk, v in (comm or {}).items()}}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    out = None
+    if rank == 0:
+        cm = lambda key: [r["comm"].get(key, 0.0) for r in allr]
+        tot = [r["comm"].get("allgather", 0.0) + r["comm"].get("alltoall", 0.0) + r["comm"].get("allreduce", 0.0) for r in allr]
+        compute_only = max(r["echo_ms"] for r in allr)
+        out = {"comm_ms_per_step": {"mean": sum(tot) / world, "max": max(tot)},
+               "allgather_ms_per_step": {"mean": sum(cm("allgather")) / world, "max": max(cm("allgather"))},
+               "alltoall_ms_per_step": {"mean": sum(cm("alltoall")) / world, "max": max(cm("alltoall"))},
+               "collectives_timed_per_step": allr[0]["comm"].get("count"),
+               "product_ms_per_rank": [r["product_ms"] for r in allr],
+               "compute_only_ms_per_step": compute_only,
+               "compute_only_steps_all_fused": all(r["echo_fused"] for r in allr),
+               "exposed_comm_ms_per_step": 1e3 * dt / steps - compute_only,
+               "how": "comm: HIP events around each collective on the issuing stream, timed steps; compute only: the same steps with "
+                      "every collective answered by the rank's own data (sharded.run_echo), max over ranks; exposed = ms_per_step - "
+                      "compute only" + (" [ranks share ONE GPU over gloo: plumbing test, not a measurement]" if shared_gpu else "")}
+    # the same attack on ONE rank (rank 0, when its HBM holds a second engine): the state check
+    check = None
+    if rank == 0:
+        try:
+            free, total = torch.cuda.mem_get_info(dev)
+            need = 16.5 * 4.0 * n * ((n + 31) // 32 * 32)            # N x N buffers of a monolithic HSIC engine + planes
+            if free > 1.15 * need:
+                e1, inp1, adj1 = build_engine(pkg, torch, dev, a.workload, a.seed)
+                for _ in range(a.warmup + steps):
+                    e1.step()
+                    if monitor:
+                        e1.monitor()
+                lab = torch.as_tensor(inp1["labels"], device=dev)
+                fin1 = e1.finalize(0, e1.buffer("HA"), e1.buffer("YA"), (lab[:, None] == lab[None, :]).float())
+                auc1 = gpu_auc(adj1, fin1, torch)
+                check = {"auc_sharded": auc, "auc_one_rank": auc1, "abs_diff": abs(auc - auc1), "ok": abs(auc - auc1) <= 1e-4,
+                         "steps": a.warmup + steps, "how": "rank 0 replayed the attack monolithically behind the timed region"}
+                del e1, fin1
+                torch.cuda.empty_cache()
+            else:
+                check = {"auc_sharded": auc, "auc_one_rank": None, "ok": None,
+                         "how": f"not replayed: {free / 2**30:.0f} GiB free on rank 0, a second engine needs ~{need / 2**30:.0f} GiB"}
+        except Exception as e:
+            check = {"auc_sharded": auc, "auc_one_rank": None, "ok": None, "how": f"replay failed: {type(e).__name__}: {e}"[:300]}
+    dist.barrier()
+    if out is not None:
+        out["state_check"] = check
+    return out
+
+
 def launch_ranks(n_ranks, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, exactly as the driver's
     own multi-GPU command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
@@ -432,15 +525,22 @@ def launch_ranks(n_ranks, argv):
     1-GPU test mode.)"""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)          # the ranks' stderr passes through
+    for attempt in range(3):
+        # (a free port found by bind(0) can be taken before the launcher binds it -- two bench invocations on one box: the
+        # launch is tried again on another one when the rendezvous reports the address in use)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        err = r.stderr or ""
+        sys.stderr.write(err)                                                         # the ranks' stderr passes through
+        if r.returncode == 0 or not ("EADDRINUSE" in err or "address already in use" in err.lower()):
+            break
     line = None
     for ln in r.stdout.splitlines():
         if ln.startswith("{"):
@@ -494,17 +594,19 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", 0))
     # MCGRA_BENCH_SHARED_GPU=1 (tests on a 1-GPU box): every rank on cuda:0, the collectives over gloo with host-staged
     # arena slices (RCCL refuses two ranks on one device); same engine, protocol and timing contract, never a reported number
-    shared_gpu = world > 1 and os.environ.get("MCGRA_BENCH_SHARED_GPU") == "1"
+    shared_gpu = world > 1 and "1" in (os.environ.get("MCGRA_BENCH_SHARED_GPU"), os.environ.get("MCGRA_SHARED_GPU"))
     # CPU baseline first (N = 1 only): its child process is forked before anything here touches the GPU, and it is over
     # before the timed region starts, so the host cores are idle while the GPU is timed
     cpu = cpu_baseline(a.workload, a.seed) if (world == 1 and not a.no_cpu_baseline) else None
     # ... and so are the two PMC passes that measure this build's memory-side traffic on this box (children under rocprofv3)
-    live = None
+    live, live_error = None, None
     if world == 1 and not a.no_live_traffic and not a.no_split_probe and WORKLOADS[a.workload][5] == "HSIC":
         try:
             live = live_traffic(a.workload, a.seed)
-        except Exception:
-            live = None
+        except Exception as e:
+            live = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if live is not None and "error" in live:      # the line says why the committed passes of profiles/ stand in
+            live, live_error = None, live["error"]
     import torch
     import torch.distributed as dist
     if shared_gpu:
@@ -548,7 +650,12 @@ def main(argv=None):
         one_step()
     eng.profile(True); eng.gemm_stats(reset=True)
     ex0 = stepper.exchanges if stepper is not None else 0
+    if stepper is not None:
+        stepper.time_exchanges(True)          # HIP events around every collective of the timed steps (comm_ms_per_step below)
     dt = timed_region(one_step, a.steps, 0, torch.cuda.synchronize, world, dist, red_dev, torch)
+    comm = stepper.comm_ms() if stepper is not None else None
+    if stepper is not None:
+        stepper.time_exchanges(False)
     st = eng.gemm_stats(reset=True)
     eng.profile(False)
     eng_path = dict(eng.path_stats(), fused_steps=eng.fused_steps(), gram_split_steps=eng.gram_split_steps(),
@@ -578,6 +685,12 @@ def main(argv=None):
     H_A = eng.buffer("HA"); Y_A = eng.buffer("YA")
     final = eng.finalize(0, H_A, Y_A, label_adj)
     auc = gpu_auc(adj_dev, final, torch)
+
+    # N > 1: what makes the first multi-GPU line explain itself -- the collectives' time by kind, every rank's product time, the
+    # same steps with nothing exchanged (compute only), and the sharded attack's result against the 1-rank attack's
+    multi = None
+    if world > 1:
+        multi = multi_rank_diagnostics(pkg, torch, dist, dev, rank, world, a, eng, stepper, plan, comm, st, auc, dt, monitor, shared_gpu)
 
     # the other evaluation of the N x N x N product beside the headline: pure fp32 MFMA when the default (bf16 split,
     # fp32-level error) ran, the split when MCGRA_SPLIT_BF16=0 was given
@@ -683,6 +796,8 @@ def main(argv=None):
         }
         if replicas is not None:
             out["replica_probe"] = replicas
+        if multi is not None:
+            out["multi_rank"] = multi
         if stepper_exchanges is not None:
             out["collectives_per_step"] = stepper_exchanges
             # steps (warm-up + timed) whose product ran the peers' row panels first and handed them to the all-to-all while the
@@ -736,6 +851,8 @@ def main(argv=None):
                                    "launches_per_step": st["launches"] / a.steps, "avg_launch_ms": avg_ms,
                                    "gemm_share_of_step": st["ms"] / (1e3 * dt),
                                    "side_stream": side_stream}
+                if live_error:
+                    out["roofline"]["live_traffic_error"] = live_error
                 if replay_ms or (alone is not None and "product_avg_launch_ms" in alone):
                     # the same launch with nothing beside it: 20 back-to-back replays on this engine's planes
                     # (mcgra_attack_product_replay), else the MCGRA_OVERLAP=0 run's launches: faster product, slower step

@@ -92,6 +92,27 @@ class ShardedStepper:
         self.dist, self.group, self.clone_input, self.always = dist, group, clone_input, always
         self.host_staged = host_staged
         self.exchanges = 0
+        self._timed = None          # time_exchanges(): [(kind, event before, event after)] of the collectives since
+
+    def time_exchanges(self, on=True):
+        """Bracket every collective with HIP events on the caller's stream from now on (comm_ms reads and clears them).  The
+        event behind a collective is recorded once the caller's stream has been made to wait for it (torch.distributed's
+        synchronous collectives), so the pair measures what the compute stream loses to it."""
+        self._timed = [] if on else None
+
+    def comm_ms(self):
+        """{"allgather": ms, "alltoall": ms, "allreduce": ms, "count": n} of the collectives since time_exchanges() / the last
+        call; synchronises the device."""
+        out = {"allgather": 0.0, "alltoall": 0.0, "allreduce": 0.0, "count": 0}
+        if not self._timed:
+            return out
+        torch.cuda.synchronize()
+        names = {XCHG_ALLGATHER: "allgather", XCHG_ALLTOALL: "alltoall", XCHG_ALLREDUCE_F64: "allreduce"}
+        for kind, e0, e1 in self._timed:
+            out[names[kind]] += e0.elapsed_time(e1)
+            out["count"] += 1
+        self._timed = []
+        return out
 
     def _run(self, what, want_scalars):
         self.b.begin(what, want_scalars)
@@ -99,7 +120,14 @@ class ShardedStepper:
             ex = self.b.next()
             if ex[0] == XCHG_DONE:
                 break
-            run_exchange(ex, self.b.arena, self.plan, self.dist, self.group, self.clone_input, self.always, self.host_staged)
+            if self._timed is not None and self.plan.world > 1 and self.dist is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run_exchange(ex, self.b.arena, self.plan, self.dist, self.group, self.clone_input, self.always, self.host_staged)
+                e1.record()
+                self._timed.append((ex[0], e0, e1))
+            else:
+                run_exchange(ex, self.b.arena, self.plan, self.dist, self.group, self.clone_input, self.always, self.host_staged)
             self.exchanges += 1
         return self.b.scalars() if want_scalars else None
 
@@ -163,6 +191,29 @@ def run_lockstep(backends, what=SHARD_STEP, want_scalars=False):
                     arenas[dst][off2 + src * chunk: off2 + (src + 1) * chunk].copy_(
                         arenas[src][off + dst * chunk: off + (dst + 1) * chunk])
     return [b.scalars() for b in backends] if want_scalars else n_ex
+
+
+def run_echo(backend, what=SHARD_STEP, want_scalars=False):
+    """ONE rank of a `world`-rank attack by itself, for TIMING only: every collective is answered with the rank's own data (an
+    all-gather fills every peer's chunk with the own chunk, an all-to-all hands the send blocks back as the received ones), so
+    the rank runs exactly the launches of a real step -- its share of every N x N pass, the replicated node chain -- with
+    nothing exchanged.  The state it leaves is NOT the attack's.  For the per-rank compute of configurations whose `world`
+    engines do not fit one GPU side by side (scripts/shard_emulate.py --echo) and for bench.py's compute-only pass."""
+    plan, arena = backend.plan, backend.arena
+    w, r = plan.world, plan.rank
+    backend.begin(what, want_scalars)
+    n_ex = 0
+    while True:
+        kind, count, off, off2, chunk = backend.next()
+        if kind == XCHG_DONE:
+            break
+        n_ex += 1
+        if kind == XCHG_ALLGATHER:
+            full = arena[off:off + w * chunk].view(w, chunk)
+            full.copy_(full[r].clone().unsqueeze(0).expand(w, chunk))
+        elif kind == XCHG_ALLTOALL:
+            arena[off2:off2 + w * chunk].copy_(arena[off:off + w * chunk])
+    return n_ex
 
 
 class HipShardBackend:

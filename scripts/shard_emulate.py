@@ -5,6 +5,9 @@ a real job spends computing per step -- the part of a multi-GPU step that is not
 rank 0 into sharded N x N passes and replicated node-level work by running the same step with world = 1.
 
     python scripts/shard_emulate.py [--workload synthetic-10k-hsic] [--worlds 1,2,4,8] [--steps 6]
+    python scripts/shard_emulate.py --echo --workload synthetic-30k-hsic-3layer --worlds 4,8
+--echo: ONE rank of each world by itself with its collectives answered by its own data (sharded.run_echo) -- the launches
+of a real rank's step, for configurations whose `world` engines do not fit one GPU side by side (N = 30 000: 58 GB each).
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,11 +22,39 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="synthetic-10k-hsic")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--echo", action="store_true")
+ap.add_argument("--rank", type=int, default=-1, help="--echo: which rank (default: the middle one)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n = bench.WORKLOADS[a.workload][0]
 out = {"workload": a.workload, "what": __doc__.split("\n\n")[0], "rows": []}
 for world in [int(x) for x in a.worlds.split(",")]:
+    if a.echo:
+        rk = a.rank if a.rank >= 0 else world // 2
+        plan = S.RowBlockPlan(n, world, rk)
+        eng = bench.build_engine(pkg, torch, dev, a.workload, 0, plan=plan)[0]
+        bk = S.HipShardBackend(eng, plan)
+        for _ in range(3):
+            S.run_echo(bk, S.SHARD_STEP); S.run_echo(bk, S.SHARD_MONITOR)
+        torch.cuda.synchronize()
+        eng.profile(True); eng.gemm_stats(reset=True)
+        t0 = time.perf_counter()
+        nex = 0
+        for _ in range(a.steps):
+            nex += S.run_echo(bk, S.SHARD_STEP); nex += S.run_echo(bk, S.SHARD_MONITOR)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        st = eng.gemm_stats(reset=True)
+        row = {"world": world, "rank": rk, "rows_per_rank": plan.rows_per_rank, "mode": "echo (one rank alone, collectives answered by its own data)",
+               "per_rank_compute_ms": 1e3 * dt, "product_ms_per_step": st["ms"] / max(1, a.steps), "collectives_per_step": nex / a.steps,
+               "fused_steps": eng.fused_steps(), "general_steps": eng.path_stats()["general_steps"], "steps": a.steps + 3,
+               "alltoall_bytes_per_rank": 4 * world * plan.rows_per_rank ** 2 if world > 1 else 0,
+               "allgather_node_bytes_per_rank": plan.n_pad * 64 * 4}
+        out["rows"].append(row)
+        print(json.dumps(row), flush=True)
+        del bk, eng
+        torch.cuda.empty_cache()
+        continue
     plans = [S.RowBlockPlan(n, world, r) for r in range(world)]
     bks = S.lockstep_backends([bench.build_engine(pkg, torch, dev, a.workload, 0, plan=p)[0] for p in plans], plans)
     for _ in range(2):

@@ -171,7 +171,9 @@ def test_live_traffic_accounting(monkeypatch):
         seen.append(cmd)
         ctr = cmd[cmd.index("--pmc") + 1]
         assert "--kernel-trace" in cmd and not any(x in cmd for x in ("-s", "--sys-trace", "-r", "--runtime-trace", "--hip-trace"))
-        assert cmd[cmd.index("--") + 1] == sys.executable and "--no-live-traffic" in cmd and "--no-split-probe" in cmd
+        # the program behind `--` is the interpreter ITSELF (resolved, an ELF binary): a shim that execs it would be an exec after
+        # the profiler's library initialised the GPU
+        assert cmd[cmd.index("--") + 1] == os.path.realpath(sys.executable) and "--no-live-traffic" in cmd and "--no-split-probe" in cmd
         d = os.path.join(cmd[cmd.index("-d") + 1], "host")
         os.makedirs(d)
         with open(os.path.join(d, "1_counter_collection.csv"), "w", newline="") as fh:
@@ -191,8 +193,13 @@ def test_live_traffic_accounting(monkeypatch):
     # one product per step = every launch of the split kernel (parts of a cut launch, split-K tail) + the sum of its slabs
     assert out["product_bytes_per_launch"] == pytest.approx(((2 * 3000.0 + 400.0) + (2 * 200.0 + 60.0) + (2 * 500.0 + 80.0) + (2 * 30.0 + 20.0)) * 1024)
     assert out["outside_product_bytes_per_step"] == ((2 * 400.0 + 900.0) + 3 * (2 * 200.0 + 16.0)) * 1024
+    # a pass that cannot run says why (the bench line then quotes the committed passes and carries `live_traffic_error`)
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 3))
+    assert "exit code 3" in bench.live_traffic("synthetic-10k-hsic", 0)["error"]
+    monkeypatch.setattr(sys, "executable", __file__)             # not an ELF binary: a launcher script
+    assert "ELF" in bench.live_traffic("synthetic-10k-hsic", 0)["error"]
     monkeypatch.setattr(shutil, "which", lambda name: None)
-    assert bench.live_traffic("synthetic-10k-hsic", 0) is None
+    assert "rocprofv3" in bench.live_traffic("synthetic-10k-hsic", 0)["error"]
 
 
 def _class_worker(rank, world, port, q):

@@ -142,6 +142,17 @@ def test_bench_world2_branch_on_a_shared_gpu(tmp_path):
     auc1, fused1 = _one_rank_auc("synthetic-4k-hsic", 3)
     assert fused1 == 3 and 0.5 < auc1 < 1.0
     assert abs(line["auc"] - auc1) <= 1e-6, (line["auc"], auc1)
+    # the fields that make a multi-GPU line explain itself: collective time by kind (HIP events, mean / max over ranks), every
+    # rank's product time, the compute-only pass (collectives answered by the rank's own data), the exposed communication, and
+    # the state check: rank 0 replays the attack on one rank
+    m = line["multi_rank"]
+    assert m["collectives_timed_per_step"] == 8 and m["comm_ms_per_step"]["max"] >= m["comm_ms_per_step"]["mean"] > 0
+    assert m["alltoall_ms_per_step"]["mean"] > 0 and m["allgather_ms_per_step"]["mean"] > 0
+    assert len(m["product_ms_per_rank"]) == 2 and all(x > 0 for x in m["product_ms_per_rank"])
+    assert m["compute_only_ms_per_step"] > 0 and m["compute_only_steps_all_fused"]
+    assert abs(m["exposed_comm_ms_per_step"] - (line["ms_per_step"] - m["compute_only_ms_per_step"])) < 1e-9
+    sc = m["state_check"]
+    assert sc["ok"] is True and sc["abs_diff"] <= 1e-6 and abs(sc["auc_one_rank"] - auc1) <= 1e-9 and sc["steps"] == 3
 
 
 def test_plain_bench_gpus2_starts_its_own_ranks(tmp_path):
