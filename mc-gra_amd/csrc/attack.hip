@@ -323,7 +323,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     // (measured: 21.2-21.5 ms with the side stream, 21.6 without).  MCGRA_OVERLAP=0 / 1 overrides.
     const char* eo = getenv("MCGRA_OVERLAP");
     h->overlap = (eo && eo[0]) ? eo[0] == '1' : (h->split_mode == 2 && h->split_planes == 2);
-    if (!rc && h->lr_ok) {
+    if (h->gram_split) { A_(gram_diag, 2 * ld); }
+    if (!rc && (h->lr_ok || h->gram_split)) {
       int pr_least = 0, pr_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
       // The two side streams are shared by all engines of a device in this process: a process has few hardware queues
@@ -359,6 +360,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         set_error("stream / event creation failed"); rc = MCGRA_EHIP;
       }
       if (h->mask_host) { h->mask_host[0] = 0u; h->mask_host[1] = 0u; }
+      // Gram evaluation: its four products on the side stream, beside the HBM-bound rest of the step (step_impl).
+      // MCGRA_GRAM_OVERLAP=0: everything on the caller's stream, same launches in the same order (bit-identical: A/B test)
+      { const char* eg2 = getenv("MCGRA_GRAM_OVERLAP"); h->gram_ovl = h->gram_split && !rc && !(eg2 && eg2[0] == '0'); }
     }
   }
   {
@@ -554,6 +558,10 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
         split_absmax(st, n, ld, h->KFC, nullptr, true, h->amax);
       }
       split3_pack(st, n, ld, h->KFC, nullptr, true, h->Apack, h->split_planes, h->amax);
+    }
+    if (h->gram_split) {      // max |H Kf H|: part of the scale bound of the combined Gram (split_symm_bf16.hip: k_gram_scales)
+      MCGRA_HIP(hipMemsetAsync(h->amax + 5, 0, sizeof(float), st));
+      split_absmax(st, n, ld, h->KFC, nullptr, false, h->amax + 5);
     }
     launch_rowsumsq(st, n, ld, h->KFC, h->rowsx);
     launch_reduce_rows(st, h->rowsx, n, 1, h->cst + 0);      // hsic(feature_adj, feature_adj)
@@ -853,6 +861,39 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   const int t0 = 0, t1 = t_all;          // (row-block ranks run the fused step: attack_fused.hip)
   const bool sharded = false;
 
+  // The part of the backward that needs the forward only: small-operand terms c9 (:237-258) and c10 (:259-272), and the
+  // victim(adj_norm) chain's backward down to G_P of every layer.  (A Gram-evaluation step runs it beside its Grams.)
+  auto early_bwd = [&]() -> int {
+    MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
+    if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
+    if (w10 != 0) {
+      MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
+      CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
+      launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
+    }
+    // ---- backward: victim(adj_norm) chain -> G_adjn
+    if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z, h->GZ);     // through elu(out_att(x)) (gat.py:206)
+    launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
+                       h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
+    CHK(chain_backward(h, st, h->ADJN, ld, L - 1, h->Pv, h->GPv, -1, nullptr, 0));
+    return 0;
+  };
+  // G_adjn += sum_l G_P_l T_l^T (+ the low-rank 2 s2 (U M1^T - D Z W^T) of a low-rank step, in the same pass)
+  auto victim_rankk = [&]() -> int {
+    if (hsic && h->lr_step && use2 && rankk_nt_supported(n, n, hs, 2 * he)) {
+      MCGRA_HIP(rankk_nt(st, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 2 * he, 2.f * (float)(sg * k2), h->lrL, 2 * he, h->lrR,
+                         2 * he, 1.f, h->G_ADJN, ld));
+    } else {
+      if (hsic && h->lr_step && use2)
+        CHK(eg(h, st, false, true, n, n, 2 * he, 2.f * (float)(sg * k2), h->lrL, 2 * he, h->lrR, 2 * he, 1.f, h->G_ADJN, ld));
+      CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 1.f, h->G_ADJN, ld));   // sum_l G_P_l T_l^T
+    }
+    return 0;
+  };
+  bool gs_path = false, kx_started = false, gs_early_bwd = false, gs_p4 = false, gs_p3 = false, gs_rankk_done = false;
+  hipStream_t sg_ = st;
+  std::function<int()> gs_fork, launch_kx;
+  std::function<int(int, int, int)> pair;
   if (PH(0)) {
   const bool adopt = h->fwd_cached && !gen;         // forward of this iteration already done by the last monitor call
   h->fwd_cached = false;
@@ -870,18 +911,50 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   else CHK(forward_common(h, st, h->ADJN, noise_ld, (want_xc && !gen) ? h->rowsx : nullptr));
   h->p1_inflight = false;
   std::function<int()> fork_p1;       // the forked product of a low-rank step, when its launch is deferred
+  // ---- Gram evaluation on the split kernel (steps the low-rank forms do not cover): four N x N x N products.  They run on
+  // the side stream (gram_ovl) beside the HBM-bound rest of the step:
+  //   Kx = Xc Xc^T   beside the forward chains, the decode, the entropy pass and Yc's centring / packs
+  //   Ky = Yc Yc^T   beside the small-operand terms and the victim chain's backward
+  //   G_A1 += LX Yc  beside the victim chain's rank-k update of G_adjn
+  //   G_adjn += LY Xc  beside the decode backward and the modified_adj chain's backward
+  // split-K slabs: G_A (Kx, Ky: idle until the tail), KY / KX (the two gradient products: dead once combined and packed)
+  gs_path = h->gram_split && !gen && want_xc;
+  sg_ = (gs_path && h->gram_ovl && h->st2) ? h->st2 : st;
+  gs_fork = [=]() -> int {      // the side stream picks up behind everything enqueued on the caller's so far
+    if (sg_ != st) { MCGRA_HIP(hipEventRecord(h->ev_fork, st)); MCGRA_HIP(hipStreamWaitEvent(sg_, h->ev_fork, 0)); }
+    return 0;
+  };
+  pair = [=](int slot, int ia, int ib) -> int {      // (A, B) operand magnitudes of product `slot`
+    MCGRA_HIP(hipMemcpyAsync(h->amax + 8 + 2 * slot, h->amax + ia, sizeof(float), hipMemcpyDeviceToDevice, st));
+    MCGRA_HIP(hipMemcpyAsync(h->amax + 9 + 2 * slot, h->amax + ib, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+  };
+  launch_kx = [=]() -> int {      // Kx: lower tiles, mirrored by the epilogue (full, bitwise symmetric matrix)
+    split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
+    CHK(pair(0, 1, 1));
+    CHK(gs_fork());
+    CHK(timer_begin(h, sg_, h->profile));
+    MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->G_A, sizeof(float) * (size_t)n * ld, 2, h->amax + 8, 0, -1, 2));
+    CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
+    return 0;
+  };
   if (want_xc) {
     // Xc = H adj_norm (and, for the low-rank path, |xc_i|^2 = diag(Kx) from the same pass)
     if (gen) {                               // possibly asymmetric: true column sums
       if (!h->colpart_d) CHK(dalloc(h, &h->colpart_d, (size_t)h->nstrips * ld));
       launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);
     }
-    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, (h->lr_ok && !cka && use2) ? h->lrRs : nullptr,
+    // (gram_diag: |xc_i|^2 = diag(Kx) for the scale bound of the combined Grams -- only when the low-rank path does not want it)
+    const bool want_lrrs = h->lr_ok && !cka && use2;
+    launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, want_lrrs ? h->lrRs : (gs_path ? h->gram_diag : nullptr),
                        ((h->split_mode == 2 && h->split_planes == 2) || h->gram_split) ? h->amax + 1 : nullptr);
     // Gram evaluation through the split kernel: planes of Xc^T now (cmean is reused by Yc's centring), unless the
     // low-rank product below packs them anyway
     if (h->gram_split && !gen && !(h->lr_ok && !cka && use1 && h->split_on))
       split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, 2, h->amax + 1);
+    // ... and when the configuration has no low-rank form at all (GAT / GraphSAGE victims, CKA, widths > 32,
+    // MCGRA_NO_LOWRANK) this step IS a Gram evaluation: Kx = Xc Xc^T starts now, beside the forward chains and the decode
+    if (gs_path && !h->lr_ok) { CHK(launch_kx()); kx_started = true; }
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
@@ -1019,8 +1092,11 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         if (use2) {
           launch_rowsum(st, n, ld, h->A1, h->rowsy);
           const bool gs = h->gram_split && !gen;
-          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC, nullptr, gs ? h->amax + 2 : nullptr);
-          if (gs) split3_pack(st, n, ld, h->A1, h->cmean, false, h->Gp2, 2, h->amax + 2);      // Yc^T (A1 is symmetric)
+          launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC, gs ? h->gram_diag + ld : nullptr, gs ? h->amax + 2 : nullptr);
+          if (gs) {
+            split3_pack(st, n, ld, h->A1, h->cmean, false, h->Gp2, 2, h->amax + 2);      // Yc^T (A1 is symmetric)
+            split3_pack(st, n, ld, h->YC, nullptr, false, h->Gp1, 2, h->amax + 2);       // Yc: both operands of Ky = Yc Yc^T
+          }
         }
       }
     }
@@ -1041,65 +1117,90 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       h->p1_inflight = false;
     }
     if (h->lr_step) {
-    } else if (h->gram_split && !gen) {
-      // full Kx and Ky from the fp16 planes of Xc and Yc (split_symm_bf16.hip); split-K slabs in G_A, idle until phase 3
+    } else if (gs_path) {
+      // full Kx and Ky from the fp16 planes of Xc and Yc (split_symm_bf16.hip): tiles on or below the diagonal, mirrored by
+      // the epilogue; split-K slabs in G_A, idle until the tail.  The four products of the step run back to back on the
+      // side stream: Kx, Ky, G_A1 += LX Yc (needs Kx only: LX = 2 s2 Kxc is packed beside Ky), G_adjn += LY Xc (LY = 2 (s1
+      // Kfc + s2 Kyc) is combined and packed beside the third).  linear_CKA's factors need both Grams: it combines first.
       const size_t slab = sizeof(float) * (size_t)n * ld;
-      const bool big = h->profile;
-      auto pair = [&](int slot, int ia, int ib) -> int {
-        MCGRA_HIP(hipMemcpyAsync(h->amax + 8 + 2 * slot, h->amax + ia, sizeof(float), hipMemcpyDeviceToDevice, st));
-        MCGRA_HIP(hipMemcpyAsync(h->amax + 9 + 2 * slot, h->amax + ib, sizeof(float), hipMemcpyDeviceToDevice, st));
-        return MCGRA_OK;
-      };
-      CHK(pair(0, 1, 1));
-      // Kx and Ky are symmetric: tiles on or below the diagonal, mirrored by the epilogue
-      const int gram_flags = 2;
-      split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
-      CHK(timer_begin(h, st, big));
-      MCGRA_HIP(split3_symm(st, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->G_A, slab, 2, h->amax + 8, 0, -1, gram_flags));
-      CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
+      const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
+      if (!kx_started) { CHK(launch_kx()); kx_started = true; }      // (a low-rank configuration whose decode found a dead row)
+      if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_first, sg_));    // Kx done
       if (use2) {
         CHK(pair(1, 2, 2));
-        split3_pack(st, n, ld, h->YC, nullptr, false, h->Gp1, 2, h->amax + 2);
-        CHK(timer_begin(h, st, big));
-        MCGRA_HIP(split3_symm(st, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->G_A, slab, 2, h->amax + 10, 0, -1, gram_flags));
-        CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
+        CHK(gs_fork());
+        CHK(timer_begin(h, sg_, h->profile));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->G_A, slab, 2, h->amax + 10, 0, -1, 2));
+        CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
+        if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));   // Ky done
       }
       ++h->gram_split_steps;
+      // beside the Grams: everything of the backward that needs the forward only
+      CHK(early_bwd()); gs_early_bwd = true;
+      if (!cka) {
+        // operand scales of LY / LX from the diagonals of the centred Grams (known since the centring passes)
+        hsic_gram_scales(st, n, (h->lr_ok && use2) ? h->lrRs : h->gram_diag, h->gram_diag + ld, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->amax);
+        if (sg_ != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_first, 0));
+        if (use2) {
+          // LX = 2 s2 Kxc into the planes Xc's rows held (Kx is done with them); G_A1 += LX Yc right behind Ky, slabs in G_A
+          split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp0, 2, h->amax + 4, 2.f * s2);
+          MCGRA_HIP(hipMemcpyAsync(h->amax + 14, h->amax + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
+          MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
+          CHK(gs_fork());
+          CHK(timer_begin(h, sg_, h->profile));
+          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->G_A, slab, 2, h->amax + 14, 0, -1, 1));
+          CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
+          if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));   // G_A1 complete
+          gs_p4 = true;
+          if (sg_ != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));      // the combine reads Ky
+        }
+        // LY straight into its packed planes (the planes Yc's rows held: Ky is done with them), the two value sums from the same
+        // pass (partials in YC, dead once packed) -- beside G_A1 += LX Yc
+        hsic_combine_pack(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->amax, h->Gp1, nullptr,
+                          reinterpret_cast<double*>(h->YC), h->rowvals + 4 * (size_t)ld);
+        launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+      } else if (sg_ != st) {
+        MCGRA_HIP(hipStreamWaitEvent(st, use2 ? h->ev_join : h->ev_first, 0));
+      }
     } else
     if (use2) CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, h->YC, h->KY, t0, t1 - t0));   // H Kx H and H Ky H
     else CHK(eg_syrk(h, st, sym, n, n, h->XC, ld, h->KX, ld, nullptr, nullptr, t0, t1 - t0));    // H Kx H
   }
 
-  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && h->gram_split && !gen) {
-    const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
+  if (PH(2) && hsic && (use1 || use2) && !h->lr_step && gs_path) {
     const size_t slab = sizeof(float) * (size_t)n * ld;
     const bool big = h->profile;
-    MCGRA_HIP(hipMemsetAsync(h->amax + 3, 0, 2 * sizeof(float), st));
+    const void* LY = h->Gp1;
     if (cka) {      // linear_CKA (:486): the same two gradient products with left factors L1 -> KY, L2 -> KX
+      MCGRA_HIP(hipMemsetAsync(h->amax + 3, 0, 2 * sizeof(float), st));
       launch_cka_sums(st, n, ld, h->KX, h->KY, h->KFC, use1, use2, h->rowvals + 4 * (size_t)ld, false);
       launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 4, h->scal + S_CK0);
       launch_cka_coef(st, h->scal + S_CK0, h->cst + 0, use1 ? (float)k1 : 0.f, use2 ? (float)k2 : 0.f, h->coef);
       launch_cka_lincomb(st, n, ld, h->KX, h->KY, h->KFC, h->coef, use1, use2, false, h->amax + 4, h->amax + 3);
-    } else {
-      launch_hsic_combine(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->rowvals + 4 * (size_t)ld, false,
-                          h->amax + 4, h->amax + 3);
-      launch_reduce_rows(st, h->rowvals + 4 * (size_t)ld, n, 2, h->scal + S_H1);
+      split3_pack(st, n, ld, h->KY, nullptr, false, h->Gp0, 2, h->amax + 3);
+      LY = h->Gp0;
+      if (use2) {
+        split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp1, 2, h->amax + 4);
+        MCGRA_HIP(hipMemcpyAsync(h->amax + 14, h->amax + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
+        MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
+        CHK(gs_fork());
+        CHK(timer_begin(h, sg_, big));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->G_A, slab, 2, h->amax + 14, 0, -1, 1));
+        CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
+        if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));
+        gs_p4 = true;
+      }
     }
-    // G_adjn += 2 (s1 Kfc + s2 Kyc) Xc ;  G_A1 += 2 s2 Kxc Yc
+    // G_adjn += LY Xc behind the victim chain's rank-k update of G_adjn; slabs in KX (dead: combined and packed)
     MCGRA_HIP(hipMemcpyAsync(h->amax + 12, h->amax + 3, sizeof(float), hipMemcpyDeviceToDevice, st));
     MCGRA_HIP(hipMemcpyAsync(h->amax + 13, h->amax + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
-    split3_pack(st, n, ld, h->KY, nullptr, false, h->Gp0, 2, h->amax + 3);
-    CHK(timer_begin(h, st, big));
-    MCGRA_HIP(split3_symm(st, n, h->Gp0, h->Bpack, h->G_ADJN, ld, 0, -1, h->G_A, slab, 2, h->amax + 12, 0, -1, 1));
-    CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
-    if (use2) {
-      MCGRA_HIP(hipMemcpyAsync(h->amax + 14, h->amax + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
-      MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
-      split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp1, 2, h->amax + 4);
-      CHK(timer_begin(h, st, big));
-      MCGRA_HIP(split3_symm(st, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->G_A, slab, 2, h->amax + 14, 0, -1, 1));
-      CHK(timer_end(h, st, big, 2.0 * (double)n * n * n));
-    }
+    CHK(victim_rankk()); gs_rankk_done = true;
+    CHK(gs_fork());
+    CHK(timer_begin(h, sg_, big));
+    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->KX, slab, 2, h->amax + 12, 0, -1, 1));
+    CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
+    if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));
+    gs_p3 = true;
     MCGRA_KERNEL_CHECK();
   } else
   if (PH(2) && hsic && (use1 || use2) && !h->lr_step) {
@@ -1127,29 +1228,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       CHK(eg(h, st, false, true, n, n, he, 2.f * (float)(sg * k2), h->lrQ, 2 * he, h->Zn, h->hmax, 1.f, h->G_A1, ld));
     MCGRA_KERNEL_CHECK();
   }
-  // ---- small-operand terms c9 (:237-258) and c10 (:259-272)
-  MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
-  if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
-  if (w10 != 0) {
-    MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
-    CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
-    launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
-  }
-
-  // ---- backward: victim(adj_norm) chain -> G_adjn
-  if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z, h->GZ);     // through elu(out_att(x)) (gat.py:206)
-  launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
-                     h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
-  CHK(chain_backward(h, st, h->ADJN, ld, L - 1, h->Pv, h->GPv, -1, nullptr, 0));
-  if (hsic && h->lr_step && use2 && rankk_nt_supported(n, n, hs, 2 * he)) {
-    // sum_l G_P_l T_l^T and the low-rank 2 s2 (U M1^T - D Z W^T) in one pass over G_adjn
-    MCGRA_HIP(rankk_nt(st, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 2 * he, 2.f * (float)(sg * k2), h->lrL, 2 * he, h->lrR,
-                       2 * he, 1.f, h->G_ADJN, ld));
-  } else {
-    if (hsic && h->lr_step && use2)
-      CHK(eg(h, st, false, true, n, n, 2 * he, 2.f * (float)(sg * k2), h->lrL, 2 * he, h->lrR, 2 * he, 1.f, h->G_ADJN, ld));
-    CHK(eg(h, st, false, true, n, n, hs, 1.f, h->GPv, hs, h->Tv, hs, 1.f, h->G_ADJN, ld));   // sum_l G_P_l T_l^T
-  }
+  if (!gs_early_bwd) CHK(early_bwd());           // (a Gram-evaluation step ran them beside its Grams, phase 1)
+  if (!gs_rankk_done) CHK(victim_rankk());       // (... and this one in front of G_adjn += LY Xc, phase 2)
+  // the decode backward reads G_A1: behind G_A1 += LX Yc on the side stream
+  if (gs_p4 && sg_ != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_second, 0));
 
   // ---- backward: decode (S = Zn Zn^T, A1 = offdiag relu(S))
   if (hsic && h->lr_step && use2 && lr_decode_supported(he)) {
@@ -1201,6 +1283,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   }
   CHK(chain_backward(h, st, A, ld, ltop, h->Pu, h->GPu, Le - 1, h->Gem, h->hmax));
   }
+  // the normalisation backward reads G_adjn: behind G_adjn += LY Xc on the side stream
+  if (gs_p3 && sg_ != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   bool normbwd_parts = false;
   float* nb_colpart = h->colpart;       // column partials of the normalisation backward: [nb_strips][n]
   int nb_strips = h->nstrips;

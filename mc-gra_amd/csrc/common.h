@@ -81,7 +81,7 @@ hipError_t ssymm_lower(hipStream_t st, int n, int m, float alpha, const float* S
 size_t split3_pack_bytes(int n, int planes = 3);
 void split_absmax(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, float* amax);
 void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out, int planes = 3,
-                 const float* amax = nullptr);
+                 const float* amax = nullptr, float mul = 1.f);      // packs mul (X - sub 1^T)
 int split3_pack_rsq_parts(int n, int planes);
 int split3_chunks(int n, int planes);   // 16-k chunks per panel of a packed operand
 void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const float* rvec, const float* mean, void* out, int planes,
@@ -92,6 +92,12 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
                        int first_tiles = 0, hipEvent_t ev_first = nullptr,             // 4 = all row panels from panel_off, wrapping; first_tiles: cut of the linear tile range, ev_first recorded behind the first part
                        int second_tiles = 0, hipEvent_t ev_second = nullptr);          // a second cut behind the first
 int split3_panel();
+size_t hsic_combine_pack_scratch_doubles(int n);
+// amax: the engine's scale slots ([5] = max |KFC| on entry; [3], [4] receive the bounds of the two results); rowvals[0 .. n) = row sums
+// of KFC o KX, [n .. 2n) of KX o KY
+void hsic_gram_scales(hipStream_t st, int n, const double* diagx, const double* diagy, float s1, float s2, float* amax);
+void hsic_combine_pack(hipStream_t st, int n, int ld, const float* KX, const float* KY, const float* KFC, float s1, float s2,
+                       float* amax, void* outY, void* outX, double* scratch, double* rowvals);      // outX may be NULL (LX packed by split3_pack)
 int split3_slots();      // tiles per round of the chip (= CUs of the current device): cuts of a launch are multiples of it
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------

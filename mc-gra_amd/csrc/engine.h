@@ -145,6 +145,8 @@ struct mcgra_attack {
   // Grams and Yc^T; amax[2] = max |Yc|, [3] = max |2 (s1 Kfc + s2 Kyc)|, [4] = max |2 s2 Kxc|, [8..15] = the
   // (A, B) scale pairs of the four products
   bool gram_split = false;
+  bool gram_ovl = false;           // its four products on the side stream, beside the rest of the step (MCGRA_GRAM_OVERLAP=0: caller's stream)
+  double* gram_diag = 0;           // [2][ld]: |xc_i|^2, |yc_i|^2 (diagonals of the centred Grams: scale bound of the combined Grams)
   unsigned char *Gp0 = 0, *Gp1 = 0, *Gp2 = 0;
   int64_t gram_split_steps = 0;
   GemmTimer timer;

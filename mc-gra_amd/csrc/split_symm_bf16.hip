@@ -77,7 +77,8 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __restrict__ X, const float* __restrict__ sub,
                                               int sym, int nkc, char* __restrict__ out, const float* __restrict__ amax,
                                               const float* __restrict__ rvec, int row_base, float* __restrict__ rsq_part,
-                                              float* __restrict__ rsum_part) {
+                                              float* __restrict__ rsum_part, float mul) {
+  // (mul: the packed value is mul (X - sub) -- plain matrices only; 1 elsewhere)
   // block: 32 rows x 8 (k chunk pairs of 8): thread (r, c): row = blockIdx.y * 32 + r, k0 = (blockIdx.x * 8 + c) * 8
   const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
   const int row = row_base + blockIdx.y * 32 + r;
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __rest
     const float4 x1 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0 + 4);
     v[0] = x0.x - mu; v[1] = x0.y - mu; v[2] = x0.z - mu; v[3] = x0.w - mu;
     v[4] = x1.x - mu; v[5] = x1.y - mu; v[6] = x1.z - mu; v[7] = x1.w - mu;
+    if (mul != 1.f) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= mul;
+    }
   } else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __rest
         const int lim = (row / SYM_TILE + 1) * SYM_TILE;
         x = k < lim ? X[(size_t)row * ld + k] : X[(size_t)k * ld + row];
       } else {
-        x = X[(size_t)row * ld + k] - mu;
+        x = (X[(size_t)row * ld + k] - mu) * mul;
       }
     }
     v[j] = x;
@@ -156,6 +161,119 @@ __global__ __launch_bounds__(256) void k_pack(int n, int ld, const float* __rest
     }
     *reinterpret_cast<f16x8*>(base) = p0;
     *reinterpret_cast<f16x8*>(base + PLANE) = p1;
+  }
+}
+
+// Gram evaluation of linear_HSIC (attack.hip, phases 1 - 2): the elementwise combine of the centred Grams and the packs of its
+// two results in ONE pass.  With KX = Xc Xc^T, KY = Yc Yc^T and the constant KFC the gradient products need
+//   LY = 2 (s1 KFC + s2 KY)   (G_adjn += LY Xc)      and      LX = 2 s2 KX   (G_A1 += LX Yc)
+// as A operands of the split kernel: both are written straight into the packed fp16 planes (outY, outX) -- the fp32 forms are
+// never stored (round 4: k_hsic_combine wrote them and two k_pack<2> launches read them back: 1.6 GB and 0.3 ms per step at
+// N = 10 000).  The operand scales come in amax[0] (LY), amax[1] (LX): upper bounds known BEFORE the pass (k_gram_scales: a
+// centred Gram is positive semi-definite, its largest magnitude sits on its diagonal).  The value sums of the two terms,
+// sum KFC o KX and sum KX o KY, leave as per-(k block, row) partials in fp64 (part1 / part2 [gridDim.x][n]), summed in block
+// order by k_sum_parts: deterministic.  Thread mapping and plane layout: k_pack<2>.
+__global__ __launch_bounds__(256) void k_hsic_combine_pack(int n, int ld, const float* __restrict__ KX, const float* __restrict__ KY,
+                                                           const float* __restrict__ KFC, float s1, float s2, int nkc,
+                                                           char* __restrict__ outY, char* __restrict__ outX,
+                                                           const float* __restrict__ amax, double* __restrict__ part1,
+                                                           double* __restrict__ part2) {
+  const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+  const int row = blockIdx.y * 32 + r;
+  const int k0 = (blockIdx.x * 8 + c) * 8;
+  const bool act = k0 < nkc * KC;      // (no early return: the row's 8 lanes meet in the shuffles below)
+  float a[8], b[8];
+  double v1 = 0.0, v2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.f;
+  if (row < n && act) {
+    float kx[8], ky[8], kf[8];
+    if (k0 + 7 < n) {
+      const float4 x0 = *reinterpret_cast<const float4*>(KX + (size_t)row * ld + k0), x1 = *reinterpret_cast<const float4*>(KX + (size_t)row * ld + k0 + 4);
+      kx[0] = x0.x; kx[1] = x0.y; kx[2] = x0.z; kx[3] = x0.w; kx[4] = x1.x; kx[5] = x1.y; kx[6] = x1.z; kx[7] = x1.w;
+      if (s2 != 0.f) {
+        const float4 y0 = *reinterpret_cast<const float4*>(KY + (size_t)row * ld + k0), y1 = *reinterpret_cast<const float4*>(KY + (size_t)row * ld + k0 + 4);
+        ky[0] = y0.x; ky[1] = y0.y; ky[2] = y0.z; ky[3] = y0.w; ky[4] = y1.x; ky[5] = y1.y; ky[6] = y1.z; ky[7] = y1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ky[j] = 0.f;
+      }
+      if (s1 != 0.f) {
+        const float4 f0 = *reinterpret_cast<const float4*>(KFC + (size_t)row * ld + k0), f1 = *reinterpret_cast<const float4*>(KFC + (size_t)row * ld + k0 + 4);
+        kf[0] = f0.x; kf[1] = f0.y; kf[2] = f0.z; kf[3] = f0.w; kf[4] = f1.x; kf[5] = f1.y; kf[6] = f1.z; kf[7] = f1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = k0 + j < n;
+        kx[j] = in ? KX[(size_t)row * ld + k0 + j] : 0.f;
+        ky[j] = (in && s2 != 0.f) ? KY[(size_t)row * ld + k0 + j] : 0.f;
+        kf[j] = (in && s1 != 0.f) ? KFC[(size_t)row * ld + k0 + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v1 += (double)kf[j] * (double)kx[j];
+      v2 += (double)kx[j] * (double)ky[j];
+      a[j] = 2.f * s2 * kx[j];                        // the arithmetic of k_hsic_combine, value for value
+      b[j] = 2.f * (s1 * kf[j] + s2 * ky[j]);
+    }
+  }
+  // the 8 threads of a row hold its 64 values of this k block
+  v1 += __shfl_xor(v1, 1); v1 += __shfl_xor(v1, 2); v1 += __shfl_xor(v1, 4);
+  v2 += __shfl_xor(v2, 1); v2 += __shfl_xor(v2, 2); v2 += __shfl_xor(v2, 4);
+  if (c == 0 && row < n) { part1[(size_t)blockIdx.x * n + row] = v1; part2[(size_t)blockIdx.x * n + row] = v2; }
+  if (!act) return;
+  const int panel = row / TB, rin = row % TB, kc = k0 / KC, half = (k0 % KC) / 8;
+  const size_t off = ((size_t)panel * nkc + kc) * (2 * PLANE) + (size_t)half * (PLANE / 2) + (size_t)rin * 16;
+  const float sy = ldexpf(1.f, 15 - amax_exp(amax[0])), sx = ldexpf(1.f, 15 - amax_exp(amax[1]));
+  f16x8 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float t = b[j] * sy; p0[j] = (_Float16)t; p1[j] = (_Float16)(t - (float)p0[j]); }
+  *reinterpret_cast<f16x8*>(outY + off) = p0;
+  *reinterpret_cast<f16x8*>(outY + off + PLANE) = p1;
+  if (outX) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = a[j] * sx; p0[j] = (_Float16)t; p1[j] = (_Float16)(t - (float)p0[j]); }
+    *reinterpret_cast<f16x8*>(outX + off) = p0;
+    *reinterpret_cast<f16x8*>(outX + off + PLANE) = p1;
+  }
+}
+// rowvals[v][row] = sum over the k blocks of part_v[block][row], in block order
+__global__ __launch_bounds__(256) void k_sum_parts(int n, int nblk, const double* __restrict__ part1, const double* __restrict__ part2,
+                                                   double* __restrict__ rowvals) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  const double* p = blockIdx.y ? part2 : part1;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += p[(size_t)b * n + row];
+  rowvals[(size_t)blockIdx.y * n + row] = s;
+}
+// Operand scales of the two combined Grams BEFORE they exist: amax[3] >= max |2 (s1 KFC + s2 KY)|, amax[4] >= max |2 s2 KX|.
+// KX, KY, KFC are centred Grams (positive semi-definite): |K_ij| <= max_i K_ii, and K_ii = |row i of the centred operand|^2
+// came out of the centring passes (diag[0 .. n): Xc, diag[ldd ..): Yc); max |KFC| was taken once per graph (amax[5]).
+__global__ __launch_bounds__(1024) void k_gram_scales(int n, const double* __restrict__ diagx, const double* __restrict__ diagy,
+                                                      float s1, float s2, float* __restrict__ amax) {
+  __shared__ double sh[16];
+  double mx = 0.0, my = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { mx = fmax(mx, diagx[i]); if (diagy) my = fmax(my, diagy[i]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o)); my = fmax(my, __shfl_xor(my, o)); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) for (int i = 1; i < 16; ++i) mx = fmax(mx, sh[i]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = my;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) my = fmax(my, sh[i]);
+    // (1 + 2^-20: the float roundings of the diagonal sums and of the combine itself stay below the bound)
+    amax[3] = (float)(2.0 * (fabs((double)s1) * (double)amax[5] + fabs((double)s2) * my) * (1.0 + 9.5e-7));
+    amax[4] = (float)(2.0 * fabs((double)s2) * mx * (1.0 + 9.5e-7));
   }
 }
 
@@ -600,13 +718,26 @@ void split_absmax(hipStream_t st, int n, int ld, const float* X, const float* su
   hipLaunchKernelGGL(k_split_absmax, dim3(n), dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, (unsigned*)amax);
 }
 void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub, bool sym_lower, void* out, int planes,
-                 const float* amax) {
+                 const float* amax, float mul) {
   const int nkc = chunks_of(n, planes), panels = (n + TB - 1) / TB;
   dim3 grid((nkc * 2 + 7) / 8, panels * (TB / 32));
   if (planes == 2)
-    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr, nullptr, mul);
   else
-    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, X, sub, sym_lower ? 1 : 0, nkc, (char*)out, amax, nullptr, 0, nullptr, nullptr, mul);
+}
+// linear_HSIC's combine + both packs in one pass (k_hsic_combine_pack); scratch: 2 x split3_pack_rsq_parts(n, 2) x n doubles
+size_t hsic_combine_pack_scratch_doubles(int n) { return 2 * (size_t)((chunks_of(n, 2) * 2 + 7) / 8) * n; }
+void hsic_gram_scales(hipStream_t st, int n, const double* diagx, const double* diagy, float s1, float s2, float* amax) {
+  hipLaunchKernelGGL(k_gram_scales, dim3(1), dim3(1024), 0, st, n, diagx, s2 != 0.f ? diagy : nullptr, s1, s2, amax);
+}
+void hsic_combine_pack(hipStream_t st, int n, int ld, const float* KX, const float* KY, const float* KFC, float s1, float s2,
+                       float* amax, void* outY, void* outX, double* scratch, double* rowvals) {
+  const int nkc = chunks_of(n, 2), panels = (n + TB - 1) / TB, nblk = (nkc * 2 + 7) / 8;
+  double* p1 = scratch; double* p2 = scratch + (size_t)nblk * n;
+  hipLaunchKernelGGL(k_hsic_combine_pack, dim3(nblk, panels * (TB / 32)), dim3(256), 0, st, n, ld, KX, KY, KFC, s1, s2, nkc, (char*)outY,
+                     (char*)outX, amax + 3, p1, p2);
+  hipLaunchKernelGGL(k_sum_parts, dim3((n + 255) / 256, 2), dim3(256), 0, st, n, nblk, p1, p2, rowvals);
 }
 // Panels [panel_off, panel_off + panel_rows) of the centred normalised adjacency formed from M on the fly (see k_pack);
 // rsq_part [n][split3_pack_rsq_parts(n, planes)] receives the per-block sums of squares of each packed row.
@@ -618,9 +749,9 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
   if (pr <= 0) return;
   dim3 grid((nkc * 2 + 7) / 8, pr * (TB / 32));
   if (planes == 2)
-    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part, rsum_part);
+    hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part, rsum_part, 1.f);
   else
-    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part, rsum_part);
+    hipLaunchKernelGGL(k_pack<3>, grid, dim3(256), 0, st, n, ld, M, mean, 0, nkc, (char*)out, amax, rvec, panel_off * TB, rsq_part, rsum_part, 1.f);
 }
 // C[rows of panels [panel_off, panel_off + panel_rows)][0..n) (row-major, ldc) = A' B'^T from the packed planes
 // (panel_rows < 0: all panels).  Tiles are independent; a row range gives the same bits as the full launch except for

@@ -1516,3 +1516,29 @@ def test_kde_steps_of_a_large_graph_match_the_oracle(pkg, torch_, n, widths, ncl
         o.set_adj_changes(eng.get_adj_changes().cpu().numpy())
     assert eng.path_stats() == {"lowrank_steps": 0, "general_steps": 0} and eng.fused_steps() == 0
     eng.close()
+
+
+@pytest.mark.parametrize("wp", [(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 0)], ids=["all", "c1only"])
+def test_gram_products_beside_the_step_are_bit_identical(pkg, monkeypatch, wp):
+    """Gram-evaluation steps (here MCGRA_NO_LOWRANK=1 at n = 1100) run their four N x N x N products on the side stream -- Kx
+    beside the forward chains and the decode, Ky beside the small-operand terms and the victim chain's backward, G_A1 += LX Yc
+    beside the rank-k update of G_adjn, G_adjn += LY Xc beside the decode backward -- with the combine of the centred Grams and
+    the packs of its two results in one pass.  Same launches in the same order on ONE stream (MCGRA_GRAM_OVERLAP=0): the same
+    bits, gradient and state, over three steps with the monitoring forward in between."""
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5, weight_param=wp)
+    monkeypatch.setenv("MCGRA_NO_LOWRANK", "1")
+    outs = []
+    for ovl in ("1", "0"):
+        monkeypatch.setenv("MCGRA_GRAM_OVERLAP", ovl)
+        eng = H.engine_from(pkg, z)
+        gs = []
+        for t in range(3):
+            eng.step(); eng.monitor()
+            gs.append(eng.buffer("G_sym").clone())
+        outs.append((gs, eng.buffer("M").clone()))
+        assert eng.gram_split_steps() == 3 and eng.fused_steps() == 0
+        eng.close()
+    import torch
+    for t in range(3):
+        assert torch.equal(outs[0][0][t], outs[1][0][t]), t
+    assert torch.equal(outs[0][1], outs[1][1])
