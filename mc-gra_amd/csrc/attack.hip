@@ -277,6 +277,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   { const char* e = getenv("MCGRA_NO_FWD_REUSE"); h->fwd_reuse = cfg->eps == 0.f && !(e && e[0] == '1'); }
   { const char* e = getenv("MCGRA_NO_FUSED_TAIL"); h->fuse_tail = !(e && e[0] == '1'); }
   if (h->fwd_reuse) { A_(ADJN_next, nn); }
+  A_(cm_part, (size_t)64 * 256);      // column-sum partials of launch_colmean_center (small-operand terms)
   A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
   {
     const char* e = getenv("MCGRA_NO_LOWRANK");
@@ -421,7 +422,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       if (!h->sharded) { A_(FY, n * (size_t)fc); }      // a row-block rank keeps FY in the exchange arena
       A_(rkbuf, fl_tail_pack_bytes((int)n));           // packed fp16 planes of the tail's rank-k panels
       A_(Zpair, (n + 2) * (size_t)h->hmax);
-      if (!h->sharded) { A_(ws_dec, (size_t)lr_decode_slabs((int)n) * n * he); }
+      // (a row-block rank cuts the columns of its rows' decode into up to 64 slices: fused_lowrank.hip: fl_decode_slabs)
+      A_(ws_dec, (size_t)(h->sharded ? 64 : lr_decode_slabs((int)n)) * n * he);
       h->fused_ok = (rc == 0);
     }
   }
@@ -617,7 +619,7 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
   } else if (h->cfg.measure == MCGRA_MEASURE_CKA) {
     // linear_CKA(X, Y) (utils.py:1091-1096): value hxy / (sqrt(hxx) sqrt(hyy)); Q = Xc^T Yc, R = Yc^T Yc,
     // d/dY = (2/den) Xc Q - (2 hxy / (den hyy)) Yc R.  hxx is the constant in cst[cst_slot].
-    launch_colmean_center(st, na, width, h->Yg, hm);
+    launch_colmean_center(st, na, width, h->Yg, hm, h->cm_part);
     MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)hm * hm, st));
     MCGRA_HIP(hipMemsetAsync(h->Q2, 0, sizeof(float) * (size_t)hm * hm, st));
     CHK(eg(h, st, true, false, width, width, na, 1.f, Xc, hm, h->Yg, hm, 0.f, h->Q, hm));
@@ -647,7 +649,7 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
   } else {  // HSIC: value |Xc^T Yc|_F^2, gradient 2 Xc (Xc^T Yc)   (utils.py:1085-1089)
     // Y is centred explicitly: Xc^T Y == Xc^T Yc only in exact arithmetic, and with identical rows of Y
     // (adj_changes == 0) the fp32 residue of Xc's column sums would otherwise be the whole "gradient"
-    launch_colmean_center(st, na, width, h->Yg, hm);
+    launch_colmean_center(st, na, width, h->Yg, hm, h->cm_part);
     // one Q per term (c9: Q, c10: Q2): each is only ever written on its term's width x width block, so its pad columns
     // keep the zeros of the allocation and no fill is needed per step
     float* Qb = slot == S_C10 ? h->Q2 : h->Q;
@@ -892,7 +894,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   };
   bool gs_path = false, kx_started = false, gs_early_bwd = false, gs_p4 = false, gs_p3 = false, gs_rankk_done = false;
   hipStream_t sg_ = st;
-  std::function<int()> gs_fork, launch_kx;
+  std::function<int()> gs_fork;
+  std::function<int(bool)> launch_kx;
   std::function<int(int, int, int)> pair;
   if (PH(0)) {
   const bool adopt = h->fwd_cached && !gen;         // forward of this iteration already done by the last monitor call
@@ -919,6 +922,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   //   G_adjn += LY Xc  beside the decode backward and the modified_adj chain's backward
   // split-K slabs: G_A (Kx, Ky: idle until the tail), KY / KX (the two gradient products: dead once combined and packed)
   gs_path = h->gram_split && !gen && want_xc;
+  const bool gs_only = gs_path && !h->lr_ok;      // known now that the step evaluates the Grams
   sg_ = (gs_path && h->gram_ovl && h->st2) ? h->st2 : st;
   gs_fork = [=]() -> int {      // the side stream picks up behind everything enqueued on the caller's so far
     if (sg_ != st) { MCGRA_HIP(hipEventRecord(h->ev_fork, st)); MCGRA_HIP(hipStreamWaitEvent(sg_, h->ev_fork, 0)); }
@@ -929,8 +933,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     MCGRA_HIP(hipMemcpyAsync(h->amax + 9 + 2 * slot, h->amax + ib, sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
   };
-  launch_kx = [=]() -> int {      // Kx: lower tiles, mirrored by the epilogue (full, bitwise symmetric matrix)
-    split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
+  launch_kx = [=](bool packed) -> int {      // Kx: lower tiles, mirrored by the epilogue (full, bitwise symmetric matrix)
+    if (!packed) split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
     CHK(pair(0, 1, 1));
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, h->profile));
@@ -944,6 +948,15 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       if (!h->colpart_d) CHK(dalloc(h, &h->colpart_d, (size_t)h->nstrips * ld));
       launch_colsum(st, n, ld, h->ADJN, h->colpart_d, h->nstrips, h->rowsx);
     }
+    if (gs_only) {
+      // This step IS a Gram evaluation (no low-rank form: GAT / GraphSAGE victims, CKA, widths > 32, MCGRA_NO_LOWRANK): both
+      // packed orientations of Xc in ONE pass over adj_norm -- rows of Xc (the operands of Kx = Xc Xc^T) and rows of Xc^T (the B
+      // operand of G_adjn += LY Xc) -- with diag(Kx) from the same pass; the fp32 Xc is never stored.  Kx starts now, beside
+      // the forward chains and the decode.
+      launch_colmean_f32(st, n, ld, h->rowsx, h->cmean);
+      pack_center_both(st, n, ld, h->ADJN, h->cmean, h->r, 0.f, h->Gp0, h->Bpack, h->amax + 1, h->gram_diag, reinterpret_cast<double*>(h->XC));
+      CHK(launch_kx(true)); kx_started = true;
+    } else {
     // (gram_diag: |xc_i|^2 = diag(Kx) for the scale bound of the combined Grams -- only when the low-rank path does not want it)
     const bool want_lrrs = h->lr_ok && !cka && use2;
     launch_center_cols(st, n, ld, h->ADJN, h->rowsx, h->cmean, h->XC, want_lrrs ? h->lrRs : (gs_path ? h->gram_diag : nullptr),
@@ -952,9 +965,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     // low-rank product below packs them anyway
     if (h->gram_split && !gen && !(h->lr_ok && !cka && use1 && h->split_on))
       split3_pack(st, n, ld, h->ADJN, h->cmean, false, h->Bpack, 2, h->amax + 1);
-    // ... and when the configuration has no low-rank form at all (GAT / GraphSAGE victims, CKA, widths > 32,
-    // MCGRA_NO_LOWRANK) this step IS a Gram evaluation: Kx = Xc Xc^T starts now, beside the forward chains and the decode
-    if (gs_path && !h->lr_ok) { CHK(launch_kx()); kx_started = true; }
+    }
     if (h->lr_ok && !cka && use1) {
       // P1 = (H Kf H) Xc: value and gradient of c1 in the low-rank path; the only N x N x N product of such a
       // step.  Forked onto st2 now (it needs nothing else of the step), joined in phase 1.
@@ -1092,10 +1103,18 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         if (use2) {
           launch_rowsum(st, n, ld, h->A1, h->rowsy);
           const bool gs = h->gram_split && !gen;
+          if (gs && !h->lr_ok) {
+            // rows of Yc (both operands of Ky = Yc Yc^T) and of Yc^T (B operand of G_A1 += LX Yc) in one pass over the symmetric
+            // modified_adj1 (entries in [0, 1]), diag(Ky) from the same pass
+            launch_colmean_f32(st, n, ld, h->rowsy, h->cmean);
+            pack_center_both(st, n, ld, h->A1, h->cmean, nullptr, 1.0002f, h->Gp1, h->Gp2, h->amax + 2, h->gram_diag + ld,
+                             reinterpret_cast<double*>(h->YC));
+          } else {
           launch_center_cols(st, n, ld, h->A1, h->rowsy, h->cmean, h->YC, gs ? h->gram_diag + ld : nullptr, gs ? h->amax + 2 : nullptr);
           if (gs) {
             split3_pack(st, n, ld, h->A1, h->cmean, false, h->Gp2, 2, h->amax + 2);      // Yc^T (A1 is symmetric)
             split3_pack(st, n, ld, h->YC, nullptr, false, h->Gp1, 2, h->amax + 2);       // Yc: both operands of Ky = Yc Yc^T
+          }
           }
         }
       }
@@ -1124,7 +1143,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       // Kfc + s2 Kyc) is combined and packed beside the third).  linear_CKA's factors need both Grams: it combines first.
       const size_t slab = sizeof(float) * (size_t)n * ld;
       const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
-      if (!kx_started) { CHK(launch_kx()); kx_started = true; }      // (a low-rank configuration whose decode found a dead row)
+      if (!kx_started) { CHK(launch_kx(false)); kx_started = true; }      // (a low-rank configuration whose decode found a dead row)
       if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_first, sg_));    // Kx done
       if (use2) {
         CHK(pair(1, 2, 2));

@@ -537,20 +537,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       MCGRA_HIP(hipMemcpy2DAsync(h->em_last, (size_t)h->hmax * 4, h->Hv + h->off[Le - 1], (size_t)hs * 4, (size_t)he * 4, n,
                                  hipMemcpyDeviceToDevice, st));
 
-      // ---- small-operand terms c9 (:237-258) and c10 (:259-272): they need only the forward, and at small n their ~16
-      //      tiny launches are a tenth of the step -- forked onto a third stream, joined in front of the backward of em
+      // (the small-operand terms c9 / c10 pick up here on a third stream; their ~16 tiny launches are ENQUEUED further down: the
+      // host needs ~0.1 ms for them, during which the caller's stream -- the critical path of a short step: a row-block rank at
+      // world 8, a small graph -- would sit idle with the head backward, the decode and the factor chain still to come)
       if (s3 != st) {
         MCGRA_HIP(hipEventRecord(h->ev_fork3, st));
         MCGRA_HIP(hipStreamWaitEvent(s3, h->ev_fork3, 0));
       }
-      MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
-      if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9, want_vals));
-      if (w10 != 0) {
-        MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s3));
-        CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10, want_vals));
-        launch_softmax_bwd(s3, n, C, h->sm2, h->Gsm, C, h->GZ2);
-      }
-      if (s3 != st) MCGRA_HIP(hipEventRecord(h->ev_join3, s3));
 
       // ---- CE loss (:172) and its gradient into the victim chain
       if (h->fused_post && fl_head_bwd_supported(C, h->wdt[L - 1], he)) {      // k_nll_grad + k_rowmat_mask in one launch
@@ -590,18 +583,29 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (s4 != st) MCGRA_HIP(hipEventRecord(h->ev_join4, s4));
         h->fs_dec_forked = s4 != st;
       } else {
-        MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), st));
+        // row-block rank: the decode of the own rows -- the longest node-level kernel of a rank's step, and at world 8 that
+        // chain, not the product, is the rank's critical path -- on the fourth stream with its own slabs, beside the column
+        // statistics, the factor prep and the first low-rank product; joined in front of the gather its results ride in
+        const bool dec_side = use2 && s3 != st && h->ws_dec != nullptr;
+        hipStream_t s4 = dec_side ? h->st4 : st;
+        if (dec_side) {
+          MCGRA_HIP(hipEventRecord(h->ev_fork4, st));
+          MCGRA_HIP(hipStreamWaitEvent(s4, h->ev_fork4, 0));
+        }
+        MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
-        h->fs_np = fl_decode_fly(st, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws, h->rowvals + 6 * (size_t)ld, h->GZn,
-                                 h->hmax, h->nmask, h->Zpair, true);
+        h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), dec_side ? h->ws_dec : h->ws,
+                                 h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->nmask, h->Zpair, true);
         // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair and dead-row counts and its entropy partial:
         // they ride in the gather of the first low-rank product below (or, without c2, in a gather of their own)
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
-        hipLaunchKernelGGL(k_u32x2_to_f64, dim3(1), dim3(1), 0, st, h->nmask, lane_slot(h, sg, 0), lane_slot(h, sg, 1));
-        if (h->fs_np > 0) launch_reduce_rows(st, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 2));
-        else MCGRA_HIP(hipMemsetAsync(lane_slot(h, sg, 2), 0, sizeof(double), st));
-        if (use2) rows_to_stage2(h, st, sg, he, h->GZn, h->hmax, 0, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
-        else rows_to_stage(h, st, sg, he, h->GZn, h->hmax, 0);
+        hipLaunchKernelGGL(k_u32x2_to_f64, dim3(1), dim3(1), 0, s4, h->nmask, lane_slot(h, sg, 0), lane_slot(h, sg, 1));
+        if (h->fs_np > 0) launch_reduce_rows(s4, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 2));
+        else MCGRA_HIP(hipMemsetAsync(lane_slot(h, sg, 2), 0, sizeof(double), s4));
+        if (use2) rows_to_stage2(h, s4, sg, he, h->GZn, h->hmax, 0, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
+        else rows_to_stage(h, s4, sg, he, h->GZn, h->hmax, 0);
+        if (dec_side) MCGRA_HIP(hipEventRecord(h->ev_join4, s4));
+        h->fs_dec_forked = dec_side;
       }
       MCGRA_KERNEL_CHECK();
       if (!use2) { FS_XCHG(h->fs_state, 2, X_SG(h)) }
@@ -620,6 +624,23 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         fl_wcolsum(st, n, 2 * he, h->lrV, h->lr_ldv, nullptr, h->fstat, nullptr, h->fstat + 256);
         if (!h->fused_post) fl_cat_scaled(st, n, 2 * he, 2 * he, h->lrV, h->lr_ldv, h->r, h->FV, fc, 0);
         CHK(mm_rows(h, st, 2 * he));
+      }
+      // ---- small-operand terms c9 (:237-258) and c10 (:259-272): they need only the forward, and at small n their ~16
+      //      tiny launches are a tenth of the step -- on a third stream (forked behind the forward, above), joined in front of the
+      //      backward of em.  ENQUEUED here, behind the decode and the first low-rank product: while the host spends its ~0.1 ms on
+      //      them the caller's stream has the column statistics, the factor prep and that product to run
+      MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
+      if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9, want_vals));
+      if (w10 != 0) {
+        MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s3));
+        CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10, want_vals));
+        launch_softmax_bwd(s3, n, C, h->sm2, h->Gsm, C, h->GZ2);
+      }
+      if (s3 != st) MCGRA_HIP(hipEventRecord(h->ev_join3, s3));
+
+      if (h->sharded && h->fs_dec_forked) {      // the decode's rows and lane slots ride in the gather below
+        MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join4, 0));
+        h->fs_dec_forked = false;
       }
       if (use2) { FS_XCHG(h->fs_state, 5, X_FY(h)) }
       if (h->sharded) {

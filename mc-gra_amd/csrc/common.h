@@ -95,6 +95,8 @@ int split3_panel();
 size_t hsic_combine_pack_scratch_doubles(int n);
 // amax: the engine's scale slots ([5] = max |KFC| on entry; [3], [4] receive the bounds of the two results); rowvals[0 .. n) = row sums
 // of KFC o KX, [n .. 2n) of KX o KY
+void pack_center_both(hipStream_t st, int n, int ld, const float* X, const float* mean, const float* rvec, float vmax, void* outR,
+                      void* outT, float* amax, double* diag, double* scratch);
 void hsic_gram_scales(hipStream_t st, int n, const double* diagx, const double* diagy, float s1, float s2, float* amax);
 void hsic_combine_pack(hipStream_t st, int n, int ld, const float* KX, const float* KY, const float* KFC, float s1, float s2,
                        float* amax, void* outY, void* outX, double* scratch, double* rowvals);      // outX may be NULL (LX packed by split3_pack)

@@ -77,6 +77,7 @@ struct mcgra_attack {
   float* Abuf = 0;                 // modified_adj after adding_noise (only when eps != 0 or ori != 0; otherwise it is M itself)
   unsigned char* gate = 0;         // clamp pass-through mask of adding_noise's torch.clamp
   double* colpart_d = 0;
+  double* cm_part = 0;             // scratch of launch_colmean_center
   double* kde = 0;                 // measure KDE: tables + per-block partials of one term (kde_kernels.hip: kde_scratch_doubles)
   double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)
   float* ws = 0;

@@ -20,6 +20,7 @@ void launch_rowsum(hipStream_t st, int n, int ld, const float* K, double* rows);
 void launch_center(hipStream_t st, int n, int ld, float* K, const double* rows, const double* total);
 void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const double* rows, float* mean_scratch,
                         float* out, double* rowsq = nullptr, float* absmax = nullptr);
+void launch_colmean_f32(hipStream_t st, int n, int ld, const double* colsum, float* mean);      // mean_j = colsum_j / n, zero padded to ld
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower, float* amax_kx = nullptr, float* amax_ky = nullptr);
 void launch_row_softmax(hipStream_t st, int n, int ld, const float* X, float* out);
@@ -82,7 +83,7 @@ void launch_cka_small_coef(hipStream_t st, const double* hxx, const double* hxy,
                            double* val);
 void launch_scatter_add2_rows(hipStream_t st, int m, int h, const float* S1, const float* S2, int lds_, const int* idx,
                               const float* ab, float* dst, int ldd);
-void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld);
+void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld, double* part = nullptr);      // part: 64 x h doubles of scratch (without: one block per column)
 void launch_sumsq(hipStream_t st, size_t count, const float* X, double* out);
 void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* out);
 void launch_kl_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* rowval);

@@ -960,6 +960,9 @@ void launch_center_cols(hipStream_t st, int n, int ld, const float* X, const dou
   LAUNCH(k_colmean_f32, dim3((ld + 255) / 256), dim3(256), st, n, ld, rows, mean_scratch, (unsigned*)absmax);
   LAUNCH(k_center_cols, dim3(n), dim3(ROW_THREADS), st, n, ld, X, mean_scratch, out, rowsq, (unsigned*)absmax);
 }
+void launch_colmean_f32(hipStream_t st, int n, int ld, const double* colsum, float* mean) {
+  LAUNCH(k_colmean_f32, dim3((ld + 255) / 256), dim3(256), st, n, ld, colsum, mean, (unsigned*)nullptr);
+}
 void launch_hsic_combine(hipStream_t st, int n, int ld, float* KX, float* KY, const float* KFC, float s1, float s2,
                          double* rowvals, bool lower, float* amax_kx, float* amax_ky) {
   LAUNCH(k_hsic_combine, dim3(n), dim3(ROW_THREADS), st, n, ld, KX, KY, KFC, s1, s2, rowvals, lower ? 1 : 0, (unsigned*)amax_kx,

@@ -242,16 +242,88 @@ __global__ __launch_bounds__(256) void k_hsic_combine_pack(int n, int ld, const 
     *reinterpret_cast<f16x8*>(outX + off + PLANE) = p1;
   }
 }
-// rowvals[v][row] = sum over the k blocks of part_v[block][row], in block order
+// rowvals[v][row] = sum over the k blocks of part_v[block][row]: four interleaved chains per row (blocks b = q mod 4), added
+// in the order ((0 + 1) + (2 + 3)) -- a fixed order: deterministic.  64 rows x 4 chains per block of threads.
 __global__ __launch_bounds__(256) void k_sum_parts(int n, int nblk, const double* __restrict__ part1, const double* __restrict__ part2,
                                                    double* __restrict__ rowvals) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= n) return;
+  __shared__ double sh[4][64];
+  const int lr = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + lr;
   const double* p = blockIdx.y ? part2 : part1;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += p[(size_t)b * n + row];
-  rowvals[(size_t)blockIdx.y * n + row] = s;
+  if (row < n) for (int b = q; b < nblk; b += 4) s += p[(size_t)b * n + row];
+  sh[q][lr] = s;
+  __syncthreads();
+  if (q == 0 && row < n) rowvals[(size_t)blockIdx.y * n + row] = (sh[0][lr] + sh[1][lr]) + (sh[2][lr] + sh[3][lr]);
 }
+// Both packed orientations of the column-centred form of a SYMMETRIC matrix X in one pass over it (Gram evaluation: Xc from
+// adj_norm, Yc from modified_adj1; round 4 wrote the centred matrix in fp32 and packed it twice: three reads and three writes
+// of 400 MB at N = 10 000 where this is one read and two writes):
+//   outR  rows of Xc:    value(row, k) = X[row][k] - mean[k]      (both operands of the Gram Xc Xc^T)
+//   outT  rows of Xc^T:  value(row, k) = X[k][row] - mean[row] = X[row][k] - mean[row]   (B operand of L Xc)
+// rsq_part[k block][row] = the block's share of |row of Xc|^2 in fp64 (diag of the centred Gram: scale bound of the combined
+// Grams).  amax[0]: an upper bound of max |Xc| known beforehand.  Thread mapping and plane layout: k_pack<2>.
+__global__ __launch_bounds__(256) void k_pack_center_both(int n, int ld, const float* __restrict__ X, const float* __restrict__ mean,
+                                                          int nkc, char* __restrict__ outR, char* __restrict__ outT,
+                                                          const float* __restrict__ amax, double* __restrict__ rsq_part) {
+  const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+  const int row = blockIdx.y * 32 + r;
+  const int k0 = (blockIdx.x * 8 + c) * 8;
+  const bool act = k0 < nkc * KC;
+  float vr[8], vt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vr[j] = vt[j] = 0.f;
+  double sq = 0.0;
+  if (row < n && act) {
+    const float mrow = mean[row];
+    if (k0 + 7 < n) {
+      const float4 x0 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0), x1 = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0 + 4);
+      const float4 m0 = *reinterpret_cast<const float4*>(mean + k0), m1 = *reinterpret_cast<const float4*>(mean + k0 + 4);
+      const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, ms[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { vr[j] = xs[j] - ms[j]; vt[j] = xs[j] - mrow; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < n) { const float x = X[(size_t)row * ld + k0 + j]; vr[j] = x - mean[k0 + j]; vt[j] = x - mrow; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf(vr[j], vr[j], s);
+    sq = (double)s;
+  }
+  sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+  if (c == 0 && row < n) rsq_part[(size_t)blockIdx.x * n + row] = sq;
+  if (!act) return;
+  const int panel = row / TB, rin = row % TB, kc = k0 / KC, half = (k0 % KC) / 8;
+  const size_t off = ((size_t)panel * nkc + kc) * (2 * PLANE) + (size_t)half * (PLANE / 2) + (size_t)rin * 16;
+  const float sc = ldexpf(1.f, 15 - amax_exp(amax[0]));
+  f16x8 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float t = vr[j] * sc; p0[j] = (_Float16)t; p1[j] = (_Float16)(t - (float)p0[j]); }
+  *reinterpret_cast<f16x8*>(outR + off) = p0;
+  *reinterpret_cast<f16x8*>(outR + off + PLANE) = p1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float t = vt[j] * sc; p0[j] = (_Float16)t; p1[j] = (_Float16)(t - (float)p0[j]); }
+  *reinterpret_cast<f16x8*>(outT + off) = p0;
+  *reinterpret_cast<f16x8*>(outT + off + PLANE) = p1;
+}
+// amax_out[0] = bound of max |X - 1 mean^T| for a matrix with entries in [0, vmax] and column means in [0, vmax]: vmax itself.
+// rvec != nullptr: X = adj_norm = R (M + I) R with M in [0, 1]: entries <= (max r)^2; else vmax = `given`.
+__global__ __launch_bounds__(1024) void k_centered_bound(int n, const float* __restrict__ rvec, float given, float* __restrict__ amax_out) {
+  __shared__ float sh[16];
+  float m = 0.f;
+  if (rvec) for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, rvec[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, sh[i]);
+    amax_out[0] = rvec ? m * m * (1.f + 2.4e-7f) : given;
+  }
+}
+
 // Operand scales of the two combined Grams BEFORE they exist: amax[3] >= max |2 (s1 KFC + s2 KY)|, amax[4] >= max |2 s2 KX|.
 // KX, KY, KFC are centred Grams (positive semi-definite): |K_ij| <= max_i K_ii, and K_ii = |row i of the centred operand|^2
 // came out of the centring passes (diag[0 .. n): Xc, diag[ldd ..): Yc); max |KFC| was taken once per graph (amax[5]).
@@ -728,6 +800,16 @@ void split3_pack(hipStream_t st, int n, int ld, const float* X, const float* sub
 }
 // linear_HSIC's combine + both packs in one pass (k_hsic_combine_pack); scratch: 2 x split3_pack_rsq_parts(n, 2) x n doubles
 size_t hsic_combine_pack_scratch_doubles(int n) { return 2 * (size_t)((chunks_of(n, 2) * 2 + 7) / 8) * n; }
+// Planes of Xc (outR) and of Xc^T (outT) of the column-centred symmetric X, |rows of Xc|^2 to diag [n] (fp64), the operand
+// scale bound to amax[0]; mean: the column means, zero padded to ld; scratch: split3_pack_rsq_parts(n, 2) x n doubles
+void pack_center_both(hipStream_t st, int n, int ld, const float* X, const float* mean, const float* rvec, float vmax, void* outR,
+                      void* outT, float* amax, double* diag, double* scratch) {
+  const int nkc = chunks_of(n, 2), panels = (n + TB - 1) / TB, nblk = (nkc * 2 + 7) / 8;
+  hipLaunchKernelGGL(k_centered_bound, dim3(1), dim3(1024), 0, st, n, rvec, vmax, amax);
+  hipLaunchKernelGGL(k_pack_center_both, dim3(nblk, panels * (TB / 32)), dim3(256), 0, st, n, ld, X, mean, nkc, (char*)outR, (char*)outT,
+                     amax, scratch);
+  hipLaunchKernelGGL(k_sum_parts, dim3((n + 63) / 64, 1), dim3(256), 0, st, n, nblk, scratch, scratch, diag);
+}
 void hsic_gram_scales(hipStream_t st, int n, const double* diagx, const double* diagy, float s1, float s2, float* amax) {
   hipLaunchKernelGGL(k_gram_scales, dim3(1), dim3(1024), 0, st, n, diagx, s2 != 0.f ? diagy : nullptr, s1, s2, amax);
 }
@@ -737,7 +819,7 @@ void hsic_combine_pack(hipStream_t st, int n, int ld, const float* KX, const flo
   double* p1 = scratch; double* p2 = scratch + (size_t)nblk * n;
   hipLaunchKernelGGL(k_hsic_combine_pack, dim3(nblk, panels * (TB / 32)), dim3(256), 0, st, n, ld, KX, KY, KFC, s1, s2, nkc, (char*)outY,
                      (char*)outX, amax + 3, p1, p2);
-  hipLaunchKernelGGL(k_sum_parts, dim3((n + 255) / 256, 2), dim3(256), 0, st, n, nblk, p1, p2, rowvals);
+  hipLaunchKernelGGL(k_sum_parts, dim3((n + 63) / 64, 2), dim3(256), 0, st, n, nblk, p1, p2, rowvals);
 }
 // Panels [panel_off, panel_off + panel_rows) of the centred normalised adjacency formed from M on the fly (see k_pack);
 // rsq_part [n][split3_pack_rsq_parts(n, planes)] receives the per-block sums of squares of each packed row.

@@ -26,3 +26,15 @@ print(f"{steps} steps: wall {(t1 - t0) / 1e3 / steps:.0f} us per step; kernel ti
 print(f"{'us/step':>10} {'launches':>8}  kernel")
 for k, v in dur.most_common(45):
     print(f"{v / 1e3 / steps:10.1f} {cnt[k] / steps:8.2f}  {k}")
+if len(sys.argv) > 3 and sys.argv[3] == "--timeline":
+    # launch list of the last step, per queue: start relative to the step, duration, gap to the previous launch of the queue
+    a2, b2 = adam[-2] + 1, adam[-1] + 1
+    t0 = int(rows[a2]["Start_Timestamp"])
+    last = {}
+    print(f"--- last step, launch by launch ({b2 - a2} launches, {(int(rows[b2 - 1]['End_Timestamp']) - t0) / 1e3:.0f} us)")
+    for r in rows[a2:b2]:
+        s_, e_, q = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]
+        gap = (s_ - last[q]) / 1e3 if q in last else 0.0
+        last[q] = e_
+        g = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
+        print(f"{(s_ - t0) / 1e3:8.1f} {(e_ - s_) / 1e3:7.1f} gap {gap:6.1f} q{q} g{g:5d}x{r['Grid_Size_Y']:>3} {nm(r)}")

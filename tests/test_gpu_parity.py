@@ -411,7 +411,12 @@ def test_engine_invariants_and_determinism(pkg, torch_):
 def test_unsupported_arguments_fail_loudly(pkg, torch_):
     z = H.load_case("s48_mse")
     with pytest.raises(ValueError):
-        H.engine_from(pkg, z, measure="KDE")
+        H.engine_from(pkg, z, measure="Wasserstein")          # (topology_attack.py:194-208 knows six measures; all six are built)
+    from mc_gra_amd._lib import McgraNotSupported
+    wide = H.synthetic_case(300, 11, (16, 48), 4, seed=1, measure="KDE")
+    wide["emb_nlayer"] = np.array(2)
+    with pytest.raises(McgraNotSupported, match="KDE"):      # the c x c joint of utils.MutualInformation: widths <= 32
+        H.engine_from(pkg, wide)
 
 
 # ------------------------------------------------------------------ class surface + Cora
