@@ -450,8 +450,11 @@ def multi_rank_diagnostics(pkg, torch, dist, dev, rank, world, a, eng, stepper, 
     steps = a.steps
     prod_ms = st["ms"] / steps if st["launches"] else None
     # compute only: from the workload's own start again (the echo leaves a state that is not the attack's)
-    eng.set_adj_changes(torch.as_tensor(masked_variant(a.workload, make_inputs(*WORKLOADS[a.workload][:5], a.seed),
-                                                       make_a0(n, a.seed, start_scale(a.workload, n)), a.seed)[1], device=dev))
+    a0 = make_a0(n, a.seed, start_scale(a.workload, n))
+    if a.workload in MASKED_VARIANTS:
+        a0 = masked_variant(a.workload, make_inputs(*WORKLOADS[a.workload][:5], a.seed), a0, a.seed)[1]
+    eng.set_adj_changes(torch.as_tensor(a0, device=dev))
+    del a0
     k = max(2, min(steps, 20))
     f0 = eng.fused_steps()
     for _ in range(2):
