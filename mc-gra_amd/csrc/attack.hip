@@ -325,7 +325,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const char* eo = getenv("MCGRA_OVERLAP");
     h->overlap = (eo && eo[0]) ? eo[0] == '1' : (h->split_mode == 2 && h->split_planes == 2);
     if (h->gram_split) { A_(gram_diag, 2 * ld); }
-    if (!rc && (h->lr_ok || h->gram_split)) {
+    // (the fused MSELoss step -- attack_fused.hip -- uses the side streams of the small-operand terms and of the decode too)
+    const bool mse_fusable = cfg->measure == MCGRA_MEASURE_MSE && cfg->eps == 0.f && !h->has_self && h->act == 0 && h->head_act == 0;
+    if (!rc && (h->lr_ok || h->gram_split || mse_fusable)) {
       int pr_least = 0, pr_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
       // The two side streams are shared by all engines of a device in this process: a process has few hardware queues
@@ -373,17 +375,28 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const int he = h->wdt[h->Le - 1];
     int fc = 2 * he + 1 + h->wdt[h->L - 1];
     for (int l = 0; l < h->L; ++l) fc = (2 * h->wdt[l] + 1) > fc ? 2 * h->wdt[l] + 1 : fc;
+    if (cfg->measure == MCGRA_MEASURE_MSE) {      // the fused MSELoss step: no means column, no low-rank factors -- [r o Tv | Tu] only
+      fc = 0;
+      for (int l = 0; l < h->L; ++l) fc = 2 * h->wdt[l] > fc ? 2 * h->wdt[l] : fc;
+    }
     fc = (fc + 3) & ~3;
     const int kmax = h->hsum > 2 * he ? h->hsum : 2 * he;
     h->fused_ok = !rc && !(e && e[0] == '1') && cfg->measure == MCGRA_MEASURE_HSIC && h->lr_ok && cfg->eps == 0.f &&
                   !h->has_self && h->act == 0 && h->head_act == 0 && h->split_on && h->split_mode == 2 &&
                   lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
                   (cfg->w[0] != 0.f || cfg->w[1] != 0.f);
+    // The fused MSELoss step (round 5): calc = MSELoss is elementwise in (M, feature_adj, r, Zn), so the same two tail passes
+    // over tile pairs serve it with no N x N x N product and no N x N intermediate (adj_norm, modified_adj1, the gradients
+    // w.r.t. them are never stored) -- and a row-block rank needs no N x N exchange at all.  Any n >= 256.
+    h->fused_mse = !rc && !(e && e[0] == '1') && cfg->measure == MCGRA_MEASURE_MSE && cfg->eps == 0.f && !h->has_self &&
+                   h->act == 0 && h->head_act == 0 && lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
+                   h->st3 != nullptr;
+    if (h->fused_mse) h->fused_ok = true;
     h->row0 = 0; h->row1 = (int)n;
     { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
     { const char* ee = getenv("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
     { const char* ee = getenv("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
-    h->late_mean = h->fused_ok && cfg->shard_world == 0;
+    h->late_mean = h->fused_ok && !h->fused_mse && cfg->shard_world == 0;
     {
       const char* ep = getenv("MCGRA_PLANES_MM");
       // default from n = 8192: on smaller graphs the step is bound by its chain of launches, and the two extra launches per
@@ -397,8 +410,9 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       // row-block rank: only the fused step is sharded, and the host-driven bisection of the projection is not
       if (!h->fused_ok || cfg->num_edges < 0.5 * (double)n * (double)n) {
         if (!rc) {
-          set_error("shard_world > 0 needs a configuration the fused low-rank step covers (HSIC, ReLU GCN victim, eps == 0, "
-                    "n >= 1024 or MCGRA_SPLIT_BF16=2/3, widths <= 32) and a projection budget that cannot bind");
+          set_error("shard_world > 0 needs a configuration a fused step covers (HSIC: ReLU GCN victim, eps == 0, n >= 1024 or "
+                    "MCGRA_SPLIT_BF16=2/3, widths <= 32; MSELoss: ReLU GCN victim, eps == 0, n >= 256, widths <= 32) and a projection "
+                    "budget that cannot bind");
           rc = MCGRA_ENOSUP;
         }
       } else {
@@ -1522,6 +1536,8 @@ int mcgra_attack_buffer(mcgra_attack_t* h, const char* name, float** ptr, int* r
       {"em", (h->has_ori ? h->He : h->Hu) + h->off[le], n, h->wdt[le], h->hsum}, {"G_em", h->Gem, n, h->wdt[le], h->hmax},
       {"HA", h->HA, n, h->wdt[le], h->hmax}, {"YA", h->YA, n, h->C, h->C}, {"T0", h->Tv, n, h->wdt[0], h->hsum},
       {"KFC", h->KFC, n, n, ld},
+      {"GPu", h->GPu, n, h->hsum, h->hsum}, {"GPv", h->GPv, n, h->hsum, h->hsum}, {"GZn", h->GZn, n, h->wdt[le], h->hmax},
+      {"Zn", h->Zn, n, h->wdt[le], h->hmax}, {"gd", h->gd, 1, n, ld},
   };
   for (const E& e : tab)
     if (strcmp(e.nm, name) == 0) {

@@ -279,7 +279,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
           const float* Xs[3] = {h->Tv + h->off[l], h->Tu + h->off[l], h->r};
           const float* rs[3] = {h->r, nullptr, nullptr};
           const int lds[3] = {hs, hs, 1}, ws[3] = {w, w, 1};
-          const bool with_r = l == 0 && !h->late_mean;         // (late mean: the means come out of the pack)
+          const bool with_r = l == 0 && !h->late_mean && !h->fused_mse;   // (late mean: the means come out of the pack; MSELoss: no means)
           // [r o Tv | Tu (| r)] -- already in FV when the previous layer's post pass wrote it (fl_layer_post_next)
           if (!(l >= 1 && fused_post && fl_layer_post_fused_supported(h->wdt[l - 1], w)))
             fl_cat_segs(st, n, with_r ? 3 : 2, Xs, lds, rs, ws, h->FV, fc);
@@ -288,7 +288,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         FS_XCHG(h->fw_state, 3, X_FY(h))
         {
           const int l = h->fs_l, w = h->wdt[l];
-          const bool wr = l == 0 && !h->late_mean;
+          const bool wr = l == 0 && !h->late_mean && !h->fused_mse;
           // the post pass and what follows it on the same rows in ONE launch where the widths allow (<= 32): the next
           // layer's T of both chains + the next product's right-hand side, or -- last layer -- both linear heads with their
           // log-softmax (same operations in the same order as the separate kernels)
@@ -315,7 +315,7 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
       }
       if (h->late_mean) { if (h->amax && !h->early_pack) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(1024), 0, st, n, h->r, h->amax + 1); }
-      else fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
+      else if (!h->fused_mse) fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
       MCGRA_KERNEL_CHECK();
   }
   h->fw_state = 0;
@@ -333,8 +333,8 @@ static void fused_commit(mcgra_attack* h) {
   h->planes_valid = false;          // the Adam pass is enqueued: Bpack no longer describes M
   const size_t cnt = (size_t)n * fl_tail_tiles(n);
   const bool may_project = h->cfg.num_edges < 0.5 * (double)n * (double)n;
-  h->lr_step = true;
-  ++h->lr_steps;
+  h->lr_step = !h->fused_mse;
+  if (!h->fused_mse) ++h->lr_steps;      // (the fused MSELoss step has no low-rank form: it counts as a fused step only)
   ++h->fused_steps;
   h->t += 1;
   h->prep_valid = !may_project && 3 * cnt + 4 <= (size_t)n * h->ld;
@@ -372,14 +372,14 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
 // product's ragged rounds, and the second part of a cut product writes them while the early pass over the finished rows runs.)
 static size_t tail_ps_floats(const mcgra_attack* h) {
   const size_t nt = fl_tail_tiles(h->n);
-  return ((((size_t)h->n * nt + 1) & ~(size_t)1) + 4 * nt * nt + 3) & ~(size_t)3;
+  return ((((size_t)h->n * nt + 1) & ~(size_t)1) + 6 * nt * nt + 3) & ~(size_t)3;      // (value partials: up to three per block, fp64)
 }
-static float* tail_ps(const mcgra_attack* h) { return h->KY + (size_t)h->n * h->ld - tail_ps_floats(h); }
+static float* tail_ps(const mcgra_attack* h) { return (h->KY ? h->KY : h->KX) + (size_t)h->n * h->ld - tail_ps_floats(h); }      // (MSELoss engines keep no KY; KX is idle there)
 
 // k_tail_reduce of the step (phase 1: only its rank-k panels are packed -- their inputs are ready before the N x N x N
 // product is joined; 2: the pass itself).  Returns the number of blocks (partials of the loss-term values).
 static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pair, int R0, int R1, bool use1, bool use2, float a1,
-                            float a2, float kie6, bool want_vals) {
+                            float a2, float kie6, bool want_vals, float kmse1 = 0.f, float kmse2 = 0.f) {
   const int n = h->n, hs = h->hsum, he = h->wdt[h->Le - 1], nt = fl_tail_tiles(n);
   float* ps1 = tail_ps(h);                                       // [n][nt]
   double* vpart = reinterpret_cast<double*>(ps1 + (((size_t)n * nt + 1) & ~(size_t)1));
@@ -388,6 +388,10 @@ static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pai
   const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
   const bool no_rk = h->test_mutate == 2;      // (TEST-ONLY mutation, see the join below)
   const float al[2] = {no_rk ? 0.f : 1.f, no_rk ? 0.f : a2};
+  if (h->fused_mse)      // calc = MSELoss: feature_adj in the place of P1, S = Zn Zn^T as a third rank-k group
+    return fl_tail_reduce(st, n, h->ld, pair, R0, R1, 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M, h->FADJ, h->r,
+                          h->cmean, nullptr, nullptr, 0.f, 0.f, kie6, h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf, phase, h->Zn,
+                          h->hmax, he, kmse1, kmse2);
   return fl_tail_reduce(st, n, h->ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M,
                         use1 ? h->KX : nullptr, h->r, h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr, a1, a2, kie6,
                         h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf, phase);
@@ -398,11 +402,15 @@ static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pai
 static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C, fc = h->fcols, R0 = h->row0, R1 = h->row1;
-  const double sg = -1.0;      // measure == HSIC
+  // measure == HSIC (sign -1: :217-220), or -- h->fused_mse -- MSELoss: no product (use1) and no low-rank factors (use2); its two
+  // N x N terms are elementwise and live in the decode (d / d modified_adj1) and in the tail's first pass (d / d adj_norm)
+  const bool mse = h->fused_mse;
+  const double sg = mse ? 1.0 : -1.0;
   const double w1 = c.w[0], w2 = c.w[1], w6 = c.w[5], w7 = c.w[6], w9 = c.w[8], w10 = c.w[9];
   const double k1 = w1 * 1000 * AP_C1, k2 = w2 * 100 * AP_C2, k6 = w6 * 100 * AP_C6, k7 = w7 * AP_C7;
   const double k9 = w9 * AP_C9, k10 = w10 * AP_C10, n2 = (double)n * n;
-  const bool use1 = w1 != 0, use2 = w2 != 0;
+  const bool use1 = !mse && w1 != 0, use2 = !mse && w2 != 0;
+  const float kmse1 = mse ? (float)(k1 * 2.0 / n2) : 0.f, kmse2 = mse ? (float)(k2 * 2.0 / n2) : 0.f;      // k_loss_elem's multipliers
   const float* em = h->Hu + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
   const float a1 = use1 ? 2.f * (float)(sg * k1) : 0.f, a2 = use2 ? 2.f * (float)(sg * k2) : 0.f;
@@ -458,7 +466,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         }
         h->planes_valid = h->planes_mm_on;          // (the means themselves: behind the fork, below)
       } else
-      if (p_cnt > 0) {
+      if (p_cnt > 0 && !mse) {
         split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
                            use2 ? h->A1 : nullptr);
         if (use2)
@@ -573,7 +581,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         // (with c2, k_post_mask leaves the counter at zero for the next fused step; the general path does not)
         if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
-        h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask, h->Zpair, want_vals);
+        h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask, h->Zpair, want_vals,
+                                 mse ? h->M : nullptr, ld, h->r, kmse2);
         if (want_vals) launch_reduce_rows(s4, h->rowvals, h->fs_np, 1, h->scal + S_V7);
         if (use2) {
           hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, s4, h->nmask, nullptr, h->mask_seq_dev, h->mask_host_dev);
@@ -595,7 +604,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), dec_side ? h->ws_dec : h->ws,
-                                 h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->nmask, h->Zpair, true);
+                                 h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->nmask, h->Zpair, true, mse ? h->M : nullptr, ld, h->r, kmse2);
         // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair and dead-row counts and its entropy partial:
         // they ride in the gather of the first low-rank product below (or, without c2, in a gather of their own)
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
@@ -752,7 +761,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       // ---- tail: everything above ran beside the forked product; so do the two tiny launches of the tail that need
       //      nothing of it (the rank-k panels, the coefficient of the norm term).  A row-block rank holds the column block
       //      P1[:, rows]; the all-to-all of tile blocks hands it the row block P1[rows, :] as well.
-      (void)tail_reduce_call(h, st, 1, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
+      (void)tail_reduce_call(h, st, 1, pair, R0, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals, kmse1, kmse2);
       // (the coefficient of the norm term comes out of k_tail_gd's launch; a rank without rows has no Adam pass to feed)
       if (!(h->fused_post && R1 > R0)) hipLaunchKernelGGL(k_cn, dim3(1), dim3(1), 0, st, h->scal, (float)(c.weight_sup * 0.001), h->mm + 2);
       // (a cut product: the peers' row panels are done at ev_first; the own ones are joined behind the all-to-all)
@@ -784,13 +793,15 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       {
         float* ps1 = tail_ps(h);
         double* vpart = reinterpret_cast<double*>(ps1 + (((size_t)n * nt + 1) & ~(size_t)1));
-        h->fs_nblk = tail_reduce_call(h, st, 2, pair, h->sharded ? R0 : h->tail_rows, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals);
+        h->fs_nblk = tail_reduce_call(h, st, 2, pair, h->sharded ? R0 : h->tail_rows, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals, kmse1, kmse2);
         h->tail_rows = 0;
         const Stage sgt = narrow_stage(h);
-        if (h->sharded && !(h->fs_nblk > 0 && want_vals)) CHK(lane_zero(h, st, sgt, 2));
+        if (h->sharded && !(h->fs_nblk > 0 && want_vals)) CHK(lane_zero(h, st, sgt, mse ? 3 : 2));
         if (h->fs_nblk > 0 && want_vals) {
-          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 0) : h->scal + S_H1);
+          // HSIC: sum P1 o Xc -> S_H1; MSELoss: sum (F - adj_norm)^2 -> S_V1 and sum (adj_norm - A1)^2 -> S_V2 (k_loss_elem's slots)
+          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 0) : h->scal + (mse ? S_V1 : S_H1));
           launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 1) : h->scal + S_V6);
+          if (mse) launch_reduce_rows(st, vpart + 2 * (size_t)h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 2) : h->scal + S_V2);
         }
         {
           const bool cn_in_gd = h->fused_post && R1 > R0;
@@ -803,6 +814,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->sharded) {
         const Stage sgt = narrow_stage(h);
         stage_to_rows(h, st, sgt, 1, 0, h->gd, 1);
+        if (mse) lane_sum(h, st, sgt, 3, h->SC + 12);            // SC[12] sum (F - adj_norm)^2, SC[13] entropy term of adj_norm, SC[14] sum (adj_norm - A1)^2
+        else
         lane_sum(h, st, sgt, 2, h->SC + 4);                      // SC[4] sum P1 o Xc, SC[5] entropy term of adj_norm
       }
       // ---- the decision, on the host
@@ -874,8 +887,14 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->fs_want) { FS_XCHG(h->fs_state, 11, X_SG(h)) }
       if (h->sharded && h->fs_want) {
         lane_sum(h, st, narrow_stage(h), 1, h->SC + 6);
+        if (mse) {
+          MCGRA_HIP(hipMemcpyAsync(h->scal + S_V1, h->SC + 12, sizeof(double), hipMemcpyDeviceToDevice, st));
+          MCGRA_HIP(hipMemcpyAsync(h->scal + S_V6, h->SC + 13, sizeof(double), hipMemcpyDeviceToDevice, st));
+          MCGRA_HIP(hipMemcpyAsync(h->scal + S_V2, h->SC + 14, sizeof(double), hipMemcpyDeviceToDevice, st));
+        } else {
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_H1, h->SC + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_V6, h->SC + 5, sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_CLAMPSUM, h->SC + 6, sizeof(double), hipMemcpyDeviceToDevice, st));
       }
   }
@@ -990,7 +1009,7 @@ int mcgra_attack_test_mutate(mcgra_attack_t* h, int what) {
 
 int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, double* ms_per_launch) {
   if (!h || reps < 1) { set_error("bad argument"); return MCGRA_EINVAL; }
-  if (!h->fused_ok || !h->fused_last || h->cfg.w[0] == 0.f) {
+  if (!h->fused_ok || h->fused_mse || !h->fused_last || h->cfg.w[0] == 0.f) {
     set_error("product_replay: the last step must have been a fused low-rank step with the c1 term (w1 != 0)");
     return MCGRA_EINVAL;
   }

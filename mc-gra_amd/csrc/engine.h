@@ -153,6 +153,7 @@ struct mcgra_attack {
   GemmTimer timer;
   // fused low-rank step (attack_fused.hip): everything N x N from M and n-vectors; MCGRA_NO_FUSED_LR=1 disables
   bool fused_ok = false;           // configuration allows it
+  bool fused_mse = false;          // ... as the fused MSELoss step (calc = MSELoss: no product, no low-rank factors; attack_fused.hip)
   // create-time values of the path switches a non-zero ori_adj turns off (set_graph restores them when ori_adj goes away)
   bool lr_ok0 = false, fused_ok0 = false, gram_split0 = false, fwd_reuse0 = false, late_mean0 = false, planes_mm_on0 = false;
   bool fused_fwd_valid = false;    // both chains, heads, d / r / mean of the CURRENT M are in place (left by the monitor call)

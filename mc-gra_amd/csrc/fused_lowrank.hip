@@ -360,11 +360,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 2 x H / 2 ds_read_b128 per pair of columns and wave: bit-identical, 1.5 % slower per step at n = 2708 / 4096, no different at
 // N = 10 000 -- there the pass is paid for in the clock of the product it runs beside, LDS or not: DESIGN.md section 8.)
 // V7 = false: the entropy VALUE (a returned loss term only) is not summed.
-template <int H, bool V7>
+// MSE (the fused MSELoss step, attack_fused.hip): the gradient w.r.t. modified_adj1 also carries calc(adj_norm, modified_adj1) =
+// MSELoss (:194-195, :221-229): d/dA1_ij = ie'(A1_ij) - kmse2 (adj_norm_ij - A1_ij), symmetric like the entropy part, with
+// adj_norm_ij = (r_i r_j) M_ij formed on the fly -- M_ij read as M[j][i] (M is bitwise symmetric): coalesced along the block's rows.
+template <int H, bool V7, bool MSE>
 __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
                                                       const f32x2* __restrict__ Zp, float kie7, int jper,
                                                       float* __restrict__ slabs, double* __restrict__ v7part,
-                                                      unsigned int* __restrict__ nmask) {
+                                                      unsigned int* __restrict__ nmask, const float* __restrict__ Mm, int ldm,
+                                                      const float* __restrict__ rvec, float kmse2) {
   __shared__ double sh[16];
   const int i = row0 + blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < row1;
@@ -381,11 +385,19 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
   }
   double v7 = 0.0;
   int masked = 0;
+  const float ri = (MSE && valid) ? rvec[i] : 0.f;
+  const int ic = valid ? i : row0;                            // (a clamped, always valid column of M for the idle lanes)
   for (int P = j0 >> 1; 2 * P < j1; ++P) {
     const f32x2* __restrict__ zp = Zp + (size_t)P * H;      // wave-uniform
     f32x2 t[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) t[k] = zp[k];
+    f32x2 mij = {0.f, 0.f}, rj = {0.f, 0.f};
+    if (MSE) {
+      const int ja = min(2 * P, n - 1), jb = min(2 * P + 1, n - 1);
+      mij = f32x2{Mm[(size_t)ja * ldm + ic], Mm[(size_t)jb * ldm + ic]};
+      rj = f32x2{rvec[ja], rvec[jb]};
+    }
     f32x2 s = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < H; ++k) s = __builtin_elementwise_fma(f32x2{zi[k], zi[k]}, t[k], s);
@@ -400,6 +412,7 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
       float val, g;
       ie_term(a1, kie7, val, g);
       if (V7 && valid && in) v7 += (double)val;
+      if (MSE) g -= kmse2 * (mij[u] * (ri * rj[u]) - a1);       // adj_norm_ij as mx (r_i r_j): the tail's arithmetic
       w[u] = (off && a1 > 0.f) ? 2.f * g : 0.f;
     }
 #pragma unroll
@@ -456,7 +469,10 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int rk_exp(float amax) {       // amax = f 2^e, f in [0.5, 1); 0 for amax == 0 / inf / nan
   int e = 0;
   if (amax > 0.f && amax < 3.0e38f) frexpf(amax, &e);
-  return e;
+  // (a panel of denormal-sized values -- the gradient behind a saturated softmax, 1e-43 on README usair line 100 -- would ask for
+  //  the scale 2^(15 - e) > FLT_MAX: inf times the values, NaN in every tile pair the panel meets.  Below 2^-100 the panel is
+  //  scaled as if its largest magnitude were 2^-100: its values lose bits they do not have and the product's share underflows.)
+  return e < -100 ? -100 : e;
 }
 
 // One block per (64-row tile, job): job = one round of one factor.  256 threads: thread = (row, k octet).
@@ -568,13 +584,18 @@ __device__ __forceinline__ void rk_sym(const RkRounds& F, int ti, int tj, float 
 //                                                          normalisation backward, mx = M + I)
 //   WANT_V: vpart[block] = { sum P1 o Xc over the block's elements (both orientations when pair), sum ie_value(adj_norm) }
 //           -- the values of the c1 / c6 terms, only when the caller asked for the loss terms
-template <bool WANT_V>
-__global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair, int tile_row0, RkRounds F, RkRounds FU,
+// MSE (the fused MSELoss step): calc = MSELoss (:194-195) instead of linear_HSIC.  P1 then points at feature_adj (the tile and
+// its mirror: F need not be bitwise symmetric), FZ holds the packed panels of (0.5 Zn, Zn): its rank-k sum is S_ij = zn_i . zn_j,
+// modified_adj1_ij = [i != j] relu(S_ij) recomputed per pair, and
+//   Gs_ij = rank-k + 2 ie'(an) + kmse1 (2 an - F_ij - F_ji) + 2 kmse2 (an - A1_ij)        (an = adj_norm_ij; a1 / a2 unused)
+// vpart: v1 = sum (F - an)^2 (both orientations), v6 as before, and a third block of partials v2 = sum (an - A1)^2.
+template <bool WANT_V, bool MSE>
+__global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair, int tile_row0, RkRounds F, RkRounds FU, RkRounds FZ,
                                                      const float* __restrict__ M, const float* __restrict__ P1,
                                                      const float* __restrict__ r, const float* __restrict__ mean,
                                                      const float* __restrict__ delta, const float* __restrict__ cvec,
-                                                     float a1, float a2, float kie6, float* __restrict__ G2,
-                                                     float* __restrict__ ps, double* __restrict__ vpart) {
+                                                     float a1, float a2, float kie6, float kmse1, float kmse2,
+                                                     float* __restrict__ G2, float* __restrict__ ps, double* __restrict__ vpart) {
   // T: hand-over of the rank-k sums, then the transposed P1 tile, then the column sums: 16.6 KB per block
   __shared__ float T[FT][FT + 1];
   __shared__ double shd[16];
@@ -582,18 +603,18 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
   const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
   const size_t vslot = (size_t)blockIdx.y * nt + blockIdx.x, vtot = (size_t)gridDim.y * nt;   // v1 partials, then v6 partials
   if (pair && tj > ti) {
-    if (WANT_V && threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; }
+    if (WANT_V && threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; if (MSE) vpart[2 * vtot + vslot] = 0.0; }
     return;
   }
   const int bi = ti * FT, bj = tj * FT;
   const bool offdiag = ti != tj;
   const bool mirror = pair && offdiag;
   const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;
-  float acc[4][4], accu[4][4];
+  float acc[4][4], accu[4][4], accs[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.f; accu[a][b] = 0.f; }
+    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.f; accu[a][b] = 0.f; accs[a][b] = 0.f; }
   // the tile's row-side n-vectors (r, mean, delta, cvec of rows bi ..): one load per thread into LDS now, read back in the
   // element pass (published by the barriers of rk_sym) -- as four global loads per row inside that pass they were four
   // more dependent round trips
@@ -605,6 +626,7 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
   }
   rk_sym(F, ti, tj, T, r0, c0, acc);
   if (FU.count > 0) rk_sym(FU, ti, tj, T, r0, c0, accu);
+  if (MSE) rk_sym(FZ, ti, tj, T, r0, c0, accs);              // S_ij = zn_i . zn_j
   // Every HBM operand of the element pass goes out in ONE batch, ahead of the barriers (the registers of the rank-k rounds
   // are free again): the mirrored P1 tile, and the block's own rows of M and P1 -- one memory round trip instead of two.
   float pts[4][4], mss[4][4], pds[4][4], rjs[4], mjs[4], djs[4], cjs[4];
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
     }
   }
   __syncthreads();
-  double v1 = 0.0, v6 = 0.0;
+  double v1 = 0.0, v6 = 0.0, v2 = 0.0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -671,15 +693,29 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
         const float pt = P1 ? T[c0 + b][r0 + a] : 0.f;       // P1_ji
         float val, g6;
         ie_term(an, kie6, val, g6);
-        const float g = acc[a][b] + 2.f * g6 + a1 * (pd[b] + pt) + a2 * (fmaf(di * di, xij, cjs[b]) + fmaf(djs[b] * djs[b], xji, ci));
-        const float w = g * mx;
-        rowacc += w * rjs[b];
-        cs[b] += w * ri;
+        float g;
+        if (MSE) {
+          const float y = i != j ? fmaxf(accs[a][b], 0.f) : 0.f;      // modified_adj1_ij
+          const float e2 = an - y;
+          g = acc[a][b] + 2.f * g6 + kmse1 * ((an - pd[b]) + (an - pt)) + 2.f * kmse2 * e2;
+          if (WANT_V) {
+            const float e1 = pd[b] - an, e1t = pt - an;
+            v1 += (double)e1 * (double)e1;
+            if (mirror) v1 += (double)e1t * (double)e1t;
+            v2 += (mirror ? 2.0 : 1.0) * ((double)e2 * (double)e2);
+            v6 += mirror ? 2.0 * (double)val : (double)val;
+          }
+        } else {
+        g = acc[a][b] + 2.f * g6 + a1 * (pd[b] + pt) + a2 * (fmaf(di * di, xij, cjs[b]) + fmaf(djs[b] * djs[b], xji, ci));
         if (WANT_V) {
           v1 += (double)pd[b] * (double)xij;
           if (mirror) v1 += (double)pt * (double)xji;
           v6 += mirror ? 2.0 * (double)val : (double)val;
         }
+        }
+        const float w = g * mx;
+        rowacc += w * rjs[b];
+        cs[b] += w * ri;
         g2 = fmaf(g, rr, accu[a][b]);
       }
       gs[b] = g2;
@@ -706,7 +742,8 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
   if (WANT_V) {
     v1 = block_sum_d(v1, shd);
     v6 = block_sum_d(v6, shd);
-    if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; }
+    if (MSE) v2 = block_sum_d(v2, shd);
+    if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; if (MSE) vpart[2 * vtot + vslot] = v2; }
   }
 }
 
@@ -960,15 +997,19 @@ int fl_decode_slabs(int n, int rows) {
   return js < js0 ? js0 : js;
 }
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
-                  double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7) {
+                  double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7, const float* Mm, int ldm,
+                  const float* rvec, float kmse2) {
   const int rows = row1 - row0;
   if (rows <= 0) return 0;
   const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows), jper = (n + js - 1) / js;
   const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);
+  const bool mse = Mm != nullptr;      // the fused MSELoss step: + d calc(adj_norm, modified_adj1) / d modified_adj1
 #define MCGRA_DECODE(H_)                                                                                                          \
   do {                                                                                                                            \
-    if (want_v7) LAUNCH((k_decode_fly<H_, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask); \
-    else LAUNCH((k_decode_fly<H_, false>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask);       \
+    if (mse && want_v7) LAUNCH((k_decode_fly<H_, true, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \
+    else if (mse) LAUNCH((k_decode_fly<H_, false, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \
+    else if (want_v7) LAUNCH((k_decode_fly<H_, true, false>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \
+    else LAUNCH((k_decode_fly<H_, false, false>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2);       \
   } while (0)
   if (h == 8) MCGRA_DECODE(8); else if (h == 16) MCGRA_DECODE(16); else MCGRA_DECODE(32);
 #undef MCGRA_DECODE
@@ -992,11 +1033,12 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
                    const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha,
                    const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
-                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase) {
+                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase, const float* Zn, int ldz,
+                   int hz, float kmse1, float kmse2) {
   const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
   if (t1 <= t0) return 0;
   RkPackJobs J{};
-  RkRounds F{}, FU{};
+  RkRounds F{}, FU{}, FZ{};
   const size_t slot = (size_t)nt * RK_PANEL, eslot = ((size_t)nt * sizeof(int) + 255) & ~(size_t)255;
   char* cur = rkbuf;
   auto add = [&](RkRounds& G, const float* Lm, int ll, const float* Rm, int lr_, int Kf, float al) {
@@ -1015,14 +1057,21 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
   };
   for (int f = 0; f < nfac; ++f) add(F, L[f], ldl[f], R[f], ldr[f], K[f], alpha[f]);
   if (Ku > 0) add(FU, Lu, ldlu, Ru, ldru, Ku, 1.f);
+  if (Zn) add(FZ, Zn, ldz, Zn, ldz, hz, 0.5f);      // (0.5 zn_i) . zn_j + zn_i . (0.5 zn_j) = S_ij: the fused MSELoss step
   // phase 1: only the panels are packed (their inputs are ready before the N x N x N product is joined); 2: only the pass
   if (phase != 2) LAUNCH(k_pack_rk, dim3(nt, J.count), dim3(256), st, n, J);
   if (phase == 1) return nt * (t1 - t0);
   dim3 grid(nt, t1 - t0);
+  if (Zn) {
+    if (vpart)
+      LAUNCH((k_tail_reduce<true, true>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, vpart);
+    else
+      LAUNCH((k_tail_reduce<false, true>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, nullptr);
+  } else
   if (vpart)
-    LAUNCH(k_tail_reduce<true>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, M, P1, r, mean, delta, cvec, a1, a2, kie6, G2, ps, vpart);
+    LAUNCH((k_tail_reduce<true, false>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, 0.f, 0.f, G2, ps, vpart);
   else
-    LAUNCH(k_tail_reduce<false>, grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, M, P1, r, mean, delta, cvec, a1, a2, kie6, G2, ps, nullptr);
+    LAUNCH((k_tail_reduce<false, false>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, 0.f, 0.f, G2, ps, nullptr);
   return nt * (t1 - t0);
 }
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd, const double* sq, float coef,

@@ -158,14 +158,16 @@ void fl_lrq_pre(hipStream_t st, int n, int w, const float* W, int ldw, const flo
 void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv, const float* r, const float* mean,
                  const double* colsum, const double* mw, const double* msum, float* Q, int ldq);
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
-                  double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7 = true);   // zpair: Zn pair-interleaved, (n + 1) / 2 * 2 * h floats (launch_row_normalize writes it)
+                  double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7 = true,
+                  const float* Mm = nullptr, int ldm = 0, const float* rvec = nullptr, float kmse2 = 0.f);      // Mm != NULL: the fused MSELoss step (+ kmse2 (adj_norm - A1) term)   // zpair: Zn pair-interleaved, (n + 1) / 2 * 2 * h floats (launch_row_normalize writes it)
 int fl_tail_tiles(int n);
 bool fl_tail_supported(int n, int ld, int kmax);
 int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
                    const int* ldl, const float* const* R, const int* ldr, const int* K, const float* alpha,
                    const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
-                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase = 0);
+                   float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase = 0,
+                   const float* Zn = nullptr, int ldz = 0, int hz = 0, float kmse1 = 0.f, float kmse2 = 0.f);      // Zn != NULL: the fused MSELoss step (P1 = feature_adj)
 size_t fl_tail_pack_bytes(int n);
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd, const double* sq = nullptr,
                 float coef = 0.f, float* cn_out = nullptr);

@@ -14,8 +14,8 @@ from victim_model.gc).
 
 Several GPUs: when ``torch.distributed`` is initialised with more than one rank (``torchrun ... main.py``: one process
 per GPU, backend "nccl" = RCCL), ``attack`` runs ONE attack row-block sharded over the ranks (mc-gra_amd/sharded.py,
-DESIGN.md section 6) whenever the configuration is one the fused low-rank step covers (measure HSIC, ReLU GCN victim,
-eps == 0, ori_adj == 0, n >= 1024, hidden widths <= 32, w1 or w2 non-zero, a projection budget that cannot bind); every
+DESIGN.md section 6) whenever the configuration is one a fused step covers (measure HSIC -- n >= 1024, w1 or w2 non-zero -- or
+MSELoss -- n >= 256 --, ReLU GCN victim, eps == 0, ori_adj == 0, hidden widths <= 32, a projection budget that cannot bind); every
 rank returns the same ``modified_adj``.  Any other configuration says on stderr that it runs replicated.
 """
 import os
@@ -174,8 +174,8 @@ class PGDAttack(BaseAttack):
     def _replicated_reason(measure, eps, ori_np, Ws, act, head_act, loss_type, n, dims, w1, w2, num_edges):
         """None when the row-block sharded fused step covers this configuration (include/mcgra.h: mcgra_attack_shard_*;
         csrc/attack.hip: the create-time rule), else why it does not."""
-        if measure != "HSIC":
-            return f"measure {measure} (only the fused low-rank HSIC step is sharded)"
+        if measure not in ("HSIC", "MSELoss"):
+            return f"measure {measure} (the fused HSIC and MSELoss steps are the sharded ones)"
         if loss_type != "CE":
             return "loss_type 'CW' takes no step"
         if eps != 0:
@@ -184,11 +184,13 @@ class PGDAttack(BaseAttack):
             return "a non-zero ori_adj (general step)"
         if Ws is not None or act != "relu" or head_act != "none":
             return "a GAT / GraphSAGE victim (Gram evaluation of linear_HSIC)"
-        if n < 1024 and os.environ.get("MCGRA_SPLIT_BF16", "") not in ("2", "3"):
+        if measure == "HSIC" and n < 1024 and os.environ.get("MCGRA_SPLIT_BF16", "") not in ("2", "3"):
             return f"n = {n} < 1024 (the product runs on the fp32 kernel: nothing to shard)"
+        if n < 256:
+            return f"n = {n} < 256"
         if max(dims[1:]) > 32:
             return f"hidden width {max(dims[1:])} > 32"
-        if w1 == 0 and w2 == 0:
+        if measure == "HSIC" and w1 == 0 and w2 == 0:
             return "w1 == w2 == 0 (no N x N HSIC term)"
         if num_edges < 0.5 * float(n) * float(n):
             return "a projection budget that can bind (host-driven bisection)"

@@ -238,7 +238,8 @@ def test_class_finds_the_process_group_and_knows_what_it_can_shard():
     ok = dict(measure="HSIC", eps=0.0, ori_np=None, Ws=None, act="relu", head_act="none", loss_type="CE", n=2708,
               dims=[1433, 16, 16], w1=0.01, w2=0.01, num_edges=1e30)
     assert why(**ok) is None
-    for change, word in ((dict(measure="MSELoss"), "MSELoss"), (dict(eps=0.1), "eps"), (dict(ori_np=object()), "ori_adj"),
+    assert why(**dict(ok, measure="MSELoss", n=300, w1=0, w2=0)) is None          # the fused MSELoss step: any n >= 256
+    for change, word in ((dict(measure="KL"), "KL"), (dict(measure="MSELoss", n=200), "256"), (dict(eps=0.1), "eps"), (dict(ori_np=object()), "ori_adj"),
                          (dict(Ws=[1]), "GraphSAGE"), (dict(act="elu"), "GAT"), (dict(n=300), "1024"),
                          (dict(dims=[10, 64, 64]), "width"), (dict(w1=0, w2=0), "w1"), (dict(num_edges=5.0), "projection"),
                          (dict(loss_type="CW"), "CW")):

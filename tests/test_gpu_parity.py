@@ -1547,3 +1547,99 @@ def test_gram_products_beside_the_step_are_bit_identical(pkg, monkeypatch, wp):
     for t in range(3):
         assert torch.equal(outs[0][0][t], outs[1][0][t]), t
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+# ---- the fused MSELoss step (round 5): calc = MSELoss evaluated from M, feature_adj, r and Zn -- no N x N intermediate ------
+@pytest.mark.parametrize("n,widths,wp", [
+    (1100, (16, 16), None), (300, (16, 16), NXN_ONLY), (515, (8, 8), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    (1030, (16, 16, 16), None), (700, (16, 32), (0.01, 0, 0, 0, 0, 0, 10, 0, 10, 0))])
+def test_fused_mse_step_matches_general_path_and_oracle(pkg, n, widths, wp, monkeypatch):
+    """measure = MSELoss through attack_fused.hip (adj_norm, modified_adj1 and the gradients w.r.t. them are never stored: the
+    decode carries d / d modified_adj1, the tail's first pass d / d adj_norm with feature_adj in the place of the HSIC product
+    and S = Zn Zn^T as a third rank-k group) against the general step (MCGRA_NO_FUSED_LR=1) and the oracle, teacher-forced,
+    with the monitoring forward adopted in between: mirrored gradient, every loss term, the updated adjacency."""
+    kw = {} if wp is None else {"weight_param": wp}
+    z = _synthetic_case(n, 11, widths, 4, seed=n, measure="MSELoss", **kw)
+    fused = H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
+    gen = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_FUSED_LR")
+    orc = H.oracle_from(z)
+    for t in range(3):
+        a, b = fused.step(want_scalars=True), gen.step(want_scalars=True)
+        orc.step()
+        gf, gg = fused.buffer("G_sym").cpu().numpy(), gen.buffer("G_sym").cpu().numpy()
+        gr = orc.last["G_sym"]
+        scale = np.abs(gr).max()
+        assert np.abs(gf - gg).max() <= 3e-5 * scale, (t, np.abs(gf - gg).max() / scale)
+        assert np.abs(gf - gr).max() <= 1e-4 * scale, (t, np.abs(gf - gr).max() / scale)
+        for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "origin_loss"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-6 * max(1.0, abs(b["loss"]))), (t, k, a[k], b[k])
+        assert abs(a["loss"] - orc.last["loss"]) <= 2e-4 * abs(orc.last["loss"]) + 1e-5
+        Mf = fused.buffer("M")
+        assert bool((Mf == Mf.T).all()), "the learnable adjacency must stay symmetric bit for bit"
+        gsf = fused.buffer("G_sym")
+        assert bool((gsf == gsf.T).all())
+        ma, mb = fused.get_adj_changes(), gen.get_adj_changes()
+        lr = float(z["lr"])
+        assert float(((ma - mb).abs() > 0.05 * lr).float().mean()) < 2e-3       # Adam: +-lr on noise-level gradients
+        la, _ = fused.monitor(); lb, _ = gen.monitor()
+        assert float((la - lb).abs().max()) < 1e-4
+        nxt = O.pack_tril(orc.M)
+        fused.set_adj_changes(nxt); gen.set_adj_changes(nxt)                   # teacher forcing (drops the adopted forward)
+    assert fused.fused_steps() == 3 and gen.fused_steps() == 0
+    assert fused.path_stats() == gen.path_stats() == {"lowrank_steps": 0, "general_steps": 0}
+
+
+def test_fused_mse_free_run_and_finalize(pkg, monkeypatch):
+    """Free-running fused MSELoss steps with and without monitor calls in between give the same bits, and the post-loop
+    ensemble after a fused loop equals the one after the same loop on the general path (em_last stands in for
+    embedding(features, adj_norm))."""
+    import torch
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5, measure="MSELoss")
+    e1, e2 = H.engine_from(pkg, z), H.engine_from(pkg, z)
+    monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
+    e3 = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_NO_FUSED_LR")
+    for t in range(3):
+        e1.step(); e1.monitor()
+        e2.step()
+        e3.step(); e3.monitor()
+    assert torch.equal(e1.get_adj_changes(), e2.get_adj_changes())
+    lr = float(z["lr"])
+    assert float(((e1.get_adj_changes() - e3.get_adj_changes()).abs() > 0.05 * lr).float().mean()) < 2e-3
+    lab = z["labels"]
+    la = (lab[:, None] == lab[None, :]).astype(np.float32)
+    f1 = e1.finalize(0, e1.buffer("HA"), e1.buffer("YA"), la)
+    f3 = e3.finalize(0, e3.buffer("HA"), e3.buffer("YA"), la)
+    assert float((f1 - f3).abs().max()) < 2e-3 * float(f3.abs().max())
+    assert abs(O.metric_pool(z["adj"], f1.cpu().numpy(), z["idx_attack"]) - O.metric_pool(z["adj"], f3.cpu().numpy(), z["idx_attack"])) < 1e-4
+    assert e1.fused_steps() == 3 and e3.fused_steps() == 0
+
+
+@pytest.mark.parametrize("n,widths,world", [(1100, (16, 16), 2), (1100, (16, 16), 3), (600, (16, 16, 16), 4)])
+def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world):
+    """The fused MSELoss step as `world` row-block ranks in lockstep: no N x N exchange at all (all-gathers of node arrays with
+    the partial scalars in their lane only) -- the union of the ranks' rows equals the monolithic fused step, mirrored entries
+    bit for bit across the ranks, loss terms identical on every rank."""
+    from mc_gra_amd import sharded as S
+    z = _synthetic_case(n, 11, widths, 4, seed=n, measure="MSELoss")
+    mono = H.engine_from(pkg, z)
+    plans, bks = _shard_engines(pkg, z, world, joint=world == 3)
+    lr = float(z["lr"])
+    nex = 0
+    for t in range(3):
+        a = mono.step(want_scalars=True); mono.monitor()
+        sc = S.run_lockstep(bks, S.SHARD_STEP, want_scalars=True)
+        S.run_lockstep(bks, S.SHARD_MONITOR)
+        rows = _gather_rows(bks)
+        M = mono.buffer("M")
+        assert rows.shape == M.shape
+        assert float(((rows - M).abs() > 0.05 * lr).float().mean()) < 2e-3, t
+        assert float((rows - rows.T).abs().max()) == 0.0, "ranks must agree on mirrored entries bit for bit"
+        for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "clamp_sum"):
+            for b in sc:
+                assert b[k] == pytest.approx(a[k], rel=3e-5, abs=1e-6 * max(1.0, abs(a["loss"]))), (t, k, b[k], a[k])
+            assert all(b[k] == sc[0][k] for b in sc), "scalars are identical on every rank"
+    assert all(b.eng.fused_steps() == 3 for b in bks) and mono.fused_steps() == 3
+    assert all(b.eng.cut_product_steps() == 0 for b in bks)
