@@ -437,7 +437,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(rkbuf, fl_tail_pack_bytes((int)n));           // packed fp16 planes of the tail's rank-k panels
       A_(Zpair, (n + 2) * (size_t)h->hmax);
       // (a row-block rank cuts the columns of its rows' decode into up to 64 slices: fused_lowrank.hip: fl_decode_slabs)
-      A_(ws_dec, (size_t)(h->sharded ? 64 : lr_decode_slabs((int)n)) * n * he);
+      A_(ws_dec, (size_t)((h->sharded || h->fused_mse) ? 64 : lr_decode_slabs((int)n)) * n * he);      // (MSELoss: up to 64 slices too, nothing runs beside its decode)
       h->fused_ok = (rc == 0);
     }
   }
@@ -628,7 +628,7 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
   };
   launch_gather_rows(st, na, width, Ysrc, ldy, h->idx, h->Yg, hm);
   if (h->cfg.measure == MCGRA_MEASURE_MSE) {
-    launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot);   // sum of squares
+    launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot, h->cm_part);   // sum of squares
     launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
   } else if (h->cfg.measure == MCGRA_MEASURE_CKA) {
     // linear_CKA(X, Y) (utils.py:1091-1096): value hxy / (sqrt(hxx) sqrt(hyy)); Q = Xc^T Yc, R = Yc^T Yc,

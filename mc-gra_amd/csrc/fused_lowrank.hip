@@ -987,7 +987,14 @@ void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv
 // fill the chip (N = 10 000 on 8 ranks: 5 row blocks x 13 slices = 65 blocks took 0.49 ms per rank, as long as the whole
 // matrix on one GPU; 5 x 64 slices: 0.14 ms beside the product).  The full range keeps lr_decode_slabs (the monolithic engine's bits do not move).
 // slabs: fl_decode_slabs * n * h floats (<= 64 slices: fits the 64 x n x 64 split-K workspace for h <= 32; more slices make the sum of the slabs the longer kernel).
-int fl_decode_slabs(int n, int rows) {
+int fl_decode_slabs(int n, int rows, bool alone) {
+  if (alone) {      // nothing MFMA-bound beside the pass (the fused MSELoss step): fill the chip four times over
+    const int nb = (rows + 255) / 256;
+    int js = (1024 + nb - 1) / nb;
+    if (js > 64) js = 64;
+    if (js > n / 64) js = n / 64;
+    return js < 1 ? 1 : js;
+  }
   if (rows >= n) return lr_decode_slabs(n);
   const int nb = (rows + 255) / 256;
   int js = 256 / nb;                 // (one block per CU: lr_decode_slabs)
@@ -1001,9 +1008,9 @@ int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float*
                   const float* rvec, float kmse2) {
   const int rows = row1 - row0;
   if (rows <= 0) return 0;
-  const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows), jper = (n + js - 1) / js;
-  const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);
   const bool mse = Mm != nullptr;      // the fused MSELoss step: + d calc(adj_norm, modified_adj1) / d modified_adj1
+  const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows, mse), jper = (n + js - 1) / js;
+  const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);      // the fused MSELoss step: + d calc(adj_norm, modified_adj1) / d modified_adj1
 #define MCGRA_DECODE(H_)                                                                                                          \
   do {                                                                                                                            \
     if (mse && want_v7) LAUNCH((k_decode_fly<H_, true, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \

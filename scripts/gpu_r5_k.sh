@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "mse" 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_readme.py -x -q -k "mse" 2>&1 | tail -3
+for wl in synthetic-10k-mse cora-shape-mse; do
+python3 bench.py --workload $wl --steps 100 --warmup 20 --no-cpu-baseline --no-split-probe 2>/dev/null | python3 -c "
+import sys, json
+d=json.loads(sys.stdin.read()); print(d['config']['workload'], round(d['value'],1), round(d['ms_per_step'],4), d['auc'], d['config']['fused_steps'], d['config']['general_steps'])
+"; done
+python3 scripts/shard_emulate.py --echo --workload synthetic-10k-mse --worlds 1,2,4,8 --steps 20 2>&1 | grep '^{"world"' | python3 -c "
+import sys, json
+for l in sys.stdin:
+    d=json.loads(l); print('echo 10k-mse world', d['world'], round(d['per_rank_compute_ms'],3), 'fused', d['fused_steps'], d['general_steps'], 'collectives', d['collectives_per_step'])
+"
