@@ -895,6 +895,18 @@ def main(argv=None):
                     out["roofline"]["alone"] = {"avg_launch_ms": alone_ms,
                                                 "achieved": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12,
                                                 "frac": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        elif measure == "MSELoss" and eng_path["fused_steps"] > 0 and eng_path["general_steps"] == 0 and world == 1:
+            # the fused MSELoss step has no N x N x N product: it is a chain of HBM-bound passes over the learnable adjacency.
+            # Algorithmic bytes per step = the passes its formulation cannot do without, p = 4 n^2 bytes each: L forward products
+            # + (L - 1) backward products on M, the decode's read of M (adj_norm_ij per pair), the tail's first pass (M and G2 on
+            # the lower tile pairs, feature_adj whole: 2 p), the Adam pass (G2, M, both moments read on the lower pairs; M written
+            # whole, the moments on the lower pairs: 4 p), + the monitoring forward's L products.
+            p = 4.0 * n * n
+            passes = nl + (nl - 1) + 1 + 2 + 4 + (nl if monitor and not out["config"]["forward_reuse"] else 0)
+            ach = passes * p / (1e-3 * 1e3 * dt / a.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "the fused MSELoss step as a whole (k_tail_adam, the skinny products on M, k_tail_reduce, "
+                               "k_decode_fly: no N x N x N product, no N x N intermediate)", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                               "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p, "traffic": None, "traffic_unit": "bytes/step"}
         else:
             out["roofline"] = None
         # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed

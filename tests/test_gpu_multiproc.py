@@ -267,20 +267,22 @@ def test_plain_bench_measures_its_traffic_live(tmp_path):
 
 # ---- the sharded step behind the class surface and main.py (north_star: "keep the PGDAttack / BaseAttack class surface and
 # main.py entry" AND "partition ... row-block across up to 8 MI355X") ------------------------------------------------------
-def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path):
-    """Two processes call PGDAttack.attack on Cora (reference-trained weights of cora_hsic_sparse.npz, HSIC, sparse start)
-    under a process group: the class builds RowBlockPlan + HipShardBackend + ShardedStepper itself, every step is a fused
-    row-block step, both ranks return the SAME modified_adj, its AUC equals the 1-process run's to 1e-6 and the REFERENCE's
-    (the fixture's) to 1e-4."""
+@pytest.mark.parametrize("fixture", ["cora_hsic_sparse", "cora_mse_short"])
+def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, fixture):
+    """Two processes call PGDAttack.attack on Cora (reference-trained weights of the fixture: HSIC from the sparse start, and the
+    README's MSELoss configuration -- BASELINE.json configs[0] -- for 20 epochs) under a process group: the class builds
+    RowBlockPlan + HipShardBackend + ShardedStepper itself, every step is a fused row-block step (the MSELoss one exchanges no
+    N x N data at all), both ranks return the SAME modified_adj, its AUC equals the 1-process run's to 1e-6 and the
+    REFERENCE's (the fixture's) to 1e-4."""
     out = str(tmp_path / "cls")
-    _run_ranks(W.run_class_rank, 2, (dict(name="cora_hsic_sparse"),), out)
-    z, final1, auc1, model1 = W.run_cora_class("cora_hsic_sparse")
+    _run_ranks(W.run_class_rank, 2, (dict(name=fixture),), out)
+    z, final1, auc1, model1 = W.run_cora_class(fixture)
     assert model1.history["path"]["sharded_world"] == 1
     ranks = [np.load(f"{out}.rank{r}.npz") for r in range(2)]
     epochs = int(z["epochs"])
     for r in ranks:
         assert int(r["sharded_world"]) == 2 and int(r["fused_steps"]) == epochs and int(r["general_steps"]) == 0
-        assert int(r["collectives"]) > 8 * epochs
+        assert int(r["collectives"]) >= (8 if "hsic" in fixture else 6) * epochs
         assert abs(float(r["auc"]) - auc1) <= 1e-6, (float(r["auc"]), auc1)
         assert abs(float(r["auc"]) - float(z["auc"])) <= 1e-4, (float(r["auc"]), float(z["auc"]))
         assert len(r["acc_test"]) == epochs and np.allclose(r["acc_test"], model1.history["acc_test"])
