@@ -753,6 +753,21 @@ def main(argv=None):
             extra = {"cora-shape-hsic": {"value": 100 / dt2, "unit": "attack-steps/s", "ms_per_step": 10.0 * dt2,
                                          "nodes": WORKLOADS["cora-shape-hsic"][0], "steps": 100}}
             del e2
+            # ... and calc = MSELoss (the measure of the reference's README headline run, configs[0]) through the fused MSELoss
+            # step: Cora shape and the headline's N
+            for wl2, k2 in (("cora-shape-mse", 100), ("synthetic-10k-mse", 60)):
+                torch.cuda.empty_cache()
+                e3, _, _ = build_engine(pkg, torch, dev, wl2, a.seed)
+
+                def mse_step():
+                    e3.step()
+                    if monitor:
+                        e3.monitor()
+
+                dt3 = timed_region(mse_step, k2, 10, torch.cuda.synchronize, 1, None, dev, torch)
+                extra[wl2] = {"value": k2 / dt3, "unit": "attack-steps/s", "ms_per_step": 1e3 * dt3 / k2, "nodes": WORKLOADS[wl2][0], "steps": k2,
+                              "fused_steps": e3.fused_steps(), "general_steps": e3.path_stats()["general_steps"]}
+                del e3
         except Exception as e:
             extra = {"error": f"{type(e).__name__}: {e}"[:300]}
 
