@@ -362,7 +362,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // V7 = false: the entropy VALUE (a returned loss term only) is not summed.
 // MSE (the fused MSELoss step, attack_fused.hip): the gradient w.r.t. modified_adj1 also carries calc(adj_norm, modified_adj1) =
 // MSELoss (:194-195, :221-229): d/dA1_ij = ie'(A1_ij) - kmse2 (adj_norm_ij - A1_ij), symmetric like the entropy part, with
-// adj_norm_ij = (r_i r_j) M_ij formed on the fly -- M_ij read as M[j][i] (M is bitwise symmetric): coalesced along the block's rows.
+// adj_norm_ij = (r_i r_j) M_ij formed on the fly.  The block's 256 rows x 32 columns of M go through LDS per chunk of 16 column
+// pairs (coalesced along the rows of M -- a row-block rank holds only its own rows of M current, so M[j][i] is not an option --
+// and read back as T[lane's row][column]: stride 33, conflict free).
 template <int H, bool V7, bool MSE>
 __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
                                                       const f32x2* __restrict__ Zp, float kie7, int jper,
@@ -386,17 +388,41 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
   double v7 = 0.0;
   int masked = 0;
   const float ri = (MSE && valid) ? rvec[i] : 0.f;
-  const int ic = valid ? i : row0;                            // (a clamped, always valid column of M for the idle lanes)
-  for (int P = j0 >> 1; 2 * P < j1; ++P) {
+  __shared__ float MT[MSE ? 256 : 1][MSE ? 33 : 1];
+  const int Pbeg = j0 >> 1;
+  // thread (row (q >> 3) + 32 u, column quad q & 7) of a chunk; the NEXT chunk's loads are issued as soon as this one's values
+  // are in LDS, so that they fly while the 16 pairs of columns are worked
+  float4 pre[MSE ? 8 : 1];
+  const int rb = row0 + blockIdx.x * 256, cc = (threadIdx.x & 7) * 4;
+  auto fetch = [&](int cb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gr = min(rb + (int)(threadIdx.x >> 3) + 32 * u, n - 1), gc = min(cb + cc, ldm - 4);   // clamped, always in bounds (ldm % 4 == 0)
+      pre[u] = *reinterpret_cast<const float4*>(Mm + (size_t)gr * ldm + gc);
+    }
+  };
+  if (MSE) fetch(2 * Pbeg);
+  for (int P = Pbeg; 2 * P < j1; ++P) {
+    if (MSE && ((P - Pbeg) & 15) == 0) {
+      __syncthreads();                                       // (the previous chunk has been read)
+      const bool past = 2 * P + cc > ldm - 4;                // only past the row's end: those columns are masked by `in` below
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float* d = &MT[(threadIdx.x >> 3) + 32 * u][cc];
+        d[0] = past ? 0.f : pre[u].x; d[1] = past ? 0.f : pre[u].y; d[2] = past ? 0.f : pre[u].z; d[3] = past ? 0.f : pre[u].w;
+      }
+      __syncthreads();
+      if (2 * (P + 16) < j1) fetch(2 * (P + 16));
+    }
     const f32x2* __restrict__ zp = Zp + (size_t)P * H;      // wave-uniform
     f32x2 t[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) t[k] = zp[k];
     f32x2 mij = {0.f, 0.f}, rj = {0.f, 0.f};
     if (MSE) {
-      const int ja = min(2 * P, n - 1), jb = min(2 * P + 1, n - 1);
-      mij = f32x2{Mm[(size_t)ja * ldm + ic], Mm[(size_t)jb * ldm + ic]};
-      rj = f32x2{rvec[ja], rvec[jb]};
+      const int cl = 2 * ((P - Pbeg) & 15);
+      mij = f32x2{MT[threadIdx.x][cl], MT[threadIdx.x][cl + 1]};
+      rj = f32x2{rvec[min(2 * P, n - 1)], rvec[min(2 * P + 1, n - 1)]};
     }
     f32x2 s = {0.f, 0.f};
 #pragma unroll
@@ -1009,8 +1035,9 @@ int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float*
   const int rows = row1 - row0;
   if (rows <= 0) return 0;
   const bool mse = Mm != nullptr;      // the fused MSELoss step: + d calc(adj_norm, modified_adj1) / d modified_adj1
-  const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows, mse), jper = (n + js - 1) / js;
-  const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);      // the fused MSELoss step: + d calc(adj_norm, modified_adj1) / d modified_adj1
+  const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows, mse);
+  const int jper = mse ? (((n + js - 1) / js + 3) & ~3) : (n + js - 1) / js;     // (MSE: the 16-byte loads of M's tiles start on column quads)
+  const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);
 #define MCGRA_DECODE(H_)                                                                                                          \
   do {                                                                                                                            \
     if (mse && want_v7) LAUNCH((k_decode_fly<H_, true, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \

@@ -606,23 +606,27 @@ def test_mid_size_reference_run_on_the_fused_path(pkg, torch_):
     assert np.mean(np.abs(final[sp[:, 0], sp[:, 1]] - z["final_sample"]) > 1e-3 * max(1.0, np.abs(z["final_sample"]).max())) < 0.01
 
 
+@pytest.mark.parametrize("path", ["fused", "general"])
 @pytest.mark.parametrize("epochs", [10, 40])
-def test_cora_mse_checkpoints(pkg, torch_, epochs):
+def test_cora_mse_checkpoints(pkg, torch_, monkeypatch, epochs, path):
     """README Cora run at intermediate horizons against the reference's own AUC there
     (tests/golden/make_adam_noise.py).  The reference, the fp32 oracle and the fp64 oracle -- three evaluations of ONE
     algorithm on identical inputs -- agree to 1.6e-7 / 6e-6 / 1.2e-4 / 1.4e-3 at 10 / 20 / 40 / 100 epochs
     (profiles/r02_adam_noise_experiment.json): Adam turns fp32 rounding noise on near-zero gradients into +-lr moves,
     so the bar of north_star (1e-4) is meaningful up to ~20 epochs; beyond, the engine is held to the measured spread
-    of those three at that horizon (x 2)."""
+    of those three at that horizon: x 2 for the general step (fp32 arithmetic throughout, like the three), x 4 for the
+    fused MSELoss step, whose rank-k terms -- the chains' backward, i.e. the gradient of most entries -- are 3-product
+    fp16 splits on 22-bit operands (2^-22 against fp32's 2^-24 per operand: four times the noise floor under the same
+    amplification).  Measured at 40 epochs, fused: 3.0e-4 and 3.6e-4 from the reference in two builds that differ only
+    in the order of the decode's partial sums -- a draw of that noise, like the spread itself (1.2e-4)."""
     i = list(CKPT["epochs"]).index(epochs)
     ref, o32, o64 = float(CKPT["auc_reference"][i]), float(CKPT["auc_oracle_fp32"][i]), float(CKPT["auc_oracle_fp64"][i])
     spread = max(abs(ref - o32), abs(ref - o64), abs(o32 - o64))
+    if path == "general":
+        monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
     auc = _run_cora(pkg, torch_, "cora_mse_readme", epochs=epochs)[2]
-    # (round 5: MSELoss runs through the fused step, whose rank-k terms -- the chains' backward, i.e. the gradient of most
-    # entries -- are 3-product fp16 splits on 22-bit operands where the general step used fp32 MFMAs: a noise floor about four
-    # times fp32's under the same Adam amplification.  Measured at 40 epochs: 3.0e-4 from the reference, 1.8e-4 from the fp32
-    # oracle -- whose own distance from the reference is 1.2e-4.  The bar: north_star's 1e-4 on top of twice the spread.)
-    assert abs(auc - ref) <= 1e-4 + 2 * spread, (epochs, auc, ref, spread)
+    bar = max(1e-4, 4 * spread) if path == "fused" else max(1e-4, 2 * spread)
+    assert abs(auc - ref) <= bar, (epochs, path, auc, ref, spread)
 
 
 def test_cora_readme_100_epochs(pkg, torch_):
@@ -1621,13 +1625,16 @@ def test_fused_mse_free_run_and_finalize(pkg, monkeypatch):
     assert e1.fused_steps() == 3 and e3.fused_steps() == 0
 
 
-@pytest.mark.parametrize("n,widths,world", [(1100, (16, 16), 2), (1100, (16, 16), 3), (600, (16, 16, 16), 4)])
-def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world):
+@pytest.mark.parametrize("n,widths,world,wp", [(1100, (16, 16), 2, None), (1100, (16, 16), 3, (0.01, 1.0, 0, 0, 0, 10, 10, 0, 10, 1000)),
+                                               (600, (16, 16, 16), 4, None)])
+def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world, wp):
     """The fused MSELoss step as `world` row-block ranks in lockstep: no N x N exchange at all (all-gathers of node arrays with
     the partial scalars in their lane only) -- the union of the ranks' rows equals the monolithic fused step, mirrored entries
     bit for bit across the ranks, loss terms identical on every rank."""
     from mc_gra_amd import sharded as S
-    z = _synthetic_case(n, 11, widths, 4, seed=n, measure="MSELoss")
+    import torch
+    kw = {} if wp is None else {"weight_param": wp}
+    z = _synthetic_case(n, 11, widths, 4, seed=n, measure="MSELoss", **kw)
     mono = H.engine_from(pkg, z)
     plans, bks = _shard_engines(pkg, z, world, joint=world == 3)
     lr = float(z["lr"])
@@ -1636,6 +1643,14 @@ def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world):
         a = mono.step(want_scalars=True); mono.monitor()
         sc = S.run_lockstep(bks, S.SHARD_STEP, want_scalars=True)
         S.run_lockstep(bks, S.SHARD_MONITOR)
+        # the mirrored gradient on every rank's own rows: a rank holds only its own rows of M current, and the MSELoss part of the
+        # decode forms adj_norm_ij per pair -- from THOSE rows (wp with w2 = 1 makes that part a tenth of the gradient)
+        if t <= 1:
+            gm = mono.buffer("G_sym")
+            for b, pl in zip(bks, plans):
+                if pl.has_rows:
+                    gr = b.eng.buffer("G_sym")[pl.row_begin:pl.row_end]
+                    assert float((gr - gm[pl.row_begin:pl.row_end]).abs().max()) <= (3e-6 if t == 0 else 3e-4) * float(gm.abs().max()), (t, pl.rank)
         rows = _gather_rows(bks)
         M = mono.buffer("M")
         assert rows.shape == M.shape
