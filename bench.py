@@ -449,36 +449,42 @@ def multi_rank_diagnostics(pkg, torch, dist, dev, rank, world, a, eng, stepper, 
     n = WORKLOADS[a.workload][0]
     steps = a.steps
     prod_ms = st["ms"] / steps if st["launches"] else None
-    # compute only: from the workload's own start again (the echo leaves a state that is not the attack's)
-    a0 = make_a0(n, a.seed, start_scale(a.workload, n))
-    if a.workload in MASKED_VARIANTS:
-        a0 = masked_variant(a.workload, make_inputs(*WORKLOADS[a.workload][:5], a.seed), a0, a.seed)[1]
-    eng.set_adj_changes(torch.as_tensor(a0, device=dev))
-    del a0
-    k = max(2, min(steps, 20))
-    f0 = eng.fused_steps()
-    for _ in range(2):
-        S.run_echo(stepper.b, S.SHARD_STEP)
-        if monitor:
-            S.run_echo(stepper.b, S.SHARD_MONITOR)
-    torch.cuda.synchronize(); dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(k):
-        S.run_echo(stepper.b, S.SHARD_STEP)
-        if monitor:
-            S.run_echo(stepper.b, S.SHARD_MONITOR)
-    torch.cuda.synchronize()
-    echo_ms = 1e3 * (time.perf_counter() - t0) / k
-    echo_fused = eng.fused_steps() - f0
-    mine = {"rank": rank, "product_ms": prod_ms, "echo_ms": echo_ms, "echo_fused": echo_fused == k + 2,
-            "comm": {kk: (v / steps if kk != "count" else v / steps) for kk, v in (comm or {}).items()}}
+    # (a rank that fails here still answers the collectives below: the line must not hang on one rank's diagnostics)
+    try:
+        # compute only: from the workload's own start again (the echo leaves a state that is not the attack's)
+        a0 = make_a0(n, a.seed, start_scale(a.workload, n))
+        if a.workload in MASKED_VARIANTS:
+            a0 = masked_variant(a.workload, make_inputs(*WORKLOADS[a.workload][:5], a.seed), a0, a.seed)[1]
+        eng.set_adj_changes(torch.as_tensor(a0, device=dev))
+        del a0
+        k = max(2, min(steps, 20))
+        f0 = eng.fused_steps()
+        for _ in range(2):
+            S.run_echo(stepper.b, S.SHARD_STEP)
+            if monitor:
+                S.run_echo(stepper.b, S.SHARD_MONITOR)
+        torch.cuda.synchronize()                 # (rank-local: the echo exchanges nothing, no barrier inside this try)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            S.run_echo(stepper.b, S.SHARD_STEP)
+            if monitor:
+                S.run_echo(stepper.b, S.SHARD_MONITOR)
+        torch.cuda.synchronize()
+        echo_ms = 1e3 * (time.perf_counter() - t0) / k
+        echo_fused = eng.fused_steps() - f0
+        mine = {"rank": rank, "product_ms": prod_ms, "echo_ms": echo_ms, "echo_fused": echo_fused == k + 2,
+                "comm": {kk: (v / steps if kk != "count" else v / steps) for kk, v in (comm or {}).items()}}
+    except Exception as e:
+        mine = {"rank": rank, "product_ms": prod_ms, "echo_ms": None, "echo_fused": False, "comm": {},
+                "error": f"{type(e).__name__}: {e}"[:300]}
     allr = [None] * world
     dist.all_gather_object(allr, mine)
     out = None
     if rank == 0:
         cm = lambda key: [r["comm"].get(key, 0.0) for r in allr]
         tot = [r["comm"].get("allgather", 0.0) + r["comm"].get("alltoall", 0.0) + r["comm"].get("allreduce", 0.0) for r in allr]
-        compute_only = max(r["echo_ms"] for r in allr)
+        echo = [r["echo_ms"] for r in allr]
+        compute_only = max(echo) if all(x is not None for x in echo) else None
         out = {"comm_ms_per_step": {"mean": sum(tot) / world, "max": max(tot)},
                "allgather_ms_per_step": {"mean": sum(cm("allgather")) / world, "max": max(cm("allgather"))},
                "alltoall_ms_per_step": {"mean": sum(cm("alltoall")) / world, "max": max(cm("alltoall"))},
@@ -486,7 +492,8 @@ def multi_rank_diagnostics(pkg, torch, dist, dev, rank, world, a, eng, stepper, 
                "product_ms_per_rank": [r["product_ms"] for r in allr],
                "compute_only_ms_per_step": compute_only,
                "compute_only_steps_all_fused": all(r["echo_fused"] for r in allr),
-               "exposed_comm_ms_per_step": 1e3 * dt / steps - compute_only,
+               "exposed_comm_ms_per_step": (1e3 * dt / steps - compute_only) if compute_only is not None else None,
+               "errors": [r["error"] for r in allr if r.get("error")] or None,
                "how": "comm: HIP events around each collective on the issuing stream, timed steps; compute only: the same steps with "
                       "every collective answered by the rank's own data (sharded.run_echo), max over ranks; exposed = ms_per_step - "
                       "compute only" + (" [ranks share ONE GPU over gloo: plumbing test, not a measurement]" if shared_gpu else "")}
@@ -637,25 +644,33 @@ def main(argv=None):
         eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed, plan=plan)
         stepper = ShardedStepper(HipShardBackend(eng, plan), plan, dist=dist, host_staged=shared_gpu)
 
-        def one_step():
+        def one_step(last=False):
             stepper.step()
             if monitor:
-                stepper.monitor()
+                stepper.monitor(last=last)
     else:
         eng, inp, adj_dev = build_engine(pkg, torch, dev, a.workload, a.seed)
 
-        def one_step():
+        def one_step(last=False):
             eng.step()
             if monitor:
                 eng.monitor()
 
-    for _ in range(a.warmup):
-        one_step()
+    # (a row-block rank's monitoring forward forks the NEXT step's product: the last warm-up step and the last timed step say
+    # `last`, so the timed region holds exactly K steps' worth of products -- none started in front of it, none left behind it)
+    for i in range(a.warmup):
+        one_step(last=(i == a.warmup - 1))
     eng.profile(True); eng.gemm_stats(reset=True)
     ex0 = stepper.exchanges if stepper is not None else 0
     if stepper is not None:
         stepper.time_exchanges(True)          # HIP events around every collective of the timed steps (comm_ms_per_step below)
-    dt = timed_region(one_step, a.steps, 0, torch.cuda.synchronize, world, dist, red_dev, torch)
+    k_done = [0]
+
+    def timed_step():
+        k_done[0] += 1
+        one_step(last=(k_done[0] == a.steps))
+
+    dt = timed_region(timed_step, a.steps, 0, torch.cuda.synchronize, world, dist, red_dev, torch)
     comm = stepper.comm_ms() if stepper is not None else None
     if stepper is not None:
         stepper.time_exchanges(False)

@@ -287,12 +287,16 @@ typedef struct mcgra_exchange {
 } mcgra_exchange_t;
 #define MCGRA_SHARD_STEP 0          /* one iteration of the loop (:161-283) */
 #define MCGRA_SHARD_MONITOR 1       /* the monitoring forward (:290-296); the next step adopts it */
+#define MCGRA_SHARD_MONITOR_LAST 2  /* the same forward behind the LAST iteration of a run: no step follows, so nothing is
+                                     * started for one (a row-block rank's forward otherwise forks the next step's pack and
+                                     * N x N x N product as soon as the degree vector is complete; a product nobody takes is
+                                     * dropped safely, but it is a product's worth of GPU time) */
 int64_t mcgra_attack_exchange_bytes(mcgra_attack_t* h);
 int mcgra_attack_bind_exchange(mcgra_attack_t* h, void* arena, int64_t bytes);
 int mcgra_attack_shard_begin(mcgra_attack_t* h, void* stream, int what, int want_scalars);
 int mcgra_attack_shard_next(mcgra_attack_t* h, void* stream, mcgra_exchange_t* ex);
 /* after a MCGRA_SHARD_STEP begun with want_scalars: the ten values of mcgra_attack_step's scalars_out (identical on
- * every rank); after MCGRA_SHARD_MONITOR: out[0] = mean(modified_adj).  Synchronises. */
+ * every rank); after MCGRA_SHARD_MONITOR(_LAST): out[0] = mean(modified_adj).  Synchronises. */
 int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out);
 /* rows [row_begin, row_end) of adj_changes' dense form: out [row_end - row_begin][n] fp32 (tests, checkpoints) */
 int mcgra_attack_get_rows(mcgra_attack_t* h, void* stream, float* out);

@@ -395,6 +395,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     h->row0 = 0; h->row1 = (int)n;
     { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
     { const char* ee = getenv("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
+    { const char* ee = getenv("MCGRA_EARLY_P1"); h->early_p1_on = cfg->shard_world > 0 && !(ee && ee[0] == '0'); }
     { const char* ee = getenv("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
     h->late_mean = h->fused_ok && !h->fused_mse && cfg->shard_world == 0;
     {
@@ -500,6 +501,7 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   if (!h->model_set) { set_error("mcgra_attack_set_model must be called first"); return MCGRA_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }
+  CHK(drop_early_p1(h, st));
   const int n = h->n, ld = h->ld, hs = h->hsum;
   if (ori_adj) {
     // general path only: the fused / low-rank forms assume modified_adj == M and modified_adj1 == offdiag relu(Zn Zn^T)
@@ -602,6 +604,7 @@ int mcgra_attack_set_adj_changes(mcgra_attack_t* h, void* stream, const float* p
     MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_pack, 0));
     h->early_pack = false;
   }
+  CHK(drop_early_p1(h, (hipStream_t)stream));      // (likewise the product a row-block rank's forward forked)
   launch_unpack_sym((hipStream_t)stream, h->n, h->ld, packed, nullptr, 0, h->M);
   MCGRA_KERNEL_CHECK();
   h->m_is_full = true;
@@ -855,6 +858,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   h->fused_last = false;
   h->fused_fwd_valid = false;
   if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }      // (the general step packs its own operands)
+  CHK(drop_early_p1(h, st));
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C;
   const double sg = sign_of(h);
@@ -1484,6 +1488,7 @@ int mcgra_attack_finalize(mcgra_attack_t* h, void* stream, int decode_mode, cons
   const int n = h->n, ld = h->ld, hs = h->hsum, Le = h->Le, L = h->L;
   // (a pack a monitor call forked for a step that never came: it reads M, which is overwritten below, and writes scratch)
   if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }
+  CHK(drop_early_p1(h, st));
   if (!h->have_step) {               // epochs == 0: adj_norm of :142
     if (h->has_ori) CHK(forward_ori_unclamped(h, st, h->ADJN));
     else CHK(forward_common(h, st, h->ADJN, nullptr));
@@ -1561,6 +1566,7 @@ int mcgra_attack_copy_buffer(mcgra_attack_t* h, void* stream, const char* name, 
   CHK(mcgra_attack_buffer(h, name, &p, &r, &c, &l));
   if (!dst || dst_ld < c) { set_error("bad destination"); return MCGRA_EINVAL; }
   if (h->early_pack) MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_pack, 0));      // (scratch buffers under a forked pack)
+  if (h->p1_early) MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));      // (... or under a forked product)
   MCGRA_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 4, p, (size_t)l * 4, (size_t)c * 4, r, hipMemcpyDeviceToDevice,
                              (hipStream_t)stream));
   return 0;

@@ -34,6 +34,21 @@ __global__ __launch_bounds__(256) void k_rsq_fin(int row0, int row1, int np, con
   s = wave_sum_d(s);
   if (lane == 0) out[i] = s;
 }
+// |xc_i|^2 of rows [row0, row1) from the per-block partials of an UNCENTRED pack (row sums psum, sums of squares psq) and the
+// column means the forward left: sum_k (a_ik - m_i)^2 = sum a^2 - 2 m_i sum a + n m_i^2 -- an identity in m_i, whichever
+// evaluation of the mean it is (fp64)
+__global__ __launch_bounds__(256) void k_rsq_fin_unc(int row0, int row1, int n, int np, const float* __restrict__ psq,
+                                                     const float* __restrict__ psum, const float* __restrict__ mean,
+                                                     double* __restrict__ out) {
+  const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= row1) return;
+  double s = 0.0, q = 0.0;
+  for (int p = lane; p < np; p += 64) { s += (double)psum[(size_t)i * np + p]; q += (double)psq[(size_t)i * np + p]; }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  const double m = (double)mean[i];
+  if (lane == 0) out[i] = q - 2.0 * m * s + (double)n * m * m;
+}
 // stage[i][c0 + k] = src[i][k] for rows [row0, row1), k < w      (own rows of an n-vector block into the exchange stage)
 __global__ void k_rows_to_stage(int row0, int row1, int w, const float* __restrict__ src, int lds_, float* __restrict__ stage,
                                 int sgw, int c0) {
@@ -224,6 +239,16 @@ static int mm_rows(mcgra_attack* h, hipStream_t st, int ncol) {
   if (h->sharded) { (var) = (label); setup; return 1; }         \
   case label:;
 
+static int fork_p1_early(mcgra_attack* h, hipStream_t st);
+// A product forked by a forward whose step never came (or comes by another path): ordered in front of whatever the caller's
+// stream does next, its result dropped.
+int drop_early_p1(mcgra_attack* h, hipStream_t st) {
+  if (!h->p1_early) return 0;
+  MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+  h->p1_early = h->p1_inflight = h->p1_first = false;
+  return 0;
+}
+
 // d, r, both chains, heads, the means of adj_norm's columns and the operand-scale bound of the current M.
 // Returns 1 at an exchange point (ex filled), 0 when done, < 0 on error.
 static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) {
@@ -272,6 +297,8 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         const Stage sg = narrow_stage(h);
         stage_to_rows2(h, st, sg, 1, 0, h->r, 1, 1, 1, h->d, 1);
         lane_sum(h, st, sg, 2, h->scal + S_SQ);          // S_SQ | S_SUM are adjacent
+        // r is complete: the N x N x N product needs nothing else of this forward (uncentred planes: KFC 1 = 0)
+        if (h->early_p1_on && R1 > R0 && !(h->fs_active && h->fs_what == MCGRA_SHARD_MONITOR && h->fs_last)) CHK(fork_p1_early(h, st));
       }
       for (h->fs_l = 0; h->fs_l < L; ++h->fs_l) {
         {
@@ -315,7 +342,8 @@ static int fused_forward_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* e
         CHK(head_forward(h, st, h->Hu, h->Z2, nullptr, h->sm2));
       }
       if (h->late_mean) { if (h->amax && !h->early_pack) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(1024), 0, st, n, h->r, h->amax + 1); }
-      else if (!h->fused_mse) fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, h->amax ? h->amax + 1 : h->mm + 3);
+      else if (!h->fused_mse)      // (p1_early: the operand-scale bound is k_rmax2's, and the product in flight reads it)
+        fl_mean_stats(st, n, h->cmean, h->r, h->fstat + 192, (h->amax && !h->p1_early) ? h->amax + 1 : h->mm + 3);
       MCGRA_KERNEL_CHECK();
   }
   h->fw_state = 0;
@@ -356,7 +384,7 @@ static int fused_resync(mcgra_attack* h, hipStream_t st) {
   MCGRA_HIP(hipMemcpy(&seq, h->mask_seq_dev, sizeof(seq), hipMemcpyDeviceToHost));
   h->mask_seq = h->mask_want = seq;
   h->p1_inflight = h->fs_dec_forked = false;
-  h->p1_first = false;
+  h->p1_first = h->p1_early = false;
   h->tail_rows = 0;
   // (the streams were drained above, but st2 is non-blocking and shared with other engines: a pack forked for the abandoned
   // step is ordered in front of this stream's next launches explicitly, as at every other site that drops the flag)
@@ -395,6 +423,100 @@ static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pai
   return fl_tail_reduce(st, n, h->ld, pair, R0, R1, use2 ? 2 : 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M,
                         use1 ? h->KX : nullptr, h->r, h->cmean, use2 ? h->lrDelta : nullptr, use2 ? h->lrC : nullptr, a1, a2, kie6,
                         h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf, phase);
+}
+
+// The N x N x N product P1 = KFC Xc^T[:, own rows] (c1) on the side stream -- forked here: the caller's stream is recorded, the side
+// stream waits for it, ev_join marks the product's end (ev_first / ev_second the cuts).  Sets p1_inflight (and p1_first / tail_rows).
+static int fork_p1(mcgra_attack* h, hipStream_t st, bool want_vals) {
+  const int n = h->n, ld = h->ld, R0 = h->row0, R1 = h->row1;
+  const int P = split3_panel(), p_off = R0 / P, p_cnt = R1 > R0 ? (R1 - R0 + P - 1) / P : 0;
+  const bool ovl = h->overlap;
+  h->p1_inflight = false;
+  if (p_cnt <= 0) return 0;
+  hipStream_t sp = ovl ? h->st2 : st;
+  if (ovl) {
+    MCGRA_HIP(hipEventRecord(h->ev_fork, st));
+    MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+  }
+  CHK(timer_begin(h, sp, h->profile));
+  h->p1_first = false;
+  if (h->sharded && h->a2a_overlap && ovl && h->world > 1 && h->test_mutate != 1) {
+    // Row panels of the peers first (rotated start: the panel behind the own ones, wrapping), own panels last, the launch
+    // cut behind the peers' tiles: the all-to-all that hands them over waits for ev_first only and runs beside the rest.
+    // The cut sits on a whole round of the chip when that still leaves own tiles behind it (a cut costs a ragged round).
+    const int tiles_all = (n + P - 1) / P, rot = (p_off + p_cnt) % tiles_all;
+    const int span = min(tiles_all, (tiles_all - p_cnt + 3) & ~3) * p_cnt, total = tiles_all * p_cnt;
+    const int slots = split3_slots();
+    int first = (span + slots - 1) / slots * slots;
+    // (no whole round left behind the peers' tiles: a cut there costs a second ragged round -- taken while the own
+    // panels are at least a quarter of the product, world <= 4, or when forced)
+    if (first >= total) first = (h->world <= 4 || h->a2a_overlap == 2) ? span : 0;
+    if (first > 0 && first < total) {
+      MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, rot, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
+                            h->amax, p_off, p_cnt, 4, first, h->ev_first));
+      h->p1_first = true;
+      ++h->cut_product_steps;
+    }
+  }
+  h->tail_rows = h->tail_rows2 = 0;
+  if (!h->p1_first && !h->sharded && ovl && h->early_tail_on && n >= 8192 && !want_vals && h->test_mutate != 1) {
+    // The tail's first pass needs P1_ij and P1_ji: the rows the product has finished in BOTH orientations.  Its tiles run
+    // in groups of four row panels, so behind a cut on whole rounds of the chip at ~0.8 of the launch the first
+    // `tail_rows` rows are complete, and the pass over them runs beside the product's last rounds (N = 10 000: the cut
+    // at 1 280 of 1 600 tiles = five rounds = eight groups = 8 192 rows, two thirds of the pass).
+    const int tiles_all = (n + P - 1) / P, total = tiles_all * tiles_all, group = 4 * tiles_all;
+    const int slots = split3_slots();
+    const int cut = (int)(0.8 * total) / slots * slots;
+    const int rows = min(n, cut / group * 4 * P);
+    // ... and a second cut behind the last whole round: the rows that one completes, beside the ragged rest
+    int cut2 = total / slots * slots, rows2 = min(n, cut2 / group * 4 * P);
+    if (cut2 <= cut || cut2 >= total || rows2 <= rows) { cut2 = 0; rows2 = 0; }
+    if (cut >= slots && cut < total && rows >= n / 2) {
+      MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * ((size_t)n * ld - tail_ps_floats(h)),
+                            h->split_planes, h->amax, p_off, p_cnt, 0, cut, h->ev_first, cut2, cut2 ? h->ev_second : nullptr));
+      h->tail_rows = rows;
+      h->tail_rows2 = rows2;
+      ++h->cut_product_steps;
+    }
+  }
+  if (!h->p1_first && h->tail_rows == 0)
+  MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
+                        h->amax, p_off, p_cnt));
+  CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
+  ++h->split_steps;
+  if (ovl) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
+  h->p1_inflight = true;
+  return 0;
+}
+
+// Row-block rank: pack and product forked by the FORWARD (a monitor call's, adopted by the next step, or the step's own) as
+// soon as r is complete.  On a rank the forward is a chain of ~25 short launches and three gathers -- 0.16 ms at N = 10 000,
+// world 8, a quarter of the rank's product -- and nothing in it feeds the product: the planes are packed UNCENTRED (the product
+// does not see the centring vector: KFC 1 = 0; the monolithic step packs the same way), their scale bound is max r^2, and the
+// rows' |xc_i|^2 come from the pack's partials once the forward has the means (k_rsq_fin_unc).  The step finds p1_early set.
+// A forward whose step never comes (the last monitor call of a run) leaves a product nobody reads: drop_early_p1.
+static int fork_p1_early(mcgra_attack* h, hipStream_t st) {
+  const mcgra_attack_config_t& c = h->cfg;
+  const bool use1 = !h->fused_mse && c.w[0] != 0, use2 = !h->fused_mse && c.w[1] != 0;
+  CHK(drop_early_p1(h, st));      // (two forwards in a row)
+  if (!use1 || !h->overlap || !h->st2 || h->test_mutate == 1) return 0;
+  const int n = h->n, ld = h->ld, R0 = h->row0, R1 = h->row1;
+  const int P = split3_panel(), p_off = R0 / P, p_cnt = (R1 - R0 + P - 1) / P;
+  const int np = split3_pack_rsq_parts(n, h->split_planes);
+  float* psum = h->A1 + (((size_t)n * np + 3) & ~(size_t)3);
+  MCGRA_HIP(hipEventRecord(h->ev_r, st));
+  MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_r, 0));
+  if (h->amax) hipLaunchKernelGGL(k_rmax2, dim3(1), dim3(1024), 0, h->st2, n, h->r, h->amax + 1);
+  split3_pack_from_m(h->st2, n, ld, h->M, h->r, nullptr, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
+                     use2 ? h->A1 : nullptr, use2 ? psum : nullptr);
+  MCGRA_HIP(hipEventRecord(h->ev_pack, h->st2));
+  const auto cut0 = h->cut_product_steps, split0 = h->split_steps;
+  CHK(fork_p1(h, st, true));
+  h->p1_early = h->p1_inflight;
+  // (the counters move with the step that takes the product, not with a forward whose step may never come)
+  h->p1_early_cut = (int)(h->cut_product_steps - cut0); h->cut_product_steps = cut0;
+  h->p1_early_split = (int)(h->split_steps - split0); h->split_steps = split0;
+  return 0;
 }
 
 // Returns 1 at an exchange point, 0 when the step is done, 2 when the step must be redone by the general path (a
@@ -466,7 +588,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         }
         h->planes_valid = h->planes_mm_on;          // (the means themselves: behind the fork, below)
       } else
-      if (p_cnt > 0 && !mse) {
+      if (p_cnt > 0 && !mse && !h->p1_early) {
         split3_pack_from_m(st, n, ld, h->M, h->r, h->cmean, h->Bpack, h->split_planes, h->amax ? h->amax + 1 : nullptr, p_off, p_cnt,
                            use2 ? h->A1 : nullptr);
         if (use2)
@@ -474,61 +596,18 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
 
       // ---- P1 (column block of the own rows: Xc^T rows = adj_norm rows by symmetry) forked onto the side stream
-      h->p1_inflight = false;
-      if (p_cnt > 0 && use1) {
-        hipStream_t sp = ovl ? h->st2 : st;
-        if (ovl) {
-          MCGRA_HIP(hipEventRecord(h->ev_fork, st));
-          MCGRA_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-        }
-        CHK(timer_begin(h, sp, h->profile));
-        h->p1_first = false;
-        if (h->sharded && h->a2a_overlap && ovl && h->world > 1 && h->test_mutate != 1) {
-          // Row panels of the peers first (rotated start: the panel behind the own ones, wrapping), own panels last, the launch
-          // cut behind the peers' tiles: the all-to-all that hands them over waits for ev_first only and runs beside the rest.
-          // The cut sits on a whole round of the chip when that still leaves own tiles behind it (a cut costs a ragged round).
-          const int tiles_all = (n + P - 1) / P, rot = (p_off + p_cnt) % tiles_all;
-          const int span = min(tiles_all, (tiles_all - p_cnt + 3) & ~3) * p_cnt, total = tiles_all * p_cnt;
-          const int slots = split3_slots();
-          int first = (span + slots - 1) / slots * slots;
-          // (no whole round left behind the peers' tiles: a cut there costs a second ragged round -- taken while the own
-          // panels are at least a quarter of the product, world <= 4, or when forced)
-          if (first >= total) first = (h->world <= 4 || h->a2a_overlap == 2) ? span : 0;
-          if (first > 0 && first < total) {
-            MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, rot, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
-                                  h->amax, p_off, p_cnt, 4, first, h->ev_first));
-            h->p1_first = true;
-            ++h->cut_product_steps;
-          }
-        }
-        h->tail_rows = h->tail_rows2 = 0;
-        if (!h->p1_first && !h->sharded && ovl && h->early_tail_on && n >= 8192 && !want_vals && h->test_mutate != 1) {
-          // The tail's first pass needs P1_ij and P1_ji: the rows the product has finished in BOTH orientations.  Its tiles run
-          // in groups of four row panels, so behind a cut on whole rounds of the chip at ~0.8 of the launch the first
-          // `tail_rows` rows are complete, and the pass over them runs beside the product's last rounds (N = 10 000: the cut
-          // at 1 280 of 1 600 tiles = five rounds = eight groups = 8 192 rows, two thirds of the pass).
-          const int tiles_all = (n + P - 1) / P, total = tiles_all * tiles_all, group = 4 * tiles_all;
-          const int slots = split3_slots();
-          const int cut = (int)(0.8 * total) / slots * slots;
-          const int rows = min(n, cut / group * 4 * P);
-          // ... and a second cut behind the last whole round: the rows that one completes, beside the ragged rest
-          int cut2 = total / slots * slots, rows2 = min(n, cut2 / group * 4 * P);
-          if (cut2 <= cut || cut2 >= total || rows2 <= rows) { cut2 = 0; rows2 = 0; }
-          if (cut >= slots && cut < total && rows >= n / 2) {
-            MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * ((size_t)n * ld - tail_ps_floats(h)),
-                                  h->split_planes, h->amax, p_off, p_cnt, 0, cut, h->ev_first, cut2, cut2 ? h->ev_second : nullptr));
-            h->tail_rows = rows;
-            h->tail_rows2 = rows2;
-            ++h->cut_product_steps;
-          }
-        }
-        if (!h->p1_first && h->tail_rows == 0)
-        MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
-                              h->amax, p_off, p_cnt));
-        CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
-        ++h->split_steps;
-        if (ovl) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
-        h->p1_inflight = true;
+      if (h->p1_early) {
+        // a row-block rank's forward forked pack and product as soon as r was complete (fork_p1_early): in flight since then.
+        // The pack's row partials (|xc_i|^2 below) are ready at ev_pack.
+        MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));
+        h->p1_early = false;
+        h->cut_product_steps += h->p1_early_cut; h->split_steps += h->p1_early_split;
+        if (use2)
+          hipLaunchKernelGGL(k_rsq_fin_unc, dim3((R1 - R0 + 3) / 4), dim3(256), 0, st, R0, R1, n, split3_pack_rsq_parts(n, h->split_planes),
+                             h->A1, h->A1 + (((size_t)n * split3_pack_rsq_parts(n, h->split_planes) + 3) & ~(size_t)3), h->cmean, h->lrRs);
+      } else {
+        h->p1_inflight = false;
+        if (p_cnt > 0 && use1) CHK(fork_p1(h, st, want_vals));
       }
 
       // (behind the fork: nothing in front of the product needs them)
@@ -941,10 +1020,12 @@ int mcgra_attack_shard_begin(mcgra_attack_t* h, void* stream, int what, int want
   (void)stream;
   if (!h || !h->graph_set) { set_error("engine not set up"); return MCGRA_EINVAL; }
   if (!h->sharded || !h->arena) { set_error("not a row-block rank, or no exchange arena bound"); return MCGRA_EINVAL; }
-  if (what != MCGRA_SHARD_STEP && what != MCGRA_SHARD_MONITOR) { set_error("what = %d", what); return MCGRA_EINVAL; }
+  if (what != MCGRA_SHARD_STEP && what != MCGRA_SHARD_MONITOR && what != MCGRA_SHARD_MONITOR_LAST) { set_error("what = %d", what); return MCGRA_EINVAL; }
   // a step that was begun and never ran to XCHG_DONE (the caller gave up on a collective): its leftovers are dropped
   // by fused_resync at the top of the next step (fs_open is still set); a monitor call holds no such state
   if (h->fs_active && h->fs_what == MCGRA_SHARD_MONITOR) h->fused_fwd_valid = false;
+  h->fs_last = what == MCGRA_SHARD_MONITOR_LAST;
+  if (h->fs_last) what = MCGRA_SHARD_MONITOR;
   h->fs_what = what; h->fs_want = want_scalars ? 1 : 0;
   h->fs_state = 0; h->fw_state = 0;
   h->fs_active = true;

@@ -110,6 +110,10 @@ struct mcgra_attack {
   hipEvent_t ev_r = nullptr, ev_pack = nullptr;
   bool early_pack_on = true;       // MCGRA_EARLY_PACK=0 disables (A/B)
   bool early_pack = false;         // Bpack / the pack's row partials describe the CURRENT M (packed by the forward of this M)
+  bool early_p1_on = false;        // row-block rank: pack (uncentred) + N x N x N product forked by the FORWARD, as soon as r is complete
+  bool p1_early = false;           // ... and in flight: forked by the forward of the CURRENT M (a monitor call, or the step's own)
+  bool fs_last = false;            // the monitor call in progress was begun as MCGRA_SHARD_MONITOR_LAST
+  int p1_early_cut = 0, p1_early_split = 0;      // what that launch adds to cut_product_steps / split_steps once a step takes it
   // third stream of the fused step: the small-operand terms c9 / c10 (a chain of ~16 tiny launches that needs only the
   // forward) run beside the low-rank factor chain; its products use their own split-K workspace
   hipStream_t st3 = nullptr;
@@ -193,6 +197,7 @@ struct mcgra_attack {
 
 // attack_fused.hip
 bool fused_step_possible(const mcgra_attack* h);
+int drop_early_p1(mcgra_attack* h, hipStream_t st);      // a product forked by a row-block rank's forward whose step never came
 int fused_forward(mcgra_attack* h, hipStream_t st);
 // returns 1 when the step must be redone by the general path (a relu-masked pair in the decode), 0 when done
 int fused_step(mcgra_attack* h, hipStream_t st, double* scalars_out);

@@ -19,7 +19,7 @@ import torch
 
 PANEL = 256          # row blocks are whole 256-row panels (split_symm_bf16.hip), i.e. whole 64-row tiles of the tail
 XCHG_DONE, XCHG_ALLGATHER, XCHG_ALLREDUCE_F64, XCHG_ALLTOALL = 0, 1, 2, 3
-SHARD_STEP, SHARD_MONITOR = 0, 1
+SHARD_STEP, SHARD_MONITOR, SHARD_MONITOR_LAST = 0, 1, 2
 
 
 class RowBlockPlan:
@@ -135,9 +135,10 @@ class ShardedStepper:
         """One iteration of the loop (topology_attack.py:161-283) on this rank's row block."""
         return self._run(SHARD_STEP, want_scalars)
 
-    def monitor(self, want_sparsity=False):
-        """The monitoring forward (:290-296); the next step adopts it.  Returns mean(modified_adj) if asked."""
-        out = self._run(SHARD_MONITOR, want_sparsity)
+    def monitor(self, want_sparsity=False, last=False):
+        """The monitoring forward (:290-296); the next step adopts it.  Returns mean(modified_adj) if asked.
+        last: no step follows (the final epoch) -- the rank's forward then does not fork the next step's product."""
+        out = self._run(SHARD_MONITOR_LAST if last else SHARD_MONITOR, want_sparsity)
         return out[0] if want_sparsity else None
 
 

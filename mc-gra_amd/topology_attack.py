@@ -321,7 +321,7 @@ class PGDAttack(BaseAttack):
                     eng.step(noise=torch.randn(n, n, device=dev) if eps != 0 else None)
             if monitor:
                 if stepper is not None:
-                    stepper.monitor()                                    # (:290-296), the next step adopts it
+                    stepper.monitor(last=(t == epochs - 1))              # (:290-296), the next step adopts it
                     out2 = eng.buffer("logp") if idx_test_t is not None else None
                 else:
                     out2, spars = eng.monitor(want_sparsity=False)       # (:290-296)

@@ -42,11 +42,12 @@ for world in [int(x) for x in a.worlds.split(",")]:
         nex = 0
         for _ in range(a.steps):
             nex += S.run_echo(bk, S.SHARD_STEP); nex += S.run_echo(bk, S.SHARD_MONITOR)
+        host = (time.perf_counter() - t0) / a.steps          # the host is done enqueueing: if this is the step time, the host binds
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
         st = eng.gemm_stats(reset=True)
         row = {"world": world, "rank": rk, "rows_per_rank": plan.rows_per_rank, "mode": "echo (one rank alone, collectives answered by its own data)",
-               "per_rank_compute_ms": 1e3 * dt, "product_ms_per_step": st["ms"] / max(1, a.steps), "collectives_per_step": nex / a.steps,
+               "per_rank_compute_ms": 1e3 * dt, "host_enqueue_ms": 1e3 * host, "product_ms_per_step": st["ms"] / max(1, a.steps), "collectives_per_step": nex / a.steps,
                "fused_steps": eng.fused_steps(), "general_steps": eng.path_stats()["general_steps"], "steps": a.steps + 3,
                "alltoall_bytes_per_rank": 4 * world * plan.rows_per_rank ** 2 if world > 1 else 0,
                "allgather_node_bytes_per_rank": plan.n_pad * 64 * 4}

@@ -809,6 +809,61 @@ def test_sharded_ranks_hand_masked_steps_to_the_general_path(pkg, monkeypatch):
     assert torch.equal(_gather_rows(bks), mono.buffer("M"))
 
 
+def test_row_block_forward_forks_the_next_products_and_a_product_nobody_takes_is_dropped(pkg, monkeypatch):
+    """A row-block rank's forward (the monitor call's, adopted by the next step) forks the NEXT step's pack and N x N x N product as
+    soon as the degree vector is complete (attack_fused.hip: fork_p1_early).  (1) Against the same ranks with MCGRA_EARLY_P1=0
+    -- product forked by the step, centred planes: the same adjacency to fp32 rounding, step by step.  (2) One product launch
+    per step either way: the forward's launch is the step's, MCGRA_SHARD_MONITOR_LAST starts none.  (3) A forked product
+    nobody takes -- the caller sets another adj_changes, calls the forward twice, finalizes -- is dropped: results equal a rank
+    that never forked."""
+    import torch
+    from mc_gra_amd import sharded as S
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5)
+    lr = float(z["lr"])
+    _, early = _shard_engines(pkg, z, 2)
+    monkeypatch.setenv("MCGRA_EARLY_P1", "0")
+    _, late = _shard_engines(pkg, z, 2)
+    monkeypatch.delenv("MCGRA_EARLY_P1")
+    for b in early + late:
+        b.eng.profile(True); b.eng.gemm_stats(reset=True)
+    for t in range(3):
+        S.run_lockstep(early, S.SHARD_STEP); S.run_lockstep(late, S.SHARD_STEP)
+        re_, rl = _gather_rows(early), _gather_rows(late)
+        assert float(((re_ - rl).abs() > 0.05 * lr).float().mean()) < 2e-3, t
+        last = S.SHARD_MONITOR_LAST if t == 2 else S.SHARD_MONITOR
+        S.run_lockstep(early, last); S.run_lockstep(late, last)
+        torch.cuda.synchronize()
+        # launches so far: t + 1 steps, + the one the forward forked for the next step (not behind the last)
+        assert [b.eng.gemm_stats(reset=False)["launches"] for b in early] == [t + 1 + (t < 2)] * 2, t
+        assert [b.eng.gemm_stats(reset=False)["launches"] for b in late] == [t + 1] * 2, t
+    assert all(b.eng.fused_steps() == 3 for b in early + late)
+    assert [b.eng.cut_product_steps() for b in early] == [b.eng.cut_product_steps() for b in late] == [3, 3]
+
+    # (3) a forked product nobody takes
+    _, (a,) = _shard_engines(pkg, z, 1)
+    monkeypatch.setenv("MCGRA_EARLY_P1", "0")
+    _, (b,) = _shard_engines(pkg, z, 1)
+    monkeypatch.delenv("MCGRA_EARLY_P1")
+    for e in (a, b):
+        S.run_lockstep([e], S.SHARD_STEP); S.run_lockstep([e], S.SHARD_MONITOR)      # a: a product in flight
+    a0 = a.eng.get_adj_changes() * 0.5
+    for e in (a, b):
+        e.eng.set_adj_changes(a0)                       # another M: the product of the old one is dropped
+        S.run_lockstep([e], S.SHARD_MONITOR); S.run_lockstep([e], S.SHARD_MONITOR)      # two forwards in a row
+        S.run_lockstep([e], S.SHARD_STEP)
+    ra, rb = a.eng.get_rows(), b.eng.get_rows()
+    assert float(((ra - rb).abs() > 0.05 * lr).float().mean()) < 2e-3
+    for e in (a, b):
+        S.run_lockstep([e], S.SHARD_MONITOR)            # a: forks again -- and finalize takes the engine from there
+    HA, YA = a.eng.buffer("HA"), a.eng.buffer("YA")
+    lab = torch.as_tensor(z["labels"], device="cuda")
+    la = (lab[:, None] == lab[None, :]).float()
+    fa, fb = a.eng.finalize(0, HA, YA, la), b.eng.finalize(0, HA, YA, la)
+    assert float((fa - fb).abs().max()) <= 1e-4 * float(fb.abs().max())
+    S.run_lockstep([a], S.SHARD_STEP); S.run_lockstep([b], S.SHARD_STEP)      # ... and the attack goes on
+    assert a.eng.fused_steps() == b.eng.fused_steps() == 3
+
+
 def test_abandoned_row_block_step_is_dropped_cleanly(pkg):
     """A row-block step the caller gives up on after a failed collective (mcgra_attack_shard_begin again without having
     reached XCHG_DONE) has already enqueued its masked-pair post, forked the product and the small-operand terms: the
