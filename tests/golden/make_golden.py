@@ -22,6 +22,7 @@ main.py:440-450; the zip that ships it is a missing large blob), so the script
 works in a temp cwd and writes label_adj[i,j] = (labels[i] == labels[j]) there.
 """
 import argparse
+import time as _time
 import os
 import random
 import sys
@@ -701,9 +702,11 @@ README_RUNS = {
 }
 
 
-def gen_readme(tmp, only=None, epochs=6):
+def gen_readme(tmp, only=None, epochs=6, horizon=None):
     """The reference on its README.md lines, through its own Dataset, preprocess and GCN.fit (main.py:147-190), `epochs`
-    steps each.  Per dataset one `readme_<dataset>_graph.npz` with what the loader produced (edges, diagonal -- brazil has
+    steps each.  (horizon: a dict -- nothing is written per line; the eps == 0 lines are run for `epochs` steps as they are and
+    once more with the reference's own code in float64, and only what a longer horizon can be held to is kept: both AUCs, a
+    sample of the ensemble and its sum -- gen_readme_horizon.)  Per dataset one `readme_<dataset>_graph.npz` with what the loader produced (edges, diagonal -- brazil has
     self loops --, attributes as bits / the identity flag / float32, labels, the three index splits, idx_attack) and the
     trained weights; per line one `readme_<dataset>_<tag>.npz` with the per-step gradient at sampled packed positions,
     adj_changes there after the last step, a sample of the post-loop ensemble, its sum and the AUC."""
@@ -726,6 +729,12 @@ def gen_readme(tmp, only=None, epochs=6):
         victim = GCN(nfeat=features.shape[1], nclass=labels.max().item() + 1, nhid=16, nlayer=2,
                      dropout=0.5, weight_decay=5e-4, device=device).to(device)
         victim.fit(features, adj, labels, idx_train, idx_val, verbose=False)
+        victim_clean = None
+        if horizon is not None:      # (fit and attack leave non-leaf tensors on the module: a copy for the float64 run is built from the weights)
+            victim_clean = GCN(nfeat=features.shape[1], nclass=labels.max().item() + 1, nhid=16, nlayer=2,
+                               dropout=0.5, weight_decay=5e-4, device=device).to(device)
+            victim_clean.load_state_dict(victim.state_dict())
+            victim_clean.eval()
         idx_attack = np.array(random.sample(range(adj.shape[0]), int(adj.shape[0] * 1.0)))   # main.py:244
         num_edges = int(0.5 * 1e7 * adj.sum() / adj.shape[0] ** 2 * len(idx_attack) ** 2)
         lab = labels.numpy()
@@ -760,6 +769,20 @@ def gen_readme(tmp, only=None, epochs=6):
                 extra.update(a0_seed=start[0], a0_scale=start[1] / n)
                 if lr is None:
                     lr = start[1] / (50.0 * n)
+            if horizon is not None:
+                if eps != 0:
+                    continue
+                t0 = _time.time()
+                res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs, ds,
+                                           tuple(bool(u) for u in use), num_edges, a0=a0, capture_steps=False)
+                res64 = run_reference_attack(adj, features, labels, deepcopy(victim_clean), idx_attack, measure, wp, wsup, lr, epochs, ds,
+                                             tuple(bool(u) for u in use), num_edges, a0=a0, capture_steps=False, f64=True)
+                horizon[f"{name}_auc"] = res["auc"]; horizon[f"{name}_auc64"] = res64["auc"]
+                horizon[f"{name}_final_sample"] = res["final"][samp[:, 0], samp[:, 1]].astype(np.float32)
+                horizon[f"{name}_final_sum"] = float(res["final"].astype(np.float64).sum())
+                print(name, epochs, "epochs: auc", res["auc"], "float64", res64["auc"], "diff", abs(res["auc"] - res64["auc"]),
+                      "seconds", round(_time.time() - t0, 1), flush=True)
+                continue
             torch.manual_seed(1000 + line)       # (the noise of an eps != 0 line; recorded below)
             res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs, ds,
                                        tuple(bool(u) for u in use), num_edges, eps=eps, a0=a0, noise_seed=NOISE_SEEDS.get(line))
@@ -780,8 +803,25 @@ def gen_readme(tmp, only=None, epochs=6):
                        final_sum=float(res["final"].astype(np.float64).sum()))
             np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
             print(name, "auc", res["auc"], "gmax per step", np.abs(sg).max(1), flush=True)
-        if H_A2 is not None:
+        if H_A2 is not None and horizon is None:
             np.savez_compressed(os.path.join(OUT, f"readme_{ds.lower()}_graph.npz"), H_A2=H_A2, Y_A=Y_A, **graph)
+
+
+def gen_readme_horizon(tmp, epochs=20, only=None):
+    """The README lines (eps == 0) at a longer horizon than the per-step fixtures' six epochs: the reference for `epochs` steps in
+    float32 (as it runs) and in float64 (its own code under torch float64) from the same trained victim -- their distance is what
+    the reference's own arithmetic leaves of "the" AUC at that horizon (Adam turns rounding noise on near-zero gradients into
+    +-lr moves).  One file, readme_horizon<epochs>.npz: per line both AUCs, a sample of the ensemble, its sum.  About an hour
+    on 8 cores."""
+    out = {}
+    path = os.path.join(OUT, f"readme_horizon{epochs}.npz")
+    gen_readme(tmp, only=only, epochs=epochs, horizon=out)
+    if only is not None and os.path.exists(path):      # a partial regeneration keeps the other lines
+        old = dict(np.load(path))
+        old.update(out)
+        out = old
+    out["epochs"] = epochs
+    np.savez_compressed(path, **out)
 
 
 def gen_citeseer_gat(tmp, train_iters=6):
@@ -1025,6 +1065,8 @@ if __name__ == "__main__":
             gen_mid(tmp)
         if a.only in ("all", "readme") or a.only.startswith("readme:"):      # README lines on brazil / usair / polblogs / AIDS
             gen_readme(tmp, only=a.only.split(":", 1)[1].split(",") if ":" in a.only else None)
+        if a.only == "readme_horizon" or a.only.startswith("readme_horizon:"):      # ~1 h on 8 cores: not part of "all"
+            gen_readme_horizon(tmp, only=a.only.split(":", 1)[1].split(",") if ":" in a.only else None)
         if a.only in ("citeseer",):         # ~20 min on 8 cores: not part of "all"
             gen_citeseer_gat(tmp)
         if a.only in ("bench10k",):         # ~25 min and ~20 GB on 8 cores: not part of "all"
