@@ -382,6 +382,11 @@ def replica_probe(pkg, torch, dist, dev, rank, world, workload, seed, steps, war
             "replicas": world, "steps": steps, "what": "independent attacks, one per GPU, no collective (weak scaling)"}
 
 
+def ab_switch(name):
+    """An A/B switch of the engine as the engine reads it: honoured only beside MCGRA_AB=1 (attack.hip: ab_env)."""
+    return os.environ.get(name) if os.environ.get("MCGRA_AB") == "1" else None
+
+
 PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
                  2: "3-plane bf16 split, hand-written split3_symm_kernel on packed planes (256 x 256 tiles)",
                  3: "2-plane fp16 split (3 plane products, exact power-of-two operand scales), hand-written "
@@ -393,7 +398,7 @@ def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode,
     """The same workload with another evaluation of the one N x N x N product (MCGRA_SPLIT_BF16=mode): the pure fp32
     MFMA path beside a split headline, or the other way round; overlap=0: the product alone on the chip instead of
     beside the step's HBM-bound kernels.  Never the reported `value`."""
-    env = {"MCGRA_SPLIT_BF16": str(mode)}
+    env = {"MCGRA_SPLIT_BF16": str(mode), "MCGRA_AB": "1"}      # (A/B switches are honoured only beside MCGRA_AB=1)
     if overlap is not None:
         env["MCGRA_OVERLAP"] = str(overlap)
     env.update(extra_env or {})
@@ -733,7 +738,7 @@ def main(argv=None):
             replay_ms = None
     # ... and the step without the side stream (same engine configuration with MCGRA_OVERLAP=0): what the fork is worth
     alone = None
-    side_stream = (os.environ.get("MCGRA_OVERLAP") or ("1" if pmode == 3 else "0")) == "1"
+    side_stream = (ab_switch("MCGRA_OVERLAP") or ("1" if pmode == 3 else "0")) == "1"
     if world == 1 and measure == "HSIC" and pmode in (2, 3) and side_stream and not a.no_split_probe:
         try:
             alone = product_probe(pkg, torch, dev, a.workload, a.seed + rank, min(a.steps, 40), min(a.warmup, 10), monitor, pmode, overlap=0)
@@ -818,7 +823,7 @@ def main(argv=None):
                        # fused steps whose decode relu-masked pairs of live embedding rows (they stand; only a dead row falls back)
                        "masked_fused_steps": eng_path["masked_fused_steps"],
                        "monitor_forward": monitor,
-                       "forward_reuse": bool(monitor and os.environ.get("MCGRA_NO_FWD_REUSE") != "1"),
+                       "forward_reuse": bool(monitor and ab_switch("MCGRA_NO_FWD_REUSE") != "1"),
                        "parallelism": (f"row-block x{world}: one attack, rows of the learnable adjacency and of every N x N pass "
                                        f"split over the ranks ({plan.rows_per_rank} rows each); per step one all-to-all of "
                                        "P1 tile blocks and all-gathers of n x c node arrays with the partial scalars in their lane "

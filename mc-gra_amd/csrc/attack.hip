@@ -180,6 +180,17 @@ int mcgra_device_count(void) {
   return c;
 }
 
+// The A/B switches of the parity suite and of the measurements under profiles/  are honoured only when
+// MCGRA_AB=1 is set beside them: a variable left in the environment of a real run changes nothing -- and says so once.
+static const char* ab_env(const char* name) {
+  const char* v = getenv(name);
+  if (!v) return nullptr;
+  const char* on = getenv("MCGRA_AB");
+  if (on && on[0] == '1') return v;
+  fprintf(stderr, "[mcgra] %s=%s is ignored: A/B switches are honoured only under MCGRA_AB=1\n", name, v);
+  return nullptr;
+}
+
 int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) {
   if (!out || !cfg) { set_error("null argument"); return MCGRA_EINVAL; }
   if (cfg->n < 2 || cfg->nlayer < 2 || cfg->nlayer > MCGRA_MAX_LAYERS || cfg->emb_nlayer < 1 ||
@@ -243,7 +254,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
 #define A_(p, cnt) if (!rc) rc = dalloc(h, &h->p, (cnt))
   A_(M, nn); A_(am, nn); A_(av, nn); A_(ADJN, nn); A_(A1, nn); A_(G_ADJN, nn); A_(G_A1, nn); A_(G_A, nn);
   A_(KX, nn); A_(FADJ, nn);
-  { const char* e = getenv("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
+  { const char* e = ab_env("MCGRA_KEEP_GSYM"); h->keep_gsym = e && e[0] == '1'; }
   { const char* e = getenv("MCGRA_TESTING"); h->testing = e && e[0] == '1'; }
   if (h->keep_gsym) { A_(GSYM, nn); }
   if (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) {
@@ -274,13 +285,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
   const size_t am_ = (size_t)h->na * h->hmax;
   A_(HA, nm); A_(YA, nc); A_(HAg, am_); A_(HAc, am_); A_(YAg, am_); A_(YAc, am_); A_(Yg, am_); A_(Gg, am_);
   if (cfg->eps != 0.f) { A_(Abuf, nn); A_(gate, nn); A_(colpart_d, (size_t)h->nstrips * ld); }
-  { const char* e = getenv("MCGRA_NO_FWD_REUSE"); h->fwd_reuse = cfg->eps == 0.f && !(e && e[0] == '1'); }
-  { const char* e = getenv("MCGRA_NO_FUSED_TAIL"); h->fuse_tail = !(e && e[0] == '1'); }
+  { const char* e = ab_env("MCGRA_NO_FWD_REUSE"); h->fwd_reuse = cfg->eps == 0.f && !(e && e[0] == '1'); }
+  { const char* e = ab_env("MCGRA_NO_FUSED_TAIL"); h->fuse_tail = !(e && e[0] == '1'); }
   if (h->fwd_reuse) { A_(ADJN_next, nn); }
   A_(cm_part, (size_t)64 * 256);      // column-sum partials of launch_colmean_center (small-operand terms)
   A_(Q, (size_t)h->hmax * h->hmax); A_(Q2, (size_t)h->hmax * h->hmax); A_(Gg2, am_); A_(coef, 16); A_(cst, 8);
   {
-    const char* e = getenv("MCGRA_NO_LOWRANK");
+    const char* e = ab_env("MCGRA_NO_LOWRANK");
     const int he = h->wdt[h->Le - 1];
     h->lr_ok = cfg->measure == MCGRA_MEASURE_HSIC && h->act == 0 && he <= 32 && !(e && e[0] == '1');
     if (h->lr_ok) {
@@ -307,7 +318,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     // MCGRA_NO_LOWRANK) through the 2-plane fp16 kernel as well: Kx = Xc Xc^T and Ky = Yc Yc^T as full matrices, then
     // G_adjn += Ky' Xc and G_A1 += Kx' Yc -- four products of 2 n^3 instead of 3 n^3 MACs of fp32 SYMM at a third of
     // their rate.  MCGRA_GRAM_SPLIT=0: fp32 path.
-    const char* eg_ = getenv("MCGRA_GRAM_SPLIT");
+    const char* eg_ = ab_env("MCGRA_GRAM_SPLIT");
     const bool gram_auto = (es[0] == '3') && !(eg_ && eg_[0] == '0');
     if (!rc && (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) && cfg->eps == 0.f && gram_auto) {
       if (!h->split_on) { h->split_planes = 2; A_(Bpack, split3_pack_bytes((int)n, 2)); A_(amax, 16); }
@@ -322,7 +333,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     // step at N = 10 000 although the product itself slows from 4.8 to 5.6 ms); the fp32 SYMM and the 3-plane kernel
     // hold every CU's LDS and registers, so what runs beside them crawls and slows them by about as much as it hides
     // (measured: 21.2-21.5 ms with the side stream, 21.6 without).  MCGRA_OVERLAP=0 / 1 overrides.
-    const char* eo = getenv("MCGRA_OVERLAP");
+    const char* eo = ab_env("MCGRA_OVERLAP");
     h->overlap = (eo && eo[0]) ? eo[0] == '1' : (h->split_mode == 2 && h->split_planes == 2);
     if (h->gram_split) { A_(gram_diag, 2 * ld); }
     // (the fused MSELoss step -- attack_fused.hip -- uses the side streams of the small-operand terms and of the decode too)
@@ -365,13 +376,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       if (h->mask_host) { h->mask_host[0] = 0u; h->mask_host[1] = 0u; }
       // Gram evaluation: its four products on the side stream, beside the HBM-bound rest of the step (step_impl).
       // MCGRA_GRAM_OVERLAP=0: everything on the caller's stream, same launches in the same order (bit-identical: A/B test)
-      { const char* eg2 = getenv("MCGRA_GRAM_OVERLAP"); h->gram_ovl = h->gram_split && !rc && !(eg2 && eg2[0] == '0'); }
+      { const char* eg2 = ab_env("MCGRA_GRAM_OVERLAP"); h->gram_ovl = h->gram_split && !rc && !(eg2 && eg2[0] == '0'); }
     }
   }
   {
     // The fused low-rank step (attack_fused.hip): HSIC with a ReLU GCN embedding, eps == 0, the split product, widths
     // that fit the 64-column skinny products and the rank-k panels of the tail.  MCGRA_NO_FUSED_LR=1: general path only.
-    const char* e = getenv("MCGRA_NO_FUSED_LR");
+    const char* e = ab_env("MCGRA_NO_FUSED_LR");
     const int he = h->wdt[h->Le - 1];
     int fc = 2 * he + 1 + h->wdt[h->L - 1];
     for (int l = 0; l < h->L; ++l) fc = (2 * h->wdt[l] + 1) > fc ? 2 * h->wdt[l] + 1 : fc;
@@ -393,13 +404,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                    h->st3 != nullptr;
     if (h->fused_mse) h->fused_ok = true;
     h->row0 = 0; h->row1 = (int)n;
-    { const char* ef = getenv("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
-    { const char* ee = getenv("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
-    { const char* ee = getenv("MCGRA_EARLY_P1"); h->early_p1_on = cfg->shard_world > 0 && !(ee && ee[0] == '0'); }
-    { const char* ee = getenv("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
+    { const char* ef = ab_env("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
+    { const char* ee = ab_env("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
+    { const char* ee = ab_env("MCGRA_EARLY_P1"); h->early_p1_on = cfg->shard_world > 0 && !(ee && ee[0] == '0'); }
+    { const char* ee = ab_env("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
     h->late_mean = h->fused_ok && !h->fused_mse && cfg->shard_world == 0;
     {
-      const char* ep = getenv("MCGRA_PLANES_MM");
+      const char* ep = ab_env("MCGRA_PLANES_MM");
       // default from n = 8192: on smaller graphs the step is bound by its chain of launches, and the two extra launches per
       // product (magnitude + pack of the right-hand side) cost more than the matrix-pipe time they free (Cora-shape step
       // 0.51 -> 0.56 ms, N = 4096 0.86 -> 0.92 ms with it); MCGRA_PLANES_MM=1 forces it on (tests), =0 off
@@ -428,7 +439,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
         // the all-to-all of P1 beside the own row panels of the product (attack_fused.hip): free when a whole round of the chip
         // ends behind the peers' tiles, worth a second ragged round while world <= 4 (world 8 at N = 10 000: 200 tiles on 256
         // CUs, nothing to run beside)
-        { const char* ee = getenv("MCGRA_A2A_OVERLAP"); h->a2a_overlap = ee ? (ee[0] == '1' ? 2 : 0) : (h->world >= 2 ? 1 : 0); }
+        { const char* ee = ab_env("MCGRA_A2A_OVERLAP"); h->a2a_overlap = ee ? (ee[0] == '1' ? 2 : 0) : (h->world >= 2 ? 1 : 0); }
       }
     }
     if (h->fused_ok && !rc) {

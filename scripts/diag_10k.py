@@ -5,7 +5,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MCGRA_KEEP_GSYM", "1")
+os.environ.setdefault("MCGRA_KEEP_GSYM", "1"); os.environ.setdefault("MCGRA_AB", "1")
 import torch
 import mcgra_loader
 pkg = mcgra_loader.load()

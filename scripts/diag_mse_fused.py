@@ -3,7 +3,7 @@ import os, sys, argparse
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["MCGRA_KEEP_GSYM"] = "1"
+os.environ["MCGRA_KEEP_GSYM"] = "1"; os.environ["MCGRA_AB"] = "1"
 import torch
 import mcgra_loader
 pkg = mcgra_loader.load()

@@ -5,7 +5,7 @@ for w in cora-shape-hsic cora-shape-mse synthetic-10k-mse synthetic-4k-hsic synt
   python bench.py --workload $w --no-cpu-baseline --no-split-probe --steps $st --warmup 5 > gpurun_out/${TAG}_bench_$w.json 2>/dev/null
   tail -c 200 gpurun_out/${TAG}_bench_$w.json | head -c 10 >/dev/null
 done
-MCGRA_NO_LOWRANK=1 python bench.py --no-cpu-baseline --no-split-probe --steps 10 > gpurun_out/${TAG}_bench_gram_path.json 2>/dev/null
+MCGRA_AB=1 MCGRA_NO_LOWRANK=1 python bench.py --no-cpu-baseline --no-split-probe --steps 10 > gpurun_out/${TAG}_bench_gram_path.json 2>/dev/null
 MCGRA_SPLIT_BF16=2 python bench.py --no-cpu-baseline --no-split-probe > gpurun_out/${TAG}_bench_split_bf16x3.json 2>/dev/null
 python - <<'PY'
 import json, glob, os

@@ -18,7 +18,7 @@ import json; l=json.loads(open('$O/bench_20_5.json').read().strip().splitlines()
 TAG=r05f/o bash scripts/gpu_other_benches.sh
 python bench.py --workload synthetic-10k-hsic-masked --no-cpu-baseline --no-split-probe --steps 20 > $O/o_bench_synthetic-10k-hsic-masked.json 2>/dev/null
 python bench.py --workload synthetic-10k-mse --no-cpu-baseline --no-split-probe --steps 100 --warmup 20 > $O/o_bench_synthetic-10k-mse.json 2>/dev/null
-MCGRA_NO_FUSED_LR=1 python bench.py --workload synthetic-10k-mse --no-cpu-baseline --no-split-probe --steps 40 --warmup 10 > $O/o_bench_synthetic-10k-mse_general.json 2>/dev/null
+MCGRA_AB=1 MCGRA_NO_FUSED_LR=1 python bench.py --workload synthetic-10k-mse --no-cpu-baseline --no-split-probe --steps 40 --warmup 10 > $O/o_bench_synthetic-10k-mse_general.json 2>/dev/null
 python scripts/shard_emulate.py --echo --worlds 1,2,4,8 --steps 20 > $O/shard_echo_10k_hsic.log 2>&1; grep '^{"world"' $O/shard_echo_10k_hsic.log | cut -c1-200
 python scripts/shard_emulate.py --echo --workload synthetic-10k-mse --worlds 1,2,4,8 --steps 20 > $O/shard_echo_10k_mse.log 2>&1; grep '^{"world"' $O/shard_echo_10k_mse.log | cut -c1-200
 python scripts/shard_emulate.py --echo --workload synthetic-30k-hsic-3layer --worlds 1,2,4,8 --steps 4 > $O/shard_echo_30k_hsic.log 2>&1; grep '^{"world"' $O/shard_echo_30k_hsic.log | cut -c1-200

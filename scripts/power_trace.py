@@ -57,7 +57,7 @@ def main():
     phases = [("idle", None, {}),
               ("bench_in_situ", bench, {}),
               ("cooldown1", None, {}),
-              ("bench_serial", bench, {"MCGRA_OVERLAP": "0"}),
+              ("bench_serial", bench, {"MCGRA_OVERLAP": "0", "MCGRA_AB": "1"}),
               ("cooldown2", None, {}),
               ("product_alone", [py, os.path.join(ROOT, "scripts", "product_loop.py"), "--seconds", "5"], {})]
     lines = {}

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the suite IS the A/B harness: the engine honours its switches (MCGRA_NO_LOWRANK, MCGRA_KEEP_GSYM, ...) only beside MCGRA_AB=1
+# (attack.hip: ab_env); set before the fork server of the multi-process tests starts, so their ranks inherit it
+os.environ["MCGRA_AB"] = "1"
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -811,10 +811,10 @@ def gen_readme_horizon(tmp, epochs=20, only=None):
     """The README lines (eps == 0) at a longer horizon than the per-step fixtures' six epochs: the reference for `epochs` steps in
     float32 (as it runs) and in float64 (its own code under torch float64) from the same trained victim -- their distance is what
     the reference's own arithmetic leaves of "the" AUC at that horizon (Adam turns rounding noise on near-zero gradients into
-    +-lr moves).  One file, readme_horizon<epochs>.npz: per line both AUCs, a sample of the ensemble, its sum.  About an hour
+    +-lr moves).  One file, horizon<epochs>_readme.npz: per line both AUCs, a sample of the ensemble, its sum.  About an hour
     on 8 cores."""
     out = {}
-    path = os.path.join(OUT, f"readme_horizon{epochs}.npz")
+    path = os.path.join(OUT, f"horizon{epochs}_readme.npz")
     gen_readme(tmp, only=only, epochs=epochs, horizon=out)
     if only is not None and os.path.exists(path):      # a partial regeneration keeps the other lines
         old = dict(np.load(path))

@@ -5,6 +5,7 @@ import os
 import numpy as np
 
 os.environ.setdefault("MCGRA_KEEP_GSYM", "1")     # the parity tests read each step's mirrored gradient ("G_sym")
+os.environ.setdefault("MCGRA_AB", "1")            # ... and the engine honours such switches only beside MCGRA_AB=1 (attack.hip: ab_env)
 
 from oracle import mcgra_oracle as O
 

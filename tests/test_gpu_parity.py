@@ -864,6 +864,28 @@ def test_row_block_forward_forks_the_next_products_and_a_product_nobody_takes_is
     assert a.eng.fused_steps() == b.eng.fused_steps() == 3
 
 
+def test_ab_switches_are_ignored_without_MCGRA_AB(pkg, monkeypatch, capfd):
+    """A variable left in the environment of a real run changes nothing: the engine reads its A/B switches only beside
+    MCGRA_AB=1 (attack.hip: ab_env) and says on stderr what it ignored.  MCGRA_NO_FUSED_LR=1 would send every step through the
+    general path, MCGRA_KEEP_GSYM=1 would keep the mirrored gradient."""
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=3)
+    monkeypatch.delenv("MCGRA_AB", raising=False)
+    monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
+    monkeypatch.setenv("MCGRA_KEEP_GSYM", "1")
+    eng = H.engine_from(pkg, z)
+    eng.step()
+    assert eng.fused_steps() == 1
+    with pytest.raises(Exception, match="MCGRA_KEEP_GSYM"):
+        eng.buffer("G_sym")
+    err = capfd.readouterr().err
+    assert "MCGRA_NO_FUSED_LR=1 is ignored" in err and "MCGRA_AB=1" in err
+    monkeypatch.setenv("MCGRA_AB", "1")
+    eng2 = H.engine_from(pkg, z)
+    eng2.step()
+    assert eng2.fused_steps() == 0 and eng2.path_stats()["lowrank_steps"] == 1      # (the unfused low-rank step of attack.hip)
+    assert eng2.buffer("G_sym").shape[0] == 1100
+
+
 def test_abandoned_row_block_step_is_dropped_cleanly(pkg):
     """A row-block step the caller gives up on after a failed collective (mcgra_attack_shard_begin again without having
     reached XCHG_DONE) has already enqueued its masked-pair post, forked the product and the small-operand terms: the

@@ -111,10 +111,10 @@ def test_readme_line_through_the_class(pkg, name):
     _final_checks(z, _class_run(pkg, z, int(z["epochs"])), name)
 
 
-HORIZON = np.load(os.path.join(H.GOLDEN, "readme_horizon20.npz"))
+HORIZON = np.load(os.path.join(H.GOLDEN, "horizon20_readme.npz"))
 
 
-@pytest.mark.parametrize("name", [c for c in CASES if "_eps" not in c])
+@pytest.mark.parametrize("name", [c for c in CASES if f"{c}_auc" in HORIZON.files])
 def test_readme_line_at_the_20_epoch_horizon(pkg, name):
     """The same lines for 20 epochs (the per-step fixtures above run six; the README's commands 100) against the reference's own
     20-epoch run from the same trained victim (tests/golden/make_golden.py: gen_readme_horizon).  The reference was also run in
