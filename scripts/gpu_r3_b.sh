@@ -8,6 +8,6 @@ j=json.load(open('gpurun_out/r3b/bench10k.json'))
 print('10k', round(j['value'],2), round(j['ms_per_step'],3), j['config'].get('fused_steps'), j['config'].get('general_steps'), j.get('roofline',{}).get('avg_launch_ms'), j.get('roofline',{}).get('alone'), 'auc', j['auc'], 'cora', j.get('other_workloads'))
 PY
 export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"; cd /tmp
-MCGRA_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r3b/prof_serial" -o ks -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-split-probe > "$R/gpurun_out/r3b/prof_serial.log" 2>&1
+MCGRA_AB=1 MCGRA_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r3b/prof_serial" -o ks -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-split-probe > "$R/gpurun_out/r3b/prof_serial.log" 2>&1
 cd "$R"; find gpurun_out/r3b -name "*kernel_trace*" -size +8M -delete 2>/dev/null
 python scripts/kstats.py gpurun_out/r3b/prof_serial 8 16 | grep -v "rocprim\|at::native"

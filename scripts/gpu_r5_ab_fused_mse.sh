@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 for wl in synthetic-10k-mse cora-shape-mse; do for f in 0 1; do
-MCGRA_NO_FUSED_LR=$f python3 bench.py --workload $wl --steps 100 --warmup 20 --no-cpu-baseline --no-split-probe 2>/dev/null | python3 -c "
+MCGRA_AB=1 MCGRA_NO_FUSED_LR=$f python3 bench.py --workload $wl --steps 100 --warmup 20 --no-cpu-baseline --no-split-probe 2>/dev/null | python3 -c "
 import sys, json
 d=json.loads(sys.stdin.read()); print('NO_FUSED=$f', d['config']['workload'], round(d['value'],1), round(d['ms_per_step'],4), d['auc'], d['config']['fused_steps'], d['config']['general_steps'])
 "; done; done

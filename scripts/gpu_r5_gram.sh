@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 TAG=${TAG:-r05a}
 cd /tmp
 rm -rf "$R/gpurun_out/${TAG}_gram"
-MCGRA_NO_LOWRANK=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_gram" -- \
+MCGRA_AB=1 MCGRA_NO_LOWRANK=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_gram" -- \
   python3 "$R/bench.py" --steps 8 --warmup 3 --no-cpu-baseline --no-split-probe > "$R/gpurun_out/${TAG}_gram.log" 2>&1
 cd "$R"
 python3 scripts/kstats.py gpurun_out/${TAG}_gram 11 40 > gpurun_out/${TAG}_gram_kstats.txt 2>&1
