@@ -557,7 +557,10 @@ hipError_t sgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, float al
     // (measured at N = 10 000: 1024 blocks 117 us vs 147 us at 512 for a 16-wide product; two column tiles want 2048;
     //  at N = 2708 more slabs only add combine work)
     const bool big = (double)M * K >= 33554432.0 || (double)N * K >= 33554432.0 * 2;
-    const int target = (skinny && big) ? 1024 : 512;
+    // (one 128-wide column tile, 64 < N <= 128 -- the chain of a wide victim, GAT 5 x 16 -- streams the big operand once too:
+    //  N = 10 000, w = 80: 390 -> 295 us NN, 427 -> 272 us TN at 1024 blocks; n = 3312: 49 us at 512, 59 at 1024;
+    //  scripts/gemm_mid_bench.py, where hipBLASLt does the same shapes in 172 / 37 us)
+    const int target = ((skinny || N <= 128) && big) ? 1024 : 512;
     nsplit = min(min(64, (target + tiles - 1) / tiles), K / (2 * BK));
     while (nsplit > 1 && (size_t)nsplit * M * N * sizeof(float) > ws_bytes) --nsplit;
     if (nsplit < 1) nsplit = 1;
