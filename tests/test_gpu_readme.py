@@ -120,13 +120,13 @@ def test_readme_line_at_the_20_epoch_horizon(pkg, name):
     20-epoch run from the same trained victim (tests/golden/make_golden.py: gen_readme_horizon).  The reference was also run in
     float64 there -- its own code, same inputs: |AUC - AUC64| is what its arithmetic leaves of "the" AUC at this horizon (Adam
     turns rounding noise on near-zero gradients into +-lr moves).  Bar: north_star's 1e-4, or that distance where it is larger
-    (x 4 for the lines the fused MSELoss step runs: 22-bit rank-k operands, test_cora_mse_checkpoints)."""
+    (two lines: AIDS 158 / 174, MSELoss with Y_A, where the reference's two runs are 2.8e-2 / 1.8e-2 apart).  Measured
+    (profiles/r05_readme_horizon20.txt): 36 lines within 3.4e-5, those two 1.4e-3 / 2.7e-4."""
     z = H.load_readme(name)
     final = _class_run(pkg, z, int(HORIZON["epochs"]))
     auc = O.metric_pool(z["adj"], final, z["idx_attack"])
     ref, ref64 = float(HORIZON[f"{name}_auc"]), float(HORIZON[f"{name}_auc64"])
-    k = 4.0 if str(z["measure"]) == "MSELoss" and len(z["labels"]) >= 256 else 1.0
-    bar = max(1e-4, k * abs(ref - ref64))
+    bar = max(1e-4, abs(ref - ref64))
     assert abs(auc - ref) <= bar, (name, auc, ref, ref64, bar)
     fs = float(HORIZON[f"{name}_final_sum"])
     assert abs(final.astype(np.float64).sum() - fs) <= 1e-3 * abs(fs)
