@@ -1,5 +1,6 @@
-"""GPU box: the README lines (eps == 0) through PGDAttack.attack for the horizon of tests/golden/horizon20_readme.npz (20 epochs)
-against the reference's own run of that length and its float64 run -> profiles/r05_readme_horizon20.txt"""
+"""GPU box: the README lines (eps == 0) through PGDAttack.attack for the horizon of tests/golden/horizon<epochs>_readme.npz (20 or
+100 epochs) against the reference's own run of that length and its float64 run -> profiles/r05_readme_horizon<epochs>.txt
+    python3 scripts/diag_readme_horizon.py [20|100]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +10,7 @@ from tests import helpers as H
 from tests import test_gpu_readme as T
 from oracle import mcgra_oracle as O
 
-Z = np.load(os.path.join(H.GOLDEN, "horizon20_readme.npz"))
+Z = np.load(os.path.join(H.GOLDEN, f"horizon{int(sys.argv[1]) if len(sys.argv) > 1 else 20}_readme.npz"))
 ep = int(Z["epochs"])
 print(f"{'fixture':34s} {'n':>5s} {'measure':8s} {'AUC reference':>13s} {'engine - ref':>12s} {'ref64 - ref':>12s} {'path':>14s}   ({ep} epochs)")
 worst = 0.0

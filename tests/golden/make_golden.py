@@ -813,15 +813,19 @@ def gen_readme_horizon(tmp, epochs=20, only=None):
     the reference's own arithmetic leaves of "the" AUC at that horizon (Adam turns rounding noise on near-zero gradients into
     +-lr moves).  One file, horizon<epochs>_readme.npz: per line both AUCs, a sample of the ensemble, its sum.  About an hour
     on 8 cores."""
-    out = {}
     path = os.path.join(OUT, f"horizon{epochs}_readme.npz")
-    gen_readme(tmp, only=only, epochs=epochs, horizon=out)
-    if only is not None and os.path.exists(path):      # a partial regeneration keeps the other lines
-        old = dict(np.load(path))
-        old.update(out)
-        out = old
-    out["epochs"] = epochs
-    np.savez_compressed(path, **out)
+    datasets = [d for d in README_RUNS if only is None or any(d.lower() in o for o in only)]
+    for ds in datasets:      # one dataset at a time, the file rewritten behind each (hours at 100 epochs: nothing is lost to an interruption)
+        out = {}
+        sel = [o for o in only if ds.lower() in o] if only is not None else [ds.lower()]
+        gen_readme(tmp, only=sel, epochs=epochs, horizon=out)
+        if os.path.exists(path):      # keeps the other lines
+            old = dict(np.load(path))
+            assert int(old["epochs"]) == epochs
+            old.update(out)
+            out = old
+        out["epochs"] = epochs
+        np.savez_compressed(path, **out)
 
 
 def gen_citeseer_gat(tmp, train_iters=6):
@@ -1065,8 +1069,9 @@ if __name__ == "__main__":
             gen_mid(tmp)
         if a.only in ("all", "readme") or a.only.startswith("readme:"):      # README lines on brazil / usair / polblogs / AIDS
             gen_readme(tmp, only=a.only.split(":", 1)[1].split(",") if ":" in a.only else None)
-        if a.only == "readme_horizon" or a.only.startswith("readme_horizon:"):      # ~1 h on 8 cores: not part of "all"
-            gen_readme_horizon(tmp, only=a.only.split(":", 1)[1].split(",") if ":" in a.only else None)
+        if a.only.split(":")[0] in ("readme_horizon", "readme_horizon100"):      # 35 min / 3 h on 8 cores: not part of "all"
+            gen_readme_horizon(tmp, epochs=100 if a.only.split(":")[0].endswith("100") else 20,
+                               only=a.only.split(":", 1)[1].split(",") if ":" in a.only else None)
         if a.only in ("citeseer",):         # ~20 min on 8 cores: not part of "all"
             gen_citeseer_gat(tmp)
         if a.only in ("bench10k",):         # ~25 min and ~20 GB on 8 cores: not part of "all"
