@@ -464,16 +464,16 @@ def multi_rank_diagnostics(pkg, torch, dist, dev, rank, world, a, eng, stepper, 
         del a0
         k = max(2, min(steps, 20))
         f0 = eng.fused_steps()
-        for _ in range(2):
+        for i in range(2):
             S.run_echo(stepper.b, S.SHARD_STEP)
-            if monitor:
-                S.run_echo(stepper.b, S.SHARD_MONITOR)
+            if monitor:      # (as in the timed region: k products inside the clock, none forked in front of it or left behind it)
+                S.run_echo(stepper.b, S.SHARD_MONITOR_LAST if i == 1 else S.SHARD_MONITOR)
         torch.cuda.synchronize()                 # (rank-local: the echo exchanges nothing, no barrier inside this try)
         t0 = time.perf_counter()
-        for _ in range(k):
+        for i in range(k):
             S.run_echo(stepper.b, S.SHARD_STEP)
             if monitor:
-                S.run_echo(stepper.b, S.SHARD_MONITOR)
+                S.run_echo(stepper.b, S.SHARD_MONITOR_LAST if i == k - 1 else S.SHARD_MONITOR)
         torch.cuda.synchronize()
         echo_ms = 1e3 * (time.perf_counter() - t0) / k
         echo_fused = eng.fused_steps() - f0

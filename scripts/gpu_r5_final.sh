@@ -24,3 +24,7 @@ python scripts/shard_emulate.py --echo --workload synthetic-10k-mse --worlds 1,2
 python scripts/shard_emulate.py --echo --workload synthetic-30k-hsic-3layer --worlds 1,2,4,8 --steps 4 > $O/shard_echo_30k_hsic.log 2>&1; grep '^{"world"' $O/shard_echo_30k_hsic.log | cut -c1-200
 python scripts/diag_10k.py > $O/diag_10k.txt 2>&1; tail -12 $O/diag_10k.txt | cut -c1-330
 python scripts/diag_readme.py > $O/readme_lines.txt 2>&1; tail -5 $O/readme_lines.txt | cut -c1-200
+for ep in 20 100; do [ -f tests/golden/horizon${ep}_readme.npz ] && python scripts/diag_readme_horizon.py $ep 2>/dev/null > $O/readme_horizon$ep.txt && tail -2 $O/readme_horizon$ep.txt; done
+for w in hsic kl; do python scripts/citeseer_gat_steps.py $w 40 2>&1 | grep "ms/step"; done > $O/citeseer_gat_steps.txt; cat $O/citeseer_gat_steps.txt
+python scripts/gemm_mid_bench.py 2>&1 | grep "^n " > $O/gemm_mid_bench.txt; cat $O/gemm_mid_bench.txt
+for e in 0 1; do echo "MCGRA_EARLY_P1=$e"; MCGRA_AB=1 MCGRA_EARLY_P1=$e python3 scripts/shard_emulate.py --echo --worlds 2,4,8 --steps 40 2>&1 | grep '^{"world"'; done > $O/ab_early_p1.txt; cut -c1-140 $O/ab_early_p1.txt

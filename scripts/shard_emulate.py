@@ -34,14 +34,16 @@ for world in [int(x) for x in a.worlds.split(",")]:
         plan = S.RowBlockPlan(n, world, rk)
         eng = bench.build_engine(pkg, torch, dev, a.workload, 0, plan=plan)[0]
         bk = S.HipShardBackend(eng, plan)
-        for _ in range(3):
-            S.run_echo(bk, S.SHARD_STEP); S.run_echo(bk, S.SHARD_MONITOR)
+        # (a rank's monitoring forward forks the NEXT step's product: the last warm-up and the last timed iteration say that no step
+        # follows -- as PGDAttack.attack and bench.py do -- so the timed region holds exactly a.steps products)
+        for i in range(3):
+            S.run_echo(bk, S.SHARD_STEP); S.run_echo(bk, S.SHARD_MONITOR_LAST if i == 2 else S.SHARD_MONITOR)
         torch.cuda.synchronize()
         eng.profile(True); eng.gemm_stats(reset=True)
         t0 = time.perf_counter()
         nex = 0
-        for _ in range(a.steps):
-            nex += S.run_echo(bk, S.SHARD_STEP); nex += S.run_echo(bk, S.SHARD_MONITOR)
+        for i in range(a.steps):
+            nex += S.run_echo(bk, S.SHARD_STEP); nex += S.run_echo(bk, S.SHARD_MONITOR_LAST if i == a.steps - 1 else S.SHARD_MONITOR)
         host = (time.perf_counter() - t0) / a.steps          # the host is done enqueueing: if this is the step time, the host binds
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
@@ -58,13 +60,13 @@ for world in [int(x) for x in a.worlds.split(",")]:
         continue
     plans = [S.RowBlockPlan(n, world, r) for r in range(world)]
     bks = S.lockstep_backends([bench.build_engine(pkg, torch, dev, a.workload, 0, plan=p)[0] for p in plans], plans)
-    for _ in range(2):
-        S.run_lockstep(bks, S.SHARD_STEP); S.run_lockstep(bks, S.SHARD_MONITOR)
+    for i in range(2):
+        S.run_lockstep(bks, S.SHARD_STEP); S.run_lockstep(bks, S.SHARD_MONITOR_LAST if i == 1 else S.SHARD_MONITOR)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nex = 0
-    for _ in range(a.steps):
-        nex += S.run_lockstep(bks, S.SHARD_STEP); nex += S.run_lockstep(bks, S.SHARD_MONITOR)
+    for i in range(a.steps):
+        nex += S.run_lockstep(bks, S.SHARD_STEP); nex += S.run_lockstep(bks, S.SHARD_MONITOR_LAST if i == a.steps - 1 else S.SHARD_MONITOR)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     # the emulation's own copies (what a real run replaces by RCCL collectives): the same exchanges replayed on the joint
