@@ -1100,6 +1100,7 @@ int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, doubl
   const int P = split3_panel(), p_off = h->row0 / P, p_cnt = h->row1 > h->row0 ? (h->row1 - h->row0 + P - 1) / P : 0;
   if (p_cnt == 0) { if (ms_per_launch) *ms_per_launch = 0.0; return 0; }
   if (h->early_pack) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));      // (planes a monitor call is still packing: equally valid operands)
+  if (h->p1_early) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));        // (a product a row-block rank's forward forked writes the same scratch)
   hipEvent_t e0, e1;
   MCGRA_HIP(hipEventCreate(&e0));
   MCGRA_HIP(hipEventCreate(&e1));
