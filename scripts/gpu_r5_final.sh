@@ -26,5 +26,7 @@ python scripts/diag_10k.py > $O/diag_10k.txt 2>&1; tail -12 $O/diag_10k.txt | cu
 python scripts/diag_readme.py > $O/readme_lines.txt 2>&1; tail -5 $O/readme_lines.txt | cut -c1-200
 for ep in 20 100; do [ -f tests/golden/horizon${ep}_readme.npz ] && python scripts/diag_readme_horizon.py $ep 2>/dev/null > $O/readme_horizon$ep.txt && tail -2 $O/readme_horizon$ep.txt; done
 for w in hsic kl; do python scripts/citeseer_gat_steps.py $w 40 2>&1 | grep "ms/step"; done > $O/citeseer_gat_steps.txt; cat $O/citeseer_gat_steps.txt
+(cd /tmp; rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r05f_gat" -- python3 "$GRAFT_REPO_ROOT/scripts/citeseer_gat_steps.py" hsic 12 > /dev/null 2>&1)
+python scripts/general_step_timeline.py "$(find gpurun_out/r05f_gat -name '*kernel_trace.csv' | head -1)" > $O/citeseer_gat_step_timeline.txt 2>&1; rm -rf gpurun_out/r05f_gat; head -1 $O/citeseer_gat_step_timeline.txt
 python scripts/gemm_mid_bench.py 2>&1 | grep "^n " > $O/gemm_mid_bench.txt; cat $O/gemm_mid_bench.txt
 for e in 0 1; do echo "MCGRA_EARLY_P1=$e"; MCGRA_AB=1 MCGRA_EARLY_P1=$e python3 scripts/shard_emulate.py --echo --worlds 2,4,8 --steps 40 2>&1 | grep '^{"world"'; done > $O/ab_early_p1.txt; cut -c1-140 $O/ab_early_p1.txt
