@@ -453,6 +453,14 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       h->fused_ok = (rc == 0);
     }
   }
+  if (!rc && (h->split_on || h->gram_split)) {      // a small graph's split products: room to cut them along K (its N x N buffers are too small)
+    const size_t want = split3_small_slab_bytes((int)n);
+    if (want > sizeof(float) * (size_t)n * h->ld) {
+      h->small_slab_bytes = want;
+      A_(small_slab, want / sizeof(float));
+      if (rc) { h->small_slab = nullptr; h->small_slab_bytes = 0; }
+    }
+  }
   h->ws_bytes = (size_t)64 * n * 64 * sizeof(float);
   A_(ws, h->ws_bytes / sizeof(float));
   h->ws_small_bytes = (size_t)64 * (h->na > h->hmax ? h->na : h->hmax) * h->hmax * sizeof(float);
@@ -967,7 +975,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     CHK(pair(0, 1, 1));
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, h->profile));
-    MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->G_A, sizeof(float) * (size_t)n * ld, 2, h->amax + 8, 0, -1, 2));
+    MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A,
+                          h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 8, 0, -1, 2));
     CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
     return 0;
   };
@@ -1016,8 +1025,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
           CHK(timer_begin(h, sp, big));
           const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
           // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
-          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->KY, sizeof(float) * (size_t)n * ld,
-                                h->split_planes, h->amax));
+          MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->small_slab ? h->small_slab : h->KY,
+                                h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, h->split_planes, h->amax));
           CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
           ++h->split_steps;
         } else
@@ -1048,9 +1057,12 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // ---- dot_product_decode + get_modified_adj_after (:187-188)
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
   CHK(eg(h, st, false, true, n, n, he, 1.f, h->Zn, h->hmax, h->Zn, h->hmax, 0.f, h->A1, ld));
-  MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
+  // (the count of relu-masked pairs is read by the low-rank decision below only: HSIC with c2 on a configuration that has the
+  // low-rank forms -- every other step skips the counting)
+  const bool count_masked = c.measure == MCGRA_MEASURE_HSIC && h->lr_ok && c.w[1] != 0;
+  if (count_masked) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, sizeof(unsigned int), st));
   h->nmask_zero = false;
-  launch_decode_post(st, n, ld, h->A1, h->has_ori ? h->ORI : nullptr, h->nmask);
+  launch_decode_post(st, n, ld, h->A1, h->has_ori ? h->ORI : nullptr, count_masked ? h->nmask : nullptr);
   h->lr_step = false;
 
   // ---- N x N loss terms (:212-236)
@@ -1178,7 +1190,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         CHK(pair(1, 2, 2));
         CHK(gs_fork());
         CHK(timer_begin(h, sg_, h->profile));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->G_A, slab, 2, h->amax + 10, 0, -1, 2));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 10, 0, -1, 2));
         CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
         if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));   // Ky done
       }
@@ -1196,7 +1208,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
           MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
           CHK(gs_fork());
           CHK(timer_begin(h, sg_, h->profile));
-          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->G_A, slab, 2, h->amax + 14, 0, -1, 1));
+          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 14, 0, -1, 1));
           CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
           if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));   // G_A1 complete
           gs_p4 = true;
@@ -1233,7 +1245,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
         CHK(gs_fork());
         CHK(timer_begin(h, sg_, big));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->G_A, slab, 2, h->amax + 14, 0, -1, 1));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 14, 0, -1, 1));
         CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
         if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));
         gs_p4 = true;
@@ -1245,7 +1257,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     CHK(victim_rankk()); gs_rankk_done = true;
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, big));
-    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->KX, slab, 2, h->amax + 12, 0, -1, 1));
+    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->small_slab ? h->small_slab : h->KX, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 12, 0, -1, 1));
     CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
     if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));
     gs_p3 = true;

@@ -480,8 +480,8 @@ static int fork_p1(mcgra_attack* h, hipStream_t st, bool want_vals) {
     }
   }
   if (!h->p1_first && h->tail_rows == 0)
-  MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
-                        h->amax, p_off, p_cnt));
+  MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->KY,
+                        h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, h->split_planes, h->amax, p_off, p_cnt));
   CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
   ++h->split_steps;
   if (ovl) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));

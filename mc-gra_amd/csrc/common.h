@@ -92,6 +92,7 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
                        int first_tiles = 0, hipEvent_t ev_first = nullptr,             // 4 = all row panels from panel_off, wrapping; first_tiles: cut of the linear tile range, ev_first recorded behind the first part
                        int second_tiles = 0, hipEvent_t ev_second = nullptr);          // a second cut behind the first
 int split3_panel();
+size_t split3_small_slab_bytes(int n);      // split-K slab room a small graph's products can use (0: none beyond what fits an N x N buffer anyway)
 size_t hsic_combine_pack_scratch_doubles(int n);
 // amax: the engine's scale slots ([5] = max |KFC| on entry; [3], [4] receive the bounds of the two results); rowvals[0 .. n) = row sums
 // of KFC o KX, [n .. 2n) of KX o KY

@@ -112,6 +112,8 @@ struct mcgra_attack {
   bool early_pack = false;         // Bpack / the pack's row partials describe the CURRENT M (packed by the forward of this M)
   bool early_p1_on = false;        // row-block rank: pack (uncentred) + N x N x N product forked by the FORWARD, as soon as r is complete
   bool p1_early = false;           // ... and in flight: forked by the forward of the CURRENT M (a monitor call, or the step's own)
+  float* small_slab = nullptr;     // split-K slabs of a small graph's N x N x N products (more than an N x N buffer holds: split3_small_slab_bytes)
+  size_t small_slab_bytes = 0;
   bool fs_last = false;            // the monitor call in progress was begun as MCGRA_SHARD_MONITOR_LAST
   int p1_early_cut = 0, p1_early_split = 0;      // what that launch adds to cut_product_steps / split_steps once a step takes it
   // third stream of the fused step: the small-operand terms c9 / c10 (a chain of ~16 tiny launches that needs only the

@@ -106,27 +106,48 @@ __global__ void k_lr_colstats_fin(int n, int h, const double* __restrict__ part,
 // otherwise (scripts/fused_lowrank_proto.py: error of W2 against float64 1.5e-3 -> 5.7e-5 at n = 2048).
 // rs / Vs != nullptr: also Vs[i][k] = rs_i V[i][k], k < 2h -- the right-hand side of the product M (r o V) that follows in the
 // fused step (fl_cat_scaled's launch)
-__global__ void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, const double* __restrict__ stats,
-                          float* __restrict__ Lf, float* __restrict__ V, int ldv, float* __restrict__ delta,
-                          const float* __restrict__ rs, float* __restrict__ Vs, int ldvs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* z = Z + (size_t)i * ldz;
-  float d = 0.f;
-  for (int k = 0; k < h; ++k) d += z[k] * z[k];
-  delta[i] = d;
-  const float ri = Vs ? rs[i] : 0.f;
-  for (int k = 0; k < h; ++k) {
-    const float u = z[k] - (float)stats[k];
+// (LRP_ROWS rows per block through LDS: delta_i is one thread's k-ordered chain -- the bits of the thread-per-row form, whose
+//  lanes read and wrote rows a stride of ldz / 2h / ldv / ldvs apart: 45 us at n = 10 000 -- everything else elementwise along
+//  the rows)
+constexpr int LRP_ROWS = 64;
+__global__ __launch_bounds__(256) void k_lr_prep(int n, int h, const float* __restrict__ Z, int ldz, const double* __restrict__ stats,
+                                                 float* __restrict__ Lf, float* __restrict__ V, int ldv, float* __restrict__ delta,
+                                                 const float* __restrict__ rs, float* __restrict__ Vs, int ldvs) {
+  extern __shared__ float sh[];      // z tile [LRP_ROWS][h + 1], then delta[LRP_ROWS]
+  const int r0 = blockIdx.x * LRP_ROWS, hp = h + 1;
+  float* sd = sh + LRP_ROWS * hp;
+  for (int e = threadIdx.x; e < LRP_ROWS * h; e += 256) {
+    const int r = e / h, k = e - r * h;
+    sh[r * hp + k] = (r0 + r < n) ? Z[(size_t)(r0 + r) * ldz + k] : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < LRP_ROWS) {
+    const float* z = sh + threadIdx.x * hp;
+    float d = 0.f;
+    for (int k = 0; k < h; ++k) d += z[k] * z[k];
+    sd[threadIdx.x] = d;
+    if (r0 + threadIdx.x < n) delta[r0 + threadIdx.x] = d;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < LRP_ROWS * h; e += 256) {
+    const int r = e / h, k = e - r * h, i = r0 + r;
+    if (i >= n) break;
+    const float zk = sh[r * hp + k], d = sd[r];
+    const float u = zk - (float)stats[k];
     Lf[(size_t)i * 2 * h + k] = u;
-    Lf[(size_t)i * 2 * h + h + k] = -d * z[k];
-    const float v2 = d * z[k] - (float)(stats[h + k] / (double)n);
+    Lf[(size_t)i * 2 * h + h + k] = -d * zk;
+    const float v2 = d * zk - (float)(stats[h + k] / (double)n);
     V[(size_t)i * ldv + k] = u;
     V[(size_t)i * ldv + h + k] = v2;
-    if (Vs) { Vs[(size_t)i * ldvs + k] = ri * u; Vs[(size_t)i * ldvs + h + k] = ri * v2; }
+    if (Vs) { const float ri = rs[i]; Vs[(size_t)i * ldvs + k] = ri * u; Vs[(size_t)i * ldvs + h + k] = ri * v2; }
   }
-  V[(size_t)i * ldv + 2 * h] = d * d - (float)stats[2 * h + (size_t)h * h];
-  for (int k = 2 * h + 1; k < ldv; ++k) V[(size_t)i * ldv + k] = 0.f;
+  const int tail = ldv - 2 * h;      // column 2h: delta^2 - mean; zeros behind it
+  for (int e = threadIdx.x; e < LRP_ROWS * tail; e += 256) {
+    const int r = e / tail, k = 2 * h + (e - r * tail), i = r0 + r;
+    if (i >= n) break;
+    const float d = sd[r];
+    V[(size_t)i * ldv + k] = k == 2 * h ? d * d - (float)stats[2 * h + (size_t)h * h] : 0.f;
+  }
 }
 
 // per column index j, from T = Xc^T V (ld ldv): W = T[:, :h], W2 = T[:, h:2h], t3 = T[:, 2h]
@@ -465,7 +486,8 @@ void launch_lr_colstats(hipStream_t st, int n, int h, const float* Z, int ldz, d
 }
 void launch_lr_prep(hipStream_t st, int n, int h, const float* Z, int ldz, const double* stats, float* Lf, float* V,
                     int ldv, float* delta, const float* rs, float* Vs, int ldvs) {
-  LAUNCH(k_lr_prep, dim3((n + 255) / 256), dim3(256), st, n, h, Z, ldz, stats, Lf, V, ldv, delta, rs, Vs, ldvs);
+  hipLaunchKernelGGL(k_lr_prep, dim3((n + LRP_ROWS - 1) / LRP_ROWS), dim3(256), sizeof(float) * (LRP_ROWS * (h + 1) + LRP_ROWS), st, n, h, Z,
+                     ldz, stats, Lf, V, ldv, delta, rs, Vs, ldvs);
 }
 void launch_lrt_lr_post(hipStream_t st, int n, int h, YView Y, const float* Vs, int ldvs, const float* r, const float* mean,
                         const double* colsum, float* T, int ldv, const double* stats, float* Rm, float* cvec, double* rowval) {

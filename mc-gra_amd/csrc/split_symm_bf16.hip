@@ -926,6 +926,23 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   return hipGetLastError();
 }
 int split3_panel() { return TB; }
+// Bytes of split-K slabs a product on an n x n operand can use when its tiles leave most of the chip idle: a launch of cnt tiles
+// with 2 cnt <= slots is cut min(8, slots / cnt) ways along K (run() above) -- given the room.  Largest over the full tile grid
+// and the lower triangle.  n = 2708: 121 tiles x 2 = 63 MB, more than the N x N buffer callers lend (29 MB): without the room
+// the product of a Cora-sized graph ran 121 blocks for 167 us.
+size_t split3_small_slab_bytes(int n) {
+  const int t = (n + TB - 1) / TB, slots = split3_slots();
+  size_t need = 0;
+  const int cnts[2] = {t * t, t * (t + 1) / 2};
+  for (int cnt : cnts)
+    if (cnt * 2 <= slots) {
+      int ks = slots / cnt;
+      if (ks > 8) ks = 8;
+      const size_t b = (size_t)ks * cnt * TB * TB * sizeof(float);
+      if (b > need) need = b;
+    }
+  return need;
+}
 int split3_chunks(int n, int planes) { return chunks_of(n, planes); }
 
 }  // namespace mcgra
