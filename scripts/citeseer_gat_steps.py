@@ -1,7 +1,7 @@
 """GPU box: `steps` engine steps (+ monitoring forward) of BASELINE.json configs[2]'s shape -- Citeseer (N = 3312), GAT victim
 5 x 16 ELU, priors H_A + Y, measure HSIC (Gram evaluation on the split kernel) or KL -- for a rocprofv3 kernel table:
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 scripts/citeseer_gat_steps.py hsic 40"""
-import os, sys, time
+import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mcgra_loader
@@ -27,4 +27,4 @@ for _ in range(steps):
     eng.step(); eng.monitor()
 torch.cuda.synchronize()
 print("citeseer_gat", which, "n", n, "dims", dims, "ms/step", round(1e3 * (time.perf_counter() - t0) / steps, 4), eng.path_stats(),
-      "gram_split_steps", eng.gram_split_steps())
+      "gram_split_steps", eng.gram_split_steps(), "state", hashlib.sha256(eng.buffer("M").cpu().numpy().tobytes()).hexdigest()[:16])

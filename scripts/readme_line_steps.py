@@ -1,6 +1,6 @@
 """GPU box: `steps` engine steps (+ monitoring forward) of ONE README-line fixture, for a rocprofv3 kernel table of that line:
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 scripts/readme_line_steps.py readme_cora_kde_Y 40"""
-import os, sys, time
+import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mcgra_loader
@@ -21,4 +21,4 @@ for _ in range(steps):
     eng.step(); eng.monitor()
 torch.cuda.synchronize()
 print(name, "n", len(z["labels"]), str(z["measure"]), "ms/step", round(1e3 * (time.perf_counter() - t0) / steps, 4), "fused", eng.fused_steps(),
-      eng.path_stats())
+      eng.path_stats(), "state", hashlib.sha256(eng.buffer("M").cpu().numpy().tobytes()).hexdigest()[:16])
