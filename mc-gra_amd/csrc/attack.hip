@@ -648,11 +648,13 @@ int small_term(mcgra_attack* h, hipStream_t st, int width, const float* Ysrc, in
     MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws_small, h->ws_small_bytes));
     return 0;
   };
+  if (h->cfg.measure == MCGRA_MEASURE_MSE) {      // gather, value partials, gradient and scatter in one launch (+ the value's sum)
+    launch_mse_small_fused(st, na, width, Xg, hm, Ysrc, ldy, h->idx, (float)k_signed, G, ldg, h->scal + slot, h->cm_part, want_value);
+    MCGRA_KERNEL_CHECK();
+    return 0;
+  }
   launch_gather_rows(st, na, width, Ysrc, ldy, h->idx, h->Yg, hm);
-  if (h->cfg.measure == MCGRA_MEASURE_MSE) {
-    launch_mse_small(st, na, width, Xg, h->Yg, hm, h->Gg, h->scal + slot, h->cm_part);   // sum of squares
-    launch_scatter_add_rows(st, na, width, h->Gg, hm, h->idx, (float)k_signed, G, ldg);
-  } else if (h->cfg.measure == MCGRA_MEASURE_CKA) {
+  if (h->cfg.measure == MCGRA_MEASURE_CKA) {
     // linear_CKA(X, Y) (utils.py:1091-1096): value hxy / (sqrt(hxx) sqrt(hyy)); Q = Xc^T Yc, R = Yc^T Yc,
     // d/dY = (2/den) Xc Q - (2 hxy / (den hyy)) Yc R.  hxx is the constant in cst[cst_slot].
     launch_colmean_center(st, na, width, h->Yg, hm, h->cm_part);

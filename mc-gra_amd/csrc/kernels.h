@@ -85,6 +85,8 @@ void launch_scatter_add2_rows(hipStream_t st, int m, int h, const float* S1, con
                               const float* ab, float* dst, int ldd);
 void launch_colmean_center(hipStream_t st, int m, int h, float* X, int ld, double* part = nullptr);      // part: 64 x h doubles of scratch (without: one block per column)
 void launch_sumsq(hipStream_t st, size_t count, const float* X, double* out);
+void launch_mse_small_fused(hipStream_t st, int m, int h, const float* X, int ldx, const float* Ysrc, int ldy, const int* idx, float k,
+                            float* dst, int ldd, double* out, double* part, bool want_value);      // gather + k_mse_small + scatter in one launch
 void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* out, double* part = nullptr);      // part: 64 doubles of scratch
 void launch_kl_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* rowval);
 void launch_fill(hipStream_t st, size_t count, float* p, float v);

@@ -352,6 +352,26 @@ __global__ void k_mse_small(int m, int h, const float* __restrict__ X, const flo
   if (threadIdx.x == 0) out[blockIdx.x] = s;      // one partial per block (summed in block order by k_reduce_rows: deterministic)
 }
 
+// The MSELoss small-operand term in ONE launch: gather (Y = Ysrc[idx]), k_mse_small and the scatter of k G back to the gathered
+// rows -- on a small graph these four launches of a few microseconds each sit on the step's critical path (the head backward
+// waits for them).  Same grid, same per-thread order, the scattered value k * (-sc d) from the same floats: the bits of the
+// separate kernels.
+__global__ void k_mse_small_fused(int m, int h, const float* __restrict__ X, int ldx, const float* __restrict__ Ysrc, int ldy,
+                                  const int* __restrict__ idx, float k, float* __restrict__ dst, int ldd, double* __restrict__ out) {
+  __shared__ double shd[16];
+  double s = 0;
+  const float sc = 2.f / ((float)m * (float)h);
+  for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < m * h; e += blockDim.x * gridDim.x) {
+    const int i = e / h, c = e % h, row = idx[i];
+    const float d = X[(size_t)i * ldx + c] - Ysrc[(size_t)row * ldy + c];
+    s += (double)d * d;
+    const float g = -sc * d;
+    atomicAdd(&dst[(size_t)row * ldd + c], k * g);
+  }
+  s = block_sum_d(s, shd);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 // calc_kl on small operands (:483-487): X raw (softmax target), Y raw (log_softmax input);
 // G_Y = (softmax(Y) - softmax(X)) / m ; value = sum xs (log xs - log_softmax(Y)) / m
 __global__ void k_kl_small(int m, int h, const float* __restrict__ X, const float* __restrict__ Y, int ld,
@@ -484,6 +504,11 @@ void launch_mse_small(hipStream_t st, int m, int h, const float* X, const float*
     LAUNCH(k_mse_small, dim3(64), dim3(256), st, m, h, X, Y, ld, G, part);
     launch_reduce_rows(st, part, 64, 1, out);
   } else LAUNCH(k_mse_small, dim3(1), dim3(1024), st, m, h, X, Y, ld, G, out);
+}
+void launch_mse_small_fused(hipStream_t st, int m, int h, const float* X, int ldx, const float* Ysrc, int ldy, const int* idx, float k,
+                            float* dst, int ldd, double* out, double* part, bool want_value) {
+  LAUNCH(k_mse_small_fused, dim3(64), dim3(256), st, m, h, X, ldx, Ysrc, ldy, idx, k, dst, ldd, part);
+  if (want_value) launch_reduce_rows(st, part, 64, 1, out);
 }
 void launch_kl_small(hipStream_t st, int m, int h, const float* X, const float* Y, int ld, float* G, double* rowval) {
   LAUNCH(k_kl_small, g1(m), dim3(256), st, m, h, X, Y, ld, G, rowval);
