@@ -5,6 +5,7 @@
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r05f; mkdir -p $O
 python -m pytest tests -m gpu -q --tb=short --maxfail=30 -p no:cacheprovider > $O/pytest.log 2>&1
 tail -4 $O/pytest.log
+python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' 2>&1 | tail -1
 python bench.py > $O/bench.json 2> $O/bench.err
 python - <<'PY'
 import json
