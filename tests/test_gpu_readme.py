@@ -121,17 +121,21 @@ def test_readme_line_at_a_longer_horizon(pkg, epochs, name):
     against the reference's own run of that length from the same trained victim (tests/golden/make_golden.py:
     gen_readme_horizon).  The reference was also run in float64 there -- its own code, same inputs: |AUC - AUC64| is what its
     arithmetic leaves of "the" AUC at that horizon (Adam turns rounding noise on near-zero gradients into +-lr moves).  Bar:
-    north_star's 1e-4, or that distance where it is larger.  Measured (profiles/r05_readme_horizon*.txt): at 20 epochs 36
-    of 38 lines within 3.4e-5 (AIDS 158 / 174, MSELoss with Y_A: 1.4e-3 / 2.7e-4, the reference's two runs 2.8e-2 / 1.8e-2
-    apart)."""
+    north_star's 1e-4 around the reference's run, or -- where its two evaluations are further apart -- around the interval
+    they span.  Measured (profiles/r05_readme_horizon*.txt): at 20 epochs 36 of 38 lines within 3.4e-5 (AIDS 158 / 174,
+    MSELoss with Y_A: 1.4e-3 / 2.7e-4, the reference's two runs 2.8e-2 / 1.8e-2 apart); at 100 epochs 35 lines within 6.4e-5,
+    polblogs 85 (CKA) 3.6e-4 where the reference's two runs are 3.9e-4 apart (3e-5 from the float64 one), the two AIDS lines
+    2.7e-3 / 1.0e-4 where they are 2.9e-2 / 1.8e-2 apart."""
     hz = HORIZONS[epochs]
     assert int(hz["epochs"]) == epochs
     z = H.load_readme(name)
     final = _class_run(pkg, z, epochs)
     auc = O.metric_pool(z["adj"], final, z["idx_attack"])
     ref, ref64 = float(hz[f"{name}_auc"]), float(hz[f"{name}_auc64"])
-    bar = max(1e-4, abs(ref - ref64))
-    assert abs(auc - ref) <= bar, (name, epochs, auc, ref, ref64, bar)
+    # within 1e-4 of the reference's run; where its two evaluations are D > 1e-4 apart the AUC is not determined more finely than D:
+    # within D of the reference's run, or within 1e-4 of the interval the two span
+    D = abs(ref - ref64)
+    assert abs(auc - ref) <= max(1e-4, D) or min(ref, ref64) - 1e-4 <= auc <= max(ref, ref64) + 1e-4, (name, epochs, auc, ref, ref64)
     fs = float(hz[f"{name}_final_sum"])
     assert abs(final.astype(np.float64).sum() - fs) <= 1e-3 * abs(fs)
 
