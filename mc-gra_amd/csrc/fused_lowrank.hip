@@ -463,7 +463,15 @@ __global__ void k_sum_slabs_rows(int n, int row0, int row1, int h, int nslab, co
   if (e >= (row1 - row0) * h) return;
   const int i = row0 + e / h, k = e % h;
   float t = 0.f;
-  for (int s = 0; s < nslab; ++s) t += slabs[((size_t)s * n + i) * h + k];
+  int s = 0;
+  for (; s + 8 <= nslab; s += 8) {      // (eight loads in flight, added in slab order: sum_slabs_kernel)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[((size_t)(s + u) * n + i) * h + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; s < nslab; ++s) t += slabs[((size_t)s * n + i) * h + k];
   out[(size_t)i * ldo + k] = t;
 }
 
