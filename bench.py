@@ -47,6 +47,9 @@ WORKLOADS = {
     "cora-shape-hsic": (2708, 1433, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "cora-shape-mse": (2708, 1433, 7, 16, 2, "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-4k-hsic": (4096, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    # BASELINE.json configs[2]'s shape: Citeseer-sized (N = 3312, 3703 attributes, 6 classes), a GAT victim as the engine sees it
+    # (5 heads x 16 = 80 wide, ELU: ENGINE_KW) -- no low-rank forms: the general step with its Gram evaluation on the split kernel
+    "citeseer-shape-gat-hsic": (3312, 3703, 6, 80, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     # the headline workload with ~100 relu-masked decode pairs (10 x 10 nodes whose embeddings have disjoint supports: see
     # masked_variant): rounds 1 - 3 sent every such step to the Gram evaluation (3x slower), now it stays fused
     "synthetic-10k-hsic-masked": (10000, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
@@ -54,6 +57,9 @@ WORKLOADS = {
     "synthetic-20k-hsic-3layer": (20000, 256, 7, 16, 3, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-30k-hsic-3layer": (30000, 256, 7, 16, 3, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
 }
+
+
+ENGINE_KW = {"citeseer-shape-gat-hsic": dict(act="elu", head_act="elu")}      # AttackEngine keywords a workload needs
 
 
 def make_inputs(n, f, c, hid, nlayer, seed):
@@ -355,7 +361,8 @@ def build_engine(pkg, torch, dev, workload, seed, weight_param=None, **kw):
     inp, a0 = masked_variant(workload, inp, a0, seed)
     X = torch.as_tensor(inp["features"], device=dev)
     fadj = feature_adj_cora(X, torch)
-    eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, 1.0, wp, workload_lr(workload, n), 1e30, n, device=dev, **kw)
+    eng = pkg.AttackEngine(n, inp["dims"], c, 2, measure, 1.0, wp, workload_lr(workload, n), 1e30, n, device=dev,
+                           **dict(ENGINE_KW.get(workload, {}), **kw))
     eng.set_model(inp["W"], inp["b"], inp["Wlin"], inp["blin"])
     adj_dev = torch.as_tensor(inp["adj"], device=dev)
     eng.set_graph(X, adj_dev, None, fadj, inp["labels"], inp["idx_attack"])
@@ -775,7 +782,8 @@ def main(argv=None):
             del e2
             # ... and calc = MSELoss (the measure of the reference's README headline run, configs[0]) through the fused MSELoss
             # step: Cora shape and the headline's N
-            for wl2, k2 in (("cora-shape-mse", 100), ("synthetic-10k-mse", 60)):
+            # ... and configs[2]'s shape (Citeseer-sized, GAT victim): the general step, its four Gram products on the split kernel
+            for wl2, k2 in (("cora-shape-mse", 100), ("synthetic-10k-mse", 60), ("citeseer-shape-gat-hsic", 60)):
                 torch.cuda.empty_cache()
                 e3, _, _ = build_engine(pkg, torch, dev, wl2, a.seed)
 
@@ -786,7 +794,8 @@ def main(argv=None):
 
                 dt3 = timed_region(mse_step, k2, 10, torch.cuda.synchronize, 1, None, dev, torch)
                 extra[wl2] = {"value": k2 / dt3, "unit": "attack-steps/s", "ms_per_step": 1e3 * dt3 / k2, "nodes": WORKLOADS[wl2][0], "steps": k2,
-                              "fused_steps": e3.fused_steps(), "general_steps": e3.path_stats()["general_steps"]}
+                              "fused_steps": e3.fused_steps(), "general_steps": e3.path_stats()["general_steps"],
+                              "gram_split_steps": e3.gram_split_steps()}
                 del e3
         except Exception as e:
             extra = {"error": f"{type(e).__name__}: {e}"[:300]}

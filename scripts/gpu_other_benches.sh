@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-for w in cora-shape-hsic cora-shape-mse synthetic-10k-mse synthetic-4k-hsic synthetic-30k-hsic-3layer; do
-  st=5; case $w in cora-*|synthetic-4k-*) st=100;; synthetic-10k-*) st=20;; esac      # (short steps: a 5-step run times the clock ramp)
+for w in cora-shape-hsic cora-shape-mse citeseer-shape-gat-hsic synthetic-10k-mse synthetic-4k-hsic synthetic-30k-hsic-3layer; do
+  st=5; case $w in cora-*|citeseer-*|synthetic-4k-*) st=100;; synthetic-10k-*) st=20;; esac      # (short steps: a 5-step run times the clock ramp)
   python bench.py --workload $w --no-cpu-baseline --no-split-probe --steps $st --warmup 5 > gpurun_out/${TAG}_bench_$w.json 2>/dev/null
   tail -c 200 gpurun_out/${TAG}_bench_$w.json | head -c 10 >/dev/null
 done

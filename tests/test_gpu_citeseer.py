@@ -134,3 +134,18 @@ def test_citeseer_gat_hsic_step_time(pkg):
         json.dump(out, open(os.path.join(d, "citeseer_gat_hsic_step.json"), "w"))
     print(out)
     assert ms < 6.0, ms
+
+
+def test_bench_gat_shaped_workload_takes_the_gram_evaluation(pkg):
+    """bench.py's `citeseer-shape-gat-hsic` (configs[2]'s shape on synthetic data: N = 3312, an 80-wide ELU chain): no low-rank
+    forms apply, every step is a general step whose four Gram products run on the split kernel -- the number bench.py reports
+    for it under `other_workloads` is that path's."""
+    import torch
+    import bench
+    eng, inp, adj = bench.build_engine(pkg, torch, torch.device("cuda:0"), "citeseer-shape-gat-hsic", 0)
+    for _ in range(3):
+        eng.step(); eng.monitor()
+    assert eng.fused_steps() == 0 and eng.path_stats() == {"lowrank_steps": 0, "general_steps": 3} and eng.gram_split_steps() == 3
+    lab = torch.as_tensor(inp["labels"], device="cuda:0")
+    final = eng.finalize(0, eng.buffer("HA"), eng.buffer("YA"), (lab[:, None] == lab[None, :]).float())
+    assert 0.5 < bench.gpu_auc(adj, final, torch) < 1.0
