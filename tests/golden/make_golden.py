@@ -704,7 +704,7 @@ README_RUNS = {
 
 def gen_readme(tmp, only=None, epochs=6, horizon=None):
     """The reference on its README.md lines, through its own Dataset, preprocess and GCN.fit (main.py:147-190), `epochs`
-    steps each.  (horizon: a dict -- nothing is written per line; the eps == 0 lines are run for `epochs` steps as they are and
+    steps each.  (horizon: a dict -- nothing is written per line; the lines are run for `epochs` steps as they are (eps != 0: on seeded noise) and
     once more with the reference's own code in float64, and only what a longer horizon can be held to is kept: both AUCs, a
     sample of the ensemble and its sum -- gen_readme_horizon.)  Per dataset one `readme_<dataset>_graph.npz` with what the loader produced (edges, diagonal -- brazil has
     self loops --, attributes as bits / the identity flag / float32, labels, the three index splits, idx_attack) and the
@@ -770,13 +770,17 @@ def gen_readme(tmp, only=None, epochs=6, horizon=None):
                 if lr is None:
                     lr = start[1] / (50.0 * n)
             if horizon is not None:
-                if eps != 0:
-                    continue
+                # (an eps != 0 line: every step's adding_noise draw is the seeded stream of NOISE_SEEDS -- brazil's line 149, whose
+                # six-epoch fixture keeps recorded matrices, gets a seed of its own here -- handed to both runs)
+                nseed = (NOISE_SEEDS.get(line, 5000 + line)) if eps != 0 else None
                 t0 = _time.time()
                 res = run_reference_attack(adj, features, labels, victim, idx_attack, measure, wp, wsup, lr, epochs, ds,
-                                           tuple(bool(u) for u in use), num_edges, a0=a0, capture_steps=False)
+                                           tuple(bool(u) for u in use), num_edges, eps=eps, a0=a0, capture_steps=False, noise_seed=nseed)
                 res64 = run_reference_attack(adj, features, labels, deepcopy(victim_clean), idx_attack, measure, wp, wsup, lr, epochs, ds,
-                                             tuple(bool(u) for u in use), num_edges, a0=a0, capture_steps=False, f64=True)
+                                             tuple(bool(u) for u in use), num_edges, eps=eps, a0=a0, capture_steps=False, f64=True,
+                                             noise_seed=nseed)
+                if nseed is not None:
+                    horizon[f"{name}_noise_seed"] = nseed
                 horizon[f"{name}_auc"] = res["auc"]; horizon[f"{name}_auc64"] = res64["auc"]
                 horizon[f"{name}_final_sample"] = res["final"][samp[:, 0], samp[:, 1]].astype(np.float32)
                 horizon[f"{name}_final_sum"] = float(res["final"].astype(np.float64).sum())
