@@ -44,6 +44,9 @@ WORKLOADS = {
     # name: (N, nfeat, nclass, hidden, nlayer, measure, weight_param)
     "synthetic-10k-hsic": (10000, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-10k-mse": (10000, 128, 7, 16, 2, "MSELoss", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    # calc = calc_kl (KLDivLoss over rows: 13 of the reference README's 42 command lines) through the fused KL step (round 6)
+    "synthetic-10k-kl": (10000, 128, 7, 16, 2, "KL", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
+    "cora-shape-kl": (2708, 1433, 7, 16, 2, "KL", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "cora-shape-hsic": (2708, 1433, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "cora-shape-mse": (2708, 1433, 7, 16, 2, "MSELoss", (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 1000)),
     "synthetic-4k-hsic": (4096, 128, 7, 16, 2, "HSIC", (0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
@@ -395,10 +398,12 @@ def ab_switch(name):
 
 
 PRODUCT_MODES = {0: "fp32 MFMA SYMM (gemm_f32_kernel, SYM_MM)",
+                 1: "SINGLE-plane fp16 product x0 y0 of the 2-plane operands (low planes compiled out of split2_m16_kernel): fp16 accuracy, "
+                    "2^-11 per operand -- a named mode (MCGRA_SPLIT_BF16=1), never a default",
                  2: "3-plane bf16 split, hand-written split3_symm_kernel on packed planes (256 x 256 tiles)",
                  3: "2-plane fp16 split (3 plane products, exact power-of-two operand scales), hand-written "
                     "split2_m16_kernel on packed planes (256 x 256 tiles)"}
-PLANE_PRODUCTS = {0: 1, 2: 6, 3: 3}
+PLANE_PRODUCTS = {0: 1, 1: 1, 2: 6, 3: 3}
 
 
 def product_probe(pkg, torch, dev, workload, seed, steps, warmup, monitor, mode, overlap=None, extra_env=None):
@@ -783,7 +788,9 @@ def main(argv=None):
             # ... and calc = MSELoss (the measure of the reference's README headline run, configs[0]) through the fused MSELoss
             # step: Cora shape and the headline's N
             # ... and configs[2]'s shape (Citeseer-sized, GAT victim): the general step, its four Gram products on the split kernel
-            for wl2, k2 in (("cora-shape-mse", 100), ("synthetic-10k-mse", 60), ("citeseer-shape-gat-hsic", 60)):
+            # ... and calc = calc_kl (the README's most common measure) through the fused KL step
+            for wl2, k2 in (("cora-shape-mse", 100), ("synthetic-10k-mse", 60), ("citeseer-shape-gat-hsic", 60), ("cora-shape-kl", 100),
+                            ("synthetic-10k-kl", 60)):
                 torch.cuda.empty_cache()
                 e3, _, _ = build_engine(pkg, torch, dev, wl2, a.seed)
 
@@ -797,8 +804,22 @@ def main(argv=None):
                               "fused_steps": e3.fused_steps(), "general_steps": e3.path_stats()["general_steps"],
                               "gram_split_steps": e3.gram_split_steps()}
                 del e3
+            # ... and the precision BASELINE.json's configs[2] / [4] name ("bf16 MFMA"), taken literally: the headline workload and the
+            # Cora shape with the N x N x N product as ONE fp16 plane product (MCGRA_SPLIT_BF16=1).  A named, non-headline mode: the
+            # reference's CPU path is fp32 and `value` stays on the fp32-level split; its accuracy against float64 and its AUC delta
+            # are measured by scripts/single_plane_table.py (profiles/r06_single_plane_table.txt)
+            for wl2, k2 in (("synthetic-10k-hsic", 60), ("cora-shape-hsic", 100)):
+                torch.cuda.empty_cache()
+                sp1 = product_probe(pkg, torch, dev, wl2, a.seed, k2, 10, monitor, 1)
+                extra[wl2 + "-f16-single-plane"] = {
+                    "value": sp1["value"], "unit": "attack-steps/s", "ms_per_step": sp1["ms_per_step"], "nodes": WORKLOADS[wl2][0], "steps": k2,
+                    "dtype": "f16 single plane (the N x N x N product only: x0 y0 of the power-of-two-scaled operands, fp32 accumulate; "
+                             "everything else as the headline)", "product_avg_launch_ms": sp1.get("product_avg_launch_ms"),
+                    "product_16bit_tflops": sp1.get("product_16bit_tflops_issued"), "auc": sp1["auc"],
+                    "auc_minus_headline": (sp1["auc"] - auc) if wl2 == a.workload and k2 == a.steps else None,
+                    "note": "non-headline: never `value`; accuracy table in profiles/r06_single_plane_table.txt"}
         except Exception as e:
-            extra = {"error": f"{type(e).__name__}: {e}"[:300]}
+            extra = dict(extra or {}, error=f"{type(e).__name__}: {e}"[:300])
 
     replicas = None
     if world > 1 and not a.no_shard_probe:
@@ -939,6 +960,16 @@ def main(argv=None):
                     out["roofline"]["alone"] = {"avg_launch_ms": alone_ms,
                                                 "achieved": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12,
                                                 "frac": 2.0 * n ** 3 / (alone_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        elif measure == "KL" and eng_path["fused_steps"] > 0 and eng_path["general_steps"] == 0 and world == 1:
+            # the fused KL step: the fused MSELoss step's passes (below) with softmax(feature_adj) in feature_adj's place, plus the
+            # second per-pair pass over M for the row statistics of calc_kl (k_decode_stats): one more p
+            p = 4.0 * n * n
+            passes = nl + (nl - 1) + 2 + 2 + 4 + (nl if monitor and not out["config"]["forward_reuse"] else 0)
+            ach = passes * p / (1e-3 * 1e3 * dt / a.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "the fused KL step as a whole (k_tail_adam, the skinny products on M, k_tail_reduce, "
+                               "k_decode_stats, k_decode_fly: no N x N x N product, no N x N intermediate)", "achieved": ach, "peak": 8000.0,
+                               "unit": "GB/s", "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p, "traffic": None,
+                               "traffic_unit": "bytes/step"}
         elif measure == "MSELoss" and eng_path["fused_steps"] > 0 and eng_path["general_steps"] == 0 and world == 1:
             # the fused MSELoss step has no N x N x N product: it is a chain of HBM-bound passes over the learnable adjacency.
             # Algorithmic bytes per step = the passes its formulation cannot do without, p = 4 n^2 bytes each: L forward products

@@ -48,9 +48,11 @@ enum mcgra_measure {
   MCGRA_MEASURE_CKA = 3,  /* CudaCKA.linear_CKA utils.py:1091 */
   MCGRA_MEASURE_DP = 4,   /* PGDAttack.dot_product topology_attack.py:480 */
   MCGRA_MEASURE_KDE = 5   /* utils.MutualInformation(sigma=0.4, num_bins=<operand width>, normalize=True) utils.py:980,
-                             topology_attack.py:199-201, :244-246, :261-263 */
-  /* "KDE" (utils.MutualInformation, utils.py:980) hard-codes cuda:0 and cannot
-     run on the reference CPU path; not provided. */
+                             topology_attack.py:199-201, :244-246, :261-263.  Entry (i, j) of an operand meets bin j only
+                             (utils.py:995) and exp(-((v - b_j) / 0.32)^2 / 2) is exactly 0 in float32 once b_j - v > 4.6, so the
+                             N x N terms live on the first floor(max(feature_adj) + 4.7) + 1 columns (8 for the operands the
+                             reference builds, all <= 1): mcgra_attack_set_graph measures max |feature_adj|, widens the
+                             column count up to 32 and returns MCGRA_ENOSUP beyond (values > 27.3) */
 };
 
 const char* mcgra_version(void);

@@ -187,6 +187,12 @@ static const char* ab_env(const char* name) {
   if (!v) return nullptr;
   const char* on = getenv("MCGRA_AB");
   if (on && on[0] == '1') return v;
+  // (said once per variable and process, not once per engine)
+  static std::mutex mu;
+  static std::vector<std::string> said;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const std::string& s : said) if (s == name) return nullptr;
+  said.emplace_back(name);
   fprintf(stderr, "[mcgra] %s=%s is ignored: A/B switches are honoured only under MCGRA_AB=1\n", name, v);
   return nullptr;
 }
@@ -307,8 +313,11 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const char* es = getenv("MCGRA_SPLIT_BF16");
     const char auto_mode[2] = {n >= 1024 ? '3' : '0', 0};
     if (!es || !es[0]) es = auto_mode;
-    if (!rc && h->lr_ok && cfg->eps == 0.f && es && (es[0] == '2' || es[0] == '3')) {
-      h->split_planes = es[0] == '3' ? 2 : 3;
+    // =1: the fp16 x 2 operands, ONE plane product (fp16 accuracy: 2^-11 per operand; a third of the matrix-core work) -- what "bf16 MFMA"
+    // in BASELINE.json's configs[2] / [4] means taken literally.  Never a default: the reference's CPU path is fp32.
+    if (!rc && h->lr_ok && cfg->eps == 0.f && es && (es[0] == '1' || es[0] == '2' || es[0] == '3')) {
+      h->split_planes = es[0] == '2' ? 3 : 2;
+      h->split_single = es[0] == '1';
       A_(Apack, split3_pack_bytes((int)n, h->split_planes)); A_(Bpack, split3_pack_bytes((int)n, h->split_planes));
       A_(amax, 16);
       h->split_on = (rc == 0);
@@ -319,7 +328,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     // G_adjn += Ky' Xc and G_A1 += Kx' Yc -- four products of 2 n^3 instead of 3 n^3 MACs of fp32 SYMM at a third of
     // their rate.  MCGRA_GRAM_SPLIT=0: fp32 path.
     const char* eg_ = ab_env("MCGRA_GRAM_SPLIT");
-    const bool gram_auto = (es[0] == '3') && !(eg_ && eg_[0] == '0');
+    const bool gram_auto = (es[0] == '3' || es[0] == '1') && !(eg_ && eg_[0] == '0');      // (the Gram evaluation's products stay 3-product splits under =1)
     if (!rc && (cfg->measure == MCGRA_MEASURE_HSIC || cfg->measure == MCGRA_MEASURE_CKA) && cfg->eps == 0.f && gram_auto) {
       if (!h->split_on) { h->split_planes = 2; A_(Bpack, split3_pack_bytes((int)n, 2)); A_(amax, 16); }
       if (h->split_planes == 2) {
@@ -337,7 +346,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     h->overlap = (eo && eo[0]) ? eo[0] == '1' : (h->split_mode == 2 && h->split_planes == 2);
     if (h->gram_split) { A_(gram_diag, 2 * ld); }
     // (the fused MSELoss step -- attack_fused.hip -- uses the side streams of the small-operand terms and of the decode too)
-    const bool mse_fusable = cfg->measure == MCGRA_MEASURE_MSE && cfg->eps == 0.f && !h->has_self && h->act == 0 && h->head_act == 0;
+    const bool mse_fusable = (cfg->measure == MCGRA_MEASURE_MSE || cfg->measure == MCGRA_MEASURE_KL) && cfg->eps == 0.f && !h->has_self &&
+                             h->act == 0 && h->head_act == 0;      // (and the fused KL step)
     if (!rc && (h->lr_ok || h->gram_split || mse_fusable)) {
       int pr_least = 0, pr_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
@@ -386,7 +396,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const int he = h->wdt[h->Le - 1];
     int fc = 2 * he + 1 + h->wdt[h->L - 1];
     for (int l = 0; l < h->L; ++l) fc = (2 * h->wdt[l] + 1) > fc ? 2 * h->wdt[l] + 1 : fc;
-    if (cfg->measure == MCGRA_MEASURE_MSE) {      // the fused MSELoss step: no means column, no low-rank factors -- [r o Tv | Tu] only
+    if (cfg->measure == MCGRA_MEASURE_MSE || cfg->measure == MCGRA_MEASURE_KL) {      // the fused MSELoss / KL step: no means column, no low-rank factors -- [r o Tv | Tu] only
       fc = 0;
       for (int l = 0; l < h->L; ++l) fc = 2 * h->wdt[l] > fc ? 2 * h->wdt[l] : fc;
     }
@@ -403,6 +413,13 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
                    h->act == 0 && h->head_act == 0 && lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
                    h->st3 != nullptr;
     if (h->fused_mse) h->fused_ok = true;
+    // The fused KL step (round 6): calc = calc_kl (:197-198, :483-487) is elementwise in the same quantities plus per-row softmax
+    // statistics of adj_norm and modified_adj1 -- the MSELoss step's data flow with one more per-pair pass for the statistics
+    // (attack_fused.hip).  softmax(feature_adj) (XC, constant per graph) takes feature_adj's place in the tail.
+    h->fused_kl = !rc && !(e && e[0] == '1') && cfg->measure == MCGRA_MEASURE_KL && cfg->eps == 0.f && !h->has_self &&
+                  h->act == 0 && h->head_act == 0 && lr_decode_supported(he) && fl_tail_supported((int)n, (int)ld, kmax) && fc <= 64 &&
+                  h->st3 != nullptr;
+    if (h->fused_kl) { h->fused_ok = true; h->fused_mse = true; }      // (fused_mse: "an elementwise measure" -- every branch of the MSELoss step that is not MSELoss' own arithmetic)
     h->row0 = 0; h->row1 = (int)n;
     { const char* ef = ab_env("MCGRA_NO_FUSED_POST"); h->fused_post = !(ef && ef[0] == '1'); }
     { const char* ee = ab_env("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
@@ -423,7 +440,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       if (!h->fused_ok || cfg->num_edges < 0.5 * (double)n * (double)n) {
         if (!rc) {
           set_error("shard_world > 0 needs a configuration a fused step covers (HSIC: ReLU GCN victim, eps == 0, n >= 1024 or "
-                    "MCGRA_SPLIT_BF16=2/3, widths <= 32; MSELoss: ReLU GCN victim, eps == 0, n >= 256, widths <= 32) and a projection "
+                    "MCGRA_SPLIT_BF16=2/3, widths <= 32; MSELoss, KL: ReLU GCN victim, eps == 0, n >= 256, widths <= 32) and a projection "
                     "budget that cannot bind");
           rc = MCGRA_ENOSUP;
         }
@@ -450,6 +467,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       A_(Zpair, (n + 2) * (size_t)h->hmax);
       // (a row-block rank cuts the columns of its rows' decode into up to 64 slices: fused_lowrank.hip: fl_decode_slabs)
       A_(ws_dec, (size_t)((h->sharded || h->fused_mse) ? 64 : lr_decode_slabs((int)n)) * n * he);      // (MSELoss: up to 64 slices too, nothing runs beside its decode)
+      if (h->fused_kl) { A_(klA, ld); A_(kl1, ld); A_(klv, ld); A_(klvsum, ld); A_(klpart, (size_t)64 * n * 2); }
       h->fused_ok = (rc == 0);
     }
   }
@@ -605,6 +623,10 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   }
   if (h->cfg.measure == MCGRA_MEASURE_KL && h->cfg.w[0] != 0.f)
     launch_row_softmax(st, n, ld, h->FADJ, h->XC);      // F.softmax(feature_adj) of calc_kl (:484), constant
+  if (h->cfg.measure == MCGRA_MEASURE_KDE) {           // largest magnitude of the caller's feature_adj: how many columns its bins reach (below)
+    MCGRA_HIP(hipMemsetAsync(h->coef, 0, sizeof(float), st));
+    split_absmax(st, n, ld, h->FADJ, nullptr, false, h->coef);
+  }
   // (small_term's HSIC branch relies on zero pad columns in Q / Q2: see there)
   MCGRA_HIP(hipMemsetAsync(h->Q, 0, sizeof(float) * (size_t)h->hmax * h->hmax, st));
   MCGRA_HIP(hipMemsetAsync(h->Q2, 0, sizeof(float) * (size_t)h->hmax * h->hmax, st));
@@ -612,6 +634,23 @@ int mcgra_attack_set_graph(mcgra_attack_t* h, void* stream, const float* feature
   MCGRA_KERNEL_CHECK();
   // feature_adj.max() != feature_adj.min() (topology_attack.py:212) is evaluated by the host layer
   MCGRA_HIP(hipStreamSynchronize(st));
+  if (h->cfg.measure == MCGRA_MEASURE_KDE) {
+    // utils.MutualInformation on an N x N operand: entry (i, j) meets bin j only (utils.py:995), b_j >= j, and the float32 kernel
+    // value is exactly 0 once b_j - v > 4.6 (kde_kernels.hip).  adj_norm and modified_adj1 live in [0, 1] ([0, 2] with ori_adj) by
+    // construction -- 8 columns; feature_adj is the caller's: its largest magnitude decides how far the bins reach.
+    float fmax_ = 0.f;
+    MCGRA_HIP(hipMemcpy(&fmax_, h->coef, sizeof(float), hipMemcpyDeviceToHost));
+    if (!(fmax_ < 1e30f)) { set_error("measure KDE: feature_adj holds a non-finite value"); return MCGRA_EINVAL; }
+    int cols = (int)floorf(fmax_ + 4.7f) + 1;
+    if (cols < KDE_NXN_COLS) cols = KDE_NXN_COLS;
+    if (cols > n) cols = n;
+    if (cols > KDE_MAXC) {
+      set_error("measure KDE: max |feature_adj| = %g puts %d bins of utils.MutualInformation within reach of its values; the N x N terms "
+                "are evaluated on at most %d columns (values <= %.1f)", (double)fmax_, cols, KDE_MAXC, (double)KDE_MAXC - 4.7);
+      return MCGRA_ENOSUP;
+    }
+    h->kde_cols = cols;
+  }
   h->graph_set = true;
   return 0;
 }
@@ -1028,7 +1067,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
           const int P = split3_panel(), p0 = row0 / P, p1 = (row1 + P - 1) / P;
           // (split-K slabs of the ragged last round go to KY, idle on a low-rank step)
           MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, p0, p1 - p0, h->small_slab ? h->small_slab : h->KY,
-                                h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, h->split_planes, h->amax));
+                                h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, h->split_planes, h->amax, 0, -1,
+                                h->split_single ? 8 : 0));
           CHK(timer_end(h, sp, big, 2.0 * (row1 > row0 ? row1 - row0 : 0) * (double)n * n));
           ++h->split_steps;
         } else
@@ -1096,7 +1136,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     launch_loss_elem(st, n, ld, h->ADJN, h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2), h->G_ADJN,
                      h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);      // only the entropy slots are non-zero
-    const int kc = n < KDE_NXN_COLS ? n : KDE_NXN_COLS;
+    const int kc = n < h->kde_cols ? n : h->kde_cols;      // (set_graph: 8, or as far as feature_adj's values reach)
     if (use1) launch_kde_term(st, n, kc, n, h->FADJ, ld, h->ADJN, ld, k1, nullptr, 0, false, h->G_ADJN, ld, true, h->scal + S_H1, h->kde);
     if (use2) launch_kde_term(st, n, kc, n, h->ADJN, ld, h->A1, ld, k2, h->G_ADJN, ld, true, h->G_A1, ld, true, h->scal + S_H2, h->kde);
   } else if (c.measure == MCGRA_MEASURE_KL) {
@@ -1432,7 +1472,7 @@ int step_general(mcgra_attack_t* h, void* stream, const float* noise, double* sc
 long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h) { return h ? (long long)h->masked_fused_steps : 0; }
 long long mcgra_attack_cut_product_steps(mcgra_attack_t* h) { return h ? (long long)h->cut_product_steps : 0; }
 int mcgra_attack_product_mode(mcgra_attack_t* h) {
-  return h ? (h->split_mode == 2 && h->split_planes == 2 ? 3 : h->split_mode) : 0;
+  return h ? (h->split_mode == 2 && h->split_planes == 2 ? (h->split_single ? 1 : 3) : h->split_mode) : 0;
 }
 
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps) {

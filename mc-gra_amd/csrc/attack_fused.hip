@@ -416,6 +416,10 @@ static int tail_reduce_call(mcgra_attack* h, hipStream_t st, int phase, bool pai
   const int ll[2] = {hs, 2 * he}, lr_[2] = {hs, 2 * he}, Ks[2] = {hs, 2 * he};
   const bool no_rk = h->test_mutate == 2;      // (TEST-ONLY mutation, see the join below)
   const float al[2] = {no_rk ? 0.f : 1.f, no_rk ? 0.f : a2};
+  if (h->fused_kl)       // calc = calc_kl: softmax(feature_adj) in the place of P1, the row statistics lA / l1 / v as the n-vectors
+    return fl_tail_reduce(st, n, h->ld, pair, R0, R1, 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M, h->XC, h->r,
+                          h->klA, h->kl1, h->klv, 0.f, 0.f, kie6, h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf, phase, h->Zn,
+                          h->hmax, he, kmse1, kmse2, true);
   if (h->fused_mse)      // calc = MSELoss: feature_adj in the place of P1, S = Zn Zn^T as a third rank-k group
     return fl_tail_reduce(st, n, h->ld, pair, R0, R1, 1, Ls, ll, Rs, lr_, Ks, al, h->GPu, hs, h->Tu, hs, no_rk ? 0 : hs, h->M, h->FADJ, h->r,
                           h->cmean, nullptr, nullptr, 0.f, 0.f, kie6, h->G_ADJN, ps1, want_vals ? vpart : nullptr, h->rkbuf, phase, h->Zn,
@@ -431,6 +435,7 @@ static int fork_p1(mcgra_attack* h, hipStream_t st, bool want_vals) {
   const int n = h->n, ld = h->ld, R0 = h->row0, R1 = h->row1;
   const int P = split3_panel(), p_off = R0 / P, p_cnt = R1 > R0 ? (R1 - R0 + P - 1) / P : 0;
   const bool ovl = h->overlap;
+  const int sflag = h->split_single ? 8 : 0;      // MCGRA_SPLIT_BF16=1: the single-plane product of the same operands (split_symm_bf16.hip)
   h->p1_inflight = false;
   if (p_cnt <= 0) return 0;
   hipStream_t sp = ovl ? h->st2 : st;
@@ -453,7 +458,7 @@ static int fork_p1(mcgra_attack* h, hipStream_t st, bool want_vals) {
     if (first >= total) first = (h->world <= 4 || h->a2a_overlap == 2) ? span : 0;
     if (first > 0 && first < total) {
       MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, rot, -1, h->KY, sizeof(float) * (size_t)n * ld, h->split_planes,
-                            h->amax, p_off, p_cnt, 4, first, h->ev_first));
+                            h->amax, p_off, p_cnt, 4 | sflag, first, h->ev_first));
       h->p1_first = true;
       ++h->cut_product_steps;
     }
@@ -473,7 +478,7 @@ static int fork_p1(mcgra_attack* h, hipStream_t st, bool want_vals) {
     if (cut2 <= cut || cut2 >= total || rows2 <= rows) { cut2 = 0; rows2 = 0; }
     if (cut >= slots && cut < total && rows >= n / 2) {
       MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->KY, sizeof(float) * ((size_t)n * ld - tail_ps_floats(h)),
-                            h->split_planes, h->amax, p_off, p_cnt, 0, cut, h->ev_first, cut2, cut2 ? h->ev_second : nullptr));
+                            h->split_planes, h->amax, p_off, p_cnt, sflag, cut, h->ev_first, cut2, cut2 ? h->ev_second : nullptr));
       h->tail_rows = rows;
       h->tail_rows2 = rows2;
       ++h->cut_product_steps;
@@ -481,7 +486,7 @@ static int fork_p1(mcgra_attack* h, hipStream_t st, bool want_vals) {
   }
   if (!h->p1_first && h->tail_rows == 0)
   MCGRA_HIP(split3_symm(sp, n, h->Apack, h->Bpack, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->KY,
-                        h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, h->split_planes, h->amax, p_off, p_cnt));
+                        h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, h->split_planes, h->amax, p_off, p_cnt, sflag));
   CHK(timer_end(h, sp, h->profile, 2.0 * (double)n * n * (double)(R1 - R0)));
   ++h->split_steps;
   if (ovl) MCGRA_HIP(hipEventRecord(h->ev_join, h->st2));
@@ -526,13 +531,16 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C, fc = h->fcols, R0 = h->row0, R1 = h->row1;
   // measure == HSIC (sign -1: :217-220), or -- h->fused_mse -- MSELoss: no product (use1) and no low-rank factors (use2); its two
   // N x N terms are elementwise and live in the decode (d / d modified_adj1) and in the tail's first pass (d / d adj_norm)
-  const bool mse = h->fused_mse;
+  // -- h->fused_kl (mse is set as well: "an elementwise measure") -- calc_kl: the MSELoss step's data flow with per-row softmax
+  // statistics in front of the decode (k_decode_stats: one more per-pair pass) and one more gather on a row-block rank
+  const bool mse = h->fused_mse, kl = h->fused_kl;
   const double sg = mse ? 1.0 : -1.0;
   const double w1 = c.w[0], w2 = c.w[1], w6 = c.w[5], w7 = c.w[6], w9 = c.w[8], w10 = c.w[9];
   const double k1 = w1 * 1000 * AP_C1, k2 = w2 * 100 * AP_C2, k6 = w6 * 100 * AP_C6, k7 = w7 * AP_C7;
   const double k9 = w9 * AP_C9, k10 = w10 * AP_C10, n2 = (double)n * n;
   const bool use1 = !mse && w1 != 0, use2 = !mse && w2 != 0;
-  const float kmse1 = mse ? (float)(k1 * 2.0 / n2) : 0.f, kmse2 = mse ? (float)(k2 * 2.0 / n2) : 0.f;      // k_loss_elem's multipliers
+  const float kmse1 = kl ? (float)(k1 / n) : mse ? (float)(k1 * 2.0 / n2) : 0.f;      // k_loss_elem's multipliers; KL: k / batch (batchmean over rows)
+  const float kmse2 = kl ? (float)(k2 / n) : mse ? (float)(k2 * 2.0 / n2) : 0.f;
   const float* em = h->Hu + h->off[Le - 1];
   const int he = h->wdt[Le - 1];
   const float a1 = use1 ? 2.f * (float)(sg * k1) : 0.f, a2 = use2 ? 2.f * (float)(sg * k2) : 0.f;
@@ -646,6 +654,14 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
       launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f, h->Zpair);
+      if (kl) {
+        // calc_kl's row statistics (logsumexp of adj_norm's and of modified_adj1's rows) from M, r and Zn: the decode backward and
+        // the tail need those of EVERY row (d c2 / d A1_ij + d c2 / d A1_ji), so a row-block rank gathers its peers' first
+        (void)fl_decode_stats(st, n, R0, R1, he, h->Zn, h->hmax, h->Zpair, h->M, ld, h->r, h->klpart, h->klA, h->kl1);
+        if (h->sharded) rows_to_stage2(h, st, narrow_stage(h), 1, h->klA, 1, 0, 1, h->kl1, 1, 1);
+      }
+      if (kl) { FS_XCHG(h->fs_state, 12, X_SG(h)) }
+      if (kl && h->sharded) stage_to_rows2(h, st, narrow_stage(h), 1, 0, h->klA, 1, 1, 1, h->kl1, 1);
       if (!h->sharded) {
         // monolithic, small graphs (where the step is bound by its chain of dependent node-level kernels): the decode -- the
         // longest of them, and it needs only Zn -- on a fourth stream with its own slabs, beside the low-rank factor chain;
@@ -661,8 +677,12 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (!h->nmask_zero) MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), h->ws_dec, h->rowvals, h->GZn, h->hmax, h->nmask, h->Zpair, want_vals,
-                                 mse ? h->M : nullptr, ld, h->r, kmse2);
+                                 mse ? h->M : nullptr, ld, h->r, kmse2, kl ? h->klA : nullptr, kl ? h->kl1 : nullptr, kl ? h->klpart : nullptr);
         if (want_vals) launch_reduce_rows(s4, h->rowvals, h->fs_np, 1, h->scal + S_V7);
+        if (kl) {      // v_i for the tail; their sum / n is the value of c2 (k_kl_rows' slot)
+          fl_kl_v_fin(s4, n, R0, R1, h->klpart, h->klvsum, h->klv);
+          if (want_vals) launch_reduce_rows(s4, h->klvsum, n, 1, h->scal + S_H2);
+        }
         if (use2) {
           hipLaunchKernelGGL(k_post_mask, dim3(1), dim3(1), 0, s4, h->nmask, nullptr, h->mask_seq_dev, h->mask_host_dev);
           h->mask_want = ++h->mask_seq;      // the host's count moves with the enqueue: an abandoned step cannot skew it
@@ -683,7 +703,8 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         MCGRA_HIP(hipMemsetAsync(h->nmask, 0, 2 * sizeof(unsigned int), s4));
         h->nmask_zero = false;
         h->fs_np = fl_decode_fly(s4, n, R0, R1, he, h->Zn, h->hmax, (float)(k7 / n2), dec_side ? h->ws_dec : h->ws,
-                                 h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->nmask, h->Zpair, true, mse ? h->M : nullptr, ld, h->r, kmse2);
+                                 h->rowvals + 6 * (size_t)ld, h->GZn, h->hmax, h->nmask, h->Zpair, true, mse ? h->M : nullptr, ld, h->r, kmse2,
+                                 kl ? h->klA : nullptr, kl ? h->kl1 : nullptr, kl ? h->klpart : nullptr);
         // own rows of the decode backward and of |xc_i|^2, the rank's masked-pair and dead-row counts and its entropy partial:
         // they ride in the gather of the first low-rank product below (or, without c2, in a gather of their own)
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
@@ -691,6 +712,12 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         if (h->fs_np > 0) launch_reduce_rows(s4, h->rowvals + 6 * (size_t)ld, h->fs_np, 1, lane_slot(h, sg, 2));
         else MCGRA_HIP(hipMemsetAsync(lane_slot(h, sg, 2), 0, sizeof(double), s4));
         if (use2) rows_to_stage2(h, s4, sg, he, h->GZn, h->hmax, 0, 2, reinterpret_cast<const float*>(h->lrRs), 2, he);     // |xc_i|^2 (double) as two words
+        else if (kl) {      // + the own rows' v_i, and the rank's share of c2's value in a fourth lane slot
+          fl_kl_v_fin(s4, n, R0, R1, h->klpart, h->klvsum, h->klv);
+          if (R1 > R0) launch_reduce_rows(s4, h->klvsum + R0, R1 - R0, 1, lane_slot(h, sg, 3));
+          else MCGRA_HIP(hipMemsetAsync(lane_slot(h, sg, 3), 0, sizeof(double), s4));
+          rows_to_stage2(h, s4, sg, he, h->GZn, h->hmax, 0, 1, h->klv, 1, he);
+        }
         else rows_to_stage(h, s4, sg, he, h->GZn, h->hmax, 0);
         if (dec_side) MCGRA_HIP(hipEventRecord(h->ev_join4, s4));
         h->fs_dec_forked = dec_side;
@@ -734,8 +761,9 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->sharded) {
         const Stage sg = use2 ? wide_stage(h) : narrow_stage(h);
         if (use2) stage_to_rows2(h, st, sg, he, 0, h->GZn, h->hmax, 2, he, reinterpret_cast<float*>(h->lrRs), 2);
+        else if (kl) stage_to_rows2(h, st, sg, he, 0, h->GZn, h->hmax, 1, he, h->klv, 1);
         else stage_to_rows(h, st, sg, he, 0, h->GZn, h->hmax);
-        lane_sum(h, st, sg, 3, h->SC + 8);                       // SC[8] masked pairs, SC[9] dead rows, SC[10] entropy term of modified_adj1
+        lane_sum(h, st, sg, kl ? 4 : 3, h->SC + 8);              // SC[8] masked pairs, SC[9] dead rows, SC[10] entropy term of modified_adj1 (KL: SC[11] the value of c2)
         MCGRA_HIP(hipMemcpyAsync(h->scal + S_V7, h->SC + 10, sizeof(double), hipMemcpyDeviceToDevice, st));
         // A dead embedding row voids the low-rank algebra (k_post_mask).  The counts are posted to mapped host memory now and
         // looked at only in front of the Adam pass, the first kernel that changes persistent state: by then the post has
@@ -875,12 +903,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         h->fs_nblk = tail_reduce_call(h, st, 2, pair, h->sharded ? R0 : h->tail_rows, R1, use1, use2, a1, a2, (float)(k6 / n2), want_vals, kmse1, kmse2);
         h->tail_rows = 0;
         const Stage sgt = narrow_stage(h);
-        if (h->sharded && !(h->fs_nblk > 0 && want_vals)) CHK(lane_zero(h, st, sgt, mse ? 3 : 2));
+        if (h->sharded && !(h->fs_nblk > 0 && want_vals)) CHK(lane_zero(h, st, sgt, (mse && !kl) ? 3 : 2));
         if (h->fs_nblk > 0 && want_vals) {
-          // HSIC: sum P1 o Xc -> S_H1; MSELoss: sum (F - adj_norm)^2 -> S_V1 and sum (adj_norm - A1)^2 -> S_V2 (k_loss_elem's slots)
-          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 0) : h->scal + (mse ? S_V1 : S_H1));
+          // HSIC: sum P1 o Xc -> S_H1; MSELoss: sum (F - adj_norm)^2 -> S_V1 and sum (adj_norm - A1)^2 -> S_V2 (k_loss_elem's slots);
+          // KL: calc_kl(feature_adj, adj_norm) -> S_H1 (k_kl_rows' slot; c2's value came out of the decode)
+          launch_reduce_rows(st, vpart, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 0) : h->scal + ((mse && !kl) ? S_V1 : S_H1));
           launch_reduce_rows(st, vpart + h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 1) : h->scal + S_V6);
-          if (mse) launch_reduce_rows(st, vpart + 2 * (size_t)h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 2) : h->scal + S_V2);
+          if (mse && !kl) launch_reduce_rows(st, vpart + 2 * (size_t)h->fs_nblk, h->fs_nblk, 1, h->sharded ? lane_slot(h, sgt, 2) : h->scal + S_V2);
         }
         {
           const bool cn_in_gd = h->fused_post && R1 > R0;
@@ -893,7 +922,7 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->sharded) {
         const Stage sgt = narrow_stage(h);
         stage_to_rows(h, st, sgt, 1, 0, h->gd, 1);
-        if (mse) lane_sum(h, st, sgt, 3, h->SC + 12);            // SC[12] sum (F - adj_norm)^2, SC[13] entropy term of adj_norm, SC[14] sum (adj_norm - A1)^2
+        if (mse) lane_sum(h, st, sgt, kl ? 2 : 3, h->SC + 12);   // SC[12] sum (F - adj_norm)^2 (KL: the value of c1), SC[13] entropy term of adj_norm, SC[14] sum (adj_norm - A1)^2
         else
         lane_sum(h, st, sgt, 2, h->SC + 4);                      // SC[4] sum P1 o Xc, SC[5] entropy term of adj_norm
       }
@@ -966,7 +995,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       if (h->fs_want) { FS_XCHG(h->fs_state, 11, X_SG(h)) }
       if (h->sharded && h->fs_want) {
         lane_sum(h, st, narrow_stage(h), 1, h->SC + 6);
-        if (mse) {
+        if (kl) {
+          MCGRA_HIP(hipMemcpyAsync(h->scal + S_H1, h->SC + 12, sizeof(double), hipMemcpyDeviceToDevice, st));
+          MCGRA_HIP(hipMemcpyAsync(h->scal + S_V6, h->SC + 13, sizeof(double), hipMemcpyDeviceToDevice, st));
+          MCGRA_HIP(hipMemcpyAsync(h->scal + S_H2, h->SC + 11, sizeof(double), hipMemcpyDeviceToDevice, st));
+        } else if (mse) {
           MCGRA_HIP(hipMemcpyAsync(h->scal + S_V1, h->SC + 12, sizeof(double), hipMemcpyDeviceToDevice, st));
           MCGRA_HIP(hipMemcpyAsync(h->scal + S_V6, h->SC + 13, sizeof(double), hipMemcpyDeviceToDevice, st));
           MCGRA_HIP(hipMemcpyAsync(h->scal + S_V2, h->SC + 14, sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1051,6 +1084,7 @@ int mcgra_attack_shard_next(mcgra_attack_t* h, void* stream, mcgra_exchange_t* e
   if (rc == 1) return 0;
   if (rc == 2) {      // every rank holds the full state now: the general path redoes the step, replicated
     rc = step_general(h, stream, nullptr, h->fs_want ? h->fs_scalars : nullptr);
+    if (rc == 0) h->m_is_full = true;      // (shard_begin cleared it; the replicated step left every row of M current on every rank)
     h->fs_active = false;
     h->fs_want = h->fs_want ? 2 : 0;       // scalars already collected
     return rc;
@@ -1107,7 +1141,7 @@ int mcgra_attack_product_replay(mcgra_attack_t* h, void* stream, int reps, doubl
   MCGRA_HIP(hipEventRecord(e0, st));
   for (int i = 0; i < reps; ++i)
     MCGRA_HIP(split3_symm(st, h->n, h->Apack, h->Bpack, h->KX, h->ld, 0, -1, h->KY, sizeof(float) * (size_t)h->n * h->ld, h->split_planes,
-                          h->amax, p_off, p_cnt));
+                          h->amax, p_off, p_cnt, h->split_single ? 8 : 0));
   MCGRA_HIP(hipEventRecord(e1, st));
   MCGRA_HIP(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -89,7 +89,7 @@ void split3_pack_from_m(hipStream_t st, int n, int ld, const float* M, const flo
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr,
                        int npanel_off = 0, int npanel_cols = -1, int flags = 0,      // flags: 1 = C += product; 2 = Gram product (A == B): lower tiles computed, mirrored into the upper half;
-                       int first_tiles = 0, hipEvent_t ev_first = nullptr,             // 4 = all row panels from panel_off, wrapping; first_tiles: cut of the linear tile range, ev_first recorded behind the first part
+                       int first_tiles = 0, hipEvent_t ev_first = nullptr,             // 4 = all row panels from panel_off, wrapping; 8 = (planes == 2) the single-plane product x0 y0, low planes compiled out; first_tiles: cut of the linear tile range, ev_first recorded behind the first part
                        int second_tiles = 0, hipEvent_t ev_second = nullptr);          // a second cut behind the first
 int split3_panel();
 size_t split3_small_slab_bytes(int n);      // split-K slab room a small graph's products can use (0: none beyond what fits an N x N buffer anyway)

@@ -79,6 +79,7 @@ struct mcgra_attack {
   double* colpart_d = 0;
   double* cm_part = 0;             // scratch of launch_colmean_center
   double* kde = 0;                 // measure KDE: tables + per-block partials of one term (kde_kernels.hip: kde_scratch_doubles)
+  int kde_cols = mcgra::KDE_NXN_COLS;   // ... columns of the N x N operands whose kernel values can be non-zero in float32 (set_graph: from max |feature_adj|)
   double* cst = 0;                 // constants of the CKA terms: [0] hsic(Fadj,Fadj), [1] hsic(HA,HA), [2] hsic(YA,YA)
   float* ws = 0;
   size_t ws_bytes = 0;
@@ -146,6 +147,7 @@ struct mcgra_attack {
   int split_mode = 0;              // 0: fp32 MFMA SYMM; 2: split3_symm_kernel on packed planes
   unsigned char *Apack = 0, *Bpack = 0;
   int split_planes = 3;            // 3: bf16 x 3 (six products); 2: fp16 x 2 (three products, operand scales from amax)
+  bool split_single = false;       // MCGRA_SPLIT_BF16=1 (by name only, never a default): P1 as the single-plane product x0 y0 of the fp16 x 2 operands
   float *amax = 0;                 // [0] max |H Kf H| (per graph), [1] max |Xc| (per step, from the centring pass)
   int64_t split_steps = 0;
   // Gram evaluation (masked / GAT / MCGRA_NO_LOWRANK steps) through the same kernel: planes of Xc, Yc, the combined
@@ -160,6 +162,9 @@ struct mcgra_attack {
   // fused low-rank step (attack_fused.hip): everything N x N from M and n-vectors; MCGRA_NO_FUSED_LR=1 disables
   bool fused_ok = false;           // configuration allows it
   bool fused_mse = false;          // ... as the fused MSELoss step (calc = MSELoss: no product, no low-rank factors; attack_fused.hip)
+  bool fused_kl = false;           // ... as the fused KL step (calc = calc_kl: the MSELoss step's data flow + per-row softmax statistics)
+  float *klA = 0, *kl1 = 0, *klv = 0;      // fused KL step: logsumexp of adj_norm's rows, of modified_adj1's rows, v_i = the row's share of c2
+  double *klpart = 0, *klvsum = 0;         // ... per-(column slice, row) partials of the two passes [64][n][2]; v_i in fp64 [ld]
   // create-time values of the path switches a non-zero ori_adj turns off (set_graph restores them when ori_adj goes away)
   bool lr_ok0 = false, fused_ok0 = false, gram_split0 = false, fwd_reuse0 = false, late_mean0 = false, planes_mm_on0 = false;
   bool fused_fwd_valid = false;    // both chains, heads, d / r / mean of the CURRENT M are in place (left by the monitor call)

@@ -365,12 +365,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // adj_norm_ij = (r_i r_j) M_ij formed on the fly.  The block's 256 rows x 32 columns of M go through LDS per chunk of 16 column
 // pairs (coalesced along the rows of M -- a row-block rank holds only its own rows of M current, so M[j][i] is not an option --
 // and read back as T[lane's row][column]: stride 33, conflict free).
-template <int H, bool V7, bool MSE>
+// MODE: 0 the low-rank HSIC step, 1 = MSE above, 2 = KL (the fused KL step, attack_fused.hip): calc = calc_kl (:197-198, :483-487),
+// KLDivLoss(batchmean)(log_softmax(Y), softmax(X)) over ROWS.  c2 = k2 calc_kl(adj_norm, modified_adj1) with the row statistics
+// lA_i = logsumexp_j adj_norm_ij and l1_i = logsumexp_j modified_adj1_ij of k_decode_stats (both operands live in [0, 1]: no shift):
+//   d c2 / d A1_ij = kkl2 (exp(A1_ij - l1_i) - exp(an_ij - lA_i)),     kkl2 = k2 / n
+// not symmetric -- the decode backward sees G_ij + G_ji, i.e. the statistics of row j as well (wave-uniform: scalar loads) --, and
+//   v_i = sum_j softmax(an)_ij (log_softmax(an)_ij - log_softmax(A1)_ij)      (the row's share of the value, diagonal included)
+// which the tail needs for d c2 / d adj_norm_ij = kkl2 softmax(an)_ij (t_ij - v_i): per (column slice, row) partials in fp64 -> vrow.
+template <int H, bool V7, int MODE>
 __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
                                                       const f32x2* __restrict__ Zp, float kie7, int jper,
                                                       float* __restrict__ slabs, double* __restrict__ v7part,
                                                       unsigned int* __restrict__ nmask, const float* __restrict__ Mm, int ldm,
-                                                      const float* __restrict__ rvec, float kmse2) {
+                                                      const float* __restrict__ rvec, float kmse2,
+                                                      const float* __restrict__ lseA, const float* __restrict__ lse1,
+                                                      double* __restrict__ vrow) {
+  constexpr bool MSE = MODE != 0;      // (M through LDS, adj_norm_ij per pair: MSELoss and KL alike)
+  constexpr bool KL = MODE == 2;
   __shared__ double sh[16];
   const int i = row0 + blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < row1;
@@ -385,9 +396,10 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
     for (int k = 0; k < H; ++k) nz |= zi[k] != 0.f;
     if (!nz) atomicAdd(nmask + 1, 1u);
   }
-  double v7 = 0.0;
+  double v7 = 0.0, vkl = 0.0;
   int masked = 0;
   const float ri = (MSE && valid) ? rvec[i] : 0.f;
+  const float lai_ = (KL && valid) ? lseA[i] : 0.f, l1i_ = (KL && valid) ? lse1[i] : 0.f;
   __shared__ float MT[MSE ? 256 : 1][MSE ? 33 : 1];
   const int Pbeg = j0 >> 1;
   // thread (row (q >> 3) + 32 u, column quad q & 7) of a chunk; the NEXT chunk's loads are issued as soon as this one's values
@@ -418,11 +430,15 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
     f32x2 t[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) t[k] = zp[k];
-    f32x2 mij = {0.f, 0.f}, rj = {0.f, 0.f};
+    f32x2 mij = {0.f, 0.f}, rj = {0.f, 0.f}, laj = {0.f, 0.f}, l1j = {0.f, 0.f};
     if (MSE) {
       const int cl = 2 * ((P - Pbeg) & 15);
       mij = f32x2{MT[threadIdx.x][cl], MT[threadIdx.x][cl + 1]};
       rj = f32x2{rvec[min(2 * P, n - 1)], rvec[min(2 * P + 1, n - 1)]};
+    }
+    if (KL) {
+      laj = f32x2{lseA[min(2 * P, n - 1)], lseA[min(2 * P + 1, n - 1)]};
+      l1j = f32x2{lse1[min(2 * P, n - 1)], lse1[min(2 * P + 1, n - 1)]};
     }
     f32x2 s = {0.f, 0.f};
 #pragma unroll
@@ -438,8 +454,18 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
       float val, g;
       ie_term(a1, kie7, val, g);
       if (V7 && valid && in) v7 += (double)val;
-      if (MSE) g -= kmse2 * (mij[u] * (ri * rj[u]) - a1);       // adj_norm_ij as mx (r_i r_j): the tail's arithmetic
+      if (KL) {
+        // (kmse2 carries kkl2 = k2 / n; adj_norm_ij as mx (r_i r_j) with mx = M_ij + [i == j]: the tail's arithmetic)
+        const float an = (mij[u] + (i == j ? 1.f : 0.f)) * (ri * rj[u]);
+        const float la = an - lai_, lb = a1 - l1i_;
+        const float eai = expf(la), eaj = expf(an - laj[u]), e1i = expf(lb), e1j = expf(a1 - l1j[u]);
+        if (valid && in) vkl += (double)(eai * (la - lb));
+        g = 2.f * g + kmse2 * ((e1i + e1j) - (eai + eaj));      // G_ij + G_ji
+        w[u] = (off && a1 > 0.f) ? g : 0.f;
+      } else {
+      if (MODE == 1) g -= kmse2 * (mij[u] * (ri * rj[u]) - a1);       // adj_norm_ij as mx (r_i r_j): the tail's arithmetic
       w[u] = (off && a1 > 0.f) ? 2.f * g : 0.f;
+      }
     }
 #pragma unroll
     for (int k = 0; k < H; ++k) acc[k] = __builtin_elementwise_fma(w, t[k], acc[k]);
@@ -449,6 +475,7 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
 #pragma unroll
     for (int k = 0; k < H; ++k) o[k] = acc[k][0] + acc[k][1];
   }
+  if (KL && valid) vrow[(size_t)blockIdx.y * n + i] = vkl;
   if (V7) {
     const double tt = block_sum_d(v7, sh);
     if (threadIdx.x == 0) v7part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tt;
@@ -456,6 +483,91 @@ __global__ __launch_bounds__(256) void k_decode_fly(int n, int row0, int row1, c
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o, 64);
   if ((threadIdx.x & 63) == 0 && masked) atomicAdd(nmask, (unsigned int)masked);
+}
+
+// Row statistics of calc_kl's two N x N operands for rows [row0, row1) (the fused KL step): per (column slice, row) the partial sums
+// sum_j exp(adj_norm_ij) and sum_j exp(modified_adj1_ij) in fp64 -- the same per-pair pass as k_decode_fly (S_ij's k-ordered fmaf
+// chain from the scalar-loaded column pairs, M through LDS) without the backward.  Both operands live in [0, 1] (r <= 1, M in
+// [0, 1]; a cosine of unit rows), so exp() needs no shift.  k_kl_stats_fin sums the slices in order and takes the logarithms.
+template <int H>
+__global__ __launch_bounds__(256) void k_decode_stats(int n, int row0, int row1, const float* __restrict__ Z, int ldz,
+                                                        const f32x2* __restrict__ Zp, int jper, const float* __restrict__ Mm, int ldm,
+                                                        const float* __restrict__ rvec, double* __restrict__ part) {
+  const int i = row0 + blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < row1;
+  const int j0 = blockIdx.y * jper, j1 = min(n, j0 + jper);
+  float zi[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) zi[k] = valid ? Z[(size_t)i * ldz + k] : 0.f;
+  const float ri = valid ? rvec[i] : 0.f;
+  double sa = 0.0, s1 = 0.0;
+  __shared__ float MT[256][33];
+  const int Pbeg = j0 >> 1;
+  float4 pre[8];
+  const int rb = row0 + blockIdx.x * 256, cc = (threadIdx.x & 7) * 4;
+  auto fetch = [&](int cb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gr = min(rb + (int)(threadIdx.x >> 3) + 32 * u, n - 1), gc = min(cb + cc, ldm - 4);
+      pre[u] = *reinterpret_cast<const float4*>(Mm + (size_t)gr * ldm + gc);
+    }
+  };
+  fetch(2 * Pbeg);
+  for (int P = Pbeg; 2 * P < j1; ++P) {
+    if (((P - Pbeg) & 15) == 0) {
+      __syncthreads();
+      const bool past = 2 * P + cc > ldm - 4;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float* d = &MT[(threadIdx.x >> 3) + 32 * u][cc];
+        d[0] = past ? 0.f : pre[u].x; d[1] = past ? 0.f : pre[u].y; d[2] = past ? 0.f : pre[u].z; d[3] = past ? 0.f : pre[u].w;
+      }
+      __syncthreads();
+      if (2 * (P + 16) < j1) fetch(2 * (P + 16));
+    }
+    const f32x2* __restrict__ zp = Zp + (size_t)P * H;      // wave-uniform
+    const int cl = 2 * ((P - Pbeg) & 15);
+    const f32x2 mij = {MT[threadIdx.x][cl], MT[threadIdx.x][cl + 1]};
+    const f32x2 rj = {rvec[min(2 * P, n - 1)], rvec[min(2 * P + 1, n - 1)]};
+    f32x2 s = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < H; ++k) s = __builtin_elementwise_fma(f32x2{zi[k], zi[k]}, zp[k], s);
+    float ea = 0.f, e1 = 0.f;      // (the two columns of the pair are added to each other first: one fp64 add per pair and sum)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 2 * P + u;
+      if (valid && j >= j0 && j < j1) {
+        const float a1 = i != j ? fmaxf(s[u], 0.f) : 0.f;
+        const float an = (mij[u] + (i == j ? 1.f : 0.f)) * (ri * rj[u]);
+        ea += expf(an); e1 += expf(a1);
+      }
+    }
+    sa += (double)ea; s1 += (double)e1;
+  }
+  if (valid) {
+    part[((size_t)blockIdx.y * n + i) * 2] = sa;
+    part[((size_t)blockIdx.y * n + i) * 2 + 1] = s1;
+  }
+}
+// lA_i = log sum over the slices of part[.][i][0], l1_i likewise from part[.][i][1]      (rows [row0, row1))
+__global__ void k_kl_stats_fin(int n, int row0, int row1, int nslab, const double* __restrict__ part, float* __restrict__ lseA,
+                               float* __restrict__ lse1) {
+  const int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row1) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < nslab; ++s) { a += part[((size_t)s * n + i) * 2]; b += part[((size_t)s * n + i) * 2 + 1]; }
+  lseA[i] = (float)log(a);
+  lse1[i] = (float)log(b);
+}
+// v_i = sum over the slices of vrow[.][i]: its float copy for the tail, v_i / n in fp64 (the row's share of c2's value) in vsum
+__global__ void k_kl_v_fin(int n, int row0, int row1, int nslab, const double* __restrict__ vrow, double* __restrict__ vsum,
+                           float* __restrict__ vf) {
+  const int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row1) return;
+  double a = 0.0;
+  for (int s = 0; s < nslab; ++s) a += vrow[(size_t)s * n + i];
+  vsum[i] = a / (double)n;      // (batchmean: the row's share of calc_kl's value)
+  vf[i] = (float)a;
 }
 __global__ void k_sum_slabs_rows(int n, int row0, int row1, int h, int nslab, const float* __restrict__ slabs,
                                  float* __restrict__ out, int ldo) {
@@ -623,13 +735,23 @@ __device__ __forceinline__ void rk_sym(const RkRounds& F, int ti, int tj, float 
 // modified_adj1_ij = [i != j] relu(S_ij) recomputed per pair, and
 //   Gs_ij = rank-k + 2 ie'(an) + kmse1 (2 an - F_ij - F_ji) + 2 kmse2 (an - A1_ij)        (an = adj_norm_ij; a1 / a2 unused)
 // vpart: v1 = sum (F - an)^2 (both orientations), v6 as before, and a third block of partials v2 = sum (an - A1)^2.
-template <bool WANT_V, bool MSE>
+// MODE 2 (the fused KL step): calc = calc_kl (:197-198, :483-487: KLDivLoss(batchmean) over rows).  P1 points at softmax(feature_adj)
+// (rows; constant per graph), `mean` / `delta` / `cvec` carry the row statistics lA_i = logsumexp_j an_ij, l1_i = logsumexp_j A1_ij
+// and v_i (k_decode_stats, k_decode_fly<.., 2>), kmse1 / kmse2 carry k1 / n and k2 / n:
+//   d c1 / d an_ij = (k1/n) (exp(an_ij - lA_i) - Fs_ij)            d c2 / d an_ij = (k2/n) exp(an_ij - lA_i) (t_ij - v_i),
+//   t_ij = (an_ij - lA_i) - (A1_ij - l1_i);        Gs_ij = rank-k + 2 ie'(an) + [both, (i, j) + (j, i)]
+// every sum of an (i, j) and a (j, i) quantity is formed from separately rounded products (no fp contraction in that block), so
+// that Gs stays bitwise symmetric.
+// vpart: v1 = sum Fs_ij (log Fs_ij - (an_ij - lA_i)) / n (both orientations), v6 as before (c2's value comes out of the decode).
+template <bool WANT_V, int MODE>
 __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair, int tile_row0, RkRounds F, RkRounds FU, RkRounds FZ,
                                                      const float* __restrict__ M, const float* __restrict__ P1,
                                                      const float* __restrict__ r, const float* __restrict__ mean,
                                                      const float* __restrict__ delta, const float* __restrict__ cvec,
                                                      float a1, float a2, float kie6, float kmse1, float kmse2,
                                                      float* __restrict__ G2, float* __restrict__ ps, double* __restrict__ vpart) {
+  constexpr bool MSE = MODE != 0;      // (S = Zn Zn^T as a third rank-k group, P1 = a constant N x N operand: MSELoss and KL alike)
+  constexpr bool KL = MODE == 2;
   // T: hand-over of the rank-k sums, then the transposed P1 tile, then the column sums: 16.6 KB per block
   __shared__ float T[FT][FT + 1];
   __shared__ double shd[16];
@@ -637,7 +759,7 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
   const int ti = blockIdx.y + tile_row0, tj = blockIdx.x;
   const size_t vslot = (size_t)blockIdx.y * nt + blockIdx.x, vtot = (size_t)gridDim.y * nt;   // v1 partials, then v6 partials
   if (pair && tj > ti) {
-    if (WANT_V && threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; if (MSE) vpart[2 * vtot + vslot] = 0.0; }
+    if (WANT_V && threadIdx.x == 0) { vpart[vslot] = 0.0; vpart[vtot + vslot] = 0.0; if (MODE == 1) vpart[2 * vtot + vslot] = 0.0; }
     return;
   }
   const int bi = ti * FT, bj = tj * FT;
@@ -728,7 +850,25 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
         float val, g6;
         ie_term(an, kie6, val, g6);
         float g;
-        if (MSE) {
+        if (KL) {
+          // No contraction in this block: p + q below must be the sum of two separately rounded products -- fma(eai, ., q) is not
+          // what the thread of the mirrored element computes, fma(eaj, ., p).  (__fmul_rn is a plain `x * y` in this toolchain and
+          // contracts like one: one pair per step and graph came out one ulp apart across the diagonal of a 64 x 64 tile.)
+#pragma clang fp contract(off)
+          const float y = i != j ? fmaxf(accs[a][b], 0.f) : 0.f;      // modified_adj1_ij
+          // (mean = lA, delta = l1, cvec = v: row side mi / di / ci, column side mjs / djs / cjs)
+          const float lai = an - mi, laj = an - mjs[b];               // log_softmax(adj_norm) at (i, j) and at (j, i)
+          const float eai = expf(lai), eaj = expf(laj);
+          const float tij = lai - (y - di), tji = laj - (y - djs[b]);
+          const float p = eai * (tij - ci), q = eaj * (tji - cjs[b]);
+          g = ((acc[a][b] + 2.f * g6) + kmse1 * ((eai + eaj) - (pd[b] + pt))) + kmse2 * (p + q);
+          if (WANT_V) {
+            const double invn = 1.0 / (double)n;
+            if (pd[b] > 0.f) v1 += invn * (double)pd[b] * ((double)logf(pd[b]) - (double)lai);
+            if (mirror && pt > 0.f) v1 += invn * (double)pt * ((double)logf(pt) - (double)laj);
+            v6 += mirror ? 2.0 * (double)val : (double)val;
+          }
+        } else if (MSE) {
           const float y = i != j ? fmaxf(accs[a][b], 0.f) : 0.f;      // modified_adj1_ij
           const float e2 = an - y;
           g = acc[a][b] + 2.f * g6 + kmse1 * ((an - pd[b]) + (an - pt)) + 2.f * kmse2 * e2;
@@ -776,8 +916,8 @@ __global__ __launch_bounds__(256, 4) void k_tail_reduce(int n, int ld, int pair,
   if (WANT_V) {
     v1 = block_sum_d(v1, shd);
     v6 = block_sum_d(v6, shd);
-    if (MSE) v2 = block_sum_d(v2, shd);
-    if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; if (MSE) vpart[2 * vtot + vslot] = v2; }
+    if (MODE == 1) v2 = block_sum_d(v2, shd);
+    if (threadIdx.x == 0) { vpart[vslot] = v1; vpart[vtot + vslot] = v6; if (MODE == 1) vpart[2 * vtot + vslot] = v2; }
   }
 }
 
@@ -1039,24 +1179,52 @@ int fl_decode_slabs(int n, int rows, bool alone) {
 }
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
                   double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7, const float* Mm, int ldm,
-                  const float* rvec, float kmse2) {
+                  const float* rvec, float kmse2, const float* lseA, const float* lse1, double* vrow) {
   const int rows = row1 - row0;
   if (rows <= 0) return 0;
-  const bool mse = Mm != nullptr;      // the fused MSELoss step: + d calc(adj_norm, modified_adj1) / d modified_adj1
+  const bool mse = Mm != nullptr;      // the fused MSELoss / KL step: + d calc(adj_norm, modified_adj1) / d modified_adj1
+  const bool kl = mse && lseA != nullptr;
   const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows, mse);
   const int jper = mse ? (((n + js - 1) / js + 3) & ~3) : (n + js - 1) / js;     // (MSE: the 16-byte loads of M's tiles start on column quads)
   const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);
-#define MCGRA_DECODE(H_)                                                                                                          \
-  do {                                                                                                                            \
-    if (mse && want_v7) LAUNCH((k_decode_fly<H_, true, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \
-    else if (mse) LAUNCH((k_decode_fly<H_, false, true>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \
-    else if (want_v7) LAUNCH((k_decode_fly<H_, true, false>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2); \
-    else LAUNCH((k_decode_fly<H_, false, false>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2);       \
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nb, js), dim3(256), 0, st, n, row0, row1, Z, ldz, zp, kie7, jper, slabs, v7part, nmask, Mm, ldm, rvec, kmse2,
+                       lseA, lse1, vrow);
+  };
+#define MCGRA_DECODE(H_)                                      \
+  do {                                                        \
+    if (kl && want_v7) go(k_decode_fly<H_, true, 2>);         \
+    else if (kl) go(k_decode_fly<H_, false, 2>);              \
+    else if (mse && want_v7) go(k_decode_fly<H_, true, 1>);   \
+    else if (mse) go(k_decode_fly<H_, false, 1>);             \
+    else if (want_v7) go(k_decode_fly<H_, true, 0>);          \
+    else go(k_decode_fly<H_, false, 0>);                      \
   } while (0)
   if (h == 8) MCGRA_DECODE(8); else if (h == 16) MCGRA_DECODE(16); else MCGRA_DECODE(32);
 #undef MCGRA_DECODE
   LAUNCH(k_sum_slabs_rows, g1((size_t)rows * h), dim3(256), st, n, row0, row1, h, js, slabs, GZn, ldg);
   return nb * js;
+}
+// The fused KL step's row statistics for rows [row0, row1): lseA_i = logsumexp_j adj_norm_ij, lse1_i = logsumexp_j modified_adj1_ij.
+// part: fl_decode_slabs(n, rows, true) * n * 2 doubles (<= 64 slices).  Returns the number of column slices (fl_kl_v_fin wants it).
+int fl_decode_stats(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, const float* zpair, const float* Mm, int ldm,
+                    const float* rvec, double* part, float* lseA, float* lse1) {
+  const int rows = row1 - row0;
+  if (rows <= 0) return 0;
+  const int nb = (rows + 255) / 256, js = fl_decode_slabs(n, rows, true);
+  const int jper = ((n + js - 1) / js + 3) & ~3;
+  const f32x2* zp = reinterpret_cast<const f32x2*>(zpair);
+  if (h == 8) LAUNCH((k_decode_stats<8>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, jper, Mm, ldm, rvec, part);
+  else if (h == 16) LAUNCH((k_decode_stats<16>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, jper, Mm, ldm, rvec, part);
+  else LAUNCH((k_decode_stats<32>), dim3(nb, js), dim3(256), st, n, row0, row1, Z, ldz, zp, jper, Mm, ldm, rvec, part);
+  LAUNCH(k_kl_stats_fin, g1((size_t)rows), dim3(256), st, n, row0, row1, js, part, lseA, lse1);
+  return js;
+}
+// v_i of rows [row0, row1) from the per-slice partials k_decode_fly<.., 2> left (fp64 in vsum, float in vf)
+void fl_kl_v_fin(hipStream_t st, int n, int row0, int row1, const double* vrow, double* vsum, float* vf) {
+  const int rows = row1 - row0;
+  if (rows <= 0) return;
+  LAUNCH(k_kl_v_fin, g1((size_t)rows), dim3(256), st, n, row0, row1, fl_decode_slabs(n, rows, true), vrow, vsum, vf);
 }
 
 int fl_tail_tiles(int n) { return (n + FT - 1) / FT; }
@@ -1076,7 +1244,7 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
                    const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
                    float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase, const float* Zn, int ldz,
-                   int hz, float kmse1, float kmse2) {
+                   int hz, float kmse1, float kmse2, bool kl) {
   const int nt = fl_tail_tiles(n), t0 = row0 / FT, t1 = (row1 + FT - 1) / FT;
   if (t1 <= t0) return 0;
   RkPackJobs J{};
@@ -1104,16 +1272,21 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
   if (phase != 2) LAUNCH(k_pack_rk, dim3(nt, J.count), dim3(256), st, n, J);
   if (phase == 1) return nt * (t1 - t0);
   dim3 grid(nt, t1 - t0);
-  if (Zn) {
+  if (Zn && kl) {      // the fused KL step: mean / delta / cvec = the row statistics lA / l1 / v, kmse1 / kmse2 = k1 / n, k2 / n
     if (vpart)
-      LAUNCH((k_tail_reduce<true, true>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, vpart);
+      LAUNCH((k_tail_reduce<true, 2>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, vpart);
     else
-      LAUNCH((k_tail_reduce<false, true>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, nullptr);
+      LAUNCH((k_tail_reduce<false, 2>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, nullptr);
+  } else if (Zn) {
+    if (vpart)
+      LAUNCH((k_tail_reduce<true, 1>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, vpart);
+    else
+      LAUNCH((k_tail_reduce<false, 1>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, kmse1, kmse2, G2, ps, nullptr);
   } else
   if (vpart)
-    LAUNCH((k_tail_reduce<true, false>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, 0.f, 0.f, G2, ps, vpart);
+    LAUNCH((k_tail_reduce<true, 0>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, 0.f, 0.f, G2, ps, vpart);
   else
-    LAUNCH((k_tail_reduce<false, false>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, 0.f, 0.f, G2, ps, nullptr);
+    LAUNCH((k_tail_reduce<false, 0>), grid, dim3(256), st, n, ld, pair ? 1 : 0, t0, F, FU, FZ, M, P1, r, mean, delta, cvec, a1, a2, kie6, 0.f, 0.f, G2, ps, nullptr);
   return nt * (t1 - t0);
 }
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd, const double* sq, float coef,

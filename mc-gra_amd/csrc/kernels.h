@@ -161,7 +161,12 @@ void fl_lrq_post(hipStream_t st, int n, int w, YView Y, const float* Vs, int ldv
                  const double* colsum, const double* mw, const double* msum, float* Q, int ldq);
 int fl_decode_fly(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, float kie7, float* slabs,
                   double* v7part, float* GZn, int ldg, unsigned int* nmask, const float* zpair, bool want_v7 = true,
-                  const float* Mm = nullptr, int ldm = 0, const float* rvec = nullptr, float kmse2 = 0.f);      // Mm != NULL: the fused MSELoss step (+ kmse2 (adj_norm - A1) term)   // zpair: Zn pair-interleaved, (n + 1) / 2 * 2 * h floats (launch_row_normalize writes it)
+                  const float* Mm = nullptr, int ldm = 0, const float* rvec = nullptr, float kmse2 = 0.f,
+                  const float* lseA = nullptr, const float* lse1 = nullptr, double* vrow = nullptr);      // Mm != NULL: the fused MSELoss step (+ kmse2 (adj_norm - A1) term); + lseA / lse1 / vrow: the fused KL step (kmse2 = k2 / n)   // zpair: Zn pair-interleaved, (n + 1) / 2 * 2 * h floats (launch_row_normalize writes it)
+int fl_decode_slabs(int n, int rows, bool alone);
+int fl_decode_stats(hipStream_t st, int n, int row0, int row1, int h, const float* Z, int ldz, const float* zpair, const float* Mm, int ldm,
+                    const float* rvec, double* part, float* lseA, float* lse1);      // the fused KL step: row logsumexp of adj_norm and modified_adj1
+void fl_kl_v_fin(hipStream_t st, int n, int row0, int row1, const double* vrow, double* vsum, float* vf);
 int fl_tail_tiles(int n);
 bool fl_tail_supported(int n, int ld, int kmax);
 int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1, int nfac, const float* const* L,
@@ -169,7 +174,8 @@ int fl_tail_reduce(hipStream_t st, int n, int ld, bool pair, int row0, int row1,
                    const float* Lu, int ldlu, const float* Ru, int ldru, int Ku, const float* M, const float* P1,
                    const float* r, const float* mean, const float* delta, const float* cvec,
                    float a1, float a2, float kie6, float* G2, float* ps, double* vpart, char* rkbuf, int phase = 0,
-                   const float* Zn = nullptr, int ldz = 0, int hz = 0, float kmse1 = 0.f, float kmse2 = 0.f);      // Zn != NULL: the fused MSELoss step (P1 = feature_adj)
+                   const float* Zn = nullptr, int ldz = 0, int hz = 0, float kmse1 = 0.f, float kmse2 = 0.f,
+                   bool kl = false);      // Zn != NULL: the fused MSELoss step (P1 = feature_adj); + kl: the fused KL step (P1 = softmax(feature_adj), mean / delta / cvec = lA / l1 / v)
 size_t fl_tail_pack_bytes(int n);
 void fl_tail_gd(hipStream_t st, int n, int row0, int row1, const float* ps, const float* d, float* gd, const double* sq = nullptr,
                 float coef = 0.f, float* cn_out = nullptr);

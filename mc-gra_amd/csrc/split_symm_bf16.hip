@@ -381,6 +381,8 @@ __device__ __forceinline__ f32x16 plane_mma(u32x4 a, u32x4 b, f32x16 c) {
 constexpr int SPLIT_BETA = 1;      // C += product (instead of C = product)
 constexpr int SPLIT_TRI = 2;       // A == B (Gram product): only tiles on or below the diagonal are computed; tiles below it
                                    // are stored twice, as computed and mirrored, so that C is the full, bitwise symmetric matrix
+constexpr int SPLIT_SINGLE = 8;    // 2-plane fp16 operands, ONE plane product x0 y0 (split2_m16_kernel<true>): the low planes are neither staged nor
+                                   // read nor multiplied -- fp16 accuracy (2^-11 per operand), a third of the matrix-core work.  MCGRA_SPLIT_BF16=1 only.
 constexpr int SPLIT_WRAP = 4;      // the launch covers ALL row panels starting at panel_off and wrapping around: a row-block rank
                                    // computes the row panels of its peers first and its own last (split3_symm: first_tiles)
 // linear tile index -> (tile_m, tile_n): 4-panel groups over the tile grid (gemm_f32.hip), or the lower triangle row by row
@@ -605,7 +607,11 @@ __global__ __launch_bounds__(NW * 64, 1) void split3_symm_kernel(const char* __r
 // Wave tile 128 x 64 = 8 x 4 tiles of 16 x 16 = 128 accumulator registers; 96 MFMAs and 24 fragment reads per wave and
 // step, one barrier per 32 k.  On a power-limited chip the 16 x 16 shape holds a higher clock than 32 x 32
 // (MI355X_MICROARCH.md: 1.12-1.15 x the FLOP/s at equal cycles on random operands).
+// SINGLE: the single-plane product x0 y0 of the same packed operands (the named, non-default `MCGRA_SPLIT_BF16=1` mode: what
+// "bf16 / fp16 MFMA" in BASELINE.json's configs[2] / [4] would mean taken literally).  The low planes are compiled out -- not staged
+// (two of the four 8 KB copies per operand and step), not read from LDS, not multiplied: 32 MFMAs per wave and step instead of 96.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool SINGLE>
 __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
                                                             float* __restrict__ C, int n, int ldc, int nks,
                                                             int tiles_m, int tiles_n, int panel_off, int tile_base,
@@ -650,11 +656,12 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto stage_tile = [&](int kc, int stage) {
     char* sbase = smem + stage * STAGE + (tid & ~63) * 16;          // wave-uniform; the hardware adds lane * 16
+    // (copy i of an operand's 32 KB: chunk i >> 1, plane i & 1 -- SINGLE takes the high planes only)
 #pragma unroll
-    for (int i = 0; i < AOPS; ++i)
+    for (int i = 0; i < AOPS; i += SINGLE ? 2 : 1)
       __builtin_amdgcn_global_load_lds((gptr_t)(ga + (size_t)kc * (2 * OPB) + i * COPY), (lptr_t)(sbase + i * COPY), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < AOPS; ++i)
+    for (int i = 0; i < AOPS; i += SINGLE ? 2 : 1)
       __builtin_amdgcn_global_load_lds((gptr_t)(gb + (size_t)kc * (2 * OPB) + i * COPY), (lptr_t)(sbase + (AOPS + i) * COPY), 16, 0, 0);
   };
   // lane group g: chunk g >> 1, k half g & 1
@@ -664,6 +671,22 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
   auto frag = [&](const char* s, int off) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(s + off)); };
   auto multiply = [&](int stage, auto&& before_reads) {
     const char* s = smem + stage * STAGE;
+    if constexpr (SINGLE) {
+      f16x8 b0[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = frag(s, b_off + j * 256);
+      f16x8 a0 = frag(s, a_off);
+      before_reads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f16x8 n0 = a0;
+        if (i + 1 < 8) n0 = frag(s, a_off + (i + 1) * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc[i][j], 0, 0, 0);
+        a0 = n0;
+      }
+      return;
+    }
     f16x8 b0[4], b1[4];
     f16x8 a1 = frag(s, a_off + PLANE);
 #pragma unroll
@@ -867,9 +890,16 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2) {      // 2-plane fp16 split: split2_m16_kernel (v_mfma_f32_16x16x32_f16, global_load_lds staging)
       constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;
-      hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (beta & SPLIT_SINGLE) {      // the single-plane product of the same operands (MCGRA_SPLIT_BF16=1)
+        hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(split2_m16_kernel<true>, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc, nkc / 2,
+                           tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
+        return hipSuccess;
+      }
+      hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(split2_m16_kernel, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc, nkc / 2, tm,
+      hipLaunchKernelGGL(split2_m16_kernel<false>, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc, nkc / 2, tm,
                          tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
       return hipSuccess;
     }

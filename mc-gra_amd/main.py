@@ -126,12 +126,15 @@ def victim_tensors(m):
 
 def init_distributed(args):
     """Under a launcher that set WORLD_SIZE > 1 (torchrun): join the process group BEFORE anything touches the GPU and take
-    this rank's device.  Returns (rank, world); (0, 1) for a plain single-process run."""
+    this rank's device.  Returns (rank, world); (0, 1) for a plain single-process run.  args._own_group says whether the group
+    was created here (run() then destroys it on the way out; a caller's group is the caller's)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    args._own_group = False
     if world < 2:
         return 0, 1
     import torch.distributed as dist
     if not dist.is_initialized():
+        args._own_group = True
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("MCGRA_SHARED_GPU") == "1":
             dist.init_process_group("gloo")
@@ -145,7 +148,19 @@ def init_distributed(args):
 
 
 def run(args):
+    """main.py:78-324 for one configuration.  Under a launcher every rank calls this; the process group this call created is
+    destroyed on the way out, also when the run fails (a rank that dies with the group alive leaves its peers in a collective)."""
     rank, world = init_distributed(args)
+    try:
+        return _run(args, rank, world)
+    finally:
+        if world > 1 and getattr(args, "_own_group", False):
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def _run(args, rank, world):
     device = torch.device(args.device)
     np.random.seed(args.seed); random.seed(args.seed); torch.manual_seed(args.seed)       # main.py:142-146
     data = Dataset(root=args.dataset_root, name=args.dataset, setting='GCN')
@@ -157,6 +172,9 @@ def run(args):
         if rank == 0:
             os.makedirs(args.saved_data, exist_ok=True)
             np.save(os.path.join(args.saved_data, args.dataset + ".npy"), label_adjacency(labels))
+        if world > 1:      # the file is there when any rank returns (the next command of a script reads it)
+            import torch.distributed as dist
+            dist.barrier()
         return None
     feature_adj = dot_product_decode(features, args.dataset)
     if args.nofeature:

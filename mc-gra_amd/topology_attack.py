@@ -26,6 +26,7 @@ import scipy.sparse as sp
 import torch
 
 from .base_attack import BaseAttack
+from ._lib import McgraNotSupported
 from .engine import AttackEngine
 
 # dot_product_decode2 branch -> mcgra_attack_finalize decode_mode (topology_attack.py:421-467)
@@ -171,11 +172,13 @@ class PGDAttack(BaseAttack):
         return W, b, Wlin, blin, Ws, "relu", "none", False
 
     @staticmethod
-    def _replicated_reason(measure, eps, ori_np, Ws, act, head_act, loss_type, n, dims, w1, w2, num_edges):
-        """None when the row-block sharded fused step covers this configuration (include/mcgra.h: mcgra_attack_shard_*;
-        csrc/attack.hip: the create-time rule), else why it does not."""
-        if measure not in ("HSIC", "MSELoss"):
-            return f"measure {measure} (the fused HSIC and MSELoss steps are the sharded ones)"
+    def _replicated_reason(measure, eps, ori_np, Ws, act, head_act, loss_type, n, dims, w1, w2, num_edges, emb_nlayer=None):
+        """None when the row-block sharded fused step covers this configuration (include/mcgra.h: mcgra_attack_shard_*),
+        else why it does not.  Mirrors the create-time rule of csrc/attack.hip (`fused_ok` / `fused_mse` / `fused_kl` under
+        shard_world > 0) term by term: a configuration this accepts and mcgra_attack_create refuses would fail on every rank
+        instead of running replicated (attack() also catches that refusal, should the two ever drift apart)."""
+        if measure not in ("HSIC", "MSELoss", "KL"):
+            return f"measure {measure} (the fused HSIC, MSELoss and KL steps are the sharded ones)"
         if loss_type != "CE":
             return "loss_type 'CW' takes no step"
         if eps != 0:
@@ -184,12 +187,30 @@ class PGDAttack(BaseAttack):
             return "a non-zero ori_adj (general step)"
         if Ws is not None or act != "relu" or head_act != "none":
             return "a GAT / GraphSAGE victim (Gram evaluation of linear_HSIC)"
-        if measure == "HSIC" and n < 1024 and os.environ.get("MCGRA_SPLIT_BF16", "") not in ("2", "3"):
+        split = os.environ.get("MCGRA_SPLIT_BF16", "")
+        if measure == "HSIC" and split == "0":
+            return "MCGRA_SPLIT_BF16=0 (the product runs on the fp32 kernel: nothing to shard)"
+        if measure == "HSIC" and n < 1024 and split not in ("2", "3"):
             return f"n = {n} < 1024 (the product runs on the fp32 kernel: nothing to shard)"
         if n < 256:
             return f"n = {n} < 256"
-        if max(dims[1:]) > 32:
-            return f"hidden width {max(dims[1:])} > 32"
+        widths = [int(w) for w in dims[1:]]
+        le = min(2, len(widths)) if emb_nlayer is None else int(emb_nlayer)
+        he = widths[le - 1]
+        if max(widths) > 32:
+            return f"hidden width {max(widths)} > 32"
+        if he not in (8, 16, 32):                                  # lr_decode_supported: the per-pair decode's register tiles
+            return f"embedding width {he} (the per-pair decode is built for widths 8, 16 and 32)"
+        hsum = sum((w + 3) & ~3 for w in widths)                   # the concatenated node buffers: rank-k depth of the tail
+        if max(hsum, 2 * he) > 64:                                 # fl_tail_supported: kmax <= 64
+            return (f"summed layer widths {hsum} / twice the embedding width {2 * he} > 64 (rank-k depth of the tail's "
+                    f"panels: e.g. more than four 16-wide layers)")
+        if measure == "HSIC":
+            fc = max([2 * he + 1 + widths[-1]] + [2 * w + 1 for w in widths])
+        else:
+            fc = max(2 * w for w in widths)
+        if ((fc + 3) & ~3) > 64:
+            return f"skinny products of {fc} columns > 64"
         if measure == "HSIC" and w1 == 0 and w2 == 0:
             return "w1 == w2 == 0 (no N x N HSIC term)"
         if num_edges < 0.5 * float(n) * float(n):
@@ -277,7 +298,8 @@ class PGDAttack(BaseAttack):
         dist, world, rank, host_staged = _dist_group()
         plan = stepper = None
         if world > 1:
-            why = self._replicated_reason(measure, eps, ori_np, Ws, act, head_act, self.loss_type, n, dims, w1, w2, num_edges)
+            why = self._replicated_reason(measure, eps, ori_np, Ws, act, head_act, self.loss_type, n, dims, w1, w2, num_edges,
+                                          emb_nlayer)
             if why is None:
                 from .sharded import HipShardBackend, RowBlockPlan, ShardedStepper
                 plan = RowBlockPlan(n, world, rank)
@@ -294,9 +316,20 @@ class PGDAttack(BaseAttack):
             Wlin, blin = _bcast(dist, to_dev(Wlin), host_staged), _bcast(dist, to_dev(blin), host_staged)
             idx_t = _bcast(dist, torch.as_tensor(idx, device=dev), host_staged)
             idx = idx_t.cpu().numpy()
-        eng = AttackEngine(n, dims, int(Wlin.shape[0]), emb_nlayer, measure, weight_supervised,
-                           (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev,
-                           act=act, head_act=head_act, has_self=Ws is not None, fin_layers=fin_layers, plan=plan)
+        mk = lambda pl: AttackEngine(n, dims, int(Wlin.shape[0]), emb_nlayer, measure, weight_supervised,
+                                     (w1, w2, 0, 0, 0, w6, w7, w8, w9, w10), lr_ori, num_edges, len(idx), eps=eps, device=dev,
+                                     act=act, head_act=head_act, has_self=Ws is not None, fin_layers=fin_layers, plan=pl)
+        try:
+            eng = mk(plan)
+        except McgraNotSupported as e:
+            # the create-time rule decides the same way on every rank (configuration only): all of them fall back together
+            if plan is None:
+                raise
+            if rank == 0:
+                print(f"[mc-gra_amd] PGDAttack.attack under {world} ranks runs REPLICATED: the engine refused the row-block "
+                      f"plan ({e})", file=sys.stderr, flush=True)
+            plan = None
+            eng = mk(None)
         eng.set_model(W, b, Wlin, blin, Ws)
         eng.set_graph(_dense_np(ori_features), adj_np, ori_np, fadj, lab, idx)
         if self._adj_changes_init is not None:

@@ -15,7 +15,24 @@ def case_of(spec):
     """The synthetic problem of a spec dict (same generator as the single-process sharding tests)."""
     from tests import helpers as H
     kw = {"weight_param": tuple(spec["weight_param"])} if spec.get("weight_param") else {}
-    return H.synthetic_case(spec["n"], 11, tuple(spec["widths"]), 4, seed=spec["seed"], **kw)
+    if spec.get("measure"):
+        kw["measure"] = spec["measure"]
+    return H.synthetic_case(spec["n"], spec.get("nfeat", 11), tuple(spec["widths"]), 4, seed=spec["seed"], **kw)
+
+
+def join_group(rank, world, rccl):
+    """The rank's process group and device: gloo with every rank on cuda:0 (host-staged exchanges: the one-GPU test mode), or --
+    rccl, on a box with >= world devices -- backend `nccl` (= RCCL) with rank k on cuda:k, the exchanges on device memory."""
+    import torch
+    import torch.distributed as dist
+    if rccl:
+        dev = torch.device(f"cuda:{rank}")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(dev)
+    return dist, dev
 
 
 def masked_weights(z):
@@ -34,22 +51,20 @@ def run_rank(rank, world, port, spec, out):
         for k, v in spec.get("env", {}).items():
             os.environ[k] = v
         import numpy as np
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        torch.cuda.set_device(0)
+        rccl = bool(spec.get("rccl"))
+        dist, dev = join_group(rank, world, rccl)
         import mcgra_loader
         pkg = mcgra_loader.load()
         from mc_gra_amd import sharded as S
         from tests import helpers as H
         z = case_of(spec)
         plan = S.RowBlockPlan(spec["n"], world, rank)
-        eng = H.engine_from(pkg, z, plan=plan)
+        eng = H.engine_from(pkg, z, device=str(dev), plan=plan)
         masked = spec.get("masked_steps", 0)
         if masked:
             w = masked_weights(z)
             eng.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
-        st = S.ShardedStepper(S.HipShardBackend(eng, plan), plan, dist=dist, host_staged=True)
+        st = S.ShardedStepper(S.HipShardBackend(eng, plan), plan, dist=dist, host_staged=not rccl)
         res = {}
         for t in range(spec["steps"]):
             if masked and t == masked:          # back to the original weights: the decode stops masking
@@ -160,7 +175,7 @@ def run_workload_rank(rank, world, port, spec, out):
         raise
 
 
-def run_cora_class(name, epochs=None):
+def run_cora_class(name, epochs=None, device="cuda:0", measure=None):
     """PGDAttack.attack on a Cora fixture with the reference-trained weights it carries (tests/test_gpu_parity.py:_run_cora):
     returns (fixture, modified_adj, AUC, model).  Under an initialised process group the class shards the attack itself."""
     import argparse
@@ -178,9 +193,11 @@ def run_cora_class(name, epochs=None):
     victim, emb = H.FakeGCN(w), H.FakeGCN(w)
     X, adj, lab = z["features"], z["adj"], z["labels"]
     fadj = H.cora_feature_adj(X)
-    d = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")
+    d = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=device)
+    if measure is not None:      # (the fixture's graph, weights and start under another `calc`: no reference AUC to hold it to)
+        z["measure"] = np.array(measure)
     Y_A, H_A2 = E.gcn_forward(d(X), d(adj), [d(x) for x in w.W], [d(x) for x in w.b], d(w.Wlin), d(w.blin), emb_nlayer=2)
-    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=H_A2, Y_A=Y_A, nnodes=adj.shape[0], loss_type="CE", device="cuda:0")
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=H_A2, Y_A=Y_A, nnodes=adj.shape[0], loss_type="CE", device=device)
     if H.a0_of(z) is not None:
         model.adj_changes = H.a0_of(z)
     args = argparse.Namespace(max_eval=100, lr=0, dataset="cora", eps=0, measure=str(z["measure"]), useH_A=True, useY_A=True,
@@ -203,11 +220,8 @@ def run_class_rank(rank, world, port, spec, out):
                           LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
         os.environ.pop("MCGRA_KEEP_GSYM", None)
         import numpy as np
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        torch.cuda.set_device(0)
-        z, final, auc, model = run_cora_class(spec["name"], spec.get("epochs"))
+        dist, dev = join_group(rank, world, bool(spec.get("rccl")))
+        z, final, auc, model = run_cora_class(spec["name"], spec.get("epochs"), device=str(dev), measure=spec.get("measure"))
         sp = z["sample_pos"]
         np.savez(f"{out}.rank{rank}.npz", auc=auc, final_sample=final[sp[:, 0], sp[:, 1]], final_sum=final.astype(np.float64).sum(),
                  acc_test=np.array(model.history.get("acc_test", [])), sharded_world=model.history["path"]["sharded_world"],
@@ -256,8 +270,9 @@ def run_main_rank(rank, world, port, argv, n, cwd, out):
         with open(f"{out}.rank{rank}.json", "w") as fh:
             json.dump(res, fh)
         import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        if dist.is_initialized():      # (main.run destroys the group it created itself)
+            dist.barrier()
+            dist.destroy_process_group()
     except Exception:
         with open(f"{out}.rank{rank}.err", "w") as fh:
             fh.write(traceback.format_exc())

@@ -239,7 +239,15 @@ def test_class_finds_the_process_group_and_knows_what_it_can_shard():
               dims=[1433, 16, 16], w1=0.01, w2=0.01, num_edges=1e30)
     assert why(**ok) is None
     assert why(**dict(ok, measure="MSELoss", n=300, w1=0, w2=0)) is None          # the fused MSELoss step: any n >= 256
-    for change, word in ((dict(measure="KL"), "KL"), (dict(measure="MSELoss", n=200), "256"), (dict(eps=0.1), "eps"), (dict(ori_np=object()), "ori_adj"),
+    assert why(**dict(ok, measure="KL", n=300)) is None                           # the fused KL step (round 6) likewise
+    assert why(**dict(ok, dims=[1433, 16, 16, 16, 16])) is None                   # four 16-wide layers: summed widths 64
+    # the create-time rule of csrc/attack.hip, term by term (`torchrun main.py --nlayers 5`, a victim with nhid = 24)
+    for change, word in ((dict(dims=[1433, 16, 16, 16, 16, 16]), "summed layer widths 80"), (dict(dims=[1433, 24, 24]), "embedding width 24"),
+                         (dict(dims=[1433, 32, 32, 32]), "summed"), (dict(dims=[1433, 16, 16, 16], emb_nlayer=3), None),
+                         (dict(measure="MSELoss", dims=[1433, 24, 24]), "embedding width 24")):
+        got = why(**dict(ok, **change))
+        assert (got is None) if word is None else (got is not None and word in got), (change, got)
+    for change, word in ((dict(measure="DP"), "DP"), (dict(measure="MSELoss", n=200), "256"), (dict(eps=0.1), "eps"), (dict(ori_np=object()), "ori_adj"),
                          (dict(Ws=[1]), "GraphSAGE"), (dict(act="elu"), "GAT"), (dict(n=300), "1024"),
                          (dict(dims=[10, 64, 64]), "width"), (dict(w1=0, w2=0), "w1"), (dict(num_edges=5.0), "projection"),
                          (dict(loss_type="CW"), "CW")):

@@ -50,11 +50,34 @@ def _run_ranks(target, world, args, out, timeout=600):
     assert not errs, "\n".join(errs)
 
 
-@pytest.mark.parametrize("world,n,wp", [(2, 1100, None), (3, 1100, None), (2, 1283, NXN_ONLY)])
-def test_row_block_ranks_as_processes_match_the_monolithic_step(pkg, world, n, wp, tmp_path):
+def _two_devices():
+    import torch
+    return torch.cuda.device_count() >= 2      # (counting devices does not initialise the GPU)
+
+
+needs_two_gpus = pytest.mark.skipif(not _two_devices(), reason="needs two MI355X: one device per rank, backend nccl (RCCL)")
+
+
+# (2, 4096, .., "l3"): BASELINE.json configs[4]'s shape family -- a 3-layer victim on 256 attributes -- across a process boundary
+# (three layers were sharded at n = 1030 in lockstep only); "kl" / "mse": the elementwise fused steps
+@pytest.mark.parametrize("world,n,wp,kind", [(2, 1100, None, ""), (3, 1100, None, ""), (2, 1283, NXN_ONLY, ""), (2, 4096, None, "l3"),
+                                             (2, 1100, None, "kl"), (3, 1100, None, "mse"),
+                                             pytest.param(2, 1100, None, "rccl", marks=needs_two_gpus),
+                                             pytest.param(2, 4096, None, "l3+rccl", marks=needs_two_gpus),
+                                             pytest.param(2, 1100, None, "kl+rccl", marks=needs_two_gpus)])
+def test_row_block_ranks_as_processes_match_the_monolithic_step(pkg, world, n, wp, kind, tmp_path):
     """Union of the ranks' rows == the monolithic fused step, step by step (3 steps + monitor, adopted forward), with the
-    collectives executed by a process group between separate processes; scalars identical on every rank."""
-    spec = dict(n=n, widths=(16, 16) if wp is None else (16, 8), seed=n, steps=3, weight_param=wp)
+    collectives executed by a process group between separate processes; scalars identical on every rank.  The "rccl" cases run
+    where the box has two devices: rank k on cuda:k, backend nccl, the exchanges on views of the engine's arena in device memory --
+    `all_gather_into_tensor` in place on the rank's own chunk, `all_to_all_single` on byte slices (sharded.py:73-83)."""
+    spec = dict(n=n, widths=(16, 16) if wp is None else (16, 8), seed=n, steps=3, weight_param=wp, rccl="rccl" in kind)
+    if "l3" in kind:
+        spec.update(widths=(16, 16, 16), nfeat=256)
+    if "kl" in kind:
+        spec["measure"] = "KL"
+    if "mse" in kind:
+        spec["measure"] = "MSELoss"
+    elem = "kl" in kind or "mse" in kind
     out = str(tmp_path / "mp")
     _run_ranks(W.run_rank, world, (spec,), out)
     z = W.case_of(spec)
@@ -71,11 +94,16 @@ def test_row_block_ranks_as_processes_match_the_monolithic_step(pkg, world, n, w
         ref = np.array([a[k] for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "clamp_sum")])
         for r in ranks:
             assert np.array_equal(r[f"scal{t}"], ranks[0][f"scal{t}"]), "scalars are identical on every rank"
-            assert np.allclose(r[f"scal{t}"], ref, rtol=3e-5, atol=1e-6 * max(1.0, abs(a["loss"]))), (t, r[f"scal{t}"], ref)
+            # ("l3": 256 binary attributes through three un-normalised layers -- the H_A prior runs on the raw adjacency -- give
+            # activations of 1e3 ... 1e4 and c9 = |Xc^T Yc|^2 = 5e14, a squared CENTRED cross-covariance: the ranks' forward sums its
+            # products' slabs in another order than the monolithic step and the centring amplifies that to 7e-5 of the term)
+            assert np.allclose(r[f"scal{t}"], ref, rtol=3e-4 if "l3" in kind else 3e-5, atol=1e-6 * max(1.0, abs(a["loss"]))), (t, r[f"scal{t}"], ref)
     assert all(int(r["fused_steps"]) == 3 and int(r["general_steps"]) == 0 for r in ranks) and mono.fused_steps() == 3
     nl = len(spec["widths"])
-    # 8 per step + monitor at L = 2, + 1: loss terms asked for, + the first step's own forward (no monitor call in front of it)
-    assert all(int(r["exchanges"]) == 3 * (2 * nl + 4 + 1) + (nl + 1) for r in ranks)
+    # 8 per step + monitor at L = 2, + 1: loss terms asked for, + the first step's own forward (no monitor call in front of it);
+    # the elementwise steps have no product to hand over and no low-rank factors: 6 (MSELoss) / 7 (KL: + the row statistics)
+    per_step = 2 * nl + (4 if not elem else (3 if "kl" in kind else 2))
+    assert all(int(r["exchanges"]) == 3 * (per_step + 1) + (nl + 1) for r in ranks), [int(r["exchanges"]) for r in ranks]
 
 
 def test_row_block_processes_masked_steps_then_fused_again(pkg, tmp_path, monkeypatch):
@@ -172,6 +200,33 @@ def test_bench_world2_branch_with_the_fused_mseloss_step(tmp_path):
     assert m["collectives_timed_per_step"] == 6 and m["alltoall_ms_per_step"]["max"] == 0 and m["allgather_ms_per_step"]["mean"] > 0
     assert m["product_ms_per_rank"] == [None, None] and m["compute_only_steps_all_fused"] and not m.get("errors")
     assert m["state_check"]["ok"] is True
+
+
+@needs_two_gpus
+def test_bench_gpus2_over_rccl_on_two_devices(tmp_path):
+    """`python bench.py --gpus 2 --steps 5` as the driver's multi-GPU tier runs it, on a box with two devices: no MCGRA_SHARED_GPU,
+    backend nccl (RCCL over xGMI), rank k on cuda:k.  The line explains itself (collective time by kind, the all-to-all of the
+    product's tile blocks among them) and rank 0's replay of the attack on one rank agrees with the two-rank state."""
+    out = str(tmp_path / "rccl2")
+    argv = ["--gpus", "2", "--steps", "5", "--warmup", "2", "--workload", "synthetic-4k-hsic", "--no-shard-probe"]
+    ctx = mp.get_context("forkserver")
+    p = ctx.Process(target=W.run_bench_plain, args=(argv, out, {"OMP_NUM_THREADS": "2"}))
+    p.start()
+    p.join(900)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("timeout")
+    err = out + ".rank0.err"
+    assert p.exitcode == 0, open(err).read() if os.path.exists(err) else f"exit code {p.exitcode}"
+    lines = [ln for ln in open(out + ".stdout").read().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "strong"
+    assert line["config"]["fused_steps"] == 7 and line["config"]["general_steps"] == 0
+    assert "gloo" not in line["config"]["parallelism"]
+    m = line["multi_rank"]
+    assert m["state_check"]["ok"] is True
+    assert m["alltoall_ms_per_step"]["mean"] > 0 and m["allgather_ms_per_step"]["mean"] > 0
 
 
 def test_plain_bench_gpus2_starts_its_own_ranks(tmp_path):
@@ -286,29 +341,36 @@ def test_plain_bench_measures_its_traffic_live(tmp_path):
 
 # ---- the sharded step behind the class surface and main.py (north_star: "keep the PGDAttack / BaseAttack class surface and
 # main.py entry" AND "partition ... row-block across up to 8 MI355X") ------------------------------------------------------
-@pytest.mark.parametrize("fixture", ["cora_hsic_sparse", "cora_mse_short"])
-def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, fixture):
+@pytest.mark.parametrize("fixture,kind", [("cora_hsic_sparse", ""), ("cora_mse_short", ""), ("cora_mse_short", "kl"),
+                                          pytest.param("cora_hsic_sparse", "rccl", marks=needs_two_gpus)])
+def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, fixture, kind):
     """Two processes call PGDAttack.attack on Cora (reference-trained weights of the fixture: HSIC from the sparse start, and the
     README's MSELoss configuration -- BASELINE.json configs[0] -- for 20 epochs) under a process group: the class builds
     RowBlockPlan + HipShardBackend + ShardedStepper itself, every step is a fused row-block step (the MSELoss one exchanges no
     N x N data at all), both ranks return the SAME modified_adj, its AUC equals the 1-process run's to 1e-6 (MSELoss: 1e-5) and the
     REFERENCE's (the fixture's) to 1e-4."""
+    # "kl": the fixture's graph, reference-trained weights and start with calc = calc_kl (round 6: the fused KL step, sharded like
+    # the MSELoss one) -- no reference AUC for that combination: the two-rank run is held to the one-process run
+    kl = kind == "kl"
     out = str(tmp_path / "cls")
-    _run_ranks(W.run_class_rank, 2, (dict(name=fixture),), out)
-    z, final1, auc1, model1 = W.run_cora_class(fixture)
+    _run_ranks(W.run_class_rank, 2, (dict(name=fixture, rccl=kind == "rccl", measure="KL" if kl else None, epochs=8 if kl else None),), out)
+    z, final1, auc1, model1 = W.run_cora_class(fixture, epochs=8 if kl else None, measure="KL" if kl else None)
     assert model1.history["path"]["sharded_world"] == 1
     ranks = [np.load(f"{out}.rank{r}.npz") for r in range(2)]
     epochs = int(z["epochs"])
+    if kl:
+        assert model1.history["path"]["fused_steps"] == epochs and model1.history["path"]["general_steps"] == 0
     for r in ranks:
         assert int(r["sharded_world"]) == 2 and int(r["fused_steps"]) == epochs and int(r["general_steps"]) == 0
-        assert int(r["collectives"]) >= (8 if "hsic" in fixture else 6) * epochs
+        assert int(r["collectives"]) >= (7 if kl else 8 if "hsic" in fixture else 6) * epochs
         # (the row-block ranks sum the decode's slabs and the tail's tiles in another order than the one-process step: not the
         # same bits.  HSIC from the sparse start keeps the two runs' AUC within 1e-6; the 20 MSELoss epochs amplify such
         # differences the way they do between the reference, the fp32 and the fp64 oracle -- 6e-6 apart at this horizon,
         # test_cora_mse_checkpoints -- measured 3.8e-6.  Each rank's gradient rows against the one-process step, per step:
         # test_sharded_mse_ranks_match_monolithic_step.)
         assert abs(float(r["auc"]) - auc1) <= (1e-6 if "hsic" in fixture else 1e-5), (float(r["auc"]), auc1)
-        assert abs(float(r["auc"]) - float(z["auc"])) <= 1e-4, (float(r["auc"]), float(z["auc"]))
+        if not kl:
+            assert abs(float(r["auc"]) - float(z["auc"])) <= 1e-4, (float(r["auc"]), float(z["auc"]))
         assert len(r["acc_test"]) == epochs and np.allclose(r["acc_test"], model1.history["acc_test"])
     assert np.array_equal(ranks[0]["final_sample"], ranks[1]["final_sample"]), "every rank returns the same modified_adj"
     assert float(ranks[0]["final_sum"]) == float(ranks[1]["final_sum"])

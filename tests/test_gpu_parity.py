@@ -1072,6 +1072,35 @@ def test_split_bf16_matches_fp32_path(pkg, case, mode, monkeypatch):
     assert torch.equal(e1.get_adj_changes(), e2.get_adj_changes())
 
 
+def test_single_plane_product_is_a_named_mode_with_fp16_accuracy(pkg, monkeypatch):
+    """MCGRA_SPLIT_BF16=1 (round 6; the arithmetic "bf16 MFMA" in BASELINE.json's configs[2] / [4] names, taken literally): the one
+    N x N x N product of a fused low-rank step as the SINGLE plane product x0 y0 of the same fp16 x 2 operands -- the low planes
+    are compiled out of the kernel, not zeroed.  Never a default: an engine created without the variable runs the 3-product split
+    (product_mode 3 from n = 1024, the fp32 kernel below).  With it: product_mode 1, every step fused, and the first gradient
+    sits at fp16 distance from the default's -- between 1e-5 (it IS a different arithmetic: the test would not see a mode that
+    silently ran the default) and 5e-3 of its largest magnitude on a workload whose N x N terms carry the gradient."""
+    import torch
+    z = _synthetic_case(1283, 11, (16, 16), 4, seed=1283, weight_param=NXN_ONLY)
+    ref = H.engine_from(pkg, z)
+    assert ref.product_mode() == 3
+    monkeypatch.setenv("MCGRA_SPLIT_BF16", "1")
+    one = H.engine_from(pkg, z)
+    monkeypatch.delenv("MCGRA_SPLIT_BF16")
+    assert one.product_mode() == 1
+    for t in range(3):
+        a, b = ref.step(want_scalars=True), one.step(want_scalars=True)
+        gr, gs = ref.buffer("G_sym").cpu().numpy(), one.buffer("G_sym").cpu().numpy()
+        err = np.abs(gs - gr).max() / np.abs(gr).max()
+        assert 1e-5 < err <= 5e-3, (t, err)
+        assert b["loss"] == pytest.approx(a["loss"], rel=1e-3)
+        gsf = one.buffer("G_sym")
+        assert bool((gsf == gsf.T).all())
+        one.set_adj_changes(ref.get_adj_changes())
+    assert one.fused_steps() == 3 and ref.fused_steps() == 3
+    small = H.engine_from(pkg, _synthetic_case(300, 11, (16, 16), 4, seed=300))
+    assert small.product_mode() == 0
+
+
 @pytest.mark.parametrize("case", ["s200_hsic_init", "s200_mse", "s48_kl", "s48_gat_hsic_init"])
 def test_monitor_forward_reuse_is_bit_identical(pkg, case, monkeypatch):
     """The next step adopts the monitoring forward of :290-296 instead of recomputing it: same bits as without reuse,
@@ -1608,6 +1637,36 @@ def test_kde_steps_of_a_large_graph_match_the_oracle(pkg, torch_, n, widths, ncl
     eng.close()
 
 
+def test_kde_columns_follow_the_reach_of_feature_adj(pkg, torch_):
+    """The N x N KDE terms are evaluated on the columns whose bins the operands' values can reach in float32: 8 for the operands
+    the reference builds (all <= 1).  A caller-supplied feature_adj with larger entries moves that bound -- set_graph measures
+    max |feature_adj| and widens the column count (here entries of 9.0 / 8.7 in column 9 and 10.9 in column 11: 16 columns) --
+    and values whose bins lie beyond the 32-column tables are refused by name instead of being dropped silently."""
+    z = H.synthetic_case(300, 11, (16, 16), 4, seed=3, measure="KDE")
+    g0 = None
+    for wide in (False, True):
+        zz = dict(z)
+        if wide:
+            F = z["feature_adj"].copy()
+            F[5, 9], F[17, 9], F[40, 11], F[41, 11] = 9.0, 8.7, 10.9, 11.2
+            zz["feature_adj"] = F
+        eng, o = H.engine_from(pkg, zz), H.oracle_from(zz)
+        sc = eng.step(want_scalars=True)
+        o.step()
+        g, g_or = eng.buffer("G_sym").cpu().numpy(), o.last["G_sym"]
+        assert np.abs(g - g_or).max() <= 1e-4 * np.abs(g_or).max(), (wide, np.abs(g - g_or).max(), np.abs(g_or).max())
+        assert sc["c1"] == pytest.approx(o.last["terms"]["c1"], rel=1e-4, abs=2e-8 * z["weight_param"][0] * 1e5), wide
+        if not wide:
+            g0, c10 = g_or, o.last["terms"]["c1"]
+        else:      # the wide entries do move the term: the test sees the columns beyond the eighth
+            assert abs(o.last["terms"]["c1"] - c10) > 1e-3 * abs(c10) or np.abs(g_or - g0).max() > 1e-3 * np.abs(g0).max()
+        eng.close()
+    F = z["feature_adj"].copy()
+    F[0, 0] = 40.0
+    with pytest.raises(pkg._lib.McgraNotSupported, match="max .feature_adj. = 40"):
+        H.engine_from(pkg, dict(z, feature_adj=F))
+
+
 @pytest.mark.parametrize("wp", [(0.01, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000), (0.01, 0, 0, 0, 0, 10, 10, 0, 10, 0)], ids=["all", "c1only"])
 def test_gram_products_beside_the_step_are_bit_identical(pkg, monkeypatch, wp):
     """Gram-evaluation steps (here MCGRA_NO_LOWRANK=1 at n = 1100) run their four N x N x N products on the side stream -- Kx
@@ -1635,16 +1694,20 @@ def test_gram_products_beside_the_step_are_bit_identical(pkg, monkeypatch, wp):
 
 
 # ---- the fused MSELoss step (round 5): calc = MSELoss evaluated from M, feature_adj, r and Zn -- no N x N intermediate ------
+# ---- and the fused KL step (round 6): calc = calc_kl (:197-198, :483-487), the same data flow + per-row softmax statistics
+@pytest.mark.parametrize("measure", ["MSELoss", "KL"])
 @pytest.mark.parametrize("n,widths,wp", [
     (1100, (16, 16), None), (300, (16, 16), NXN_ONLY), (515, (8, 8), (0, 0.01, 0, 0, 0, 10, 10, 0, 10, 1000)),
     (1030, (16, 16, 16), None), (700, (16, 32), (0.01, 0, 0, 0, 0, 0, 10, 0, 10, 0))])
-def test_fused_mse_step_matches_general_path_and_oracle(pkg, n, widths, wp, monkeypatch):
+def test_fused_mse_step_matches_general_path_and_oracle(pkg, n, widths, wp, measure, monkeypatch):
     """measure = MSELoss through attack_fused.hip (adj_norm, modified_adj1 and the gradients w.r.t. them are never stored: the
     decode carries d / d modified_adj1, the tail's first pass d / d adj_norm with feature_adj in the place of the HSIC product
     and S = Zn Zn^T as a third rank-k group) against the general step (MCGRA_NO_FUSED_LR=1) and the oracle, teacher-forced,
-    with the monitoring forward adopted in between: mirrored gradient, every loss term, the updated adjacency."""
+    with the monitoring forward adopted in between: mirrored gradient, every loss term, the updated adjacency.
+    measure = KL: the same through the fused KL step (softmax(feature_adj) in feature_adj's place, the row statistics of
+    adj_norm and modified_adj1 from one more per-pair pass, an asymmetric per-pair term symmetrised in the decode and the tail)."""
     kw = {} if wp is None else {"weight_param": wp}
-    z = _synthetic_case(n, 11, widths, 4, seed=n, measure="MSELoss", **kw)
+    z = _synthetic_case(n, 11, widths, 4, seed=n, measure=measure, **kw)
     fused = H.engine_from(pkg, z)
     monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
     gen = H.engine_from(pkg, z)
@@ -1658,9 +1721,16 @@ def test_fused_mse_step_matches_general_path_and_oracle(pkg, n, widths, wp, monk
         scale = np.abs(gr).max()
         assert np.abs(gf - gg).max() <= 3e-5 * scale, (t, np.abs(gf - gg).max() / scale)
         assert np.abs(gf - gr).max() <= 1e-4 * scale, (t, np.abs(gf - gr).max() / scale)
+        # (KL: the VALUE of calc_kl on the N x N operands is sum p (log p - log_softmax(adj_norm)) / n ~ 1e-2 -- a difference of
+        # row log-sum-exps of ~ log n that agree to three digits, so the float32 rounding of a row's logsumexp (6e-8 x log n) shows
+        # at 4e-5 of the value; the two paths sum the rows' exponentials differently -- fp64 partials here, fp32 block sums there)
+        vtol = 2e-4 if measure == "KL" else 2e-5
         for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "origin_loss"):
-            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-6 * max(1.0, abs(b["loss"]))), (t, k, a[k], b[k])
+            assert a[k] == pytest.approx(b[k], rel=vtol if k in ("loss", "c1", "c2") else 2e-5, abs=1e-6 * max(1.0, abs(b["loss"]))), (t, k, a[k], b[k])
         assert abs(a["loss"] - orc.last["loss"]) <= 2e-4 * abs(orc.last["loss"]) + 1e-5
+        if measure == "KL":
+            for k in ("c1", "c2"):
+                assert a[k] == pytest.approx(orc.last["terms"].get(k, 0.0), rel=2e-4, abs=1e-6 * max(1.0, abs(b["loss"]))), (t, k)
         Mf = fused.buffer("M")
         assert bool((Mf == Mf.T).all()), "the learnable adjacency must stay symmetric bit for bit"
         gsf = fused.buffer("G_sym")
@@ -1676,12 +1746,13 @@ def test_fused_mse_step_matches_general_path_and_oracle(pkg, n, widths, wp, monk
     assert fused.path_stats() == gen.path_stats() == {"lowrank_steps": 0, "general_steps": 0}
 
 
-def test_fused_mse_free_run_and_finalize(pkg, monkeypatch):
-    """Free-running fused MSELoss steps with and without monitor calls in between give the same bits, and the post-loop
+@pytest.mark.parametrize("measure", ["MSELoss", "KL"])
+def test_fused_mse_free_run_and_finalize(pkg, measure, monkeypatch):
+    """Free-running fused MSELoss (KL) steps with and without monitor calls in between give the same bits, and the post-loop
     ensemble after a fused loop equals the one after the same loop on the general path (em_last stands in for
     embedding(features, adj_norm))."""
     import torch
-    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5, measure="MSELoss")
+    z = _synthetic_case(1100, 11, (16, 16), 4, seed=5, measure=measure)
     e1, e2 = H.engine_from(pkg, z), H.engine_from(pkg, z)
     monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
     e3 = H.engine_from(pkg, z)
@@ -1702,16 +1773,17 @@ def test_fused_mse_free_run_and_finalize(pkg, monkeypatch):
     assert e1.fused_steps() == 3 and e3.fused_steps() == 0
 
 
+@pytest.mark.parametrize("measure", ["MSELoss", "KL"])
 @pytest.mark.parametrize("n,widths,world,wp", [(1100, (16, 16), 2, None), (1100, (16, 16), 3, (0.01, 1.0, 0, 0, 0, 10, 10, 0, 10, 1000)),
                                                (600, (16, 16, 16), 4, None)])
-def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world, wp):
-    """The fused MSELoss step as `world` row-block ranks in lockstep: no N x N exchange at all (all-gathers of node arrays with
-    the partial scalars in their lane only) -- the union of the ranks' rows equals the monolithic fused step, mirrored entries
-    bit for bit across the ranks, loss terms identical on every rank."""
+def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world, wp, measure):
+    """The fused MSELoss (KL) step as `world` row-block ranks in lockstep: no N x N exchange at all (all-gathers of node arrays with
+    the partial scalars in their lane only; KL: one more gather, of the rows' softmax statistics) -- the union of the ranks' rows
+    equals the monolithic fused step, mirrored entries bit for bit across the ranks, loss terms identical on every rank."""
     from mc_gra_amd import sharded as S
     import torch
     kw = {} if wp is None else {"weight_param": wp}
-    z = _synthetic_case(n, 11, widths, 4, seed=n, measure="MSELoss", **kw)
+    z = _synthetic_case(n, 11, widths, 4, seed=n, measure=measure, **kw)
     mono = H.engine_from(pkg, z)
     plans, bks = _shard_engines(pkg, z, world, joint=world == 3)
     lr = float(z["lr"])
@@ -1739,3 +1811,4 @@ def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world, wp):
             assert all(b[k] == sc[0][k] for b in sc), "scalars are identical on every rank"
     assert all(b.eng.fused_steps() == 3 for b in bks) and mono.fused_steps() == 3
     assert all(b.eng.cut_product_steps() == 0 for b in bks)
+    # (the collectives per step are counted across a process boundary: tests/test_gpu_multiproc.py -- 6 for MSELoss, 7 for KL)

@@ -113,7 +113,16 @@ def _class_run(pkg, z, epochs, noise_seed=None, monkeypatch=None):
     model.attack(_args(z), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]), z["feature_adj"], 0, 0, 0,
                  None, None, z["idx_test"], z["adj"], z["features"], np.zeros_like(z["adj"]), lab, z["idx_attack"],
                  float(z["num_edges"]), 0, epochs=epochs, label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    _check_path(z, model.history["path"], epochs)
     return model.modified_adj.cpu().numpy()
+
+
+def _check_path(z, path, epochs):
+    """calc = MSELoss (16 README lines) and calc = calc_kl (13 lines; round 6) run the fused elementwise step of attack_fused.hip on
+    every graph the tail's 64 x 64 tile pairs cover (n >= 256: all datasets but brazil, n = 131) when eps == 0: every step of such a
+    line is a fused one, none falls back."""
+    if str(z["measure"]) in ("MSELoss", "KL") and float(z["eps"]) == 0 and len(z["labels"]) >= 256:
+        assert path["fused_steps"] == epochs and path["general_steps"] == 0, (str(z["measure"]), path)
 
 
 @pytest.mark.parametrize("name", [c for c in CASES if "_eps" not in c])
@@ -147,11 +156,12 @@ def test_readme_line_at_a_longer_horizon(pkg, epochs, name, monkeypatch):
     auc = O.metric_pool(z["adj"], final, z["idx_attack"])
     ref, ref64 = float(hz[f"{name}_auc"]), float(hz[f"{name}_auc64"])
     # within 1e-4 of the reference's run; where its two evaluations are D > 1e-4 apart the AUC is not determined more finely than
-    # that: within 2 D of the reference's run (the rule of test_cora_readme_100_epochs: a third evaluation of a noise-amplifying
-    # iteration is not bound by the distance of the first two -- brazil line 149, lr = 1 with eps != 0: 1.9e-3 where D is 1.2e-3),
-    # or within 1e-4 of the interval the two span
+    # that: within D + 1e-4 of the reference's run (round 5 allowed 2 D; every line it measured sat inside 1 D), or within 1e-4 of
+    # the interval the two span.  One line keeps round 5's 2 D: brazil line 149 -- lr = 1 with eps != 0, seeded noise -- where a
+    # third evaluation of the noise-amplifying iteration measured 1.9e-3 with D = 1.2e-3 (the rule of test_cora_readme_100_epochs)
     D = abs(ref - ref64)
-    assert abs(auc - ref) <= max(1e-4, 2 * D) or min(ref, ref64) - 1e-4 <= auc <= max(ref, ref64) + 1e-4, (name, epochs, auc, ref, ref64)
+    bar = max(1e-4, 2 * D) if name == "readme_brazil_kl_all_eps" else D + 1e-4
+    assert abs(auc - ref) <= bar or min(ref, ref64) - 1e-4 <= auc <= max(ref, ref64) + 1e-4, (name, epochs, auc, ref, ref64, D)
     fs = float(hz[f"{name}_final_sum"])      # (the ensemble's sum: 1e-3 where the AUC is determined to 1e-4, 5 % on the noise-amplified lines)
     assert abs(final.astype(np.float64).sum() - fs) <= (1e-3 if D <= 1e-4 else 5e-2) * abs(fs)
 
