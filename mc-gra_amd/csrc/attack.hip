@@ -82,10 +82,10 @@ int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops) {
 
 // every GEMM of the engine goes through here (timed when profiling)
 int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A,
-              int lda, const float* B, int ldb, float beta, float* C, int ldc) {
+              int lda, const float* B, int ldb, float beta, float* C, int ldc, YView* keep) {
   const bool big = h->profile && (double)M * N * K >= 0.25 * (double)h->n * h->n * h->n;
   CHK(timer_begin(h, st, big));
-  MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws, h->ws_bytes));
+  MCGRA_HIP(sgemm(st, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, h->ws, h->ws_bytes, keep));
   return timer_end(h, st, big, 2.0 * M * N * K);
 }
 // C = A A^T (A is [n x k]); sym: lower tile storage only.  (A2, C2): second Gram in the same launch.
@@ -124,6 +124,16 @@ int chain_forward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld,
                          float* H, float* S) {
   const int n = h->n, hs = h->hsum;
   for (int l = 0; l < depth; ++l) {
+    const bool next = l + 1 < h->L;
+    if (!h->has_self && chain_post_fits(h->wdt[l], next ? h->wdt[l + 1] : 0)) {
+      // the product stays in its split-K slabs and ONE launch sums them, adds the bias, applies the activation and forms the
+      // next layer's T = H W_{l+1} (sum_slabs_kernel + k_bias_relu + k_rowmat: the same operations in the same order)
+      YView y{nullptr, 0, 1, 0};
+      CHK(eg(h, st, false, false, n, h->wdt[l], n, 1.f, adj, adj_ld, T + h->off[l], hs, 0.f, h->Y, h->hmax, &y));
+      launch_chain_post(st, n, h->wdt[l], y, h->b[l], h->act, P + h->off[l], H + h->off[l], hs, next ? h->wdt[l + 1] : 0,
+                        next ? h->W[l + 1] : nullptr, next ? h->wdt[l + 1] : 0, 1, nullptr, next ? T + h->off[l + 1] : nullptr, hs);
+      continue;
+    }
     CHK(eg(h, st, false, false, n, h->wdt[l], n, 1.f, adj, adj_ld, T + h->off[l], hs, 0.f, h->Y, h->hmax));
     const float* self = !h->has_self ? nullptr : (l == 0 ? h->S0 : S + h->off[l]);
     launch_bias_relu(st, n, h->wdt[l], h->Y, h->hmax, h->b[l], self, l == 0 ? h->hmax : hs, h->act, P + h->off[l],
@@ -155,6 +165,14 @@ int chain_backward(mcgra_attack* h, hipStream_t st, const float* adj, int adj_ld
                           float* GP, int add_at, const float* Add, int add_ld) {
   const int n = h->n, hs = h->hsum;
   for (int l = ltop; l >= 1; --l) {
+    if (!h->has_self && chain_post_fits(h->wdt[l], h->wdt[l - 1])) {
+      // G_T_l left in its split-K slabs, summed by the linear backward that reads it (one launch less per level)
+      YView y{nullptr, 0, 1, 0};
+      CHK(eg(h, st, true, false, n, h->wdt[l], n, 1.f, adj, adj_ld, GP + h->off[l], hs, 0.f, h->GT, h->hmax, &y));
+      launch_rowmat_mask_view(st, n, h->wdt[l], h->wdt[l - 1], y, h->W[l], 1, h->wdt[l], P + h->off[l - 1], hs, h->act,
+                              (l - 1 == add_at) ? Add : nullptr, add_ld, GP + h->off[l - 1], hs);
+      continue;
+    }
     // G_T_l = adj^T @ G_P_l
     CHK(eg(h, st, true, false, n, h->wdt[l], n, 1.f, adj, adj_ld, GP + h->off[l], hs, 0.f, h->GT, h->hmax));
     // G_P_{l-1} = (G_T_l @ W_l^T [+ Add]) * (P_{l-1} > 0)
@@ -387,6 +405,10 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
       // Gram evaluation: its four products on the side stream, beside the HBM-bound rest of the step (step_impl).
       // MCGRA_GRAM_OVERLAP=0: everything on the caller's stream, same launches in the same order (bit-identical: A/B test)
       { const char* eg2 = ab_env("MCGRA_GRAM_OVERLAP"); h->gram_ovl = h->gram_split && !rc && !(eg2 && eg2[0] == '0'); }
+      // ... and the first of them forked by the monitoring forward (configurations without a low-rank form; MCGRA_GRAM_KX_EARLY=0: by the step)
+      { const char* ek = ab_env("MCGRA_GRAM_KX_EARLY"); h->kx_early_on = h->gram_ovl && !h->lr_ok && h->fwd_reuse && !(ek && ek[0] == '0'); }
+      // (KDE: its small-operand terms share one scratch table with the N x N terms -- they stay on the caller's stream)
+      { const char* es3 = ab_env("MCGRA_SMALL_SIDE"); h->small_side_on = !rc && cfg->measure != MCGRA_MEASURE_KDE && !(es3 && es3[0] == '0'); }
     }
   }
   {
@@ -889,6 +911,25 @@ int collect_scalars(mcgra_attack* h, hipStream_t st, double* scalars_out, bool h
   return 0;
 }
 
+// Gram-evaluation configurations without a low-rank form (GAT / GraphSAGE victims, CKA, widths > 32, MCGRA_NO_LOWRANK): both packed
+// orientations of Xc = H adj_norm in one pass over `adjn` (rows of Xc: both operands of Kx = Xc Xc^T; rows of Xc^T: the B operand of
+// G_adjn += LY Xc), diag(Kx) from the same pass, and Kx on the side stream.  Called by the step -- or, one forward earlier, by the
+// monitor call whose adj_norm the step adopts (kx_early): the same launches on the same data, the same bits.  rowsx holds the column
+// sums of adjn.
+static int gram_pack_fork_kx(mcgra_attack* h, hipStream_t st, const float* adjn) {
+  const int n = h->n, ld = h->ld;
+  hipStream_t sg = (h->gram_ovl && h->st2) ? h->st2 : st;
+  launch_colmean_f32(st, n, ld, h->rowsx, h->cmean);
+  pack_center_both(st, n, ld, adjn, h->cmean, h->r, 0.f, h->Gp0, h->Bpack, h->amax + 1, h->gram_diag, reinterpret_cast<double*>(h->XC));
+  if (sg != st) { MCGRA_HIP(hipEventRecord(h->ev_fork, st)); MCGRA_HIP(hipStreamWaitEvent(sg, h->ev_fork, 0)); }
+  CHK(timer_begin(h, sg, h->profile));
+  MCGRA_HIP(split3_symm(sg, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A,
+                        h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2, 0, nullptr, 0, nullptr,
+                        h->amax + 1));
+  CHK(timer_end(h, sg, h->profile, 2.0 * (double)n * n * n));
+  return 0;
+}
+
 // Phases of one step (bit k of `phases`), for row-block sharding over ranks:
 //   0  replicated: forward, losses, centred operands Xc / Yc (every measure other than HSIC / CKA finishes its
 //      N x N terms here)
@@ -918,6 +959,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   h->fused_last = false;
   h->fused_fwd_valid = false;
   if (h->early_pack) { MCGRA_HIP(hipStreamWaitEvent(st, h->ev_pack, 0)); h->early_pack = false; }      // (the general step packs its own operands)
+  // Kx of this step's adj_norm, forked by the monitor call whose forward the step adopts: taken over (anything else is dropped)
+  const bool kx_adopt = h->kx_early && h->fwd_cached && !noise && !h->has_ori && phases == 0xF;
+  if (kx_adopt) h->kx_early = false;
   CHK(drop_early_p1(h, st));
   const mcgra_attack_config_t& c = h->cfg;
   const int n = h->n, ld = h->ld, hs = h->hsum, L = h->L, Le = h->Le, C = h->C;
@@ -943,14 +987,22 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
 
   // The part of the backward that needs the forward only: small-operand terms c9 (:237-258) and c10 (:259-272), and the
   // victim(adj_norm) chain's backward down to G_P of every layer.  (A Gram-evaluation step runs it beside its Grams.)
-  auto early_bwd = [&]() -> int {
-    MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, st));
-    if (w9 != 0) CHK(small_term(h, st, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
+  // (the small-operand terms need em and softmax(output2) only and feed the backward of the modified_adj chain, the last part of the
+  //  step: ~20 launches of a few microseconds each -- a sixth of a Citeseer-sized step's critical path -- that run on the third stream
+  //  beside the decode, the N x N loss passes and the Grams; their products use their own split-K workspace: small_term)
+  bool small_forked = false;
+  auto small_terms = [&](hipStream_t s) -> int {
+    MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s));
+    if (w9 != 0) CHK(small_term(h, s, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
     if (w10 != 0) {
-      MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, st));
-      CHK(small_term(h, st, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
-      launch_softmax_bwd(st, n, C, h->sm2, h->Gsm, C, h->GZ2);
+      MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s));
+      CHK(small_term(h, s, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10));
+      launch_softmax_bwd(s, n, C, h->sm2, h->Gsm, C, h->GZ2);
     }
+    return 0;
+  };
+  auto early_bwd = [&]() -> int {
+    if (!small_forked) CHK(small_terms(st));
     // ---- backward: victim(adj_norm) chain -> G_adjn
     if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z, h->GZ);     // through elu(out_att(x)) (gat.py:206)
     launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
@@ -974,7 +1026,6 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   hipStream_t sg_ = st;
   std::function<int()> gs_fork;
   std::function<int(bool)> launch_kx;
-  std::function<int(int, int, int)> pair;
   if (PH(0)) {
   const bool adopt = h->fwd_cached && !gen;         // forward of this iteration already done by the last monitor call
   h->fwd_cached = false;
@@ -1006,18 +1057,17 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     if (sg_ != st) { MCGRA_HIP(hipEventRecord(h->ev_fork, st)); MCGRA_HIP(hipStreamWaitEvent(sg_, h->ev_fork, 0)); }
     return 0;
   };
-  pair = [=](int slot, int ia, int ib) -> int {      // (A, B) operand magnitudes of product `slot`
-    MCGRA_HIP(hipMemcpyAsync(h->amax + 8 + 2 * slot, h->amax + ia, sizeof(float), hipMemcpyDeviceToDevice, st));
-    MCGRA_HIP(hipMemcpyAsync(h->amax + 9 + 2 * slot, h->amax + ib, sizeof(float), hipMemcpyDeviceToDevice, st));
-    return 0;
-  };
+  // (the (A, B) operand magnitudes of a product are read where they are: split3_symm takes B's through its own pointer.  Rounds
+  //  2 - 5 paired them up in amax[8 ..] with two 4-byte device-to-device copies per product -- eight launches of ~5 us per step on
+  //  the caller's queue.  No slot is rewritten between a product's fork and its join: amax[1] / [2] come out of the centring
+  //  passes of this step, [3] / [4] out of hsic_gram_scales / the CKA combine, all in front of the products that read them.)
   launch_kx = [=](bool packed) -> int {      // Kx: lower tiles, mirrored by the epilogue (full, bitwise symmetric matrix)
     if (!packed) split3_pack(st, n, ld, h->XC, nullptr, false, h->Gp0, 2, h->amax + 1);
-    CHK(pair(0, 1, 1));
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, h->profile));
     MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A,
-                          h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 8, 0, -1, 2));
+                          h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2, 0, nullptr, 0, nullptr,
+                          h->amax + 1));
     CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
     return 0;
   };
@@ -1032,9 +1082,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       // packed orientations of Xc in ONE pass over adj_norm -- rows of Xc (the operands of Kx = Xc Xc^T) and rows of Xc^T (the B
       // operand of G_adjn += LY Xc) -- with diag(Kx) from the same pass; the fp32 Xc is never stored.  Kx starts now, beside
       // the forward chains and the decode.
-      launch_colmean_f32(st, n, ld, h->rowsx, h->cmean);
-      pack_center_both(st, n, ld, h->ADJN, h->cmean, h->r, 0.f, h->Gp0, h->Bpack, h->amax + 1, h->gram_diag, reinterpret_cast<double*>(h->XC));
-      CHK(launch_kx(true)); kx_started = true;
+      // (kx_adopt: the monitor call of the previous iteration did exactly this on the adj_norm this step adopted)
+      if (!(kx_adopt && adopt)) CHK(gram_pack_fork_kx(h, st, h->ADJN));
+      kx_started = true;
     } else {
     // (gram_diag: |xc_i|^2 = diag(Kx) for the scale bound of the combined Grams -- only when the low-rank path does not want it)
     const bool want_lrrs = h->lr_ok && !cka && use2;
@@ -1095,6 +1145,13 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   if (h->has_ori) {      // embedding(features, modified_adj - ori_adj) (:185) no longer shares the chain of output2 (:259)
     launch_axpby2d(st, n, A, ld, 1.f, h->ORI, ld, -1.f, h->Bbuf, ld);
     CHK(chain_forward(h, st, h->Bbuf, ld, Le, h->Te, h->Pe, h->He, h->Se));
+  }
+  if (phases == 0xF && h->small_side_on && h->st3 && h->st3 != st && (w9 != 0 || w10 != 0)) {
+    MCGRA_HIP(hipEventRecord(h->ev_fork3, st));
+    MCGRA_HIP(hipStreamWaitEvent(h->st3, h->ev_fork3, 0));
+    CHK(small_terms(h->st3));
+    MCGRA_HIP(hipEventRecord(h->ev_join3, h->st3));
+    small_forked = true;
   }
   // ---- dot_product_decode + get_modified_adj_after (:187-188)
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
@@ -1229,10 +1286,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       if (!kx_started) { CHK(launch_kx(false)); kx_started = true; }      // (a low-rank configuration whose decode found a dead row)
       if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_first, sg_));    // Kx done
       if (use2) {
-        CHK(pair(1, 2, 2));
         CHK(gs_fork());
         CHK(timer_begin(h, sg_, h->profile));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 10, 0, -1, 2));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 2, 0, -1, 2, 0, nullptr, 0, nullptr, h->amax + 2));
         CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
         if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));   // Ky done
       }
@@ -1246,11 +1302,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         if (use2) {
           // LX = 2 s2 Kxc into the planes Xc's rows held (Kx is done with them); G_A1 += LX Yc right behind Ky, slabs in G_A
           split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp0, 2, h->amax + 4, 2.f * s2);
-          MCGRA_HIP(hipMemcpyAsync(h->amax + 14, h->amax + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
-          MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
           CHK(gs_fork());
           CHK(timer_begin(h, sg_, h->profile));
-          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 14, 0, -1, 1));
+          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 4, 0, -1, 1, 0, nullptr, 0, nullptr, h->amax + 2));
           CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
           if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));   // G_A1 complete
           gs_p4 = true;
@@ -1283,23 +1337,19 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       LY = h->Gp0;
       if (use2) {
         split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp1, 2, h->amax + 4);
-        MCGRA_HIP(hipMemcpyAsync(h->amax + 14, h->amax + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
-        MCGRA_HIP(hipMemcpyAsync(h->amax + 15, h->amax + 2, sizeof(float), hipMemcpyDeviceToDevice, st));
         CHK(gs_fork());
         CHK(timer_begin(h, sg_, big));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 14, 0, -1, 1));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 4, 0, -1, 1, 0, nullptr, 0, nullptr, h->amax + 2));
         CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
         if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));
         gs_p4 = true;
       }
     }
     // G_adjn += LY Xc behind the victim chain's rank-k update of G_adjn; slabs in KX (dead: combined and packed)
-    MCGRA_HIP(hipMemcpyAsync(h->amax + 12, h->amax + 3, sizeof(float), hipMemcpyDeviceToDevice, st));
-    MCGRA_HIP(hipMemcpyAsync(h->amax + 13, h->amax + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     CHK(victim_rankk()); gs_rankk_done = true;
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, big));
-    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->small_slab ? h->small_slab : h->KX, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 12, 0, -1, 1));
+    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->small_slab ? h->small_slab : h->KX, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 3, 0, -1, 1, 0, nullptr, 0, nullptr, h->amax + 1));
     CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
     if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));
     gs_p3 = true;
@@ -1352,6 +1402,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                     fused ? h->lrQtZ : nullptr, 2.f * (float)(sg * k2));
     launch_reduce_rows(st, h->rowvals + 5 * (size_t)ld, n, 1, h->scal + S_H2);
   }
+  if (small_forked) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join3, 0));      // c9 / c10: Gem, GZ2 and their scalars
   launch_row_normalize_bwd(st, n, he, h->GZn, h->Zn, h->hmax, h->nrm, h->Gem, h->hmax);
 
   // ---- backward: modified_adj chain (embedding + output2) -> G_A
@@ -1514,6 +1565,16 @@ int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, doubl
   if (h->has_ori) CHK(forward_ori_unclamped(h, st, dst));
   else
   CHK(forward_common(h, st, dst, nullptr, (h->fwd_reuse && want_xc) ? h->rowsx : nullptr));
+  if (h->kx_early_on && want_xc && h->gram_split && !h->lr_ok && !h->has_ori && h->cfg.eps == 0.f && h->have_step) {
+    // the next step of this configuration is a Gram evaluation whose first product needs this adj_norm only: packed and forked now,
+    // it runs beside the chains below and beside the next step's own forward part instead of behind them (the row partials in G_A
+    // that forward_common just consumed make room for the product's split-K slabs)
+    CHK(drop_early_p1(h, st));      // (two monitor calls in a row)
+    CHK(gram_pack_fork_kx(h, st, dst));
+    if (h->gram_ovl && h->st2) MCGRA_HIP(hipEventRecord(h->ev_first, h->st2));
+    h->kx_early = true;
+    h->prep_valid = false;
+  }
   CHK(chain_forward(h, st, dst, h->ld, h->L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->fwd_reuse ? h->sm : nullptr));
   h->fwd_cached = h->fwd_reuse;
@@ -1632,6 +1693,7 @@ int mcgra_attack_copy_buffer(mcgra_attack_t* h, void* stream, const char* name, 
   if (!dst || dst_ld < c) { set_error("bad destination"); return MCGRA_EINVAL; }
   if (h->early_pack) MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_pack, 0));      // (scratch buffers under a forked pack)
   if (h->p1_early) MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));      // (... or under a forked product)
+  if (h->kx_early && h->gram_ovl && h->st2) MCGRA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_first, 0));
   MCGRA_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 4, p, (size_t)l * 4, (size_t)c * 4, r, hipMemcpyDeviceToDevice,
                              (hipStream_t)stream));
   return 0;

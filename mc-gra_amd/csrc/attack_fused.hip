@@ -243,6 +243,10 @@ static int fork_p1_early(mcgra_attack* h, hipStream_t st);
 // A product forked by a forward whose step never came (or comes by another path): ordered in front of whatever the caller's
 // stream does next, its result dropped.
 int drop_early_p1(mcgra_attack* h, hipStream_t st) {
+  if (h->kx_early) {      // (likewise the Gram product Kx a monitor call forked for a step that never came: attack.hip, gram_kx_early)
+    if (h->gram_ovl && h->st2) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_first, 0));
+    h->kx_early = false;
+  }
   if (!h->p1_early) return 0;
   MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   h->p1_early = h->p1_inflight = h->p1_first = false;

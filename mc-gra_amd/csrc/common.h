@@ -31,8 +31,18 @@ struct YView {
   __device__ __forceinline__ float at(int i, int c) const {
     const float* q = p + (size_t)i * ld + c;
     if (nz <= 1) return *q;
+    // (eight loads in flight, added in slab order: the same sum as one load at a time -- sum_slabs_kernel's -- without its chain of
+    //  load latencies: up to 64 slabs per element on the node chain of a small graph or of a row-block rank)
     float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += q[(size_t)z * stride];
+    int z = 0;
+    for (; z + 8 <= nz; z += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(z + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < nz; ++z) s += q[(size_t)z * stride];
     return s;
   }
 };
@@ -90,7 +100,8 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
                        int panel_rows, float* slab, size_t slab_bytes, int planes = 3, const float* amax = nullptr,
                        int npanel_off = 0, int npanel_cols = -1, int flags = 0,      // flags: 1 = C += product; 2 = Gram product (A == B): lower tiles computed, mirrored into the upper half;
                        int first_tiles = 0, hipEvent_t ev_first = nullptr,             // 4 = all row panels from panel_off, wrapping; 8 = (planes == 2) the single-plane product x0 y0, low planes compiled out; first_tiles: cut of the linear tile range, ev_first recorded behind the first part
-                       int second_tiles = 0, hipEvent_t ev_second = nullptr);          // a second cut behind the first
+                       int second_tiles = 0, hipEvent_t ev_second = nullptr,           // a second cut behind the first
+                       const float* amax_b = nullptr);      // planes == 2: B's packed-with magnitude when it does not sit at amax[1] (no 4-byte copies to pair the two up)
 int split3_panel();
 size_t split3_small_slab_bytes(int n);      // split-K slab room a small graph's products can use (0: none beyond what fits an N x N buffer anyway)
 size_t hsic_combine_pack_scratch_doubles(int n);

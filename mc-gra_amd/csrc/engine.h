@@ -155,6 +155,11 @@ struct mcgra_attack {
   // (A, B) scale pairs of the four products
   bool gram_split = false;
   bool gram_ovl = false;           // its four products on the side stream, beside the rest of the step (MCGRA_GRAM_OVERLAP=0: caller's stream)
+  // a configuration whose every step is a Gram evaluation (no low-rank form): the first product, Kx = Xc Xc^T, needs adj_norm of the
+  // CURRENT M only -- the monitoring forward forks pack + Kx as soon as adj_norm stands, and the next step finds them in flight
+  bool kx_early_on = false;        // (MCGRA_GRAM_KX_EARLY=0: the step packs and forks Kx itself, as in round 5)
+  bool small_side_on = false;      // general step: the small-operand terms c9 / c10 (~20 tiny launches) on the third stream, beside the decode and the N x N passes (MCGRA_SMALL_SIDE=0: caller's stream)
+  bool kx_early = false;           // Kx of the current M is in flight / done on the side stream, forked by the last monitor call
   double* gram_diag = 0;           // [2][ld]: |xc_i|^2, |yc_i|^2 (diagonals of the centred Grams: scale bound of the combined Grams)
   unsigned char *Gp0 = 0, *Gp1 = 0, *Gp2 = 0;
   int64_t gram_split_steps = 0;
@@ -222,7 +227,7 @@ extern "C" int step_general(mcgra_attack_t* h, void* stream, const float* noise,
 int timer_begin(mcgra_attack* h, hipStream_t st, bool big);
 int timer_end(mcgra_attack* h, hipStream_t st, bool big, double flops);
 int eg(mcgra_attack* h, hipStream_t st, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
-       const float* B, int ldb, float beta, float* C, int ldc);
+       const float* B, int ldb, float beta, float* C, int ldc, mcgra::YView* keep = nullptr);      // keep: a split-K product stays in its slabs (h->ws) for the next kernel
 int head_forward(mcgra_attack* h, hipStream_t st, const float* H, float* Z, float* logp, float* sm);
 double sign_of(const mcgra_attack* h);
 extern "C" {      // (defined inside attack.hip's extern "C" block)

@@ -66,6 +66,11 @@ void launch_rowmat(hipStream_t st, int n, int kdim, int cdim, const float* In, i
 void launch_rowmat_mask(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
                         int sc, const float* In2, int ldi2, int k2dim, const float* W2, int sk2, int sc2, const float* P,
                         int ldp, int act, const float* Add, int lda, float* Out, int ldo);
+bool chain_post_fits(int kdim, int cdim);      // the one-launch chain epilogues below apply (their W and 16 rows fit 48 KB of LDS)
+bool launch_chain_post(hipStream_t st, int n, int kdim, YView Y, const float* b, int act, float* P, float* H, int ldo, int cdim,
+                       const float* W, int sk, int sc, const float* bias, float* Out, int ldo2);      // slab sum + bias + act (+ next layer's T) in one launch
+bool launch_rowmat_mask_view(hipStream_t st, int n, int kdim, int cdim, YView In, const float* W, int sk, int sc, const float* P, int ldp,
+                             int act, const float* Add, int lda, float* Out, int ldo);
 void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo,
                         int elu_in);
 void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,

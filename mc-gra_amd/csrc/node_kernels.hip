@@ -66,8 +66,10 @@ __global__ void k_rowmat_mask(int n, int kdim, int cdim, const float* __restrict
 // The two kernels above for wide layers (an 80-wide GAT chain: 28 / 55 us at n = 3312, each thread walking In's row and W's
 // column or row through the caches): RM_ROWS rows of In and the whole W through LDS, every output still ONE fmaf chain in k
 // order -- the bits of the kernels above.  mask: P != nullptr selects k_rowmat_mask's epilogue (Add, act'), else k_rowmat's (bias).
+// In comes as a YView: a plain matrix, or the slabs of a split-K product summed in slab order on the way in (sum_slabs_kernel's
+// sum, without its launch and its round trip through HBM).
 constexpr int RM_ROWS = 16;
-__global__ __launch_bounds__(256) void k_rowmat_lds(int n, int kdim, int cdim, const float* __restrict__ In, int ldi,
+__global__ __launch_bounds__(256) void k_rowmat_lds(int n, int kdim, int cdim, YView In,
                                                     const float* __restrict__ W, int sk, int sc, const float* __restrict__ bias,
                                                     const float* __restrict__ P, int ldp, int act, const float* __restrict__ Add,
                                                     int lda, float* __restrict__ Out, int ldo) {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void k_rowmat_lds(int n, int kdim, int cdim, c
   }
   for (int e = threadIdx.x; e < RM_ROWS * kdim; e += 256) {
     const int r = e / kdim, k = e - r * kdim;
-    Is[r * kp + k] = (r0 + r < n) ? In[(size_t)(r0 + r) * ldi + k] : 0.f;
+    Is[r * kp + k] = (r0 + r < n) ? In.at(r0 + r, k) : 0.f;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < RM_ROWS * cdim; e += 256) {
@@ -101,6 +103,48 @@ __global__ __launch_bounds__(256) void k_rowmat_lds(int n, int kdim, int cdim, c
   }
 }
 static inline size_t rowmat_lds_bytes(int kdim, int cdim) { return sizeof(float) * ((size_t)kdim * (cdim + 1) + (size_t)RM_ROWS * (kdim + 1)); }
+
+// One layer's epilogue of a GCN chain behind its product Y = adj (x W_l) in ONE launch (the general step's chains: every measure
+// without a fused step, GAT victims -- BASELINE.json configs[2]): the product's split-K slabs summed in slab order (sum_slabs_kernel),
+// P = Y + b, H = act(P) (k_bias_relu), and -- cdim > 0 -- the next layer's T = H W_{l+1} (k_rowmat / k_rowmat_lds: one fmaf chain in
+// k order per output): the same operations in the same order as the three launches it replaces, H handed over through LDS.
+__global__ __launch_bounds__(256) void k_chain_post(int n, int kdim, YView Y, const float* __restrict__ b, int act,
+                                                    float* __restrict__ P, float* __restrict__ H, int ldo, int cdim,
+                                                    const float* __restrict__ W, int sk, int sc, const float* __restrict__ bias,
+                                                    float* __restrict__ Out, int ldo2) {
+  extern __shared__ float sh[];      // Ws[kdim][cdim + 1] | Is[RM_ROWS][kdim + 1]
+  const int cp = cdim + 1, kp = kdim + 1, r0 = blockIdx.x * RM_ROWS;
+  float* Ws = sh;
+  float* Is = sh + kdim * cp;
+  if (cdim > 0) {
+    if (sc == 1) {
+      for (int e = threadIdx.x; e < kdim * cdim; e += 256) { const int k = e / cdim, c = e - k * cdim; Ws[k * cp + c] = W[(size_t)k * sk + c]; }
+    } else {
+      for (int e = threadIdx.x; e < kdim * cdim; e += 256) { const int c = e / kdim, k = e - c * kdim; Ws[k * cp + c] = W[(size_t)k * sk + (size_t)c * sc]; }
+    }
+  }
+  for (int e = threadIdx.x; e < RM_ROWS * kdim; e += 256) {
+    const int r = e / kdim, k = e - r * kdim, i = r0 + r;
+    float hv = 0.f;
+    if (i < n) {
+      const float p = Y.at(i, k) + b[k];
+      hv = act_fwd(p, act);
+      P[(size_t)i * ldo + k] = p;
+      H[(size_t)i * ldo + k] = hv;
+    }
+    Is[r * kp + k] = hv;
+  }
+  if (cdim <= 0) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < RM_ROWS * cdim; e += 256) {
+    const int r = e / cdim, c = e - r * cdim, i = r0 + r;
+    if (i >= n) break;
+    float s = 0.f;
+    for (int k = 0; k < kdim; ++k) s = fmaf(Is[r * kp + k], Ws[k * cp + c], s);
+    if (bias) s += bias[c];
+    Out[(size_t)i * ldo2 + c] = s;
+  }
+}
 // (narrow layers keep the thread-per-output kernels: at width 16 they are one short launch and W is a few cache lines)
 static inline bool rowmat_lds_wanted(int n, int kdim, int cdim) {
   return kdim >= 48 && n >= 256 && rowmat_lds_bytes(kdim, cdim) <= 48 * 1024;
@@ -429,8 +473,8 @@ void launch_elu_grad_mul(hipStream_t st, int n, int c, const float* Zlin, float*
 void launch_rowmat(hipStream_t st, int n, int kdim, int cdim, const float* In, int ldi, const float* W, int sk,
                    int sc, const float* bias, float* Out, int ldo) {
   if (rowmat_lds_wanted(n, kdim, cdim)) {
-    hipLaunchKernelGGL(k_rowmat_lds, dim3((n + RM_ROWS - 1) / RM_ROWS), dim3(256), rowmat_lds_bytes(kdim, cdim), st, n, kdim, cdim, In, ldi, W,
-                       sk, sc, bias, (const float*)nullptr, 0, 0, (const float*)nullptr, 0, Out, ldo);
+    hipLaunchKernelGGL(k_rowmat_lds, dim3((n + RM_ROWS - 1) / RM_ROWS), dim3(256), rowmat_lds_bytes(kdim, cdim), st, n, kdim, cdim,
+                       YView{In, ldi, 1, 0}, W, sk, sc, bias, (const float*)nullptr, 0, 0, (const float*)nullptr, 0, Out, ldo);
     return;
   }
   LAUNCH(k_rowmat, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, bias, Out, ldo);
@@ -439,12 +483,32 @@ void launch_rowmat_mask(hipStream_t st, int n, int kdim, int cdim, const float* 
                         int sc, const float* In2, int ldi2, int k2dim, const float* W2, int sk2, int sc2, const float* P,
                         int ldp, int act, const float* Add, int lda, float* Out, int ldo) {
   if (!In2 && P && rowmat_lds_wanted(n, kdim, cdim)) {
-    hipLaunchKernelGGL(k_rowmat_lds, dim3((n + RM_ROWS - 1) / RM_ROWS), dim3(256), rowmat_lds_bytes(kdim, cdim), st, n, kdim, cdim, In, ldi, W,
-                       sk, sc, (const float*)nullptr, P, ldp, act, Add, lda, Out, ldo);
+    hipLaunchKernelGGL(k_rowmat_lds, dim3((n + RM_ROWS - 1) / RM_ROWS), dim3(256), rowmat_lds_bytes(kdim, cdim), st, n, kdim, cdim,
+                       YView{In, ldi, 1, 0}, W, sk, sc, (const float*)nullptr, P, ldp, act, Add, lda, Out, ldo);
     return;
   }
   LAUNCH(k_rowmat_mask, g1((size_t)n * cdim), dim3(256), st, n, kdim, cdim, In, ldi, W, sk, sc, In2, ldi2, k2dim, W2, sk2,
          sc2, P, ldp, act, Add, lda, Out, ldo);
+}
+// The epilogue of a chain layer in one launch (k_chain_post); false when the shapes do not fit its LDS: the caller then runs the
+// separate kernels.  cdim == 0: no next layer (P and H only).
+bool chain_post_fits(int kdim, int cdim) { return kdim >= 1 && rowmat_lds_bytes(kdim, cdim > 0 ? cdim : 0) <= 48 * 1024; }
+bool launch_chain_post(hipStream_t st, int n, int kdim, YView Y, const float* b, int act, float* P, float* H, int ldo, int cdim,
+                       const float* W, int sk, int sc, const float* bias, float* Out, int ldo2) {
+  const size_t bytes = rowmat_lds_bytes(kdim, cdim > 0 ? cdim : 0);
+  if (bytes > 48 * 1024 || n < 1) return false;
+  hipLaunchKernelGGL(k_chain_post, dim3((n + RM_ROWS - 1) / RM_ROWS), dim3(256), bytes, st, n, kdim, Y, b, act, P, H, ldo, cdim, W, sk, sc,
+                     bias, Out, ldo2);
+  return true;
+}
+// Gout = (Y W^T [+ Add]) act'(P) with Y a product left as its split-K slabs (k_rowmat_lds through a YView); false: does not fit
+bool launch_rowmat_mask_view(hipStream_t st, int n, int kdim, int cdim, YView In, const float* W, int sk, int sc, const float* P, int ldp,
+                             int act, const float* Add, int lda, float* Out, int ldo) {
+  const size_t bytes = rowmat_lds_bytes(kdim, cdim);
+  if (bytes > 48 * 1024 || n < 1) return false;
+  hipLaunchKernelGGL(k_rowmat_lds, dim3((n + RM_ROWS - 1) / RM_ROWS), dim3(256), bytes, st, n, kdim, cdim, In, W, sk, sc,
+                     (const float*)nullptr, P, ldp, act, Add, lda, Out, ldo);
+  return true;
 }
 void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, float* logp, float* sm, int ldo,
                         int elu_in) {

@@ -395,7 +395,9 @@ __device__ __forceinline__ void split_tile_of(int lin, int tiles_m, int tiles_n,
     tile_m = m; tile_n = lin - m * (m + 1) / 2;
     return;
   }
-  constexpr int GROUP_M = 4;
+  // (bits 8 .. 15 of the flags: another group height -- the A/B of profiles/r06_ab_product_raster.txt only, MCGRA_SPLIT_GROUP_M under
+  //  MCGRA_AB=1: the 32 tiles an XCD runs at a time are GROUP_M x 32 / GROUP_M, i.e. GROUP_M + 32 / GROUP_M operand panels through its L2)
+  const int GROUP_M = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : 4;
   const int group_sz = GROUP_M * tiles_n;
   const int group_id = lin / group_sz;
   const int first_m = group_id * GROUP_M;
@@ -616,7 +618,8 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
                                                             float* __restrict__ C, int n, int ldc, int nks,
                                                             int tiles_m, int tiles_n, int panel_off, int tile_base,
                                                             int ksplit, float* __restrict__ slab,
-                                                            const float* __restrict__ amax, int npanel_off, int beta) {
+                                                            const float* __restrict__ amax, int npanel_off, int beta,
+                                                            const float* __restrict__ amax_b) {
   using CF = SplitCfg<2, 2>;
   constexpr int OPB = CF::OPB, STAGE = CF::STAGE;     // 16 KB per operand and chunk, 64 KB per stage
   constexpr int COPY = 512 * 16, AOPS = 2 * OPB / COPY;   // 4 copies per operand and step
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
       __syncthreads();
     }
   }
-  const float inv = ldexpf(1.f, amax_exp(amax[0]) + amax_exp(amax[1]) - 30);      // undo the operand scales: exact
+  const float inv = ldexpf(1.f, amax_exp(amax[0]) + amax_exp(amax_b[0]) - 30);      // undo the operand scales: exact (amax_b: B's, wherever it lives)
   // C/D layout of 16 x 16: col = lane & 15, row = 4 (lane >> 4) + r
   if (ksplit > 1) {
     float* o = slab + ((size_t)part * (gridDim.x / ksplit) + (lin - tile_base)) * (TB * TB);
@@ -877,7 +880,8 @@ int split3_slots() {
 
 hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpack, float* C, int ldc, int panel_off,
                        int panel_rows, float* slab, size_t slab_bytes, int planes, const float* amax, int npanel_off,
-                       int npanel_cols, int beta, int first_tiles, hipEvent_t ev_first, int second_tiles, hipEvent_t ev_second) {
+                       int npanel_cols, int beta, int first_tiles, hipEvent_t ev_first, int second_tiles, hipEvent_t ev_second,
+                       const float* amax_b) {
   const int nkc = chunks_of(n, planes), tiles_all = (n + TB - 1) / TB;
   const int tm = panel_rows >= 0 ? panel_rows : tiles_all;
   const int tiles = npanel_cols >= 0 ? npanel_cols : tiles_all;      // column panels of this launch
@@ -887,6 +891,16 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
   if ((beta & SPLIT_TRI) && (tm != tiles_all || tiles != tiles_all || panel_off || npanel_off || first_tiles > 0)) return hipErrorInvalidValue;
   if ((beta & SPLIT_WRAP) && (tm != tiles_all || panel_off < 0 || panel_off >= tiles_all || (beta & SPLIT_TRI))) return hipErrorInvalidValue;
   const int total = (beta & SPLIT_TRI) ? tiles_all * (tiles_all + 1) / 2 : tm * tiles;
+  {
+    // A/B only (honoured beside MCGRA_AB=1, like every engine switch): the height of the tile groups of a launch's raster
+    static const int group_m = []() {
+      const char* v = getenv("MCGRA_SPLIT_GROUP_M");
+      const char* on = getenv("MCGRA_AB");
+      const int g = (v && on && on[0] == '1') ? atoi(v) : 0;
+      return (g >= 1 && g <= 64) ? g : 0;
+    }();
+    if (group_m && !(beta & SPLIT_TRI)) beta |= group_m << 8;
+  }
   auto launch = [&](int grid, int tile_base, int ks, float* sl) -> hipError_t {
     if (planes == 2) {      // 2-plane fp16 split: split2_m16_kernel (v_mfma_f32_16x16x32_f16, global_load_lds staging)
       constexpr int smem = 2 * SplitCfg<2, 2>::STAGE;
@@ -894,13 +908,13 @@ hipError_t split3_symm(hipStream_t st, int n, const void* Apack, const void* Bpa
         hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(split2_m16_kernel<true>, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc, nkc / 2,
-                           tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
+                           tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta, amax_b ? amax_b : amax + 1);
         return hipSuccess;
       }
       hipError_t e = hipFuncSetAttribute((const void*)split2_m16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(split2_m16_kernel<false>, dim3(grid), dim3(512), smem, st, (const char*)Apack, (const char*)Bpack, C, n, ldc, nkc / 2, tm,
-                         tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);
+                         tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta, amax_b ? amax_b : amax + 1);
       return hipSuccess;
     }
     return launch_split<3, 1>(st, grid, Apack, Bpack, C, n, ldc, nkc, tm, tiles, panel_off, tile_base, ks, sl, amax, npanel_off, beta);

@@ -341,7 +341,7 @@ def test_plain_bench_measures_its_traffic_live(tmp_path):
 
 # ---- the sharded step behind the class surface and main.py (north_star: "keep the PGDAttack / BaseAttack class surface and
 # main.py entry" AND "partition ... row-block across up to 8 MI355X") ------------------------------------------------------
-@pytest.mark.parametrize("fixture,kind", [("cora_hsic_sparse", ""), ("cora_mse_short", ""), ("cora_mse_short", "kl"),
+@pytest.mark.parametrize("fixture,kind", [("cora_hsic_sparse", ""), ("cora_mse_short", ""), ("cora_hsic_sparse", "kl"),
                                           pytest.param("cora_hsic_sparse", "rccl", marks=needs_two_gpus)])
 def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, fixture, kind):
     """Two processes call PGDAttack.attack on Cora (reference-trained weights of the fixture: HSIC from the sparse start, and the
@@ -349,8 +349,10 @@ def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, 
     RowBlockPlan + HipShardBackend + ShardedStepper itself, every step is a fused row-block step (the MSELoss one exchanges no
     N x N data at all), both ranks return the SAME modified_adj, its AUC equals the 1-process run's to 1e-6 (MSELoss: 1e-5) and the
     REFERENCE's (the fixture's) to 1e-4."""
-    # "kl": the fixture's graph, reference-trained weights and start with calc = calc_kl (round 6: the fused KL step, sharded like
-    # the MSELoss one) -- no reference AUC for that combination: the two-rank run is held to the one-process run
+    # "kl": the fixture's graph, reference-trained weights, sparse start and weights (w1 = w2 = 0.01: both N x N terms) with calc =
+    # calc_kl (round 6: the fused KL step, sharded like the MSELoss one) -- no reference AUC for that combination: the two-rank run
+    # is held to the one-process run.  (From the MSELoss fixture's start, adj_changes = 0 with lr = 0.01, the first KL step is a
+    # sign step on gradients of 1e-7 k / n^2: two evaluations that differ in summation order are 1.5e-4 of AUC apart after 8 epochs.)
     kl = kind == "kl"
     out = str(tmp_path / "cls")
     _run_ranks(W.run_class_rank, 2, (dict(name=fixture, rccl=kind == "rccl", measure="KL" if kl else None, epochs=8 if kl else None),), out)
@@ -368,7 +370,7 @@ def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, 
         # differences the way they do between the reference, the fp32 and the fp64 oracle -- 6e-6 apart at this horizon,
         # test_cora_mse_checkpoints -- measured 3.8e-6.  Each rank's gradient rows against the one-process step, per step:
         # test_sharded_mse_ranks_match_monolithic_step.)
-        assert abs(float(r["auc"]) - auc1) <= (1e-6 if "hsic" in fixture else 1e-5), (float(r["auc"]), auc1)
+        assert abs(float(r["auc"]) - auc1) <= (1e-6 if "hsic" in fixture and not kl else 1e-5), (float(r["auc"]), auc1)
         if not kl:
             assert abs(float(r["auc"]) - float(z["auc"])) <= 1e-4, (float(r["auc"]), float(z["auc"]))
         assert len(r["acc_test"]) == epochs and np.allclose(r["acc_test"], model1.history["acc_test"])
@@ -378,7 +380,7 @@ def test_pgdattack_class_shards_the_attack_under_a_process_group(pkg, tmp_path, 
     sp = z["sample_pos"]
     # (entries that moved by a different +-lr somewhere along the run: under 0.1 % from the sparse HSIC start, 0.5 % after the 20
     # MSELoss epochs)
-    assert np.mean(np.abs(ranks[0]["final_sample"] - final1[sp[:, 0], sp[:, 1]]) > 1e-3) < (1e-3 if "hsic" in fixture else 1e-2)
+    assert np.mean(np.abs(ranks[0]["final_sample"] - final1[sp[:, 0], sp[:, 1]]) > 1e-3) < (1e-3 if "hsic" in fixture and not kl else 1e-2)
 
 
 def test_main_entry_under_a_launcher_shards_the_attack(pkg, tmp_path, monkeypatch):
