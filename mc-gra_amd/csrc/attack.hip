@@ -990,7 +990,10 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // (the small-operand terms need em and softmax(output2) only and feed the backward of the modified_adj chain, the last part of the
   //  step: ~20 launches of a few microseconds each -- a sixth of a Citeseer-sized step's critical path -- that run on the third stream
   //  beside the decode, the N x N loss passes and the Grams; their products use their own split-K workspace: small_term)
-  bool small_forked = false;
+  // The fork EVENT is recorded right behind the forward chains; the launches themselves are enqueued later in program order
+  // (early_bwd: beside the Grams, or at the top of the backward) -- the host needs ~5 us per launch, and enqueued in front of the
+  // decode they left the caller's queue empty for that long (213 us idle under the profiler, a third of the gain).
+  bool small_forked = false, small_fork_armed = false;
   auto small_terms = [&](hipStream_t s) -> int {
     MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s));
     if (w9 != 0) CHK(small_term(h, s, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9));
@@ -1002,12 +1005,18 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     return 0;
   };
   auto early_bwd = [&]() -> int {
-    if (!small_forked) CHK(small_terms(st));
+    if (!small_fork_armed) CHK(small_terms(st));
     // ---- backward: victim(adj_norm) chain -> G_adjn
     if (h->head_act) launch_elu_grad_mul(st, n, C, h->Z, h->GZ);     // through elu(out_att(x)) (gat.py:206)
     launch_rowmat_mask(st, n, C, h->wdt[L - 1], h->GZ, C, h->Wlin, h->wdt[L - 1], 1, nullptr, 0, 0, nullptr, 0, 0,
                        h->Pv + h->off[L - 1], hs, h->act, nullptr, 0, h->GPv + h->off[L - 1], hs);
     CHK(chain_backward(h, st, h->ADJN, ld, L - 1, h->Pv, h->GPv, -1, nullptr, 0));
+    if (small_fork_armed) {      // (behind the victim chain's launches in program order: the caller's queue is fed first)
+      MCGRA_HIP(hipStreamWaitEvent(h->st3, h->ev_fork3, 0));
+      CHK(small_terms(h->st3));
+      MCGRA_HIP(hipEventRecord(h->ev_join3, h->st3));
+      small_forked = true;
+    }
     return 0;
   };
   // G_adjn += sum_l G_P_l T_l^T (+ the low-rank 2 s2 (U M1^T - D Z W^T) of a low-rank step, in the same pass)
@@ -1147,11 +1156,8 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     CHK(chain_forward(h, st, h->Bbuf, ld, Le, h->Te, h->Pe, h->He, h->Se));
   }
   if (phases == 0xF && h->small_side_on && h->st3 && h->st3 != st && (w9 != 0 || w10 != 0)) {
-    MCGRA_HIP(hipEventRecord(h->ev_fork3, st));
-    MCGRA_HIP(hipStreamWaitEvent(h->st3, h->ev_fork3, 0));
-    CHK(small_terms(h->st3));
-    MCGRA_HIP(hipEventRecord(h->ev_join3, h->st3));
-    small_forked = true;
+    MCGRA_HIP(hipEventRecord(h->ev_fork3, st));      // (em and softmax(output2) stand: what the small-operand terms need)
+    small_fork_armed = true;
   }
   // ---- dot_product_decode + get_modified_adj_after (:187-188)
   launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f);
@@ -1573,7 +1579,7 @@ int mcgra_attack_monitor(mcgra_attack_t* h, void* stream, float* out_logp, doubl
     CHK(gram_pack_fork_kx(h, st, dst));
     if (h->gram_ovl && h->st2) MCGRA_HIP(hipEventRecord(h->ev_first, h->st2));
     h->kx_early = true;
-    h->prep_valid = false;
+    if (!h->small_slab) h->prep_valid = false;      // (the product's split-K slabs went into G_A, over the row partials forward_common just consumed)
   }
   CHK(chain_forward(h, st, dst, h->ld, h->L, h->Tv, h->Pv, h->Hv, h->Sv));
   CHK(head_forward(h, st, h->Hv, h->Z, h->logp, h->fwd_reuse ? h->sm : nullptr));

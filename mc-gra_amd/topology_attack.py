@@ -287,6 +287,13 @@ class PGDAttack(BaseAttack):
         # set_layers (gat.py:170-174): full depth.
         emb_nlayer = len(W) if emb_full else min(2, len(W))
         fin_layers = (len(W), len(W)) if emb_full else (1, min(2, len(W)))
+        if measure == "KDE" and max(dims[emb_nlayer], int(Wlin.shape[0])) > 32:
+            # utils.MutualInformation(num_bins = H_A1.shape[1]) on the embeddings (:244-249) / num_bins = classes (:261-265): the
+            # c x c joint pdf of kde_kernels.hip is built for c <= 32 -- said here, before any device memory is allocated
+            raise NotImplementedError(
+                f"measure 'KDE' with an embedding of width {dims[emb_nlayer]} / {int(Wlin.shape[0])} classes: the c x c joint pdf of "
+                f"utils.MutualInformation (topology_attack.py:244-249, :261-265; utils.py:980-1049) is built for widths <= 32 on this "
+                f"path (a GAT victim's 5 x 16 = 80-wide embedding is not covered)")
         label_adj = kwargs.get("label_adj", None)
         if label_adj is None and getattr(args, "useY", False):
             label_adj = np.load("./saved_data/" + args.dataset + ".npy")   # (:133)

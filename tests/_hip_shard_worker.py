@@ -277,3 +277,29 @@ def run_main_rank(rank, world, port, argv, n, cwd, out):
         with open(f"{out}.rank{rank}.err", "w") as fh:
             fh.write(traceback.format_exc())
         raise
+
+
+def run_production_line(name, out):
+    """One README-line fixture through PGDAttack.attack in the PRODUCTION configuration of the engine: neither MCGRA_AB (the parity
+    suite's A/B switches are ignored) nor MCGRA_KEEP_GSYM (no mirrored store of the gradient) nor MCGRA_TESTING in the environment --
+    what a user's process looks like.  Runs the class-level checks of tests/test_gpu_readme.py (ensemble sample, sum, AUC within
+    north_star's 1e-4 of the reference's, every step of a MSELoss / KL line fused) and writes <out>.ok."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        from tests import helpers as H                      # (sets the suite's defaults ...)
+        for k in ("MCGRA_AB", "MCGRA_KEEP_GSYM", "MCGRA_TESTING", "MCGRA_SPLIT_BF16"):
+            os.environ.pop(k, None)                         # (... which a production process does not have)
+        import mcgra_loader
+        pkg = mcgra_loader.load()
+        from tests import test_gpu_readme as R
+        z = H.load_readme(name)
+        final = R._class_run(pkg, z, int(z["epochs"]))
+        R._final_checks(z, final, name)
+        with open(f"{out}.ok", "w") as fh:
+            fh.write("ok")
+    except BaseException:
+        with open(f"{out}.rank0.err", "w") as fh:
+            fh.write(traceback.format_exc())
+        raise

@@ -508,6 +508,26 @@ def test_pgdattack_class_other_victims(pkg, torch_, name, fake):
     assert abs(O.metric_pool(z["adj"], final, z["idx_attack"]) - float(z["auc"])) < 1e-4
 
 
+def test_pgdattack_class_refuses_kde_on_a_wide_embedding_by_name(pkg, torch_):
+    """measure = KDE with a GAT victim (utils.MutualInformation(num_bins = H_A1.shape[1]), topology_attack.py:244-249; the fixture's
+    GAT is 3 heads x 16 = 48 wide, main.py's 5 x 16 = 80): the
+    c x c joint pdf of this path is built for widths <= 32 -- PGDAttack.attack says so, naming the width and the reference lines,
+    before an engine exists (VERDICT round 5, next #7)."""
+    z = H.load_case("s48_gat_hsic_init")
+    w = H.weights_from(z)
+    victim, emb = H.FakeGAT(w), H.FakeGAT(w)
+    n = z["adj"].shape[0]
+    model = pkg.PGDAttack(model=victim, embedding=emb, H_A=torch_.tensor(z["H_A2"]), Y_A=torch_.tensor(z["Y_A"]),
+                          nnodes=n, loss_type="CE", device="cuda:0")
+    lab = z["labels"]
+    with pytest.raises(NotImplementedError, match="width 48"):
+        model.attack(_args("KDE"), None, float(z["lr"]), 0, float(z["weight_sup"]), tuple(z["weight_param"]),
+                     torch_.tensor(z["feature_adj"]), 0, 0, 0, None, None, np.arange(8), torch_.tensor(z["adj"]),
+                     torch_.tensor(z["features"]), torch_.zeros(n, n), torch_.tensor(lab), z["idx_attack"],
+                     float(z["num_edges"]), 0, epochs=1, label_adj=(lab[:, None] == lab[None, :]).astype(np.float32))
+    assert model.engine is None
+
+
 def _run_cora(pkg, t, name, epochs=None):
     z = H.load_cora(name)
     if epochs is not None:
@@ -1651,14 +1671,15 @@ def test_small_operand_terms_beside_the_general_step_are_bit_identical(pkg, case
         monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
         eng = H.engine_from(pkg, z)
         res = []
-        for t in range(3):
+        nsteps = min(3, z["noise"].shape[0]) if "noise" in z else 3
+        for t in range(nsteps):
             nz = H.noise_of(z, t)
             sc = eng.step(noise=None if nz is None else torch.as_tensor(nz, device="cuda:0"), want_scalars=True)
             eng.monitor()
             res.append((eng.buffer("G_sym").clone(), sc))
         outs.append((res, eng.buffer("M").clone()))
         eng.close()
-    for t in range(3):
+    for t in range(len(outs[0][0])):
         assert torch.equal(outs[0][0][t][0], outs[1][0][t][0]), t
         assert outs[0][0][t][1] == outs[1][0][t][1], t
     assert torch.equal(outs[0][1], outs[1][1])
@@ -1807,6 +1828,42 @@ def test_fused_mse_step_matches_general_path_and_oracle(pkg, n, widths, wp, meas
 
 
 @pytest.mark.parametrize("measure", ["MSELoss", "KL"])
+def test_fused_elementwise_steps_mask_the_pairs_the_reference_masks(pkg, measure, monkeypatch):
+    """The fused MSELoss / KL steps have no data-dependent fallback: their decode backward masks exactly the pairs relu'(0) = 0 masks
+    in the reference (S_ij <= 0), dead embedding rows included (zn_i = 0: modified_adj1's row is zero, its softmax uniform).  Weights
+    whose embedding bias kills about half of em (tests/helpers.py:masked_weights: thousands of masked pairs, a third of the rows
+    dead) -- fused against the general step, every step fused.  (Not against the oracle here: the construction puts the median of
+    every embedding column AT the ReLU threshold, so rows survive on one coordinate of rounding-noise size whose direction --
+    hence modified_adj1_ij = 1 or 0 against every other such row -- is decided by the last bit of the forward's summation order:
+    oracle and engine, 1.7e-5 apart in em, differ by 1.0 on entries of 402 rows, c7 by 0.4 %.  The general step is what the
+    reference's masked fixtures pin; the two engine steps agree to 3e-7 / 1.2e-6 of the gradient's largest magnitude.)"""
+    z = _synthetic_case(600, 11, (16, 16), 4, seed=9, measure=measure)
+    w = H.masked_weights(z)
+    engs = []
+    for nofuse in (False, True):
+        if nofuse:
+            monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")
+        e = H.engine_from(pkg, z)
+        e.set_model(w.W, w.b, w.Wlin, w.blin, w.Ws)
+        e.set_graph(z["features"], z["adj"], None, z["feature_adj"], z["labels"], z["idx_attack"])
+        e.set_adj_changes(H.a0_of(z))
+        engs.append(e)
+    monkeypatch.delenv("MCGRA_NO_FUSED_LR")
+    fused, gen = engs
+    for t in range(3):
+        a, b = fused.step(want_scalars=True), gen.step(want_scalars=True)
+        em = gen.buffer("em").cpu().numpy()
+        assert (em == 0).mean() > 0.5 and (np.abs(em).sum(1) == 0).sum() > 50      # the bias does kill most of em, and whole rows
+        gf, gg = fused.buffer("G_sym").cpu().numpy(), gen.buffer("G_sym").cpu().numpy()
+        scale = np.abs(gg).max()
+        assert np.abs(gf - gg).max() <= 3e-5 * scale, (t, np.abs(gf - gg).max() / scale)
+        for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10"):
+            assert a[k] == pytest.approx(b[k], rel=2e-4 if measure == "KL" else 2e-5, abs=1e-6 * max(1.0, abs(b["loss"]))), (t, k, a[k], b[k])
+        fused.set_adj_changes(gen.get_adj_changes())
+    assert fused.fused_steps() == 3 and gen.fused_steps() == 0
+
+
+@pytest.mark.parametrize("measure", ["MSELoss", "KL"])
 def test_fused_mse_free_run_and_finalize(pkg, measure, monkeypatch):
     """Free-running fused MSELoss (KL) steps with and without monitor calls in between give the same bits, and the post-loop
     ensemble after a fused loop equals the one after the same loop on the general path (em_last stands in for
@@ -1848,30 +1905,29 @@ def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world, wp, meas
     plans, bks = _shard_engines(pkg, z, world, joint=world == 3)
     lr = float(z["lr"])
     nex = 0
-    agree = None
     for t in range(3):
         a = mono.step(want_scalars=True); mono.monitor()
         sc = S.run_lockstep(bks, S.SHARD_STEP, want_scalars=True)
         S.run_lockstep(bks, S.SHARD_MONITOR)
         # the mirrored gradient on every rank's own rows: a rank holds only its own rows of M current, and the MSELoss part of the
         # decode forms adj_norm_ij per pair -- from THOSE rows (wp with w2 = 1 makes that part a tenth of the gradient).  Second
-        # step: on the rows and columns whose state the first step left the same in both runs.  Adam moves an entry whose gradient
-        # sits at the noise level by +-lr on its sign alone -- lr = 0.01 here, against a degree d_i of ~ 16 -- and one such entry in
-        # row i moves r_i = d_i^-1/2 by 6e-4 and with it adj_norm and the gradient of the whole row and column i (calc_kl in the
-        # 3-layer case: 1.2e-3 of the gradient's largest magnitude there)
+        # step: the two runs' states differ on the entries Adam moved by +-lr on a noise-level gradient's sign (lr = 0.01 here), and
+        # the gradient is not continuous in the state everywhere (Info_entropy's clamp at 1e-4, the decode's relu): 99.99 % of the
+        # entries within 3e-4, every entry within 5e-3 (calc_kl, 3 layers, 4 ranks: ONE mirrored pair at 1.25e-3; with the ranks'
+        # state forced to the monolithic engine's the second step agrees to 5e-9: scripts/diag_r6.py 2)
         if t <= 1:
             gm = mono.buffer("G_sym")
             for b, pl in zip(bks, plans):
                 if pl.has_rows:
                     gr = b.eng.buffer("G_sym")[pl.row_begin:pl.row_end]
                     d = (gr - gm[pl.row_begin:pl.row_end]).abs()
-                    if agree is not None:
-                        d = d * agree[pl.row_begin:pl.row_end, None] * agree[None, :]
-                    assert float(d.max()) <= (3e-6 if t == 0 else 3e-4) * float(gm.abs().max()), (t, pl.rank)
+                    gmax = float(gm.abs().max())
+                    if t == 0:
+                        assert float(d.max()) <= 3e-6 * gmax, (t, pl.rank)
+                    else:
+                        assert float((d > 3e-4 * gmax).float().mean()) <= 1e-4 and float(d.max()) <= 5e-3 * gmax, (t, pl.rank, float(d.max()) / gmax)
         rows = _gather_rows(bks)
         M = mono.buffer("M")
-        agree = ((rows - M).abs() <= 0.05 * lr).all(dim=1).float()      # rows (= columns: both states are symmetric) left identical
-        assert float(agree.mean()) > 0.2
         assert rows.shape == M.shape
         assert float(((rows - M).abs() > 0.05 * lr).float().mean()) < 2e-3, t
         assert float((rows - rows.T).abs().max()) == 0.0, "ranks must agree on mirrored entries bit for bit"
