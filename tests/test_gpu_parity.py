@@ -1850,10 +1850,13 @@ def test_fused_elementwise_steps_mask_the_pairs_the_reference_masks(pkg, measure
         engs.append(e)
     monkeypatch.delenv("MCGRA_NO_FUSED_LR")
     fused, gen = engs
+    probe = O.PGDAttackOracle(w, z["features"], z["adj"], np.zeros_like(z["adj"]), z["feature_adj"], z["labels"], z["idx_attack"], H.cfg_from(z))
+    probe.set_adj_changes(H.a0_of(z))
+    probe.step()
+    em = probe.last["em"]
+    assert (em == 0).mean() > 0.5 and (np.abs(em).sum(1) == 0).sum() > 50      # the bias does kill most of em, and whole rows
     for t in range(3):
         a, b = fused.step(want_scalars=True), gen.step(want_scalars=True)
-        em = gen.buffer("em").cpu().numpy()
-        assert (em == 0).mean() > 0.5 and (np.abs(em).sum(1) == 0).sum() > 50      # the bias does kill most of em, and whole rows
         gf, gg = fused.buffer("G_sym").cpu().numpy(), gen.buffer("G_sym").cpu().numpy()
         scale = np.abs(gg).max()
         assert np.abs(gf - gg).max() <= 3e-5 * scale, (t, np.abs(gf - gg).max() / scale)
@@ -1932,8 +1935,11 @@ def test_sharded_mse_ranks_match_monolithic_step(pkg, n, widths, world, wp, meas
         assert float(((rows - M).abs() > 0.05 * lr).float().mean()) < 2e-3, t
         assert float((rows - rows.T).abs().max()) == 0.0, "ranks must agree on mirrored entries bit for bit"
         for k in ("loss", "c1", "c2", "c6", "c7", "c9", "c10", "nll", "clamp_sum"):
+            # (KL: the value of calc_kl is a difference of row log-sum-exps that agree to three digits -- see
+            # test_fused_mse_step_matches_general_path_and_oracle -- and the ranks cut the rows' sums into other slices)
+            tol = 2e-4 if measure == "KL" and k in ("loss", "c1", "c2") else 3e-5
             for b in sc:
-                assert b[k] == pytest.approx(a[k], rel=3e-5, abs=1e-6 * max(1.0, abs(a["loss"]))), (t, k, b[k], a[k])
+                assert b[k] == pytest.approx(a[k], rel=tol, abs=1e-6 * max(1.0, abs(a["loss"]))), (t, k, b[k], a[k])
             assert all(b[k] == sc[0][k] for b in sc), "scalars are identical on every rank"
     assert all(b.eng.fused_steps() == 3 for b in bks) and mono.fused_steps() == 3
     assert all(b.eng.cut_product_steps() == 0 for b in bks)
