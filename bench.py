@@ -808,13 +808,13 @@ def main(argv=None):
             # Cora shape with the N x N x N product as ONE fp16 plane product (MCGRA_SPLIT_BF16=1).  A named, non-headline mode: the
             # reference's CPU path is fp32 and `value` stays on the fp32-level split; its accuracy against float64 and its AUC delta
             # are measured by scripts/single_plane_table.py (profiles/r06_single_plane_table.txt)
-            for wl2, k2 in (("synthetic-10k-hsic", 60), ("cora-shape-hsic", 100)):
+            for wl2, k2 in (("synthetic-10k-hsic", 60), ("cora-shape-hsic", 100), ("citeseer-shape-gat-hsic", 60)):
                 torch.cuda.empty_cache()
                 sp1 = product_probe(pkg, torch, dev, wl2, a.seed, k2, 10, monitor, 1)
                 extra[wl2 + "-f16-single-plane"] = {
                     "value": sp1["value"], "unit": "attack-steps/s", "ms_per_step": sp1["ms_per_step"], "nodes": WORKLOADS[wl2][0], "steps": k2,
-                    "dtype": "f16 single plane (the N x N x N product only: x0 y0 of the power-of-two-scaled operands, fp32 accumulate; "
-                             "everything else as the headline)", "product_avg_launch_ms": sp1.get("product_avg_launch_ms"),
+                    "dtype": "f16 single plane (the N x N x N products only -- one per fused step, four per Gram-evaluation step: x0 y0 of the "
+                             "power-of-two-scaled operands, fp32 accumulate; everything else as the headline)", "product_avg_launch_ms": sp1.get("product_avg_launch_ms"),
                     "product_16bit_tflops": sp1.get("product_16bit_tflops_issued"), "auc": sp1["auc"],
                     "auc_minus_headline": (sp1["auc"] - auc) if wl2 == a.workload and k2 == a.steps else None,
                     "note": "non-headline: never `value`; accuracy table in profiles/r06_single_plane_table.txt"}

@@ -331,6 +331,7 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     const char* es = getenv("MCGRA_SPLIT_BF16");
     const char auto_mode[2] = {n >= 1024 ? '3' : '0', 0};
     if (!es || !es[0]) es = auto_mode;
+    h->split_single = es[0] == '1';      // (by name only: also the Gram evaluation's four products, below)
     // =1: the fp16 x 2 operands, ONE plane product (fp16 accuracy: 2^-11 per operand; a third of the matrix-core work) -- what "bf16 MFMA"
     // in BASELINE.json's configs[2] / [4] means taken literally.  Never a default: the reference's CPU path is fp32.
     if (!rc && h->lr_ok && cfg->eps == 0.f && es && (es[0] == '1' || es[0] == '2' || es[0] == '3')) {
@@ -924,8 +925,8 @@ static int gram_pack_fork_kx(mcgra_attack* h, hipStream_t st, const float* adjn)
   if (sg != st) { MCGRA_HIP(hipEventRecord(h->ev_fork, st)); MCGRA_HIP(hipStreamWaitEvent(sg, h->ev_fork, 0)); }
   CHK(timer_begin(h, sg, h->profile));
   MCGRA_HIP(split3_symm(sg, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A,
-                        h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2, 0, nullptr, 0, nullptr,
-                        h->amax + 1));
+                        h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2 | (h->split_single ? 8 : 0), 0, nullptr,
+                        0, nullptr, h->amax + 1));
   CHK(timer_end(h, sg, h->profile, 2.0 * (double)n * n * n));
   return 0;
 }
@@ -984,6 +985,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
   // (a trailing rank of a padded plan may own no tile rows at all: t0 == t1 == t_all)
   const int t0 = 0, t1 = t_all;          // (row-block ranks run the fused step: attack_fused.hip)
   const bool sharded = false;
+  const int sflag = h->split_single ? 8 : 0;      // MCGRA_SPLIT_BF16=1: the Gram evaluation's four products as single-plane products too
 
   // The part of the backward that needs the forward only: small-operand terms c9 (:237-258) and c10 (:259-272), and the
   // victim(adj_norm) chain's backward down to G_P of every layer.  (A Gram-evaluation step runs it beside its Grams.)
@@ -1075,7 +1077,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, h->profile));
     MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp0, h->KX, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A,
-                          h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2, 0, nullptr, 0, nullptr,
+                          h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2 | sflag, 0, nullptr, 0, nullptr,
                           h->amax + 1));
     CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
     return 0;
@@ -1294,7 +1296,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       if (use2) {
         CHK(gs_fork());
         CHK(timer_begin(h, sg_, h->profile));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 2, 0, -1, 2, 0, nullptr, 0, nullptr, h->amax + 2));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 2, 0, -1, 2 | sflag, 0, nullptr, 0, nullptr, h->amax + 2));
         CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
         if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));   // Ky done
       }
@@ -1310,7 +1312,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
           split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp0, 2, h->amax + 4, 2.f * s2);
           CHK(gs_fork());
           CHK(timer_begin(h, sg_, h->profile));
-          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 4, 0, -1, 1, 0, nullptr, 0, nullptr, h->amax + 2));
+          MCGRA_HIP(split3_symm(sg_, n, h->Gp0, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 4, 0, -1, 1 | sflag, 0, nullptr, 0, nullptr, h->amax + 2));
           CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
           if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));   // G_A1 complete
           gs_p4 = true;
@@ -1345,7 +1347,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         split3_pack(st, n, ld, h->KX, nullptr, false, h->Gp1, 2, h->amax + 4);
         CHK(gs_fork());
         CHK(timer_begin(h, sg_, big));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 4, 0, -1, 1, 0, nullptr, 0, nullptr, h->amax + 2));
+        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp2, h->G_A1, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 4, 0, -1, 1 | sflag, 0, nullptr, 0, nullptr, h->amax + 2));
         CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
         if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));
         gs_p4 = true;
@@ -1355,7 +1357,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     CHK(victim_rankk()); gs_rankk_done = true;
     CHK(gs_fork());
     CHK(timer_begin(h, sg_, big));
-    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->small_slab ? h->small_slab : h->KX, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 3, 0, -1, 1, 0, nullptr, 0, nullptr, h->amax + 1));
+    MCGRA_HIP(split3_symm(sg_, n, LY, h->Bpack, h->G_ADJN, ld, 0, -1, h->small_slab ? h->small_slab : h->KX, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 3, 0, -1, 1 | sflag, 0, nullptr, 0, nullptr, h->amax + 1));
     CHK(timer_end(h, sg_, big, 2.0 * (double)n * n * n));
     if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));
     gs_p3 = true;
@@ -1529,7 +1531,9 @@ int step_general(mcgra_attack_t* h, void* stream, const float* noise, double* sc
 long long mcgra_attack_masked_fused_steps(mcgra_attack_t* h) { return h ? (long long)h->masked_fused_steps : 0; }
 long long mcgra_attack_cut_product_steps(mcgra_attack_t* h) { return h ? (long long)h->cut_product_steps : 0; }
 int mcgra_attack_product_mode(mcgra_attack_t* h) {
-  return h ? (h->split_mode == 2 && h->split_planes == 2 ? (h->split_single ? 1 : 3) : h->split_mode) : 0;
+  if (!h) return 0;
+  if (h->split_single && (h->gram_split || (h->split_mode == 2 && h->split_planes == 2))) return 1;
+  return h->split_mode == 2 && h->split_planes == 2 ? 3 : h->split_mode;
 }
 
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps) {

@@ -124,6 +124,49 @@ def cora():
     print(f"   AUC delta (single plane - default): {aucs['1'][4] - aucs['3'][4]:+.2e} at 4 steps, {aucs['1'][20] - aucs['3'][20]:+.2e} at 20 steps")
 
 
+def citeseer_gat():
+    """BASELINE.json configs[2]: Citeseer (n = 3312), the reference-trained GAT victim, HSIC -- the general step, whose Gram
+    evaluation's FOUR N x N x N products per step run on the same kernel; against the reference's own run (fixture)."""
+    z = H.load_cora("citeseer_gat_hsic")
+    w = O.GCNWeights([z["W0"], z["W1"]], [z["b0"], z["b1"]], z["Wlin"], z["blin"], None, str(z["act"]), str(z["head_act"]))
+    n = z["adj"].shape[0]
+    dims = [w.W[0].shape[0]] + [x.shape[1] for x in w.W]
+    pi, pj = H.tril_pos(z["packed_pos"])
+    ti, tj = torch.as_tensor(pi, device=dev), torch.as_tensor(pj, device=dev)
+    lab = z["labels"]
+    la = (lab[:, None] == lab[None, :]).astype(np.float32)
+    fadj = H.cora_feature_adj(z["features"])
+    print(f"\n== Citeseer + GAT (BASELINE.json configs[2]; n = {n}, 5 x 16 = 80 wide, ELU), HSIC: the Gram evaluation, four products per step; "
+          f"against the reference's own fp32 run (its AUC: {float(z['auc']):.6f})")
+    rows = []
+    for mode, label in MODES:
+        def mk():
+            e = pkg.AttackEngine(n, dims, w.Wlin.shape[0], int(z["emb_nlayer"]), "HSIC", float(z["weight_sup"]),
+                                 tuple(float(x) for x in z["weight_param"]), float(z["lr"]), float(z["num_edges"]), len(z["idx_attack"]),
+                                 act="elu", head_act="elu", fin_layers=tuple(int(x) for x in z["fin_layers"]))
+            e.set_model(w.W, w.b, w.Wlin, w.blin)
+            e.set_graph(z["features"], z["adj"], None, fadj, lab, z["idx_attack"])
+            if "a0_seed" in z:
+                e.set_adj_changes(H.init_adj_changes(n, z["a0_seed"], z["a0_scale"]))
+            return e
+        eng = with_mode(mode, mk)
+        assert (eng.product_mode() == 1) == (mode == "1"), eng.product_mode()      # (a victim without a low-rank form reports 0 / 1: its products are the Gram evaluation's)
+        errs = []
+        for t in range(int(z["epochs"])):
+            eng.step(); eng.monitor()
+            g = eng.buffer("G_sym")[ti, tj].cpu().numpy().astype(np.float64)
+            errs.append(np.abs(g - z["step_g"][t]).max() / float(z["step_g_absmax"][t]))
+        final = eng.finalize(1, z["H_A2"], None, la).cpu().numpy()
+        auc = O.metric_pool(z["adj"], final, z["idx_attack"])
+        ms_step, ms_prod = timed(eng, 60)
+        rows.append((label, errs[0], max(errs), auc, auc - float(z["auc"]), ms_prod, ms_step))
+        eng.close()
+    print(f"   {'products':<46} {'step-0 err':>10} {'worst step':>10} {'AUC':>10} {'- reference':>12} {'ms/product':>11} {'ms/step':>8}")
+    for r in rows:
+        print(f"   {r[0]:<46} {r[1]:10.2e} {r[2]:10.2e} {r[3]:10.6f} {r[4]:+12.2e} {r[5]:11.3f} {r[6]:8.3f}")
+
+
 if __name__ == "__main__":
     bench10k()
     cora()
+    citeseer_gat()
