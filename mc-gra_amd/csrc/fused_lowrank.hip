@@ -356,7 +356,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // exp() of the fused KL step: every argument is an entry of adj_norm or modified_adj1 (in [0, 1]) or such an entry minus its row's
 // log-sum-exp (in [-log(e n), 0]: |x| <= 12 up to N = 60 000) -- no overflow, no denormal result -- and the row statistics are kept
 // in float32, i.e. the exponent already carries +-5e-7 of rounding: v_exp_f32 on x log2(e) (__expf: ~7e-7 relative at |x| = 12) is at
-// that level and a fifth of libm's expf in instructions (k_decode_stats 279 -> R6 us, the decode 390 -> R6 us at N = 10 000).
+// that level and a fifth of libm's expf in instructions (the decode 390 -> 291 us, k_decode_stats 279 -> 257 us at N = 10 000).
 __device__ __forceinline__ float kl_exp(float x) { return __expf(x); }
 // The columns' vectors come out of SCALAR registers: zn_j is the same for every lane, so the pairs (zn_2P[k], zn_2P+1[k]) are read
 // from a pair-interleaved copy of Zn through the scalar cache (wave-uniform address: s_load_dwordx16) and feed the packed FMAs
