@@ -183,21 +183,22 @@ def test_bench_world2_branch_on_a_shared_gpu(tmp_path):
     assert sc["ok"] is True and sc["abs_diff"] <= 1e-6 and abs(sc["auc_one_rank"] - auc1) <= 1e-9 and sc["steps"] == 3
 
 
-def test_bench_world2_branch_with_the_fused_mseloss_step(tmp_path):
-    """The same branch on an MSELoss workload (Cora-shaped: BASELINE.json configs[0]'s measure): the row-block MSELoss step
-    exchanges no N x N data -- six all-gathers per step + monitor, no all-to-all, no product -- and the 2-rank attack's AUC is the
-    1-rank attack's (rank 0's replay behind the timed region says so too)."""
+@pytest.mark.parametrize("workload,ncoll", [("cora-shape-mse", 6), ("cora-shape-kl", 7)])
+def test_bench_world2_branch_with_the_fused_mseloss_step(tmp_path, workload, ncoll):
+    """The same branch on an MSELoss workload (Cora-shaped: BASELINE.json configs[0]'s measure) and on a KL one (round 6): the
+    row-block MSELoss / KL steps exchange no N x N data -- six / seven all-gathers per step + monitor, no all-to-all, no product --
+    and the 2-rank attack's AUC is the 1-rank attack's (rank 0's replay behind the timed region says so too)."""
     out = str(tmp_path / "bench2mse")
-    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cora-shape-mse", "--no-shard-probe"]
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-shard-probe"]
     _run_ranks(W.run_bench_rank, 2, (argv,), out, timeout=900)
     line = json.load(open(out + ".json"))
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
     assert line["config"]["fused_steps"] == 4 and line["config"]["general_steps"] == 0
-    assert line["collectives_per_step"] == 6
-    auc1, fused1 = _one_rank_auc("cora-shape-mse", 4)
+    assert line["collectives_per_step"] == ncoll
+    auc1, fused1 = _one_rank_auc(workload, 4)
     assert fused1 == 4 and abs(line["auc"] - auc1) <= 1e-5, (line["auc"], auc1)
     m = line["multi_rank"]
-    assert m["collectives_timed_per_step"] == 6 and m["alltoall_ms_per_step"]["max"] == 0 and m["allgather_ms_per_step"]["mean"] > 0
+    assert m["collectives_timed_per_step"] == ncoll and m["alltoall_ms_per_step"]["max"] == 0 and m["allgather_ms_per_step"]["mean"] > 0
     assert m["product_ms_per_rank"] == [None, None] and m["compute_only_steps_all_fused"] and not m.get("errors")
     assert m["state_check"]["ok"] is True
 
