@@ -269,6 +269,9 @@ int mcgra_attack_step(mcgra_attack_t* h, void* stream, const float* noise,
  *     leaves its partial in row k * rows_per_rank + q, and behind the gather every rank adds the `world` partials in rank
  *     order -- the same bits on every rank, and no all-reduce.  Per step + monitoring forward at L GCN layers: 2 L + 3
  *     all-gathers and the one all-to-all (8 collectives at L = 2; one more gather when want_scalars is set).
+ *   The elementwise measures have no product and no low-rank factors: measure MSELoss exchanges 2 L + 2 all-gathers per step and
+ *   no N x N data; measure KL (round 6) 2 L + 3 -- one more gather, of the rows' softmax statistics [logsumexp(adj_norm_i) |
+ *   logsumexp(modified_adj1_i)], which the decode backward and the tail need of EVERY row.
  * The engine runs until the next exchange point and describes the collective; the host layer (mc-gra_amd/sharded.py)
  * executes it with torch.distributed (backend "nccl" = RCCL) on views of ONE caller-owned device arena:
  *     mcgra_attack_bind_exchange(h, arena, mcgra_attack_exchange_bytes(h));
@@ -304,14 +307,19 @@ int mcgra_attack_shard_scalars(mcgra_attack_t* h, void* stream, double* out);
 int mcgra_attack_get_rows(mcgra_attack_t* h, void* stream, float* out);
 /* How the one N x N x N product of a low-rank step is evaluated by this engine: 0 = fp32 MFMA SYMM, 2 = 3-plane bf16
  * split, 3 = 2-plane fp16 split (the default for n >= 1024), both by the hand-written kernel of split_symm_bf16.hip at
- * fp32-level error.  Chosen at create from MCGRA_SPLIT_BF16. */
+ * fp32-level error; 1 = the SINGLE plane product x0 y0 of the 2-plane fp16 operands (fp16 accuracy, 2^-11
+ * per operand; also the four products of a Gram-evaluation step) -- a named mode, MCGRA_SPLIT_BF16=1, never a default (the
+ * reference's CPU path is fp32).  Chosen at create from MCGRA_SPLIT_BF16. */
 int mcgra_attack_product_mode(mcgra_attack_t* h);
 /* Steps that took the low-rank / the Gram (general) evaluation of the N x N linear_HSIC terms since creation. */
 int mcgra_attack_path_stats(mcgra_attack_t* h, long long* lowrank_steps, long long* general_steps);
 /* How many of the low-rank steps ran as the fused step that evaluates every N x N quantity from the learnable
  * adjacency and n-vectors (attack_fused.hip: adj_norm, its centred copy, modified_adj1 and d loss / d adj_norm are
  * never stored).  Conditions: measure HSIC, ReLU GCN victim, eps == 0, the split product (n >= 1024 or
- * MCGRA_SPLIT_BF16=2/3), n >= 256, widths <= 32; MCGRA_NO_FUSED_LR=1 disables it. */
+ * MCGRA_SPLIT_BF16=1/2/3), n >= 256, embedding width 8 / 16 / 32, summed layer widths <= 64; MCGRA_NO_FUSED_LR=1 (beside MCGRA_AB=1)
+ * disables it.  Counted as well: the fused MSELoss step (calc = MSELoss: elementwise in the same per-pair quantities, no product) and
+ * the fused KL step (calc = calc_kl, topology_attack.py:483-487: + per-row softmax statistics from one more per-pair pass) -- same
+ * conditions on the victim, any n >= 256; they do not count as low-rank steps in mcgra_attack_path_stats. */
 long long mcgra_attack_fused_steps(mcgra_attack_t* h);
 /* Fused steps whose decode relu-masked pairs (S_ij <= 0 off the diagonal) while every embedding row was alive: they stand.
  * With a ReLU embedding zn >= 0, so a masked pair has S_ij == 0 exactly: the value of modified_adj1 is still Z Z^T - D, and
