@@ -559,8 +559,17 @@ __global__ void k_kl_stats_fin(int n, int row0, int row1, int nslab, const doubl
                                float* __restrict__ lse1) {
   const int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= row1) return;
+  // (eight slices' loads in flight, added in slice order: up to 64 dependent round trips otherwise -- 13 us of a 0.32 ms Cora-sized step)
   double a = 0.0, b = 0.0;
-  for (int s = 0; s < nslab; ++s) { a += part[((size_t)s * n + i) * 2]; b += part[((size_t)s * n + i) * 2 + 1]; }
+  int s = 0;
+  for (; s + 8 <= nslab; s += 8) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(part + ((size_t)(s + u) * n + i) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+  }
+  for (; s < nslab; ++s) { a += part[((size_t)s * n + i) * 2]; b += part[((size_t)s * n + i) * 2 + 1]; }
   lseA[i] = (float)log(a);
   lse1[i] = (float)log(b);
 }
@@ -570,7 +579,15 @@ __global__ void k_kl_v_fin(int n, int row0, int row1, int nslab, const double* _
   const int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= row1) return;
   double a = 0.0;
-  for (int s = 0; s < nslab; ++s) a += vrow[(size_t)s * n + i];
+  int s = 0;
+  for (; s + 8 <= nslab; s += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = vrow[(size_t)(s + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; s < nslab; ++s) a += vrow[(size_t)s * n + i];
   vsum[i] = a / (double)n;      // (batchmean: the row's share of calc_kl's value)
   vf[i] = (float)a;
 }
