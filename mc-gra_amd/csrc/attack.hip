@@ -1033,9 +1033,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     }
     return 0;
   };
-  bool gs_path = false, kx_started = false, gs_early_bwd = false, gs_p4 = false, gs_p3 = false, gs_rankk_done = false;
+  bool gs_path = false, kx_started = false, ky_started = false, gs_early_bwd = false, gs_p4 = false, gs_p3 = false, gs_rankk_done = false;
   hipStream_t sg_ = st;
-  std::function<int()> gs_fork;
+  std::function<int()> gs_fork, launch_ky;
   std::function<int(bool)> launch_kx;
   if (PH(0)) {
   const bool adopt = h->fwd_cached && !gen;         // forward of this iteration already done by the last monitor call
@@ -1080,6 +1080,21 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
                           h->small_slab ? h->small_slab_bytes : sizeof(float) * (size_t)n * ld, 2, h->amax + 1, 0, -1, 2 | sflag, 0, nullptr, 0, nullptr,
                           h->amax + 1));
     CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
+    return 0;
+  };
+  // Ky = Yc Yc^T behind Kx on the side stream (ev_first: Kx done, ev_join: Ky done), from the planes the centring pass of
+  // modified_adj1 just packed
+  launch_ky = [=, &ky_started]() -> int {
+    if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_first, sg_));    // Kx done
+    if (use2) {
+      const size_t slab = sizeof(float) * (size_t)n * ld;
+      CHK(gs_fork());
+      CHK(timer_begin(h, sg_, h->profile));
+      MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 2, 0, -1, 2 | sflag, 0, nullptr, 0, nullptr, h->amax + 2));
+      CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
+      if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));   // Ky done
+    }
+    ky_started = true;
     return 0;
   };
   if (want_xc) {
@@ -1232,6 +1247,16 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
     }
     // on a low-rank step with c2 the modified_adj1 side (c7 value and gradient) is folded into k_lr_decode_bwd
     const bool y_fused = h->lr_step && use2 && lr_decode_supported(he);
+    // A step that IS a Gram evaluation centres and packs modified_adj1 and starts Ky FIRST: the side stream is idle from the end of
+    // Kx until this point, and the N x N entropy pass and its reduction (40 us at n = 3312) need none of it
+    const bool ky_early = gs_only && use2 && !h->lr_step && phases == 0xF && sg_ != st && kx_started;
+    if (ky_early) {
+      launch_rowsum(st, n, ld, h->A1, h->rowsy);
+      launch_colmean_f32(st, n, ld, h->rowsy, h->cmean);
+      pack_center_both(st, n, ld, h->A1, h->cmean, nullptr, 1.0002f, h->Gp1, h->Gp2, h->amax + 2, h->gram_diag + ld,
+                       reinterpret_cast<double*>(h->YC));
+      CHK(launch_ky());
+    }
     launch_loss_elem(st, n, ld, h->ADJN, y_fused ? nullptr : h->A1, h->FADJ, 0.f, 0.f, (float)(k6 / n2), (float)(k7 / n2),
                      h->G_ADJN, y_fused ? nullptr : h->G_A1, h->rowvals);
     launch_reduce_rows(st, h->rowvals, n, 4, h->scal + S_V1);
@@ -1248,7 +1273,7 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
         }
       } else {
         ++h->general_steps;
-        if (use2) {
+        if (use2 && !ky_early) {
           launch_rowsum(st, n, ld, h->A1, h->rowsy);
           const bool gs = h->gram_split && !gen;
           if (gs && !h->lr_ok) {
@@ -1292,17 +1317,12 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
       const size_t slab = sizeof(float) * (size_t)n * ld;
       const float s1 = (float)(sg * k1), s2 = (float)(sg * k2);
       if (!kx_started) { CHK(launch_kx(false)); kx_started = true; }      // (a low-rank configuration whose decode found a dead row)
-      if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_first, sg_));    // Kx done
-      if (use2) {
-        CHK(gs_fork());
-        CHK(timer_begin(h, sg_, h->profile));
-        MCGRA_HIP(split3_symm(sg_, n, h->Gp1, h->Gp1, h->KY, ld, 0, -1, h->small_slab ? h->small_slab : h->G_A, h->small_slab ? h->small_slab_bytes : slab, 2, h->amax + 2, 0, -1, 2 | sflag, 0, nullptr, 0, nullptr, h->amax + 2));
-        CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
-        if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_join, sg_));   // Ky done
-      }
+      if (!ky_started) CHK(launch_ky());      // (phase 0 started it in front of the entropy pass when it could)
       ++h->gram_split_steps;
-      // beside the Grams: everything of the backward that needs the forward only
-      CHK(early_bwd()); gs_early_bwd = true;
+      // beside the Grams: everything of the backward that needs the forward only -- enqueued BEHIND the fork of G_A1 += LX Yc, whose
+      // operand pack needs Kx and the diagonals only: the ~20 small-operand launches cost the host ~70 us, and in front of the
+      // pack they held the third product back by that long (r06 timeline: 27 us between Ky's reduction and the product)
+      if (cka) { CHK(early_bwd()); gs_early_bwd = true; }
       if (!cka) {
         // operand scales of LY / LX from the diagonals of the centred Grams (known since the centring passes)
         hsic_gram_scales(st, n, (h->lr_ok && use2) ? h->lrRs : h->gram_diag, h->gram_diag + ld, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->amax);
@@ -1316,8 +1336,9 @@ static int step_impl(mcgra_attack_t* h, void* stream, const float* noise, double
           CHK(timer_end(h, sg_, h->profile, 2.0 * (double)n * n * n));
           if (sg_ != st) MCGRA_HIP(hipEventRecord(h->ev_second, sg_));   // G_A1 complete
           gs_p4 = true;
-          if (sg_ != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));      // the combine reads Ky
         }
+        CHK(early_bwd()); gs_early_bwd = true;
+        if (use2 && sg_ != st) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));      // the combine reads Ky
         // LY straight into its packed planes (the planes Yc's rows held: Ky is done with them), the two value sums from the same
         // pass (partials in YC, dead once packed) -- beside G_A1 += LX Yc
         hsic_combine_pack(st, n, ld, h->KX, h->KY, h->KFC, use1 ? s1 : 0.f, use2 ? s2 : 0.f, h->amax, h->Gp1, nullptr,

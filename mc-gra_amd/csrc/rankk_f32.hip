@@ -141,19 +141,28 @@ __global__ __launch_bounds__(256) void k_rankk_apply_adam(
   const int c0 = (threadIdx.x & 15) * 4, r0 = (threadIdx.x >> 4) * 4;   // 4 x 4 elements per thread
   const float cn = cn_ptr[0];
 
-  auto product = [&](float (&acc)[4][4]) {
+  // acc = sum_k GP[ra + .][k] TT[rb + .][k]: the panels go through LDS KMAX columns at a time (K <= KMAX: one round, the k-ordered
+  // fmaf chain of before; a wider victim -- GAT, two layers of 5 x 16: 160 columns -- continues the same chain over the next columns)
+  auto product = [&](float (&acc)[4][4], int ra, int rb) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float4 av4 = *reinterpret_cast<const float4*>(&As[k][r0]);
-      const float4 bv4 = *reinterpret_cast<const float4*>(&Bs[k][c0]);
-      const float as_[4] = {av4.x, av4.y, av4.z, av4.w}, bs_[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+    for (int k0 = 0; k0 < K; k0 += KMAX) {
+      const int kn = min(KMAX, K - k0);
+      if (k0) __syncthreads();              // every thread is past the previous round's panel reads
+      rk_stage<RA_T>(As, GP + k0, ldp, ra, n, kn, vecp);
+      rk_stage<RA_T>(Bs, TT + k0, ldt, rb, n, kn, vecp);
+      __syncthreads();
+      for (int k = 0; k < kn; ++k) {
+        const float4 av4 = *reinterpret_cast<const float4*>(&As[k][r0]);
+        const float4 bv4 = *reinterpret_cast<const float4*>(&Bs[k][c0]);
+        const float as_[4] = {av4.x, av4.y, av4.z, av4.w}, bs_[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(as_[a], bs_[b], acc[a][b]);
+          for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(as_[a], bs_[b], acc[a][b]);
+      }
     }
   };
   // G_A on the 4 x 4 patch at rows rb + r0.., columns cb + c0.. (gated; 0 outside the matrix)
@@ -182,21 +191,15 @@ __global__ __launch_bounds__(256) void k_rankk_apply_adam(
 
   float acc[4][4];
   // mirrored tile (J, I): rows of GP in J, rows of TT in I
-  rk_stage<RA_T>(As, GP, ldp, bj, n, K, vecp);
-  rk_stage<RA_T>(Bs, TT, ldt, bi, n, K, vecp);
-  __syncthreads();
-  product(acc);
+  product(acc, bj, bi);
   apply(acc, bj, bi);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) T[r0 + a][c0 + b] = acc[a][b];      // T[j local][i local]
-  __syncthreads();
+  __syncthreads();                          // T complete; every thread past the mirrored tile's panel reads
   // direct tile (I, J)
-  rk_stage<RA_T>(As, GP, ldp, bi, n, K, vecp);
-  rk_stage<RA_T>(Bs, TT, ldt, bj, n, K, vecp);
-  __syncthreads();
-  product(acc);
+  product(acc, bi, bj);
   apply(acc, bi, bj);
 
   float pn_[4][4], m_[4][4], v_[4][4], g_[4][4];
@@ -343,7 +346,7 @@ void prep_from_partials(hipStream_t st, int n, const float* ps, const double* pq
                      rowsum, row0, row1);
 }
 bool rankk_apply_adam_supported(int n, int ld, int K) {
-  return K > 0 && K <= RK_KMAX && (ld % 4) == 0 && n >= 256;
+  return K > 0 && K <= 4 * RK_KMAX && (ld % 4) == 0 && n >= 256;      // (beyond RK_KMAX: the panels in rounds of RK_KMAX columns)
 }
 hipError_t rankk_apply_adam(hipStream_t st, int n, int ld, int K, const float* GP, int ldp, const float* TT, int ldt,
                             const float* G, const float* rn, const float* gdn, const unsigned char* gate, float* M, float* am,

@@ -758,31 +758,51 @@ __global__ __launch_bounds__(512, 1) void split2_m16_kernel(const char* __restri
     }
 }
 
-// C tile = sum over parts of the partial tiles of the split-K tail (fixed order: deterministic)
+// C tile = sum over parts of the partial tiles of the split-K tail (fixed order: deterministic).  Block (t, y) owns rows
+// [32 y, 32 y + 32) of tile t; a Gram product's mirrored half leaves through LDS so that it, too, is written as 128-byte row pieces
+// (written element by element down a column it was the slow half of the pass: 55-73 us per reduce at n = 3312).
 __global__ __launch_bounds__(256) void k_split3_reduce(const float* __restrict__ slab, int ntile, int ksplit, float* __restrict__ C,
                                                        int n, int ldc, int tiles_m, int tiles_n, int panel_off, int tile_base,
                                                        int npanel_off, int beta) {
+  __shared__ float tr[32][TB + 1];
   const int t = blockIdx.x, lin = tile_base + t;
   int tile_m, tile_n;
   split_tile_of(lin, tiles_m, tiles_n, panel_off, npanel_off, beta, tile_m, tile_n);
-  for (int e = blockIdx.y * 256 + threadIdx.x; e < TB * TB / 4; e += gridDim.y * 256) {
-    const int row = e / (TB / 4), c4 = (e % (TB / 4)) * 4;
+  const bool acc_c = (beta & SPLIT_BETA) != 0, mir = (beta & SPLIT_TRI) && tile_m != tile_n;
+  const int tid = threadIdx.x, c4 = (tid & 63) * 4, rbase = blockIdx.y * 32;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int lr = pass * 4 + (tid >> 6), row = rbase + lr;
+    const float* src = slab + (size_t)t * (TB * TB) + (size_t)row * TB + c4;
+    float4 x[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      if (p < ksplit) x[p] = *reinterpret_cast<const float4*>(src + (size_t)p * ntile * (TB * TB));
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < ksplit; ++p) {
-      const float4 x = *reinterpret_cast<const float4*>(slab + ((size_t)p * ntile + t) * (TB * TB) + (size_t)row * TB + c4);
-      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      if (p < ksplit) { v.x += x[p].x; v.y += x[p].y; v.z += x[p].z; v.w += x[p].w; }
+    for (int p = 8; p < ksplit; ++p) {
+      const float4 y = *reinterpret_cast<const float4*>(src + (size_t)p * ntile * (TB * TB));
+      v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
+    }
+    const float vs[4] = {v.x, v.y, v.z, v.w};
+    if (mir) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tr[lr][c4 + q] = vs[q];
     }
     const int gr = tile_m * TB + row, gc = tile_n * TB + c4;
     if (gr >= n) continue;
     float* o = C + (size_t)gr * ldc + gc;
-    const bool acc_c = (beta & SPLIT_BETA) != 0, mir = (beta & SPLIT_TRI) && tile_m != tile_n;
-    const float vs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (gc + q < n) {
-        o[q] = vs[q] + (acc_c ? o[q] : 0.f);
-        if (mir) C[(size_t)(gc + q) * ldc + gr] = vs[q];
-      }
+      if (gc + q < n) o[q] = vs[q] + (acc_c ? o[q] : 0.f);
+  }
+  if (!mir) return;      // (uniform over the block)
+  __syncthreads();
+  const int lane = tid & 63, gr = tile_m * TB + rbase + (lane & 31);
+  for (int c = (tid >> 6) * 2 + (lane >> 5); c < TB; c += 8) {
+    const int gc = tile_n * TB + c;
+    if (gc < n && gr < n) C[(size_t)gc * ldc + gr] = tr[lane & 31][c];
   }
 }
 

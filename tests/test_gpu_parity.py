@@ -1234,13 +1234,16 @@ def test_split_f16_product_operand_scales(pkg, torch_, scale):
     assert np.array_equal(z, np.zeros_like(z))
 
 
-@pytest.mark.parametrize("n,measure", [(700, "HSIC"), (1100, "HSIC"), (700, "MSELoss")])
-def test_fused_tail_matches_separate_kernels(pkg, n, measure, monkeypatch):
+@pytest.mark.parametrize("n,measure,widths", [(700, "HSIC", (16, 8)), (1100, "HSIC", (16, 8)), (700, "MSELoss", (16, 8)),
+                                              (700, "HSIC", (80, 80)), (900, "MSELoss", (48, 40)), (600, "HSIC", (128, 128))])
+def test_fused_tail_matches_separate_kernels(pkg, n, measure, widths, monkeypatch):
     """n >= 256: normalisation-backward apply + rank-k update + gradient mirror + Adam run as one kernel over the lower
     tile pairs (k_rankk_apply_adam); MCGRA_NO_FUSED_TAIL=1 keeps rankk_nt + k_adam_sym.  Same per-element arithmetic:
-    the mirrored gradient agrees to rounding of the final sum and the state stays symmetric bit for bit."""
+    the mirrored gradient agrees to rounding of the final sum and the state stays symmetric bit for bit.
+    Chains wider than 64 columns in all (a GAT victim's two layers of 5 x 16: 160) take their panels through LDS 64 columns at a
+    time -- two, three and four rounds here; the separate kernels then are the apply pass, the fp32 MFMA GEMM and k_adam_sym."""
     import torch
-    z = _synthetic_case(n, 11, (16, 8), 4, seed=n, measure=measure)
+    z = _synthetic_case(n, 11, widths, 4, seed=n, measure=measure)
     monkeypatch.setenv("MCGRA_NO_FUSED_LR", "1")       # both through the general path (n >= 1024 would take the fused step)
     a = H.engine_from(pkg, z)
     monkeypatch.setenv("MCGRA_NO_FUSED_TAIL", "1")
@@ -1254,7 +1257,15 @@ def test_fused_tail_matches_separate_kernels(pkg, n, measure, monkeypatch):
         assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max()), t
         ma = a.buffer("M")
         assert torch.equal(ma[:n, :n], ma[:n, :n].T)
-        assert float((a.get_adj_changes() - b.get_adj_changes()).abs().max()) <= 1e-6
+        if sum((w + 3) // 4 * 4 for w in widths) <= 64:
+            assert float((a.get_adj_changes() - b.get_adj_changes()).abs().max()) <= 1e-6
+        else:
+            # (the separate kernels of a wide chain sum the rank-k update on the matrix cores, in another order: Adam turns a gradient
+            #  entry's rounding into lr * dg / |g| of the state -- entries whose gradient is not itself rounding noise agree, the rest
+            #  stay inside one Adam step of each other)
+            d = (ma[:n, :n] - b.buffer("M")[:n, :n]).abs()
+            big = gb[:n, :n].abs() >= 1e-2 * float(gb.abs().max())
+            assert float(d[big].max()) <= 2e-6 and float(d.max()) <= 2 * 0.01, (t, float(d[big].max()), float(d.max()))
         b.set_adj_changes(a.get_adj_changes())
 
 
