@@ -365,10 +365,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
     __syncthreads();
     int k0 = k_begin;
-    if (FASTPAIR && interior) {
-      for (; k0 + 4 * BK <= k_end; k0 += 2 * BK) {
-        step_fast(At{}, Rs0{}, k0);
-        step_fast(At{}, Rs1{}, k0 + BK);
+    if constexpr (FASTPAIR) {      // (not instantiated with one register set: step_fast names the other one)
+      if (interior) {
+        for (; k0 + 4 * BK <= k_end; k0 += 2 * BK) {
+          step_fast(At{}, Rs0{}, k0);
+          step_fast(At{}, Rs1{}, k0 + BK);
+        }
       }
     }
     while (k0 < k_end) {
