@@ -448,6 +448,8 @@ int mcgra_attack_create(mcgra_attack_t** out, const mcgra_attack_config_t* cfg) 
     { const char* ee = ab_env("MCGRA_EARLY_PACK"); h->early_pack_on = !(ee && ee[0] == '0'); }
     { const char* ee = ab_env("MCGRA_EARLY_P1"); h->early_p1_on = cfg->shard_world > 0 && !(ee && ee[0] == '0'); }
     { const char* ee = ab_env("MCGRA_EARLY_TAIL"); h->early_tail_on = !(ee && ee[0] == '0'); }
+    { const char* ee = ab_env("MCGRA_MSE_DECODE_SIDE"); h->mse_decode_side = ee && ee[0] == '1'; }
+    { const char* ee = ab_env("MCGRA_MSE_SMALL_INLINE"); h->mse_small_inline = !(ee && ee[0] == '0'); }
     h->late_mean = h->fused_ok && !h->fused_mse && cfg->shard_world == 0;
     {
       const char* ep = ab_env("MCGRA_PLANES_MM");

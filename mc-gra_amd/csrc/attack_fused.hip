@@ -556,7 +556,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   // reductions that only feed the returned loss terms are skipped when the caller did not ask for them (a row-block
   // rank keeps them: they ride in exchanges whose layout is fixed)
   const bool want_vals = h->sharded || h->fs_want;
-  hipStream_t s3 = h->st3;
+  // (the fused MSELoss step on a small graph: its small-operand terms are one launch each -- k_mse_small_fused -- and the fork and
+  //  the join of a side stream cost the caller's stream more than the two launches do: Cora-shaped 0.214 -> 0.199 ms; KL's are chains
+  //  of four, worth their stream: 0.271 against 0.284 inline; A/B MCGRA_MSE_SMALL_INLINE=0)
+  hipStream_t s3 = (mse && !kl && !h->sharded && h->mse_small_inline && n < 4096) ? st : h->st3;
   auto join = [&]() -> int {
     if (h->p1_inflight) {
       if (ovl) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -672,7 +675,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
         // joined in front of the first consumer of G_Zn (n = 2708: 0.60 -> 0.54 ms per step).  At N = 10 000 the chain hides
         // behind the product anyway and a decode that runs beside more of it only slows the product (6.4 -> 6.9 ms).
         // The masked-pair count is posted from the decode's stream (see below).
-        hipStream_t s4 = (s3 != st && n < 4096) ? h->st4 : st;
+        // (an elementwise measure -- MSELoss, KL -- has no factor chain: the caller's stream would only wait for the decode, and the
+        //  fork and the join cost it two event round trips (~17 us each): the decode stays on the caller's stream there -- Cora-shaped
+        //  MSELoss 0.248 -> 0.214 ms, KL 0.307 -> 0.271; A/B MCGRA_MSE_DECODE_SIDE=1)
+        hipStream_t s4 = (h->st3 != st && n < 4096 && (!mse || h->mse_decode_side)) ? h->st4 : st;
         if (s4 != st) {
           MCGRA_HIP(hipEventRecord(h->ev_fork4, st));
           MCGRA_HIP(hipStreamWaitEvent(s4, h->ev_fork4, 0));

@@ -111,6 +111,8 @@ struct mcgra_attack {
   hipEvent_t ev_r = nullptr, ev_pack = nullptr;
   bool early_pack_on = true;       // MCGRA_EARLY_PACK=0 disables (A/B)
   bool early_pack = false;         // Bpack / the pack's row partials describe the CURRENT M (packed by the forward of this M)
+  bool mse_small_inline = true;    // fused MSELoss step on a small graph: the two one-launch small-operand terms on the caller's stream (MCGRA_MSE_SMALL_INLINE=0: third stream; A/B)
+  bool mse_decode_side = false;    // fused MSELoss / KL step on a small graph: the decode on the fourth stream as in the HSIC step (MCGRA_MSE_DECODE_SIDE=1; A/B)
   bool early_p1_on = false;        // row-block rank: pack (uncentred) + N x N x N product forked by the FORWARD, as soon as r is complete
   bool p1_early = false;           // ... and in flight: forked by the forward of the CURRENT M (a monitor call, or the step's own)
   float* small_slab = nullptr;     // split-K slabs of a small graph's N x N x N products (more than an N x N buffer holds: split3_small_slab_bytes)

@@ -1696,6 +1696,33 @@ def test_small_operand_terms_beside_the_general_step_are_bit_identical(pkg, case
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("measure,n", [("MSELoss", 1100), ("KL", 1100), ("MSELoss", 2050)])
+def test_elementwise_fused_step_streams_on_a_small_graph_are_bit_identical(pkg, measure, n, monkeypatch):
+    """A fused MSELoss / KL step has no factor chain beside its decode: below n = 4096 the decode stays on the caller's stream
+    (a fork and a join cost it ~17 us each, and it would only wait), and MSELoss' two one-launch small-operand terms do too
+    (round 6: Cora-shaped MSELoss 0.248 -> 0.199 ms, KL 0.307 -> 0.271).  The same launches on the fourth / third stream
+    (MCGRA_MSE_DECODE_SIDE=1, MCGRA_MSE_SMALL_INLINE=0, the form of rounds 3 - 5): the same bits -- gradient, loss terms and
+    state over four steps."""
+    import torch
+    z = _synthetic_case(n, 11, (16, 16), 4, seed=n, measure=measure)
+    outs = []
+    for side in (False, True):
+        if side:
+            monkeypatch.setenv("MCGRA_MSE_DECODE_SIDE", "1"); monkeypatch.setenv("MCGRA_MSE_SMALL_INLINE", "0")
+        eng = H.engine_from(pkg, z)
+        res = []
+        for t in range(4):
+            sc = eng.step(want_scalars=True); eng.monitor()
+            res.append((eng.buffer("G_sym").clone(), sc))
+        assert eng.fused_steps() == 4
+        outs.append((res, eng.buffer("M").clone()))
+        eng.close()
+    for t in range(4):
+        assert torch.equal(outs[0][0][t][0], outs[1][0][t][0]), t
+        assert outs[0][0][t][1] == outs[1][0][t][1], t
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_gram_kx_forked_by_the_monitoring_forward_is_bit_identical(pkg, monkeypatch):
     """A configuration whose every step is a Gram evaluation (here MCGRA_NO_LOWRANK=1 at n = 1100; GAT / SAGE victims and CKA
     likewise): the monitoring forward packs both orientations of Xc and forks the step's first product Kx = Xc Xc^T as soon as
