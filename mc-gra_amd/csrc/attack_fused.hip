@@ -557,9 +557,11 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
   // rank keeps them: they ride in exchanges whose layout is fixed)
   const bool want_vals = h->sharded || h->fs_want;
   // (the fused MSELoss step on a small graph: its small-operand terms are one launch each -- k_mse_small_fused -- and the fork and
-  //  the join of a side stream cost the caller's stream more than the two launches do: Cora-shaped 0.214 -> 0.199 ms; KL's are chains
-  //  of four, worth their stream: 0.271 against 0.284 inline; A/B MCGRA_MSE_SMALL_INLINE=0)
+  //  the join of a side stream cost the caller's stream more than the two launches do: Cora-shaped 0.214 -> 0.199 ms; KL's terms stay on
+  //  their stream -- 0.270 against 0.284 inline as chains of four launches, 0.288 inline as one launch each (built, measured, removed);
+  //  A/B MCGRA_MSE_SMALL_INLINE=0)
   hipStream_t s3 = (mse && !kl && !h->sharded && h->mse_small_inline && n < 4096) ? st : h->st3;
+  const bool zero_inline = s3 == st && !h->sharded;      // (see launch_row_normalize below)
   auto join = [&]() -> int {
     if (h->p1_inflight) {
       if (ovl) MCGRA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -660,7 +662,13 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       }
 
       // ---- dot_product_decode + get_modified_adj_after (:187-188), recomputed per pair from Zn, own rows
-      launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f, h->Zpair);
+      // (small-operand terms on the caller's stream -- the fused MSELoss step of a small graph: the zero fills of what they and the
+      //  decode accumulate into ride in this launch instead of three launches of their own)
+      {
+        const ZeroFill zf{h->Gem, (size_t)n * h->hmax, w10 != 0 ? h->Gsm : nullptr, w10 != 0 ? (size_t)n * C : 0, h->nmask, 2};
+        launch_row_normalize(st, n, he, em, hs, h->Zn, h->hmax, h->nrm, 2.f, h->Zpair, zero_inline ? &zf : nullptr);
+        if (zero_inline) h->nmask_zero = true;
+      }
       if (kl) {
         // calc_kl's row statistics (logsumexp of adj_norm's and of modified_adj1's rows) from M, r and Zn: the decode backward and
         // the tail need those of EVERY row (d c2 / d A1_ij + d c2 / d A1_ji), so a row-block rank gathers its peers' first
@@ -754,10 +762,10 @@ static int fused_step_pt(mcgra_attack* h, hipStream_t st, mcgra_exchange_t* ex) 
       //      tiny launches are a tenth of the step -- on a third stream (forked behind the forward, above), joined in front of the
       //      backward of em.  ENQUEUED here, behind the decode and the first low-rank product: while the host spends its ~0.1 ms on
       //      them the caller's stream has the column statistics, the factor prep and that product to run
-      MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
+      if (!zero_inline) MCGRA_HIP(hipMemsetAsync(h->Gem, 0, sizeof(float) * (size_t)n * h->hmax, s3));
       if (w9 != 0) CHK(small_term(h, s3, he, em, hs, h->HAg, h->HAc, sg * k9, h->Gem, h->hmax, S_C9, want_vals));
       if (w10 != 0) {
-        MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s3));
+        if (!zero_inline) MCGRA_HIP(hipMemsetAsync(h->Gsm, 0, sizeof(float) * (size_t)n * C, s3));
         CHK(small_term(h, s3, C, h->sm2, C, h->YAg, h->YAc, sg * k10, h->Gsm, C, S_C10, want_vals));
         launch_softmax_bwd(s3, n, C, h->sm2, h->Gsm, C, h->GZ2);
       }

@@ -75,7 +75,10 @@ void launch_log_softmax(hipStream_t st, int n, int c, const float* Z, int ldz, f
                         int elu_in);
 void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const float* sm, int ld, const int* labels,
                      const float* cnt, float scale, float* GZ, double* rownll);
-void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p, float* zpair = nullptr);
+// buffers zero-filled by a launch that runs anyway in front of their accumulating consumers (two float ranges, a few counters)
+struct ZeroFill { float* p0; size_t n0; float* p1; size_t n1; unsigned* p2; int n2; };
+void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p, float* zpair = nullptr,
+                          const ZeroFill* zf = nullptr);
 void launch_row_normalize_bwd(hipStream_t st, int n, int h, const float* GZn, const float* Zn, int ld,
                               const float* nrm, float* GZ, int ldg);
 void launch_softmax_bwd(hipStream_t st, int n, int c, const float* sm, const float* Gsm, int ld, float* GZ);

@@ -197,9 +197,14 @@ __global__ void k_nll_grad(int n, int c, const float* __restrict__ logp, const f
 // chain -- the bits of the thread-per-row form.
 // (rb rows per block: 64, fewer for very wide embeddings -- launch_row_normalize keeps the tile under 48 KB)
 __global__ __launch_bounds__(256) void k_row_normalize(int rb, int n, int h, const float* __restrict__ Z, int ldz, float* __restrict__ Zn,
-                                                       int ldo, float* __restrict__ nrm, float pnorm, float* __restrict__ zpair) {
+                                                       int ldo, float* __restrict__ nrm, float pnorm, float* __restrict__ zpair, ZeroFill zf) {
   extern __shared__ float sh[];      // [rb][h + 1]
   const int r0 = blockIdx.x * rb, hp = h + 1;
+  // (buffers a later launch of the same stream accumulates into: zero-filled here instead of by launches of their own -- a short step
+  //  is a chain of dependent launches of 4 - 7 us each whatever they hold)
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < zf.n0; e += (size_t)gridDim.x * 256) zf.p0[e] = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < zf.n1; e += (size_t)gridDim.x * 256) zf.p1[e] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x < zf.n2) zf.p2[threadIdx.x] = 0u;
   for (int e = threadIdx.x; e < rb * h; e += 256) {
     const int r = e / h, k = e - r * h;
     sh[r * hp + k] = (r0 + r < n) ? Z[(size_t)(r0 + r) * ldz + k] : 0.f;
@@ -518,11 +523,12 @@ void launch_nll_grad(hipStream_t st, int n, int c, const float* logp, const floa
                      const float* cnt, float scale, float* GZ, double* rownll) {
   LAUNCH(k_nll_grad, g1(n), dim3(256), st, n, c, logp, sm, ld, labels, cnt, scale, GZ, rownll);
 }
-void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p, float* zpair) {
+void launch_row_normalize(hipStream_t st, int n, int h, const float* Z, int ldz, float* Zn, int ldo, float* nrm, float p, float* zpair,
+                          const ZeroFill* zf) {
   int rb = 64;
   while (rb > 1 && sizeof(float) * rb * (h + 1) > 48 * 1024) rb >>= 1;
   hipLaunchKernelGGL(k_row_normalize, dim3((n + rb - 1) / rb), dim3(256), sizeof(float) * rb * (h + 1), st, rb, n, h, Z, ldz, Zn, ldo, nrm,
-                     p, zpair);
+                     p, zpair, zf ? *zf : ZeroFill{nullptr, 0, nullptr, 0, nullptr, 0});
 }
 void launch_row_normalize_bwd(hipStream_t st, int n, int h, const float* GZn, const float* Zn, int ld,
                               const float* nrm, float* GZ, int ldg) {

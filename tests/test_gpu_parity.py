@@ -1699,10 +1699,10 @@ def test_small_operand_terms_beside_the_general_step_are_bit_identical(pkg, case
 @pytest.mark.parametrize("measure,n", [("MSELoss", 1100), ("KL", 1100), ("MSELoss", 2050)])
 def test_elementwise_fused_step_streams_on_a_small_graph_are_bit_identical(pkg, measure, n, monkeypatch):
     """A fused MSELoss / KL step has no factor chain beside its decode: below n = 4096 the decode stays on the caller's stream
-    (a fork and a join cost it ~17 us each, and it would only wait), and MSELoss' two one-launch small-operand terms do too
-    (round 6: Cora-shaped MSELoss 0.248 -> 0.199 ms, KL 0.307 -> 0.271).  The same launches on the fourth / third stream
-    (MCGRA_MSE_DECODE_SIDE=1, MCGRA_MSE_SMALL_INLINE=0, the form of rounds 3 - 5): the same bits -- gradient, loss terms and
-    state over four steps."""
+    (a fork and a join cost it ~17 us each, and it would only wait), and MSELoss' two one-launch small-operand terms do too, with
+    the zero fills of what they accumulate into riding in the row normalisation's launch (round 6: Cora-shaped MSELoss
+    0.248 -> 0.194 ms, KL 0.307 -> 0.271).  The same work on the fourth / third stream (MCGRA_MSE_DECODE_SIDE=1,
+    MCGRA_MSE_SMALL_INLINE=0: the form of rounds 3 - 5): the same bits -- gradient, loss terms and state over four steps."""
     import torch
     z = _synthetic_case(n, 11, (16, 16), 4, seed=n, measure=measure)
     outs = []
