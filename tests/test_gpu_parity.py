@@ -1235,7 +1235,8 @@ def test_split_f16_product_operand_scales(pkg, torch_, scale):
 
 
 @pytest.mark.parametrize("n,measure,widths", [(700, "HSIC", (16, 8)), (1100, "HSIC", (16, 8)), (700, "MSELoss", (16, 8)),
-                                              (700, "HSIC", (80, 80)), (900, "MSELoss", (48, 40)), (600, "HSIC", (128, 128))])
+                                              (700, "HSIC", (80, 80)), (900, "MSELoss", (48, 40)), (600, "HSIC", (128, 128)),
+                                              (4200, "HSIC", (80, 80))])      # (n > 4096: the products' split-K slabs share G_A with the tail's row sums)
 def test_fused_tail_matches_separate_kernels(pkg, n, measure, widths, monkeypatch):
     """n >= 256: normalisation-backward apply + rank-k update + gradient mirror + Adam run as one kernel over the lower
     tile pairs (k_rankk_apply_adam); MCGRA_NO_FUSED_TAIL=1 keeps rankk_nt + k_adam_sym.  Same per-element arithmetic:
