@@ -319,7 +319,9 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
                 and not any(x in k for x in _NOT_IN_STEP):
             outside += b * (n // nsteps)
     if prod_main is None:
-        return {"error": "no launch of the product kernel in the counter pass"}
+        if WORKLOADS[workload][5] == "HSIC":
+            return {"error": "no launch of the product kernel in the counter pass"}
+        prod_main = 0.0      # (the fused MSELoss / KL steps have no N x N x N product: everything is "outside")
     return {"product_bytes_per_launch": prod_main, "outside_product_bytes_per_step": outside, "steps_in_pass": nsteps,
             "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace over {nsteps} steps of this workload, run by this invocation "
                    "before its timed region; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}
@@ -606,6 +608,8 @@ def main(argv=None):
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure the memory-side traffic of this build on this box "
                          "(N = 1; implied by --no-split-probe)")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="run the two --pmc child passes even with --no-split-probe (the fused MSELoss / KL workloads: roofline.traffic per step)")
     ap.add_argument("--no-split-probe", action="store_true",
                     help="skip the extra runs at N = 1 (other evaluation of the N x N x N product, Cora-shape workload)")
     a = ap.parse_args(argv)
@@ -627,7 +631,7 @@ def main(argv=None):
     cpu = cpu_baseline(a.workload, a.seed) if (world == 1 and not a.no_cpu_baseline) else None
     # ... and so are the two PMC passes that measure this build's memory-side traffic on this box (children under rocprofv3)
     live, live_error = None, None
-    if world == 1 and not a.no_live_traffic and not a.no_split_probe and WORKLOADS[a.workload][5] == "HSIC":
+    if world == 1 and not a.no_live_traffic and (not a.no_split_probe or a.live_traffic) and WORKLOADS[a.workload][5] in ("HSIC", "MSELoss", "KL"):
         try:
             live = live_traffic(a.workload, a.seed)
         except Exception as e:
@@ -968,8 +972,9 @@ def main(argv=None):
             ach = passes * p / (1e-3 * 1e3 * dt / a.steps) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "the fused KL step as a whole (k_tail_adam, the skinny products on M, k_tail_reduce, "
                                "k_decode_stats, k_decode_fly: no N x N x N product, no N x N intermediate)", "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p, "traffic": None,
-                               "traffic_unit": "bytes/step"}
+                               "unit": "GB/s", "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p,
+                               "traffic": live["outside_product_bytes_per_step"] if live is not None else None,
+                               "traffic_unit": "bytes/step", "traffic_source": live["how"] if live is not None else live_error}
         elif measure == "MSELoss" and eng_path["fused_steps"] > 0 and eng_path["general_steps"] == 0 and world == 1:
             # the fused MSELoss step has no N x N x N product: it is a chain of HBM-bound passes over the learnable adjacency.
             # Algorithmic bytes per step = the passes its formulation cannot do without, p = 4 n^2 bytes each: L forward products
@@ -981,7 +986,9 @@ def main(argv=None):
             ach = passes * p / (1e-3 * 1e3 * dt / a.steps) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "the fused MSELoss step as a whole (k_tail_adam, the skinny products on M, k_tail_reduce, "
                                "k_decode_fly: no N x N x N product, no N x N intermediate)", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                               "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p, "traffic": None, "traffic_unit": "bytes/step"}
+                               "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p,
+                               "traffic": live["outside_product_bytes_per_step"] if live is not None else None, "traffic_unit": "bytes/step",
+                               "traffic_source": live["how"] if live is not None else live_error}
         else:
             out["roofline"] = None
         # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed

@@ -23,7 +23,8 @@ python bench.py --steps 20 --warmup 5 > $O/bench_20_5.json 2>/dev/null
 python -c "
 import json; l=json.loads(open('$O/bench_20_5.json').read().strip().splitlines()[-1]); print('20/5', l['value'], l['ms_per_step'])"
 for wl in synthetic-10k-kl cora-shape-kl synthetic-10k-mse cora-shape-mse cora-shape-hsic synthetic-4k-hsic citeseer-shape-gat-hsic synthetic-10k-hsic-masked; do
-  python bench.py --workload $wl --no-cpu-baseline --no-split-probe --steps 100 --warmup 20 > $O/o_bench_$wl.json 2>/dev/null
+  LT=""; case $wl in *-kl|*-mse) LT="--live-traffic";; esac      # (the fused MSELoss / KL steps: roofline.traffic per step from two --pmc child passes)
+  python bench.py --workload $wl --no-cpu-baseline --no-split-probe $LT --steps 100 --warmup 20 > $O/o_bench_$wl.json 2>/dev/null
   python -c "
 import json; l=json.loads(open('$O/o_bench_$wl.json').read().strip().splitlines()[-1]); print('$wl', round(l['value'],1), round(l['ms_per_step'],4), l['config'].get('fused_steps'), l['config'].get('general_steps'), (l.get('roofline') or {}).get('frac'))"
 done
