@@ -282,6 +282,7 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
     except OSError as e:
         return {"error": f"cannot read {py}: {e}"}
     per = {}
+    window = {}      # counter -> (bytes between the first and the last Adam pass of the run, steps in between)
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
@@ -297,9 +298,15 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
             if r.returncode != 0 or not fs:
                 return {"error": f"{ctr} pass: exit code {r.returncode}, {len(fs)} counter file(s)"}
             with open(fs[0]) as fh:
-                for row in csv.DictReader(fh):
-                    if row["Counter_Name"] != ctr:
-                        continue
+                rows_ = [row for row in csv.DictReader(fh) if row["Counter_Name"] == ctr]
+            # every launch between the first and the last Adam pass of the run, in dispatch order: whole iterations (step + monitoring
+            # forward) and nothing else -- no allocation fills of engine creation, no finalize
+            rows_.sort(key=lambda r_: int(r_["Dispatch_Id"]))
+            adam = [i for i, r_ in enumerate(rows_) if any(x in r_["Kernel_Name"] for x in ("k_tail_adam", "k_adam_sym", "k_rankk_apply_adam"))]
+            if len(adam) >= 2:
+                window[ctr] = (sum(float(r_["Counter_Value"]) for r_ in rows_[adam[0] + 1:adam[-1] + 1]), len(adam) - 1)
+            if True:
+                for row in rows_:
                     k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + f" grid={row['Grid_Size']}"
                     e = per.setdefault(k, {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
                     e[ctr] += float(row["Counter_Value"])
@@ -322,7 +329,13 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
         if WORKLOADS[workload][5] == "HSIC":
             return {"error": "no launch of the product kernel in the counter pass"}
         prod_main = 0.0      # (the fused MSELoss / KL steps have no N x N x N product: everything is "outside")
+    step_bytes = None
+    if "FETCH_SIZE" in window and "WRITE_SIZE" in window:
+        step_bytes = (2.0 * window["FETCH_SIZE"][0] / window["FETCH_SIZE"][1] + window["WRITE_SIZE"][0] / window["WRITE_SIZE"][1]) * 1024.0
     return {"product_bytes_per_launch": prod_main, "outside_product_bytes_per_step": outside, "steps_in_pass": nsteps,
+            "iteration_bytes": step_bytes,      # whole iterations between the run's first and last Adam pass, per iteration
+            "iteration_how": "2 x FETCH_SIZE + WRITE_SIZE over every launch between the first and the last Adam pass of a "
+                             f"{nsteps}-step run under rocprofv3 --pmc (two child passes of this invocation), per iteration",
             "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace over {nsteps} steps of this workload, run by this invocation "
                    "before its timed region; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}
 
@@ -973,8 +986,8 @@ def main(argv=None):
             out["roofline"] = {"bound": "hbm", "kernel": "the fused KL step as a whole (k_tail_adam, the skinny products on M, k_tail_reduce, "
                                "k_decode_stats, k_decode_fly: no N x N x N product, no N x N intermediate)", "achieved": ach, "peak": 8000.0,
                                "unit": "GB/s", "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p,
-                               "traffic": live["outside_product_bytes_per_step"] if live is not None else None,
-                               "traffic_unit": "bytes/step", "traffic_source": live["how"] if live is not None else live_error}
+                               "traffic": live["iteration_bytes"] if live is not None else None,
+                               "traffic_unit": "bytes/step", "traffic_source": live["iteration_how"] if live is not None else live_error}
         elif measure == "MSELoss" and eng_path["fused_steps"] > 0 and eng_path["general_steps"] == 0 and world == 1:
             # the fused MSELoss step has no N x N x N product: it is a chain of HBM-bound passes over the learnable adjacency.
             # Algorithmic bytes per step = the passes its formulation cannot do without, p = 4 n^2 bytes each: L forward products
@@ -987,8 +1000,8 @@ def main(argv=None):
             out["roofline"] = {"bound": "hbm", "kernel": "the fused MSELoss step as a whole (k_tail_adam, the skinny products on M, k_tail_reduce, "
                                "k_decode_fly: no N x N x N product, no N x N intermediate)", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                                "frac": ach / 8000.0, "algorithmic_bytes_per_step": passes * p,
-                               "traffic": live["outside_product_bytes_per_step"] if live is not None else None, "traffic_unit": "bytes/step",
-                               "traffic_source": live["how"] if live is not None else live_error}
+                               "traffic": live["iteration_bytes"] if live is not None else None, "traffic_unit": "bytes/step",
+                               "traffic_source": live["iteration_how"] if live is not None else live_error}
         else:
             out["roofline"] = None
         # the rest of the step against the HBM roofline: PMC bytes per step outside the product launches (committed
