@@ -335,9 +335,8 @@ def live_traffic(workload, seed, steps=6, timeout_s=120.0):
     return {"product_bytes_per_launch": prod_main, "outside_product_bytes_per_step": outside, "steps_in_pass": nsteps,
             "iteration_bytes": step_bytes,      # whole iterations between the run's first and last Adam pass, per iteration
             "iteration_how": "2 x FETCH_SIZE + WRITE_SIZE over every launch between the first and the last Adam pass of a "
-                             f"{nsteps}-step run under rocprofv3 --pmc (two child passes of this invocation), per iteration; an UPPER "
-                             "bound: the x 2 is calibrated on 1 KB-per-wave streaming reads, and the per-pair kernels read 256-byte tile rows "
-                             "(profiles/README.md: r06_pmc_by_kernel_kl_mse.txt)",
+                             f"{nsteps}-step run under rocprofv3 --pmc (two child passes of this invocation), per iteration "
+                             "(128-byte fabric requests confirmed for the tile kernels: profiles/r06_tcc_requests_mse_tail.txt)",
             "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace over {nsteps} steps of this workload, run by this invocation "
                    "before its timed region; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}
 
